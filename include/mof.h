@@ -1,0 +1,153 @@
+/*
+ * mof.h -- C ABI of the MI355X optic-flow core (libmof_hip.so).
+ *
+ * Drop-in boundary for the processor surface of ctu-mrs/mrs_optic_flow:
+ *   OpticFlowCalc::processImage / setImPrev      /root/reference/include/OpticFlowCalc.h:9-16
+ *   FftMethod::FftMethod / processImage          /root/reference/include/FftMethod.h:434-439,
+ *                                                /root/reference/src/FftMethod.cpp:1680-1766, :1772-1903
+ *   BlockMethod::BlockMethod / processImage      /root/reference/src/BlockMethod.cpp:3-22, :25-94
+ *   FastSpacedBMMethod::processImage             /root/reference/src/FastSpacedBMMethod_OCL.cpp:71-184
+ *
+ * Plain pointers and sizes only; no C++/torch/OpenCV types; no exceptions cross
+ * this boundary. Every entry point returns a status (0 ok, <0 error) and the text
+ * of the last error of the calling thread is available from mof_last_error().
+ * There is NO CPU fallback: when no HIP device is usable every create() fails
+ * with MOF_ERR_NO_DEVICE.
+ *
+ * Conventions
+ *   - frames are 8-bit single-channel, row-major, `pitch` bytes per row;
+ *   - FFT results are (x, y) pixel shifts, +x right, +y down, positive = image
+ *     content moved that way from the previous to the current frame (the sign of
+ *     `-cv::phaseCorrelate(cur, prev)`, FftMethod.cpp:1836); invalid patches are
+ *     (NaN, NaN) (FftMethod.cpp:1851-1853); patch (i, j) is stored at index
+ *     i + j*grid_x (FftMethod.cpp:1855);
+ *   - block-matching results are integer (dx, dy) = arg-min position minus the
+ *     scan radius (BlockMethod.cpp:63-66; FastSpacedBMMethod.cl:74-75), block
+ *     (bx, by) at index by*grid_x + bx, plus the per-axis histogram mode;
+ *   - one engine = one HIP stream, not re-entrant: a call made while another is
+ *     in flight on the same engine returns MOF_ERR_BUSY (the reference returns an
+ *     empty vector, FftMethod.cpp:1775-1776). Different engines are independent.
+ */
+#ifndef MOF_H
+#define MOF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOF_OK 0
+#define MOF_ERR_BAD_ARG (-1)
+#define MOF_ERR_BUSY (-2)
+#define MOF_ERR_HIP (-3)
+#define MOF_ERR_NOT_INIT (-4)
+#define MOF_ERR_UNSUPPORTED (-5)
+#define MOF_ERR_NO_DEVICE (-6)
+#define MOF_ERR_NO_MEMORY (-7)
+
+const char* mof_version(void);
+/* Message of the last failing call made by this thread ("" if none). */
+const char* mof_last_error(void);
+/* Number of usable HIP devices (0 when there is none; never negative). */
+int mof_device_count(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* FFT phase correlation (FftMethod)                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct mof_fft_config {
+  int frame_width, frame_height; /* pixels                                                    */
+  int patch_size;                /* samplePointSize N: 32, 64 or 128                          */
+  int grid_x, grid_y;            /* patches per row / per column                              */
+  int origin_x, origin_y;        /* top-left pixel of patch (0,0)                             */
+  int stride_x, stride_y;        /* distance between patch origins                            */
+  double max_px_speed;           /* gate on |shift| (FftMethod.cpp:1686, :1841)               */
+  int device;                    /* HIP device ordinal                                        */
+} mof_fft_config;
+
+/* Geometry exactly as FftMethod's constructor derives it (FftMethod.cpp:1706-1720):
+ * frameSize forced even; if it is not a multiple of samplePointSize the patch becomes
+ * the whole frame; sqNum = frameSize / samplePointSize; contiguous tiling from (0,0). */
+int mof_fft_config_reference(mof_fft_config* cfg, int frame_size, int sample_point_size, double max_px_speed);
+
+typedef struct mof_fft_engine mof_fft_engine;
+
+int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out);
+void mof_fft_destroy(mof_fft_engine* e);
+
+/* setImPrev (OpticFlowCalc.h:14-16): host frame copied to the device-resident previous frame.
+ * As in the reference, the first process() call after create()/reset() still correlates the
+ * frame with itself (`first`, FftMethod.cpp:1791-1793). */
+int mof_fft_set_prev(mof_fft_engine* e, const uint8_t* frame, size_t pitch);
+/* Re-arms `first` (FftMethod.cpp:1761). */
+int mof_fft_reset(mof_fft_engine* e);
+
+/* processImage (FftMethod.cpp:1772-1903), synchronous: uploads `frame`, correlates it with the
+ * previous frame, writes 2*grid_x*grid_y doubles to out_xy, then previous <- current
+ * (FftMethod.cpp:1872). n_invalid (optional) counts NaN patches. */
+int mof_fft_process(mof_fft_engine* e, const uint8_t* frame, size_t pitch, double* out_xy, int* n_invalid);
+
+/* Batched mode on DEVICE pointers: pair k correlates d_cur + k*cur_stride with
+ * d_prev + k*prev_stride (strides in bytes; a video sequence is cur = frames + frame_bytes,
+ * prev = frames, both strides frame_bytes). d_out_xy receives n_pairs*grid_x*grid_y*2 doubles.
+ * Asynchronous on `stream` (a hipStream_t; NULL is HIP's null stream, as everywhere in HIP);
+ * the caller synchronises. The engine's stateful previous frame is not touched. */
+int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                 size_t prev_stride, size_t pitch, int n_pairs, double* d_out_xy, void* stream);
+/* Same on HOST pointers (upload, run, download, synchronous). */
+int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
+                               size_t prev_stride, size_t pitch, int n_pairs, double* out_xy);
+
+/* Waits for the engine's own stream. */
+int mof_fft_sync(mof_fft_engine* e);
+
+/* ------------------------------------------------------------------------------------------ */
+/* SAD block matching (BlockMethod / FastSpacedBMMethod)                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct mof_bm_config {
+  int frame_width, frame_height;
+  int block_size;        /* samplePointSize                                                   */
+  int step_size;         /* stepSize: gap between blocks (0 = BlockMethod's contiguous blocks) */
+  int scan_radius;       /* scanRadius r; candidates are [-r, r]^2                            */
+  int grid_x, grid_y;    /* blocks per row / column                                           */
+  int low_contrast_rule; /* 1: (SAD(0,0) - min) <= 0.2 r^2 -> (0,0)  (FastSpacedBMMethod.cl:77-82) */
+  int device;
+} mof_bm_config;
+
+/* BlockMethod geometry (BlockMethod.cpp:11, :45): grid = (frameSize - 2r)/sps squared, no rule. */
+int mof_bm_config_block_method(mof_bm_config* cfg, int frame_size, int sample_point_size, int scan_radius);
+/* FastSpacedBM geometry (FastSpacedBMMethod_OCL.cpp:82-90): S = sps + step,
+ * grid = ((W - 2r)/S, (H - 2r)/S), rule on. */
+int mof_bm_config_fast_spaced(mof_bm_config* cfg, int width, int height, int sample_point_size, int step_size,
+                              int scan_radius);
+
+typedef struct mof_bm_engine mof_bm_engine;
+
+int mof_bm_create(const mof_bm_config* cfg, mof_bm_engine** out);
+void mof_bm_destroy(mof_bm_engine* e);
+int mof_bm_set_prev(mof_bm_engine* e, const uint8_t* frame, size_t pitch);
+int mof_bm_reset(mof_bm_engine* e);
+
+/* processImage of either class, synchronous. dx, dy: grid_x*grid_y int8 each. mode_xy[2]:
+ * per-axis histogram mode (BlockMethod.cpp:75-76; Histogram_C1_D0 element 0). Unlike
+ * FftMethod the block matchers do NOT self-correlate the first frame: the previous frame
+ * starts as zeros (BlockMethod.cpp:17-18) unless set_prev was called. */
+int mof_bm_process(mof_bm_engine* e, const uint8_t* frame, size_t pitch, int8_t* dx, int8_t* dy, int8_t* mode_xy);
+
+/* Batched mode on DEVICE pointers. d_dx, d_dy: n_pairs*grid_x*grid_y int8; d_mode: n_pairs*8 int8
+ * = {modeX, modeY, 2nd X, 2nd Y, 3rd X, 3rd Y, 0, 0} (the TestDepth=3 list of
+ * FastSpacedBMMethod_OCL.cpp:97 per axis). Asynchronous on `stream`. */
+int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                size_t prev_stride, size_t pitch, int n_pairs, int8_t* d_dx, int8_t* d_dy,
+                                int8_t* d_mode, void* stream);
+int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
+                              size_t prev_stride, size_t pitch, int n_pairs, int8_t* dx, int8_t* dy, int8_t* mode);
+int mof_bm_sync(mof_bm_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOF_H */

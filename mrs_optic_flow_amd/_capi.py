@@ -1,0 +1,99 @@
+"""ctypes binding of the C ABI in include/mof.h (libmof_hip.so).
+
+This is plumbing for tests, bench.py and the multi-GPU driver; the product is the
+shared library. It fails loudly: a missing library raises ImportError-like
+``MofLibraryError`` and there is no Python/CPU compute fallback anywhere.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmof_hip.so")
+
+MOF_OK = 0
+MOF_ERR_BAD_ARG = -1
+MOF_ERR_BUSY = -2
+MOF_ERR_HIP = -3
+MOF_ERR_NOT_INIT = -4
+MOF_ERR_UNSUPPORTED = -5
+MOF_ERR_NO_DEVICE = -6
+MOF_ERR_NO_MEMORY = -7
+
+
+class MofLibraryError(RuntimeError):
+    pass
+
+
+class MofError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"mof error {code}: {message}")
+        self.code = code
+
+
+class FftConfig(C.Structure):
+    _fields_ = [("frame_width", C.c_int), ("frame_height", C.c_int), ("patch_size", C.c_int),
+                ("grid_x", C.c_int), ("grid_y", C.c_int), ("origin_x", C.c_int), ("origin_y", C.c_int),
+                ("stride_x", C.c_int), ("stride_y", C.c_int), ("max_px_speed", C.c_double), ("device", C.c_int)]
+
+
+class BmConfig(C.Structure):
+    _fields_ = [("frame_width", C.c_int), ("frame_height", C.c_int), ("block_size", C.c_int),
+                ("step_size", C.c_int), ("scan_radius", C.c_int), ("grid_x", C.c_int), ("grid_y", C.c_int),
+                ("low_contrast_rule", C.c_int), ("device", C.c_int)]
+
+
+# every symbol include/mof.h declares: (name, restype, argtypes)
+_VP, _SZ, _I = C.c_void_p, C.c_size_t, C.c_int
+SYMBOLS = {
+    "mof_version": (C.c_char_p, []),
+    "mof_last_error": (C.c_char_p, []),
+    "mof_device_count": (_I, []),
+    "mof_fft_config_reference": (_I, [C.POINTER(FftConfig), _I, _I, C.c_double]),
+    "mof_fft_create": (_I, [C.POINTER(FftConfig), C.POINTER(_VP)]),
+    "mof_fft_destroy": (None, [_VP]),
+    "mof_fft_set_prev": (_I, [_VP, _VP, _SZ]),
+    "mof_fft_reset": (_I, [_VP]),
+    "mof_fft_process": (_I, [_VP, _VP, _SZ, _VP, C.POINTER(_I)]),
+    "mof_fft_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
+    "mof_fft_process_batch_host": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP]),
+    "mof_fft_sync": (_I, [_VP]),
+    "mof_bm_config_block_method": (_I, [C.POINTER(BmConfig), _I, _I, _I]),
+    "mof_bm_config_fast_spaced": (_I, [C.POINTER(BmConfig), _I, _I, _I, _I, _I]),
+    "mof_bm_create": (_I, [C.POINTER(BmConfig), C.POINTER(_VP)]),
+    "mof_bm_destroy": (None, [_VP]),
+    "mof_bm_set_prev": (_I, [_VP, _VP, _SZ]),
+    "mof_bm_reset": (_I, [_VP]),
+    "mof_bm_process": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP]),
+    "mof_bm_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP, _VP, _VP]),
+    "mof_bm_process_batch_host": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP, _VP]),
+    "mof_bm_sync": (_I, [_VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmof_hip.so (built by __graft_entry__.build() / csrc/Makefile). Never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MofLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as exc:  # pragma: no cover - depends on the host
+            raise MofLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != MOF_OK:
+        raise MofError(rc, load().mof_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,566 @@
+// mof_capi.hip -- implementation of the C ABI declared in include/mof.h.
+//
+// Host-side engine objects (device buffers, one HIP stream each, the stateful previous
+// frame of the reference's processors) around the gfx950 kernels. There is no CPU compute
+// path in this library: without a HIP device every create() fails with MOF_ERR_NO_DEVICE.
+
+#include "mof.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mof_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) return fail(MOF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));    \
+  } while (0)
+
+// Non-re-entrancy flag of the reference (`running`, FftMethod.cpp:1775-1777), made atomic.
+struct BusyGuard {
+  std::atomic<bool>& flag;
+  bool owned;
+  explicit BusyGuard(std::atomic<bool>& f) : flag(f), owned(!f.exchange(true)) {}
+  ~BusyGuard() {
+    if (owned) flag.store(false);
+  }
+};
+
+int select_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(MOF_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  }
+  if (device < 0 || device >= n) return fail(MOF_ERR_BAD_ARG, "device %d out of range (0..%d)", device, n - 1);
+  HIP_TRY(hipSetDevice(device));
+  return MOF_OK;
+}
+
+}  // namespace
+
+struct mof_fft_engine {
+  mof_fft_config cfg{};
+  hipStream_t stream = nullptr;
+  float* d_twiddles = nullptr;
+  uint8_t* d_frames[2] = {nullptr, nullptr};  // [cur_slot], [1-cur_slot] = previous
+  int prev_slot = 0;
+  size_t frame_bytes = 0;
+  double* d_out = nullptr;       // one frame's results
+  double* h_out = nullptr;       // pinned
+  uint8_t* h_stage = nullptr;    // pinned upload staging (tightly packed frame)
+  bool first = true;             // FftMethod.cpp:1761
+  std::atomic<bool> busy{false};
+};
+
+struct mof_bm_engine {
+  mof_bm_config cfg{};
+  hipStream_t stream = nullptr;
+  uint8_t* d_frames[2] = {nullptr, nullptr};
+  int prev_slot = 0;
+  size_t frame_bytes = 0;
+  int8_t* d_dx = nullptr;
+  int8_t* d_dy = nullptr;
+  int8_t* d_mode = nullptr;
+  int8_t* h_res = nullptr;     // pinned: dx | dy | mode
+  uint8_t* h_stage = nullptr;
+  std::atomic<bool> busy{false};
+};
+
+extern "C" {
+
+const char* mof_version(void) { return "mof-hip 0.1.0 (gfx950)"; }
+const char* mof_last_error(void) { return g_err; }
+
+int mof_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n < 0 ? 0 : n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* FFT                                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+int mof_fft_config_reference(mof_fft_config* cfg, int frame_size, int sample_point_size, double max_px_speed) {
+  if (!cfg || frame_size < 2 || sample_point_size < 1) return fail(MOF_ERR_BAD_ARG, "bad reference geometry");
+  std::memset(cfg, 0, sizeof(*cfg));
+  if (frame_size % 2 == 1) frame_size--;                                           // FftMethod.cpp:1706-1708
+  if (frame_size % sample_point_size != 0) sample_point_size = frame_size;         // :1709-1716
+  const int sq = frame_size / sample_point_size;                                   // :1719
+  cfg->frame_width = cfg->frame_height = frame_size;
+  cfg->patch_size = sample_point_size;
+  cfg->grid_x = cfg->grid_y = sq;
+  cfg->origin_x = cfg->origin_y = 0;
+  cfg->stride_x = cfg->stride_y = sample_point_size;
+  cfg->max_px_speed = max_px_speed;
+  cfg->device = 0;
+  return MOF_OK;
+}
+
+static int validate_fft(const mof_fft_config* c) {
+  if (!c) return fail(MOF_ERR_BAD_ARG, "null config");
+  if (c->frame_width < 1 || c->frame_height < 1 || c->grid_x < 1 || c->grid_y < 1 || c->origin_x < 0 ||
+      c->origin_y < 0 || c->stride_x < 0 || c->stride_y < 0)
+    return fail(MOF_ERR_BAD_ARG, "bad FFT geometry");
+  if (!mof::pc_patch_size_supported(c->patch_size))
+    return fail(MOF_ERR_UNSUPPORTED, "patch_size %d not supported by the HIP kernel (32, 64, 128)", c->patch_size);
+  if (c->origin_x + (long)(c->grid_x - 1) * c->stride_x + c->patch_size > c->frame_width ||
+      c->origin_y + (long)(c->grid_y - 1) * c->stride_y + c->patch_size > c->frame_height)
+    return fail(MOF_ERR_BAD_ARG, "patch grid leaves the frame");
+  if ((long)c->grid_x * c->grid_y > (1 << 20)) return fail(MOF_ERR_BAD_ARG, "too many patches");
+  if (!(c->max_px_speed >= 0.0)) return fail(MOF_ERR_BAD_ARG, "max_px_speed must be >= 0");
+  return MOF_OK;
+}
+
+int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) {
+  if (!out) return fail(MOF_ERR_BAD_ARG, "null out");
+  *out = nullptr;
+  int rc = validate_fft(cfg);
+  if (rc) return rc;
+  rc = select_device(cfg->device);
+  if (rc) return rc;
+  mof_fft_engine* e = new (std::nothrow) mof_fft_engine();
+  if (!e) return fail(MOF_ERR_NO_MEMORY, "out of host memory");
+  e->cfg = *cfg;
+  e->frame_bytes = (size_t)cfg->frame_width * cfg->frame_height;
+  const int n = cfg->patch_size;
+  const size_t res = (size_t)cfg->grid_x * cfg->grid_y * 2;
+  // twiddles W_N^k = exp(-2 pi i k / N), double -> float, axis values exact
+  std::vector<float> tw(2 * (size_t)n);
+  for (int k = 0; k < n; ++k) {
+    double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)n;
+    double c = std::cos(ang), s = std::sin(ang);
+    if ((4 * k) % n == 0) {
+      const int q = (4 * k) / n;
+      c = (q == 0) ? 1.0 : (q == 2) ? -1.0 : 0.0;
+      s = (q == 1) ? -1.0 : (q == 3) ? 1.0 : 0.0;
+    }
+    tw[2 * k] = (float)c;
+    tw[2 * k + 1] = (float)s;
+  }
+#define CREATE_TRY(expr)                                                                        \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      fail(MOF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));                                \
+      mof_fft_destroy(e);                                                                       \
+      return MOF_ERR_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+  CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipMalloc(&e->d_twiddles, tw.size() * sizeof(float)));
+  CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+  CREATE_TRY(hipMalloc(&e->d_frames[0], e->frame_bytes));
+  CREATE_TRY(hipMalloc(&e->d_frames[1], e->frame_bytes));
+  CREATE_TRY(hipMemset(e->d_frames[0], 0, e->frame_bytes));
+  CREATE_TRY(hipMemset(e->d_frames[1], 0, e->frame_bytes));
+  CREATE_TRY(hipMalloc(&e->d_out, res * sizeof(double)));
+  CREATE_TRY(hipHostMalloc(&e->h_out, res * sizeof(double), hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
+  CREATE_TRY(mof::pc_configure(n));
+#undef CREATE_TRY
+  *out = e;
+  return MOF_OK;
+}
+
+void mof_fft_destroy(mof_fft_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->d_twiddles) (void)hipFree(e->d_twiddles);
+  if (e->d_frames[0]) (void)hipFree(e->d_frames[0]);
+  if (e->d_frames[1]) (void)hipFree(e->d_frames[1]);
+  if (e->d_out) (void)hipFree(e->d_out);
+  if (e->h_out) (void)hipHostFree(e->h_out);
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+static void pack_frame(uint8_t* dst, const uint8_t* src, size_t pitch, int w, int h) {
+  for (int y = 0; y < h; ++y) std::memcpy(dst + (size_t)y * w, src + (size_t)y * pitch, (size_t)w);
+}
+
+static mof::PcArgs fft_args(const mof_fft_engine* e, const uint8_t* cur, size_t cs, const uint8_t* prev, size_t ps,
+                            size_t pitch, double* out) {
+  mof::PcArgs a{};
+  a.cur = cur;
+  a.prev = prev;
+  a.cur_stride = cs;
+  a.prev_stride = ps;
+  a.pitch = pitch;
+  a.grid_x = e->cfg.grid_x;
+  a.grid_y = e->cfg.grid_y;
+  a.origin_x = e->cfg.origin_x;
+  a.origin_y = e->cfg.origin_y;
+  a.stride_x = e->cfg.stride_x;
+  a.stride_y = e->cfg.stride_y;
+  a.max_px_speed_sq = e->cfg.max_px_speed * e->cfg.max_px_speed;  // pow(max_px_speed_t, 2), FftMethod.cpp:1686
+  a.twiddles = e->d_twiddles;
+  a.out = out;
+  return a;
+}
+
+int mof_fft_set_prev(mof_fft_engine* e, const uint8_t* frame, size_t pitch) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!frame || pitch < (size_t)e->cfg.frame_width) return fail(MOF_ERR_BAD_ARG, "bad frame/pitch");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  pack_frame(e->h_stage, frame, pitch, e->cfg.frame_width, e->cfg.frame_height);
+  HIP_TRY(hipMemcpyAsync(e->d_frames[e->prev_slot], e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MOF_OK;
+}
+
+int mof_fft_reset(mof_fft_engine* e) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  e->first = true;
+  return MOF_OK;
+}
+
+int mof_fft_process(mof_fft_engine* e, const uint8_t* frame, size_t pitch, double* out_xy, int* n_invalid) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!frame || !out_xy || pitch < (size_t)e->cfg.frame_width) return fail(MOF_ERR_BAD_ARG, "bad frame/pitch/out");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");  // reference: returns an empty vector
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int cur_slot = 1 - e->prev_slot;
+  pack_frame(e->h_stage, frame, pitch, e->cfg.frame_width, e->cfg.frame_height);
+  HIP_TRY(hipMemcpyAsync(e->d_frames[cur_slot], e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+  // `first`: the frame is correlated with itself (FftMethod.cpp:1791-1793)
+  const uint8_t* prev = e->first ? e->d_frames[cur_slot] : e->d_frames[e->prev_slot];
+  mof::PcArgs a = fft_args(e, e->d_frames[cur_slot], 0, prev, 0, (size_t)e->cfg.frame_width, e->d_out);
+  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, 1, e->stream));
+  const size_t res = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
+  HIP_TRY(hipMemcpyAsync(e->h_out, e->d_out, res * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  int bad = 0;
+  for (size_t i = 0; i < res; i += 2) {
+    out_xy[i] = e->h_out[i];
+    out_xy[i + 1] = e->h_out[i + 1];
+    if (std::isnan(e->h_out[i])) ++bad;
+  }
+  if (n_invalid) *n_invalid = bad;
+  e->prev_slot = cur_slot;  // imPrev = imCurr.clone(), FftMethod.cpp:1872
+  e->first = false;         // :1900
+  return MOF_OK;
+}
+
+int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                 size_t prev_stride, size_t pitch, int n_pairs, double* d_out_xy, void* stream) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!d_cur || !d_prev || !d_out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
+    return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if (n_pairs == 0) return MOF_OK;
+  if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
+    return fail(MOF_ERR_BAD_ARG, "batch too large for one launch");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
+  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
+  return MOF_OK;
+}
+
+int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
+                               size_t prev_stride, size_t pitch, int n_pairs, double* out_xy) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!cur || !prev || !out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
+    return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if (n_pairs == 0) return MOF_OK;
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const size_t fb = e->frame_bytes, res = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
+  uint8_t *d_c = nullptr, *d_p = nullptr;
+  double* d_o = nullptr;
+  std::vector<uint8_t> pc(fb * n_pairs), pp(fb * n_pairs);
+  for (int k = 0; k < n_pairs; ++k) {
+    pack_frame(pc.data() + fb * k, cur + cur_stride * k, pitch, e->cfg.frame_width, e->cfg.frame_height);
+    pack_frame(pp.data() + fb * k, prev + prev_stride * k, pitch, e->cfg.frame_width, e->cfg.frame_height);
+  }
+  int rc = MOF_OK;
+  hipError_t he;
+  if ((he = hipMalloc(&d_c, fb * n_pairs)) != hipSuccess || (he = hipMalloc(&d_p, fb * n_pairs)) != hipSuccess ||
+      (he = hipMalloc(&d_o, res * n_pairs * sizeof(double))) != hipSuccess ||
+      (he = hipMemcpy(d_c, pc.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess ||
+      (he = hipMemcpy(d_p, pp.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess) {
+    rc = fail(MOF_ERR_HIP, "batch upload: %s", hipGetErrorString(he));
+  }
+  if (rc == MOF_OK)
+    rc = mof_fft_process_batch_device(e, d_c, fb, d_p, fb, (size_t)e->cfg.frame_width, n_pairs, d_o, e->stream);
+  if (rc == MOF_OK && ((he = hipStreamSynchronize(e->stream)) != hipSuccess ||
+                       (he = hipMemcpy(out_xy, d_o, res * n_pairs * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess))
+    rc = fail(MOF_ERR_HIP, "batch download: %s", hipGetErrorString(he));
+  if (d_c) (void)hipFree(d_c);
+  if (d_p) (void)hipFree(d_p);
+  if (d_o) (void)hipFree(d_o);
+  return rc;
+}
+
+int mof_fft_sync(mof_fft_engine* e) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MOF_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Block matching                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+int mof_bm_config_block_method(mof_bm_config* cfg, int frame_size, int sample_point_size, int scan_radius) {
+  if (!cfg || frame_size < 1 || sample_point_size < 1 || scan_radius < 0)
+    return fail(MOF_ERR_BAD_ARG, "bad BlockMethod geometry");
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->frame_width = cfg->frame_height = frame_size;
+  cfg->block_size = sample_point_size;
+  cfg->step_size = 0;
+  cfg->scan_radius = scan_radius;
+  cfg->grid_x = cfg->grid_y = (frame_size - scan_radius * 2) / sample_point_size;  // BlockMethod.cpp:11
+  cfg->low_contrast_rule = 0;
+  return MOF_OK;
+}
+
+int mof_bm_config_fast_spaced(mof_bm_config* cfg, int width, int height, int sample_point_size, int step_size,
+                              int scan_radius) {
+  if (!cfg || width < 1 || height < 1 || sample_point_size < 1 || step_size < 0 || scan_radius < 0)
+    return fail(MOF_ERR_BAD_ARG, "bad FastSpacedBM geometry");
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->frame_width = width;
+  cfg->frame_height = height;
+  cfg->block_size = sample_point_size;
+  cfg->step_size = step_size;
+  cfg->scan_radius = scan_radius;
+  const int S = sample_point_size + step_size;            // FastSpacedBMMethod_OCL.cpp:82-83
+  cfg->grid_x = (width - scan_radius * 2) / S;            // :90
+  cfg->grid_y = (height - scan_radius * 2) / S;
+  cfg->low_contrast_rule = 1;
+  return MOF_OK;
+}
+
+static int validate_bm(const mof_bm_config* c) {
+  if (!c) return fail(MOF_ERR_BAD_ARG, "null config");
+  if (c->frame_width < 1 || c->frame_height < 1 || c->grid_x < 1 || c->grid_y < 1 || c->step_size < 0)
+    return fail(MOF_ERR_BAD_ARG, "bad block-matching geometry");
+  if (!mof::bm_config_supported(c->block_size, c->scan_radius))
+    return fail(MOF_ERR_UNSUPPORTED, "block_size %d / scan_radius %d not supported by the HIP kernel "
+                "(block multiple of 4 in 4..64, radius 1..48)", c->block_size, c->scan_radius);
+  const long S = c->block_size + c->step_size;
+  if ((c->grid_x - 1) * S + c->block_size + 2 * c->scan_radius > c->frame_width ||
+      (c->grid_y - 1) * S + c->block_size + 2 * c->scan_radius > c->frame_height)
+    return fail(MOF_ERR_BAD_ARG, "block grid leaves the frame");
+  return MOF_OK;
+}
+
+static mof::BmArgs bm_args(const mof_bm_engine* e, const uint8_t* cur, size_t cs, const uint8_t* prev, size_t ps,
+                           size_t pitch, int8_t* dx, int8_t* dy, int8_t* mode) {
+  mof::BmArgs a{};
+  a.cur = cur;
+  a.prev = prev;
+  a.cur_stride = cs;
+  a.prev_stride = ps;
+  a.pitch = pitch;
+  a.grid_x = e->cfg.grid_x;
+  a.grid_y = e->cfg.grid_y;
+  a.block = e->cfg.block_size;
+  a.step = e->cfg.step_size;
+  a.radius = e->cfg.scan_radius;
+  a.low_contrast_rule = e->cfg.low_contrast_rule;
+  a.dx = dx;
+  a.dy = dy;
+  a.mode = mode;
+  return a;
+}
+
+int mof_bm_create(const mof_bm_config* cfg, mof_bm_engine** out) {
+  if (!out) return fail(MOF_ERR_BAD_ARG, "null out");
+  *out = nullptr;
+  int rc = validate_bm(cfg);
+  if (rc) return rc;
+  rc = select_device(cfg->device);
+  if (rc) return rc;
+  mof_bm_engine* e = new (std::nothrow) mof_bm_engine();
+  if (!e) return fail(MOF_ERR_NO_MEMORY, "out of host memory");
+  e->cfg = *cfg;
+  e->frame_bytes = (size_t)cfg->frame_width * cfg->frame_height;
+  const size_t nb = (size_t)cfg->grid_x * cfg->grid_y;
+#define CREATE_TRY(expr)                                                                        \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      fail(MOF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));                                \
+      mof_bm_destroy(e);                                                                        \
+      return MOF_ERR_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+  CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipMalloc(&e->d_frames[0], e->frame_bytes));
+  CREATE_TRY(hipMalloc(&e->d_frames[1], e->frame_bytes));
+  CREATE_TRY(hipMemset(e->d_frames[0], 0, e->frame_bytes));  // imPrev = Scalar(0), BlockMethod.cpp:17-18
+  CREATE_TRY(hipMemset(e->d_frames[1], 0, e->frame_bytes));
+  CREATE_TRY(hipMalloc(&e->d_dx, nb));
+  CREATE_TRY(hipMalloc(&e->d_dy, nb));
+  CREATE_TRY(hipMalloc(&e->d_mode, 8));
+  CREATE_TRY(hipHostMalloc(&e->h_res, 2 * nb + 8, hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
+#undef CREATE_TRY
+  *out = e;
+  return MOF_OK;
+}
+
+void mof_bm_destroy(mof_bm_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->d_frames[0]) (void)hipFree(e->d_frames[0]);
+  if (e->d_frames[1]) (void)hipFree(e->d_frames[1]);
+  if (e->d_dx) (void)hipFree(e->d_dx);
+  if (e->d_dy) (void)hipFree(e->d_dy);
+  if (e->d_mode) (void)hipFree(e->d_mode);
+  if (e->h_res) (void)hipHostFree(e->h_res);
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int mof_bm_set_prev(mof_bm_engine* e, const uint8_t* frame, size_t pitch) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!frame || pitch < (size_t)e->cfg.frame_width) return fail(MOF_ERR_BAD_ARG, "bad frame/pitch");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  pack_frame(e->h_stage, frame, pitch, e->cfg.frame_width, e->cfg.frame_height);
+  HIP_TRY(hipMemcpyAsync(e->d_frames[e->prev_slot], e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MOF_OK;
+}
+
+int mof_bm_reset(mof_bm_engine* e) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemsetAsync(e->d_frames[e->prev_slot], 0, e->frame_bytes, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MOF_OK;
+}
+
+int mof_bm_process(mof_bm_engine* e, const uint8_t* frame, size_t pitch, int8_t* dx, int8_t* dy, int8_t* mode_xy) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!frame || !dx || !dy || pitch < (size_t)e->cfg.frame_width) return fail(MOF_ERR_BAD_ARG, "bad arguments");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int cur_slot = 1 - e->prev_slot;
+  const size_t nb = (size_t)e->cfg.grid_x * e->cfg.grid_y;
+  pack_frame(e->h_stage, frame, pitch, e->cfg.frame_width, e->cfg.frame_height);
+  HIP_TRY(hipMemcpyAsync(e->d_frames[cur_slot], e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+  mof::BmArgs a = bm_args(e, e->d_frames[cur_slot], 0, e->d_frames[e->prev_slot], 0, (size_t)e->cfg.frame_width,
+                          e->d_dx, e->d_dy, e->d_mode);
+  HIP_TRY(mof::launch_bm_scan(a, 1, e->stream));
+  HIP_TRY(mof::launch_bm_mode(a, 1, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->h_res, e->d_dx, nb, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->h_res + nb, e->d_dy, nb, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->h_res + 2 * nb, e->d_mode, 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::memcpy(dx, e->h_res, nb);
+  std::memcpy(dy, e->h_res + nb, nb);
+  if (mode_xy) {
+    mode_xy[0] = e->h_res[2 * nb];
+    mode_xy[1] = e->h_res[2 * nb + 1];
+  }
+  e->prev_slot = cur_slot;  // imPrev = imCurr.clone(), BlockMethod.cpp:89
+  return MOF_OK;
+}
+
+int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                size_t prev_stride, size_t pitch, int n_pairs, int8_t* d_dx, int8_t* d_dy,
+                                int8_t* d_mode, void* stream) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!d_cur || !d_prev || !d_dx || !d_dy || !d_mode || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
+    return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if (n_pairs == 0) return MOF_OK;
+  if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
+    return fail(MOF_ERR_BAD_ARG, "batch too large for one launch");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  mof::BmArgs a = bm_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_dx, d_dy, d_mode);
+  HIP_TRY(mof::launch_bm_scan(a, n_pairs, s));
+  HIP_TRY(mof::launch_bm_mode(a, n_pairs, s));
+  return MOF_OK;
+}
+
+int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
+                              size_t prev_stride, size_t pitch, int n_pairs, int8_t* dx, int8_t* dy, int8_t* mode) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!cur || !prev || !dx || !dy || !mode || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
+    return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if (n_pairs == 0) return MOF_OK;
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const size_t fb = e->frame_bytes, nb = (size_t)e->cfg.grid_x * e->cfg.grid_y;
+  std::vector<uint8_t> pc(fb * n_pairs), pp(fb * n_pairs);
+  for (int k = 0; k < n_pairs; ++k) {
+    pack_frame(pc.data() + fb * k, cur + cur_stride * k, pitch, e->cfg.frame_width, e->cfg.frame_height);
+    pack_frame(pp.data() + fb * k, prev + prev_stride * k, pitch, e->cfg.frame_width, e->cfg.frame_height);
+  }
+  uint8_t *d_c = nullptr, *d_p = nullptr;
+  int8_t *d_x = nullptr, *d_y = nullptr, *d_m = nullptr;
+  int rc = MOF_OK;
+  hipError_t he;
+  if ((he = hipMalloc(&d_c, fb * n_pairs)) != hipSuccess || (he = hipMalloc(&d_p, fb * n_pairs)) != hipSuccess ||
+      (he = hipMalloc(&d_x, nb * n_pairs)) != hipSuccess || (he = hipMalloc(&d_y, nb * n_pairs)) != hipSuccess ||
+      (he = hipMalloc(&d_m, 8 * (size_t)n_pairs)) != hipSuccess ||
+      (he = hipMemcpy(d_c, pc.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess ||
+      (he = hipMemcpy(d_p, pp.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess)
+    rc = fail(MOF_ERR_HIP, "batch upload: %s", hipGetErrorString(he));
+  if (rc == MOF_OK)
+    rc = mof_bm_process_batch_device(e, d_c, fb, d_p, fb, (size_t)e->cfg.frame_width, n_pairs, d_x, d_y, d_m, e->stream);
+  if (rc == MOF_OK && ((he = hipStreamSynchronize(e->stream)) != hipSuccess ||
+                       (he = hipMemcpy(dx, d_x, nb * n_pairs, hipMemcpyDeviceToHost)) != hipSuccess ||
+                       (he = hipMemcpy(dy, d_y, nb * n_pairs, hipMemcpyDeviceToHost)) != hipSuccess ||
+                       (he = hipMemcpy(mode, d_m, 8 * (size_t)n_pairs, hipMemcpyDeviceToHost)) != hipSuccess))
+    rc = fail(MOF_ERR_HIP, "batch download: %s", hipGetErrorString(he));
+  if (d_c) (void)hipFree(d_c);
+  if (d_p) (void)hipFree(d_p);
+  if (d_x) (void)hipFree(d_x);
+  if (d_y) (void)hipFree(d_y);
+  if (d_m) (void)hipFree(d_m);
+  return rc;
+}
+
+int mof_bm_sync(mof_bm_engine* e) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MOF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// mof_kernels.h -- internal launch interface between the C ABI (mof_capi.hip) and the
+// gfx950 kernels (pc_kernel.hip, bm_kernel.hip). Not installed; the public surface is include/mof.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mof {
+
+// ---- K1: per-patch FFT phase correlation ----------------------------------------------------
+struct PcArgs {
+  const uint8_t* cur;     // device, pair k at cur + k*cur_stride
+  const uint8_t* prev;
+  size_t cur_stride;      // bytes between consecutive pairs' frames
+  size_t prev_stride;
+  size_t pitch;           // bytes per frame row
+  int grid_x, grid_y;     // patches per frame
+  int origin_x, origin_y;
+  int stride_x, stride_y;
+  double max_px_speed_sq; // FftMethod.cpp:1686
+  const float* twiddles;  // device, N (cos, -sin) pairs, computed in double on the host
+  double* out;            // device, [pair][patch] (x, y)
+};
+
+bool pc_patch_size_supported(int n);
+hipError_t pc_configure(int patch_size);  // once per device before the first launch
+hipError_t launch_pc_field(const PcArgs& a, int patch_size, int n_pairs, hipStream_t stream);
+
+// ---- K2/K3: SAD block scan + histogram mode -------------------------------------------------
+struct BmArgs {
+  const uint8_t* cur;
+  const uint8_t* prev;
+  size_t cur_stride, prev_stride, pitch;
+  int grid_x, grid_y;
+  int block, step, radius;
+  int low_contrast_rule;
+  int8_t* dx;    // [pair][by*grid_x+bx]
+  int8_t* dy;
+  int8_t* mode;  // [pair][8]
+};
+
+bool bm_config_supported(int block, int radius);
+hipError_t launch_bm_scan(const BmArgs& a, int n_pairs, hipStream_t stream);
+hipError_t launch_bm_mode(const BmArgs& a, int n_pairs, hipStream_t stream);
+
+}  // namespace mof

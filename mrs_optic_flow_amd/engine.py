@@ -1,0 +1,239 @@
+"""Python handles on the C ABI engines, named after the reference's processors.
+
+The reference's host language is C++ (the C++ mirror is include/mof/processors.hpp);
+these classes exist so tests and bench.py read like calls on the reference's own
+classes: ``FftMethod(frameSize, samplePointSize, max_px_speed).processImage(im)``
+(/root/reference/include/FftMethod.h:434-439), ``BlockMethod``
+(/root/reference/include/BlockMethod.h:40-42) and ``FastSpacedBMMethod``
+(/root/reference/include/FastSpacedBMMethod_OCL.h:38-42). numpy uint8 arrays stand
+in for ``cv::Mat``; torch device tensors are accepted by the batched calls, which hand
+raw device pointers and the current HIP stream to the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import BmConfig, FftConfig, check
+
+
+def _np_u8(frame) -> np.ndarray:
+    a = np.asarray(frame)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise ValueError("frame must be a 2-D uint8 array (CV_8UC1)")
+    if a.strides[1] != 1:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+
+
+class FftMethod:
+    """FftMethod behind the C ABI. ``layout`` generalises the reference's square tiling
+    (origin, stride, grid); without it the constructor normalises the geometry exactly
+    as /root/reference/src/FftMethod.cpp:1706-1720 does."""
+
+    def __init__(self, frame_size: int | None = None, sample_point_size: int = 64, max_px_speed: float = 80.0, *,
+                 frame_shape: tuple[int, int] | None = None, grid: tuple[int, int] | None = None,
+                 origin: tuple[int, int] = (0, 0), stride: tuple[int, int] | None = None, device: int = 0):
+        lib = _capi.load()
+        cfg = FftConfig()
+        if frame_shape is None:
+            if frame_size is None:
+                raise ValueError("frame_size or frame_shape required")
+            check(lib.mof_fft_config_reference(C.byref(cfg), frame_size, sample_point_size, float(max_px_speed)))
+        else:
+            h, w = frame_shape
+            stride = stride or (sample_point_size, sample_point_size)
+            grid = grid or ((w - origin[0] - sample_point_size) // stride[0] + 1,
+                            (h - origin[1] - sample_point_size) // stride[1] + 1)
+            cfg = FftConfig(w, h, sample_point_size, grid[0], grid[1], origin[0], origin[1], stride[0], stride[1],
+                            float(max_px_speed), 0)
+        cfg.device = device
+        self.cfg = cfg
+        self._lib = lib
+        self._h = C.c_void_p()
+        check(lib.mof_fft_create(C.byref(cfg), C.byref(self._h)))
+
+    # -- reference surface --------------------------------------------------------------------
+    @property
+    def sqNum(self) -> int:
+        return self.cfg.grid_x
+
+    @property
+    def n_patches(self) -> int:
+        return self.cfg.grid_x * self.cfg.grid_y
+
+    def setImPrev(self, frame) -> None:
+        f = _np_u8(frame)
+        self._check_shape(f)
+        check(self._lib.mof_fft_set_prev(self._h, f.ctypes.data, f.strides[0]))
+
+    def reset(self) -> None:
+        check(self._lib.mof_fft_reset(self._h))
+
+    def processImage(self, imCurr, gui=False, debug=False, midPoint=None, yaw_angle=0.0, rot_center=None,
+                     raw_output=None, fx=300.0, fy=300.0) -> np.ndarray:
+        """Returns [grid_y*grid_x, 2] float64 shifts, index i + j*grid_x, NaN = invalid.
+        The extra arguments are accepted and ignored, as FftMethod ignores them."""
+        f = _np_u8(imCurr)
+        self._check_shape(f)
+        out = np.empty((self.n_patches, 2), np.float64)
+        ninv = C.c_int(0)
+        check(self._lib.mof_fft_process(self._h, f.ctypes.data, f.strides[0], out.ctypes.data, C.byref(ninv)))
+        self.last_invalid = ninv.value
+        return out
+
+    # -- batched --------------------------------------------------------------------------------
+    def process_batch_host(self, cur: np.ndarray, prev: np.ndarray) -> np.ndarray:
+        cur = np.ascontiguousarray(cur, dtype=np.uint8)
+        prev = np.ascontiguousarray(prev, dtype=np.uint8)
+        assert cur.shape == prev.shape and cur.ndim == 3
+        self._check_shape(cur[0])
+        n = cur.shape[0]
+        out = np.empty((n, self.n_patches, 2), np.float64)
+        fb = cur.shape[1] * cur.shape[2]
+        check(self._lib.mof_fft_process_batch_host(self._h, cur.ctypes.data, fb, prev.ctypes.data, fb, cur.shape[2], n,
+                                                   out.ctypes.data))
+        return out
+
+    def process_batch_device(self, cur, prev, out=None, stream=None):
+        """cur, prev: torch uint8 tensors [n, H, W] on this engine's device (last dim contiguous,
+        any row pitch / frame stride). Asynchronous on torch's current stream. Returns a
+        float64 tensor [n, patches, 2]."""
+        import torch
+
+        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and prev.is_cuda
+        assert cur.dim() == 3 and cur.shape == prev.shape and cur.stride(2) == 1 and prev.stride(2) == 1
+        assert cur.stride(1) == prev.stride(1)
+        self._check_shape(cur[0])
+        n = cur.shape[0]
+        if out is None:
+            out = torch.empty((n, self.n_patches, 2), dtype=torch.float64, device=cur.device)
+        assert out.is_contiguous() and out.dtype == torch.float64 and out.numel() == n * self.n_patches * 2
+        s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        check(self._lib.mof_fft_process_batch_device(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
+                                                     prev.stride(0), cur.stride(1), n, out.data_ptr(), _stream_ptr(s)))
+        return out
+
+    def _check_shape(self, f) -> None:
+        if tuple(f.shape[-2:]) != (self.cfg.frame_height, self.cfg.frame_width):
+            raise ValueError(f"frame is {tuple(f.shape[-2:])}, engine expects "
+                             f"{(self.cfg.frame_height, self.cfg.frame_width)}")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.mof_fft_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _BmBase:
+    def __init__(self, cfg: BmConfig, device: int):
+        self._lib = _capi.load()
+        cfg.device = device
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(self._lib.mof_bm_create(C.byref(cfg), C.byref(self._h)))
+
+    @property
+    def n_blocks(self) -> int:
+        return self.cfg.grid_x * self.cfg.grid_y
+
+    def setImPrev(self, frame) -> None:
+        f = _np_u8(frame)
+        check(self._lib.mof_bm_set_prev(self._h, f.ctypes.data, f.strides[0]))
+
+    def reset(self) -> None:
+        check(self._lib.mof_bm_reset(self._h))
+
+    def processBlocks(self, imCurr):
+        """Integer stage: (dx[gy,gx], dy[gy,gx], (modeX, modeY))."""
+        f = _np_u8(imCurr)
+        if f.shape != (self.cfg.frame_height, self.cfg.frame_width):
+            raise ValueError("frame shape does not match the engine")
+        dx = np.empty(self.n_blocks, np.int8)
+        dy = np.empty(self.n_blocks, np.int8)
+        mode = np.zeros(2, np.int8)
+        check(self._lib.mof_bm_process(self._h, f.ctypes.data, f.strides[0], dx.ctypes.data, dy.ctypes.data,
+                                       mode.ctypes.data))
+        g = (self.cfg.grid_y, self.cfg.grid_x)
+        return dx.reshape(g), dy.reshape(g), (int(mode[0]), int(mode[1]))
+
+    def processImage(self, imCurr, gui=False, debug=False, midPoint=None, yaw_angle=0.0, tiltCorr=None):
+        """One output vector = the histogram mode, like both reference classes
+        (BlockMethod.cpp:75-92 before Refine; FastSpacedBMMethod_OCL.cpp:172-175)."""
+        _, _, mode = self.processBlocks(imCurr)
+        return np.array([[float(mode[0]), float(mode[1])]])
+
+    def process_batch_host(self, cur: np.ndarray, prev: np.ndarray):
+        cur = np.ascontiguousarray(cur, dtype=np.uint8)
+        prev = np.ascontiguousarray(prev, dtype=np.uint8)
+        n = cur.shape[0]
+        dx = np.empty((n, self.cfg.grid_y, self.cfg.grid_x), np.int8)
+        dy = np.empty_like(dx)
+        mode = np.empty((n, 8), np.int8)
+        fb = cur.shape[1] * cur.shape[2]
+        check(self._lib.mof_bm_process_batch_host(self._h, cur.ctypes.data, fb, prev.ctypes.data, fb, cur.shape[2], n,
+                                                  dx.ctypes.data, dy.ctypes.data, mode.ctypes.data))
+        return dx, dy, mode
+
+    def process_batch_device(self, cur, prev, stream=None):
+        import torch
+
+        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and prev.is_cuda
+        assert cur.dim() == 3 and cur.shape == prev.shape and cur.stride(2) == 1 and prev.stride(2) == 1
+        assert cur.stride(1) == prev.stride(1)
+        n = cur.shape[0]
+        dx = torch.empty((n, self.cfg.grid_y, self.cfg.grid_x), dtype=torch.int8, device=cur.device)
+        dy = torch.empty_like(dx)
+        mode = torch.empty((n, 8), dtype=torch.int8, device=cur.device)
+        s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        check(self._lib.mof_bm_process_batch_device(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
+                                                    prev.stride(0), cur.stride(1), n, dx.data_ptr(), dy.data_ptr(),
+                                                    mode.data_ptr(), _stream_ptr(s)))
+        return dx, dy, mode
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.mof_bm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BlockMethod(_BmBase):
+    """BlockMethod(frameSize, samplePointSize, scanRadius, ...) -- /root/reference/src/BlockMethod.cpp:3-22."""
+
+    def __init__(self, frameSize: int, samplePointSize: int, scanRadius: int, scanDiameter: int | None = None,
+                 scanCount: int | None = None, stepSize: int = 0, device: int = 0):
+        cfg = BmConfig()
+        check(_capi.load().mof_bm_config_block_method(C.byref(cfg), frameSize, samplePointSize, scanRadius))
+        super().__init__(cfg, device)
+
+
+class FastSpacedBMMethod(_BmBase):
+    """FastSpacedBMMethod(samplePointSize, scanRadius, stepSize, ...) on a W x H frame --
+    /root/reference/src/FastSpacedBMMethod_OCL.cpp:5-6, :81-97."""
+
+    def __init__(self, samplePointSize: int, scanRadius: int, stepSize: int, frame_shape: tuple[int, int],
+                 device: int = 0):
+        cfg = BmConfig()
+        h, w = frame_shape
+        check(_capi.load().mof_bm_config_fast_spaced(C.byref(cfg), w, h, samplePointSize, stepSize, scanRadius))
+        super().__init__(cfg, device)

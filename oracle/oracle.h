@@ -1,0 +1,101 @@
+/*
+ * oracle.h -- CPU restatement of the mrs_optic_flow hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This directory is the parity oracle: a plain-C restatement of the reference's
+ * useOCL=false FFT phase-correlation path and of its two block-matching paths.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it.
+ * The shipped product (mrs_optic_flow_amd/, include/mof.h) never links or loads it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors
+ * (SURVEY.md F11, §8c), its CPU arithmetic lives in OpenCV (cv::phaseCorrelate,
+ * unpinned: CMakeLists.txt:23; 4.2.0 implied by ROS Noetic) which is absent here,
+ * and no reference translation unit compiles without OpenCV + ROS headers.
+ * The restatement therefore follows the in-repo helper copies and call sites
+ * cited per function, plus OpenCV's published phaseCorrelate algorithm for the
+ * external calls (dft/idft CCS packing, mulSpectrums, minMaxLoc, weightedCentroid).
+ * It is cross-checked against an independent numpy twin (tests/twin.py) and
+ * analytic known-answer cases, not against reference output.
+ */
+#ifndef MOF_ORACLE_H
+#define MOF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Patch layout of the FFT path. The reference tiles a square crop contiguously
+ * (src/FftMethod.cpp:1719, :1831-1832: xi=i*sps, yi=j*sps); that is the special
+ * case origin=0, stride=patch, grid=sqNum. */
+typedef struct oracle_fft_layout {
+  int width, height;      /* frame size in pixels                       */
+  int patch;              /* samplePointSize N (even)                   */
+  int grid_x, grid_y;     /* patches per row / column                   */
+  int origin_x, origin_y; /* top-left of patch (0,0)                    */
+  int stride_x, stride_y; /* distance between patch origins             */
+  double max_px_speed;    /* gate, src/FftMethod.cpp:1686, :1841        */
+} oracle_fft_layout;
+
+/* Diagnostics of one correlation (for conditioning classes in tests). */
+typedef struct oracle_pc_diag {
+  int peak_x, peak_y;     /* arg-max in fft-shifted coordinates         */
+  double peak_value;      /* surface value at the peak                  */
+  double second_value;    /* largest value outside the 5x5 window       */
+  double response;        /* sum over the 5x5 window / (N*N)            */
+} oracle_pc_diag;
+
+/* cv::phaseCorrelate(a, b) restated (src/FftMethod.cpp:1487-1498 stage order;
+ * :70-168 magSpectrums; :1086-1251 divSpectrums; :1257-1323 fftShift;
+ * :1329-1385 weightedCentroid). a,b: n x n, row strides in ELEMENTS.
+ * Returns (center - t) in out_xy[0..1]. surface (optional, n*n) receives the
+ * fft-shifted correlation surface. Return 0 ok, <0 bad argument. */
+int oracle_phase_correlate_f32(const float* a, size_t a_stride, const float* b, size_t b_stride, int n,
+                               double* out_xy, oracle_pc_diag* diag, float* surface);
+/* Same arithmetic carried in double everywhere ("truth" variant; eps stays FLT_EPSILON). */
+int oracle_phase_correlate_f64(const double* a, size_t a_stride, const double* b, size_t b_stride, int n,
+                               double* out_xy, oracle_pc_diag* diag, double* surface);
+
+/* FftMethod::processImage, useOCL=false branch (src/FftMethod.cpp:1805-1806 u8->f32,
+ * :1829-1856 patch loop + gating). out_xy: 2*grid_x*grid_y doubles, index
+ * (i + j*grid_x), (x,y); invalid -> (NaN,NaN). diag optional (grid_x*grid_y).
+ * precision: 32 or 64. */
+int oracle_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_fft_layout* layout,
+                          int precision, double* out_xy, int* n_invalid, oracle_pc_diag* diag);
+
+/* Block geometry shared by both block-matching paths.
+ * BlockMethod (src/BlockMethod.cpp:11, :45): step=0, threshold off,
+ *   grid = (fs-2r)/sps squared.
+ * FastSpacedBM (src/FastSpacedBMMethod_OCL.cpp:82-90): S=sps+step,
+ *   grid = ((W-2r)/S, (H-2r)/S), low-contrast threshold on. */
+typedef struct oracle_bm_config {
+  int width, height;
+  int block;      /* samplePointSize */
+  int step;       /* stepSize (0 for BlockMethod) */
+  int radius;     /* scanRadius */
+  int grid_x, grid_y;
+  int low_contrast_rule; /* 1: FastSpacedBMMethod.cl:77-82 */
+} oracle_bm_config;
+
+/* Fill grid_x/grid_y the way each reference class does. */
+void oracle_bm_config_block_method(oracle_bm_config* c, int frame_size, int block, int radius);
+void oracle_bm_config_fast_spaced(oracle_bm_config* c, int width, int height, int block, int step, int radius);
+
+/* Exhaustive SAD scan. dx,dy: grid_x*grid_y entries (by*grid_x+bx). mode_xy[2]:
+ * per-axis histogram mode (first max). sad_min optional (per block minimum SAD),
+ * sad_all optional (grid * (2r+1)^2 ints, [block][ys][xs]).
+ * src/BlockMethod.cpp:43-76; src/FastSpacedBMMethod.cl:4-84, :86-169. */
+int oracle_bm_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_bm_config* cfg,
+                         int8_t* dx, int8_t* dy, int8_t* mode_xy, int32_t* sad_min, int32_t* sad_all);
+
+/* Histogram_C1_D0 top-TestDepth output (src/FastSpacedBMMethod.cl:155-167):
+ * sorted shift indices per axis (stable descending by count), first `depth`. */
+int oracle_bm_histogram_top(const int8_t* d, int count, int radius, int depth, int8_t* top);
+
+const char* oracle_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,92 @@
+/*
+ * pc_ref.c -- CPU restatement of the reference's useOCL=false FFT path.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see oracle.h for why).
+ * Citations are into /root/reference/src/FftMethod.cpp unless noted.
+ */
+#include "oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int largest_prime_factor(int n) {
+  int best = 1;
+  for (int p = 2; p * p <= n; ++p)
+    while (n % p == 0) {
+      best = p;
+      n /= p;
+    }
+  if (n > 1) best = n;
+  return best;
+}
+
+#define R float
+#define SUFFIX _f32
+#include "pc_ref_impl.h"
+#undef R
+#undef SUFFIX
+
+#define R double
+#define SUFFIX _f64
+#include "pc_ref_impl.h"
+#undef R
+#undef SUFFIX
+
+int oracle_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_fft_layout* L,
+                          int precision, double* out_xy, int* n_invalid, oracle_pc_diag* diag) {
+  if (!cur || !prev || !L || !out_xy) return -1;
+  const int n = L->patch;
+  if (n < 2 || (n & 1) || largest_prime_factor(n) > 61) return -1;
+  if (L->grid_x < 1 || L->grid_y < 1 || L->origin_x < 0 || L->origin_y < 0) return -1;
+  if (L->origin_x + (L->grid_x - 1) * L->stride_x + n > L->width) return -1;
+  if (L->origin_y + (L->grid_y - 1) * L->stride_y + n > L->height) return -1;
+  if (precision != 32 && precision != 64) return -1;
+
+  const size_t nn = (size_t)n * n;
+  float* af = (float*)malloc(sizeof(float) * nn * 2);
+  double* ad = (double*)malloc(sizeof(double) * nn * 2);
+  if (!af || !ad) { free(af); free(ad); return -2; }
+  int invalid = 0;
+  const double max_sq = L->max_px_speed * L->max_px_speed; /* ref :1686 pow(max_px_speed_t, 2) */
+
+  for (int j = 0; j < L->grid_y; ++j)
+    for (int i = 0; i < L->grid_x; ++i) {
+      const int xi = L->origin_x + i * L->stride_x; /* ref :1831-1832 (origin 0, stride N) */
+      const int yi = L->origin_y + j * L->stride_y;
+      /* convertTo(CV_32FC1): exact integer values 0..255 (ref :1805-1806) */
+      for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) {
+          uint8_t c = cur[(size_t)(yi + y) * pitch + xi + x];
+          uint8_t p = prev[(size_t)(yi + y) * pitch + xi + x];
+          af[(size_t)y * n + x] = (float)c;
+          af[nn + (size_t)y * n + x] = (float)p;
+          ad[(size_t)y * n + x] = (double)c;
+          ad[nn + (size_t)y * n + x] = (double)p;
+        }
+      double pc[2];
+      oracle_pc_diag* d = diag ? &diag[i + j * L->grid_x] : NULL;
+      int rc = (precision == 32) ? oracle_phase_correlate_f32(af, (size_t)n, af + nn, (size_t)n, n, pc, d, NULL)
+                                 : oracle_phase_correlate_f64(ad, (size_t)n, ad + nn, (size_t)n, n, pc, d, NULL);
+      if (rc) { free(af); free(ad); return rc; }
+      /* shift = -cv::phaseCorrelate(cur, prev)  (ref :1836) */
+      double sx = -pc[0], sy = -pc[1];
+      /* gate (ref :1840-1856) */
+      int valid = 1;
+      if (sx * sx + sy * sy > max_sq || fabs(sx) > (double)n / 2 || fabs(sy) > (double)n / 2) valid = 0;
+      if (isnan(sx) || isnan(sy)) valid = 0;
+      if (!valid) {
+        sx = NAN;
+        sy = NAN;
+        ++invalid;
+      }
+      out_xy[2 * (i + j * L->grid_x) + 0] = sx; /* ref :1855 index i + j*sqNum */
+      out_xy[2 * (i + j * L->grid_x) + 1] = sy;
+    }
+  if (n_invalid) *n_invalid = invalid;
+  free(af);
+  free(ad);
+  return 0;
+}
+
+const char* oracle_version(void) { return "mof-oracle 0.1 (parity unpinned: no reference fixtures, OpenCV absent)"; }

@@ -1,0 +1,159 @@
+"""ctypes access to oracle/liboracle.so -- the CPU restatement used as the parity checker.
+
+Test infrastructure only: tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg are the only callers (see oracle/oracle.h). Nothing here reads
+/root/reference at run time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class FftLayout(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("patch", C.c_int),
+                ("grid_x", C.c_int), ("grid_y", C.c_int),
+                ("origin_x", C.c_int), ("origin_y", C.c_int),
+                ("stride_x", C.c_int), ("stride_y", C.c_int),
+                ("max_px_speed", C.c_double)]
+
+
+class PcDiag(C.Structure):
+    _fields_ = [("peak_x", C.c_int), ("peak_y", C.c_int), ("peak_value", C.c_double),
+                ("second_value", C.c_double), ("response", C.c_double)]
+
+
+class BmConfig(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("block", C.c_int), ("step", C.c_int),
+                ("radius", C.c_int), ("grid_x", C.c_int), ("grid_y", C.c_int),
+                ("low_contrast_rule", C.c_int)]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["-B"] if force else []))
+    return ORACLE_SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(ORACLE_SO)
+        L.oracle_phase_correlate_f32.restype = C.c_int
+        L.oracle_phase_correlate_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
+                                                  C.c_void_p, C.POINTER(PcDiag), C.c_void_p]
+        L.oracle_phase_correlate_f64.restype = C.c_int
+        L.oracle_phase_correlate_f64.argtypes = L.oracle_phase_correlate_f32.argtypes
+        L.oracle_fft_process_u8.restype = C.c_int
+        L.oracle_fft_process_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FftLayout), C.c_int,
+                                            C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+        L.oracle_bm_config_block_method.argtypes = [C.POINTER(BmConfig), C.c_int, C.c_int, C.c_int]
+        L.oracle_bm_config_fast_spaced.argtypes = [C.POINTER(BmConfig), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.oracle_bm_process_u8.restype = C.c_int
+        L.oracle_bm_process_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(BmConfig),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_bm_histogram_top.restype = C.c_int
+        L.oracle_bm_histogram_top.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def phase_correlate(a: np.ndarray, b: np.ndarray, precision: int = 32, want_surface: bool = False):
+    """cv::phaseCorrelate(a, b) restated. Returns ((x, y), diag dict[, surface])."""
+    n = a.shape[0]
+    assert a.shape == (n, n) and b.shape == (n, n)
+    dt = np.float32 if precision == 32 else np.float64
+    a = np.ascontiguousarray(a, dtype=dt)
+    b = np.ascontiguousarray(b, dtype=dt)
+    out = np.zeros(2, np.float64)
+    diag = PcDiag()
+    surf = np.zeros((n, n), dt) if want_surface else None
+    fn = lib().oracle_phase_correlate_f32 if precision == 32 else lib().oracle_phase_correlate_f64
+    rc = fn(_ptr(a), n, _ptr(b), n, n, _ptr(out), C.byref(diag), _ptr(surf) if want_surface else None)
+    if rc:
+        raise ValueError(f"oracle_phase_correlate rc={rc}")
+    d = dict(peak=(diag.peak_x, diag.peak_y), peak_value=diag.peak_value, second_value=diag.second_value,
+             response=diag.response)
+    if want_surface:
+        return (out[0], out[1]), d, surf
+    return (out[0], out[1]), d
+
+
+def fft_layout(width, height, patch, grid_x, grid_y, origin=(0, 0), stride=None, max_px_speed=80.0) -> FftLayout:
+    stride = stride or (patch, patch)
+    return FftLayout(width, height, patch, grid_x, grid_y, origin[0], origin[1], stride[0], stride[1],
+                     float(max_px_speed))
+
+
+def fft_process(cur: np.ndarray, prev: np.ndarray, layout: FftLayout, precision: int = 32, want_diag: bool = False):
+    """FftMethod::processImage (useOCL=false) on one uint8 frame pair -> [gy*gx, 2] float64."""
+    assert cur.dtype == np.uint8 and prev.dtype == np.uint8 and cur.shape == prev.shape
+    cur = np.ascontiguousarray(cur)
+    prev = np.ascontiguousarray(prev)
+    g = layout.grid_x * layout.grid_y
+    out = np.zeros((g, 2), np.float64)
+    ninv = C.c_int(0)
+    diags = (PcDiag * g)() if want_diag else None
+    rc = lib().oracle_fft_process_u8(_ptr(cur), _ptr(prev), cur.shape[1], C.byref(layout), precision, _ptr(out),
+                                     C.byref(ninv), diags)
+    if rc:
+        raise ValueError(f"oracle_fft_process_u8 rc={rc}")
+    if want_diag:
+        return out, ninv.value, diags
+    return out, ninv.value
+
+
+def bm_config_block_method(frame_size, block, radius) -> BmConfig:
+    c = BmConfig()
+    lib().oracle_bm_config_block_method(C.byref(c), frame_size, block, radius)
+    return c
+
+
+def bm_config_fast_spaced(width, height, block, step, radius) -> BmConfig:
+    c = BmConfig()
+    lib().oracle_bm_config_fast_spaced(C.byref(c), width, height, block, step, radius)
+    return c
+
+
+def bm_process(cur: np.ndarray, prev: np.ndarray, cfg: BmConfig, want_sad: bool = False):
+    """Block scan on one uint8 frame pair -> dx[gy,gx], dy[gy,gx] int8, mode (x,y)[, sad_all]."""
+    assert cur.dtype == np.uint8 and prev.dtype == np.uint8 and cur.shape == prev.shape
+    cur = np.ascontiguousarray(cur)
+    prev = np.ascontiguousarray(prev)
+    g = cfg.grid_x * cfg.grid_y
+    d = 2 * cfg.radius + 1
+    dx = np.zeros(g, np.int8)
+    dy = np.zeros(g, np.int8)
+    mode = np.zeros(2, np.int8)
+    sad = np.zeros((g, d, d), np.int32) if want_sad else None
+    rc = lib().oracle_bm_process_u8(_ptr(cur), _ptr(prev), cur.shape[1], C.byref(cfg), _ptr(dx), _ptr(dy), _ptr(mode),
+                                    None, _ptr(sad) if want_sad else None)
+    if rc:
+        raise ValueError(f"oracle_bm_process_u8 rc={rc}")
+    res = (dx.reshape(cfg.grid_y, cfg.grid_x), dy.reshape(cfg.grid_y, cfg.grid_x), (int(mode[0]), int(mode[1])))
+    return res + (sad,) if want_sad else res
+
+
+def bm_histogram_top(d: np.ndarray, radius: int, depth: int = 3) -> np.ndarray:
+    d = np.ascontiguousarray(d, dtype=np.int8).ravel()
+    top = np.zeros(depth, np.int8)
+    rc = lib().oracle_bm_histogram_top(_ptr(d), d.size, radius, depth, _ptr(top))
+    if rc:
+        raise ValueError(f"oracle_bm_histogram_top rc={rc}")
+    return top

@@ -1,0 +1,86 @@
+"""Independent numpy restatement of the hot path, used ONLY to cross-check oracle/*.c.
+
+It shares no code with the C oracle: transforms come from numpy.fft (pocketfft,
+double precision), the spectrum is processed as a full Hermitian array (no CCS
+bookkeeping), block matching uses broadcasting. Written from SURVEY.md Appendix
+A/B; nothing here imports or reads /root/reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FLT_EPS = float(np.finfo(np.float32).eps)
+DBL_EPS = float(np.finfo(np.float64).eps)
+
+
+def phase_correlate(a: np.ndarray, b: np.ndarray, quirk: bool = True):
+    """cv::phaseCorrelate(a, b) in float64. Returns ((x, y), surface, (px, py))."""
+    n = a.shape[0]
+    assert a.shape == (n, n) == b.shape and n % 2 == 0
+    A = np.fft.fft2(a.astype(np.float64))
+    B = np.fft.fft2(b.astype(np.float64))
+    P = A * np.conj(B)
+    mag = np.abs(P)
+    Cs = P * mag / (mag * mag + FLT_EPS)
+    if quirk:  # the 4 real-only CCS slots: P / (P^2 + eps)   
+        h = n // 2
+        for r in (0, h):
+            for c in (0, h):
+                p = P[r, c].real
+                Cs[r, c] = p / (p * p + FLT_EPS)
+    c = np.fft.ifft2(Cs).real * (n * n)  # cv::idft is unscaled
+    s = np.fft.fftshift(c)
+    flat = int(np.argmax(s))  # first maximum, row-major
+    py, px = divmod(flat, n)
+    y0, y1 = max(py - 2, 0), min(py + 2, n - 1)
+    x0, x1 = max(px - 2, 0), min(px + 2, n - 1)
+    cx = cy = tot = 0.0
+    for y in range(y0, y1 + 1):
+        for x in range(x0, x1 + 1):
+            v = float(s[y, x])
+            cx += x * v
+            cy += y * v
+            tot += v
+    tot += DBL_EPS
+    return (n / 2.0 - cx / tot, n / 2.0 - cy / tot), s, (px, py)
+
+
+def fft_process(cur: np.ndarray, prev: np.ndarray, patch: int, grid, origin=(0, 0), stride=None,
+                max_px_speed: float = 80.0) -> np.ndarray:
+    """FftMethod::processImage restated: [gy*gx, 2] float64 with NaN gating."""
+    stride = stride or (patch, patch)
+    gx, gy = grid
+    out = np.zeros((gx * gy, 2))
+    for j in range(gy):
+        for i in range(gx):
+            x0, y0 = origin[0] + i * stride[0], origin[1] + j * stride[1]
+            (tx, ty), _, _ = phase_correlate(cur[y0:y0 + patch, x0:x0 + patch], prev[y0:y0 + patch, x0:x0 + patch])
+            sx, sy = -tx, -ty
+            bad = sx * sx + sy * sy > max_px_speed ** 2 or abs(sx) > patch / 2 or abs(sy) > patch / 2
+            bad = bad or np.isnan(sx) or np.isnan(sy)
+            out[i + j * gx] = (np.nan, np.nan) if bad else (sx, sy)
+    return out
+
+
+def bm_process(cur: np.ndarray, prev: np.ndarray, block: int, step: int, radius: int, grid, low_contrast: bool):
+    """Block scan restated with broadcasting -> dx[gy,gx], dy[gy,gx], (modex, modey), sad[gy,gx,D,D]."""
+    gx, gy = grid
+    r, S, D = radius, block + step, 2 * radius + 1
+    dx = np.zeros((gy, gx), np.int8)
+    dy = np.zeros((gy, gx), np.int8)
+    sads = np.zeros((gy, gx, D, D), np.int64)
+    for by in range(gy):
+        for bx in range(gx):
+            cb = cur[by * S + r:by * S + r + block, bx * S + r:bx * S + r + block].astype(np.int64)
+            win = prev[by * S:by * S + block + 2 * r, bx * S:bx * S + block + 2 * r].astype(np.int64)
+            v = np.lib.stride_tricks.sliding_window_view(win, (block, block))  # [D, D, block, block]
+            sad = np.abs(v - cb[None, None]).sum(axis=(2, 3))
+            sads[by, bx] = sad
+            k = int(np.argmin(sad))  # first minimum, row-major
+            my, mx = divmod(k, D)
+            if low_contrast and float(sad[r, r] - sad[my, mx]) <= r * r * 0.2:
+                mx, my = r, r
+            dx[by, bx], dy[by, bx] = mx - r, my - r
+    hx = np.bincount(dx.ravel().astype(np.int64) + r, minlength=D)
+    hy = np.bincount(dy.ravel().astype(np.int64) + r, minlength=D)
+    return dx, dy, (int(np.argmax(hx)) - r, int(np.argmax(hy)) - r), sads
