@@ -1,0 +1,59 @@
+"""Batched-frames mode across the GPUs of one node.
+
+Frame pairs are independent, so the batch is cut into contiguous shards, one per
+rank (one process per GPU); there is no exchange step in the algorithm and no
+data-path collective. The only communication is the gather of the per-pair flow
+vectors (a few KB per pair) with one ``all_gather`` -- RCCL over xGMI when the
+process group is ``nccl``, gloo in the CPU tests. The reference itself is single
+process / single device ("Parallelism strategies: none").
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+
+def shard_bounds(n_pairs: int, rank: int, world: int) -> tuple[int, int]:
+    """Pairs [lo, hi) owned by ``rank``: contiguous shards of ceil(n/world), last ones may be short/empty."""
+    if world < 1 or not (0 <= rank < world) or n_pairs < 0:
+        raise ValueError("bad shard arguments")
+    per = -(-n_pairs // world)
+    lo = min(n_pairs, rank * per)
+    return lo, min(n_pairs, lo + per)
+
+
+def gather_results(local, n_pairs: int, group=None):
+    """All-gather per-rank result slabs ``[shard, ...]`` into ``[n_pairs, ...]`` on every rank.
+
+    Shards are padded to ceil(n/world) rows so a single fixed-size ``all_gather_into_tensor``
+    (one RCCL call) carries everything; padding rows are dropped afterwards.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        assert local.shape[0] == n_pairs
+        return local
+    world = dist.get_world_size(group)
+    per = -(-n_pairs // world)
+    tail = tuple(local.shape[1:])
+    slab = local
+    if local.shape[0] != per:
+        slab = torch.zeros((per,) + tail, dtype=local.dtype, device=local.device)
+        slab[: local.shape[0]] = local
+    slab = slab.contiguous()
+    out = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(slab) for _ in range(world)]
+        dist.all_gather(parts, slab, group=group)
+        out = torch.cat(parts, dim=0)
+    else:
+        dist.all_gather_into_tensor(out, slab, group=group)
+    return out[:n_pairs]
+
+
+def run_sharded(process_shard: Callable, n_pairs: int, rank: int, world: int, group=None):
+    """``process_shard(lo, hi) -> tensor [hi-lo, ...]`` on this rank's shard, then gather."""
+    lo, hi = shard_bounds(n_pairs, rank, world)
+    local = process_shard(lo, hi)
+    assert local.shape[0] == hi - lo
+    return gather_results(local, n_pairs, group)

@@ -1,0 +1,73 @@
+"""No-GPU tests of the C-ABI library: it loads, exports every symbol include/mof.h declares,
+its geometry helpers follow the reference constructors, and it refuses to run without a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mrs_optic_flow_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mof.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mof_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mof.h but not exported"
+    assert sorted(_capi.SYMBOLS) == declared, "ctypes table and header disagree"
+    assert lib.mof_version().startswith(b"mof-hip")
+
+
+def test_fft_reference_geometry():
+    lib = _capi.load()
+    cfg = _capi.FftConfig()
+    # FftMethod.cpp:1706-1720: odd frame size made even, sqNum = fs / sps
+    _capi.check(lib.mof_fft_config_reference(C.byref(cfg), 481, 120, 80.0))
+    assert (cfg.frame_width, cfg.patch_size, cfg.grid_x, cfg.grid_y, cfg.stride_x) == (480, 120, 4, 4, 120)
+    # not a multiple -> one window
+    _capi.check(lib.mof_fft_config_reference(C.byref(cfg), 480, 100, 80.0))
+    assert (cfg.patch_size, cfg.grid_x, cfg.grid_y) == (480, 1, 1)
+    assert lib.mof_fft_config_reference(None, 480, 100, 80.0) == _capi.MOF_ERR_BAD_ARG
+    assert b"geometry" in lib.mof_last_error()
+
+
+def test_bm_geometry_helpers():
+    lib = _capi.load()
+    cfg = _capi.BmConfig()
+    _capi.check(lib.mof_bm_config_block_method(C.byref(cfg), 272, 32, 8))
+    assert (cfg.grid_x, cfg.grid_y, cfg.step_size, cfg.low_contrast_rule) == (8, 8, 0, 0)
+    _capi.check(lib.mof_bm_config_fast_spaced(C.byref(cfg), 752, 480, 16, 8, 16))
+    assert (cfg.grid_x, cfg.grid_y, cfg.low_contrast_rule) == (30, 18, 1)
+
+
+def test_argument_validation_happens_before_any_device_use():
+    lib = _capi.load()
+    h = C.c_void_p()
+    bad = _capi.FftConfig(752, 480, 60, 8, 8, 0, 0, 90, 59, 80.0, 0)  # patch size 60 unsupported
+    assert lib.mof_fft_create(C.byref(bad), C.byref(h)) == _capi.MOF_ERR_UNSUPPORTED
+    bad = _capi.FftConfig(752, 480, 64, 8, 8, 0, 0, 100, 59, 80.0, 0)  # 7*100+64 > 752
+    assert lib.mof_fft_create(C.byref(bad), C.byref(h)) == _capi.MOF_ERR_BAD_ARG
+    assert b"leaves the frame" in lib.mof_last_error()
+    badb = _capi.BmConfig(752, 480, 18, 8, 16, 30, 18, 1, 0)  # block not a multiple of 4
+    assert lib.mof_bm_create(C.byref(badb), C.byref(h)) == _capi.MOF_ERR_UNSUPPORTED
+    assert lib.mof_fft_process(None, None, 0, None, None) == _capi.MOF_ERR_NOT_INIT
+
+
+def test_no_cpu_fallback_without_a_device():
+    lib = _capi.load()
+    if lib.mof_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    from mrs_optic_flow_amd import FftMethod, MofError
+
+    with pytest.raises(MofError) as exc:
+        FftMethod(448, 64)
+    assert exc.value.code == _capi.MOF_ERR_NO_DEVICE

@@ -1,0 +1,113 @@
+"""GPU parity tests of K2/K3 (SAD block scan + histogram mode) through the C ABI. Integer work:
+every comparison with the CPU oracle is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from mrs_optic_flow_amd import BlockMethod, FastSpacedBMMethod, synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["bm_fast_spaced_c3.npz", "bm_block_method_c1.npz"])
+def test_golden_vectors(gpu, name):
+    g = np.load(os.path.join(GOLDEN, name))
+    block, step, radius, fast = (int(v) for v in g["params"])
+    h, w = g["cur"].shape[1:]
+    eng = FastSpacedBMMethod(block, radius, step, (h, w)) if fast else BlockMethod(h, block, radius)
+    dx, dy, mode = eng.process_batch_host(g["cur"], g["prev"])
+    assert (dx == g["dx"]).all() and (dy == g["dy"]).all()
+    assert (mode[:, :2] == g["mode"]).all()
+    assert (mode[:, 0:6:2] == g["top"][:, 0]).all() and (mode[:, 1:6:2] == g["top"][:, 1]).all()
+
+
+@pytest.mark.parametrize("fast,shape,block,step,radius", [
+    (True, (480, 752), 16, 8, 16),    # BASELINE c3
+    (False, (272, 272), 32, 0, 8),    # BASELINE c1 (crop 272^2, 8x8 blocks of 32, +-8)
+    (True, (100, 140), 8, 4, 5),
+    (False, (120, 120), 16, 0, 21),   # default.yaml scan_radius 21
+    (True, (150, 150), 64, 0, 3),     # >256 px per block: u16 partial sums are flushed
+])
+def test_seeded_batches_bit_exact(gpu, fast, shape, block, step, radius):
+    h, w = shape
+    B = 5
+    cur, prev, shifts, kinds = synth.batch_np(B, h, w, min(radius - 2, 12), k0=0)
+    if fast:
+        eng, cfg = FastSpacedBMMethod(block, radius, step, shape), O.bm_config_fast_spaced(w, h, block, step, radius)
+    else:
+        eng, cfg = BlockMethod(h, block, radius), O.bm_config_block_method(h, block, radius)
+    assert (eng.cfg.grid_x, eng.cfg.grid_y) == (cfg.grid_x, cfg.grid_y)
+    dx, dy, mode = eng.process_batch_device(torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu))
+    dx, dy, mode = dx.cpu().numpy(), dy.cpu().numpy(), mode.cpu().numpy()
+    for k in range(B):
+        wdx, wdy, wmode = O.bm_process(cur[k], prev[k], cfg)
+        assert (dx[k] == wdx).all() and (dy[k] == wdy).all(), (k, kinds[k])
+        assert tuple(mode[k, :2]) == wmode
+        assert list(mode[k, 0:6:2]) == list(O.bm_histogram_top(wdx, radius, 3))
+        assert list(mode[k, 1:6:2]) == list(O.bm_histogram_top(wdy, radius, 3))
+        if kinds[k] == "shift":
+            assert wmode == (-shifts[k][0], -shifts[k][1])  # block matching reports the opposite sign
+
+
+def test_ties_and_low_contrast_rule(gpu):
+    f = np.full((112, 112), 90, np.uint8)
+    dx, dy, mode = BlockMethod(112, 32, 8).process_batch_host(f[None], f[None])
+    assert (dx == -8).all() and (dy == -8).all() and tuple(mode[0, :2]) == (-8, -8)  # BlockMethod.cpp:63 first min
+    dx, dy, mode = FastSpacedBMMethod(16, 8, 8, (112, 112)).process_batch_host(f[None], f[None])
+    assert (dx == 0).all() and (dy == 0).all()                                      # FastSpacedBMMethod.cl:77-82
+    rng = np.random.default_rng(7)
+    for _ in range(8):  # tiny alphabet -> many exact ties; the first minimum in row-major order must win
+        prev = rng.integers(0, 3, (40, 40), dtype=np.uint8)
+        cur = rng.integers(0, 3, (40, 40), dtype=np.uint8)
+        cfg = O.bm_config_block_method(40, 8, 4)
+        dx, dy, _ = BlockMethod(40, 8, 4).process_batch_host(cur[None], prev[None])
+        wdx, wdy, _ = O.bm_process(cur, prev, cfg)
+        assert (dx[0] == wdx).all() and (dy[0] == wdy).all()
+    r, b = 5, 8  # threshold 5.0 exactly: gap 5 zeroed, gap 6 kept (double compare, .cl:2)
+    size = b + 2 * r
+    for gap in (5, 6):
+        prev = np.full((size, size), 100, np.uint8)
+        prev[r, r] = 100 + gap
+        cur = np.full((size, size), 100, np.uint8)
+        dx, dy, _ = FastSpacedBMMethod(b, r, 0, (size, size)).process_batch_host(cur[None], prev[None])
+        wdx, wdy, _ = O.bm_process(cur, prev, O.bm_config_fast_spaced(size, size, b, 0, r))
+        assert (dx[0] == wdx).all() and (dy[0] == wdy).all()
+
+
+def test_stateful_processimage(gpu):
+    """prev starts as zeros (BlockMethod.cpp:17-18), then prev <- cur after every call (:89)."""
+    fs = 144
+    seq = [synth.pair_np(5, fs, fs, 2 * t, -t, blur=False)[0] for t in range(3)]
+    eng = BlockMethod(fs, 32, 8)
+    cfg = O.bm_config_block_method(fs, 32, 8)
+    prev = np.zeros((fs, fs), np.uint8)
+    for f in seq:
+        dx, dy, mode = eng.processBlocks(f)
+        wdx, wdy, wmode = O.bm_process(f, prev, cfg)
+        assert (dx == wdx).all() and (dy == wdy).all() and mode == wmode
+        prev = f
+    assert eng.processImage(seq[0]).shape == (1, 2)
+
+
+def test_full_size_c3_batch_properties(gpu):
+    """BASELINE c3 at full size (752x480, sps 16, step 8, r 16, batch 1024)."""
+    B, h, w = 1024, 480, 752
+    cur, prev, shifts, kinds = synth.batch_torch(B, h, w, 12, gpu)
+    eng = FastSpacedBMMethod(16, 16, 8, (h, w))
+    dx, dy, mode = eng.process_batch_device(cur, prev)
+    torch.cuda.synchronize()
+    dx, dy, mode, sh = dx.cpu().numpy(), dy.cpu().numpy(), mode.cpu().numpy(), shifts.numpy()
+    for k in range(B):
+        if kinds[k] == "shift":
+            assert (dx[k] == -sh[k, 0]).all() and (dy[k] == -sh[k, 1]).all()  # SAD 0 at the planted offset
+            assert tuple(mode[k, :2]) == (-sh[k, 0], -sh[k, 1])
+        elif kinds[k] in ("identical", "constant"):
+            assert (dx[k] == 0).all() and (dy[k] == 0).all()
+    cfg = O.bm_config_fast_spaced(w, h, 16, 8, 16)
+    for k in (11, 531):  # noisy pairs against the oracle
+        wdx, wdy, wmode = O.bm_process(cur[k].cpu().numpy(), prev[k].cpu().numpy(), cfg)
+        assert (dx[k] == wdx).all() and (dy[k] == wdy).all() and tuple(mode[k, :2]) == wmode

@@ -1,0 +1,166 @@
+"""GPU parity tests of K1 (FFT phase correlation) through the C ABI, against the CPU oracle.
+
+Tolerance: 1e-4 px (BASELINE.json north_star) on well-conditioned patches -- a clear single
+peak, second-highest surface value outside the 5x5 window below half the peak. On the rest
+(flat / ambiguous patches, where the arg-max itself is decided by rounding noise) the GPU must
+agree with the oracle on validity (NaN or not) unless the oracle's own f32/f64 variants disagree.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from mrs_optic_flow_amd import FftMethod, synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+def _compare(got, cur, prev, lay, label=""):
+    want64, _, diags = O.fft_process(cur, prev, lay, 64, want_diag=True)
+    want32, _ = O.fft_process(cur, prev, lay, 32)
+    well = np.array([d.second_value < 0.5 * d.peak_value for d in diags])
+    n_checked = 0
+    for p in range(want64.shape[0]):
+        if well[p]:
+            assert np.allclose(got[p], want64[p], rtol=0, atol=TOL, equal_nan=True), (label, p, got[p], want64[p])
+            assert np.allclose(got[p], want32[p], rtol=0, atol=TOL, equal_nan=True), (label, p, got[p], want32[p])
+            n_checked += 1
+        elif np.array_equal(np.isnan(want64[p]), np.isnan(want32[p])) and np.allclose(want64[p], want32[p], rtol=0, atol=TOL, equal_nan=True):
+            # the two oracle precisions agree, so the surface has a stable arg-max: so must the GPU
+            assert np.allclose(got[p], want64[p], rtol=0, atol=TOL, equal_nan=True), (label, "ill", p, got[p], want64[p])
+    return n_checked
+
+
+@pytest.mark.parametrize("name", ["fft_n64_unaligned.npz", "fft_n128.npz", "fft_n32_tiled.npz"])
+def test_golden_vectors(gpu, name):
+    g = np.load(os.path.join(GOLDEN, name))
+    w, h, n, gx, gy, ox, oy, sx, sy = (int(v) for v in g["layout"])
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(ox, oy), stride=(sx, sy))
+    got = fm.process_batch_device(torch.from_numpy(g["cur"]).to(gpu), torch.from_numpy(g["prev"]).to(gpu)).cpu().numpy()
+    ok = g["well_conditioned"]
+    assert ok.sum() > 0.8 * ok.size
+    assert np.allclose(got[ok], g["expected"][ok], rtol=0, atol=TOL, equal_nan=True)
+    assert np.array_equal(np.isnan(got), np.isnan(g["expected"]))
+    # the host-pointer batch entry gives the same bits as the device-pointer one
+    got_h = fm.process_batch_host(g["cur"], g["prev"])
+    assert np.array_equal(got_h, got, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,shape,grid,origin,stride", [
+    (64, (480, 752), (8, 8), (1, 1), (98, 59)),        # BASELINE c2 layout
+    (128, (270, 480), (3, 2), (0, 0), (119, 63)),      # c4 patch/stride on a reduced frame
+    (64, (448, 448), (7, 7), (0, 0), (64, 64)),        # the reference's own square tiling (sqNum = 7)
+    (32, (70, 130), (3, 1), (2, 3), (33, 1)),
+])
+def test_seeded_batches_match_oracle(gpu, n, shape, grid, origin, stride):
+    h, w = shape
+    B = 6
+    cur, prev, shifts, kinds = synth.batch_np(B, h, w, n // 8, k0=0)
+    fm = FftMethod(sample_point_size=n, frame_shape=shape, grid=grid, origin=origin, stride=stride)
+    got = fm.process_batch_device(torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)).cpu().numpy()
+    lay = O.fft_layout(w, h, n, grid[0], grid[1], origin, stride)
+    checked = sum(_compare(got[k], cur[k], prev[k], lay, f"pair{k}/{kinds[k]}") for k in range(B))
+    assert checked > 0.7 * B * grid[0] * grid[1]
+    for k in range(B):
+        if kinds[k] == "shift":
+            assert np.allclose(np.nanmedian(got[k], axis=0), shifts[k], rtol=0, atol=0.5)
+
+
+def test_pitch_and_frame_stride_are_honoured(gpu):
+    """Frames embedded in a larger allocation: row pitch > width, pair stride > frame, video-style cur/prev."""
+    h, w, n = 96, 160, 64
+    frames = np.stack([synth.pair_np(9, h, w, 2 * t, -t)[0] for t in range(4)])  # a 4-frame sequence
+    big = torch.zeros((4, h + 5, w + 24), dtype=torch.uint8, device=gpu)
+    big[:, 2:2 + h, 8:8 + w] = torch.from_numpy(frames).to(gpu)
+    view = big[:, 2:2 + h, 8:8 + w]
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(2, 1), origin=(5, 7), stride=(90, 1))
+    got = fm.process_batch_device(view[1:], view[:-1]).cpu().numpy()  # cur = frames[1:], prev = frames[:-1]
+    lay = O.fft_layout(w, h, n, 2, 1, (5, 7), (90, 1))
+    for t in range(3):
+        want, _ = O.fft_process(frames[t + 1], frames[t], lay, 64)
+        assert np.allclose(got[t], want, rtol=0, atol=TOL, equal_nan=True)
+
+
+def test_stateful_processimage_mirrors_the_reference(gpu):
+    """first frame correlates with itself (FftMethod.cpp:1791-1793), then prev <- cur (:1872); setImPrev does not
+    clear `first`; reset() re-arms it."""
+    fs, n = 128, 64
+    seq = [synth.pair_np(21, fs, fs, 3 * t, 2 * t, blur=True)[0] for t in range(3)]
+    fm = FftMethod(fs, n, 80.0)
+    assert (fm.cfg.grid_x, fm.cfg.grid_y) == (2, 2) and fm.sqNum == 2
+    lay = O.fft_layout(fs, fs, n, 2, 2)
+    fm.setImPrev(np.zeros((fs, fs), np.uint8))  # what the nodelet does at start-up (optic_flow.cpp:1016-1018)
+    out0 = fm.processImage(seq[0])
+    assert np.allclose(out0, O.fft_process(seq[0], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    assert np.allclose(out0, 0.0, rtol=0, atol=1e-5)
+    out1 = fm.processImage(seq[1])
+    assert np.allclose(out1, O.fft_process(seq[1], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    out2 = fm.processImage(np.ascontiguousarray(seq[2]))
+    assert np.allclose(out2, O.fft_process(seq[2], seq[1], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    fm.reset()
+    assert np.allclose(fm.processImage(seq[0]), out0, rtol=0, atol=0, equal_nan=True)
+    # a strided (non-contiguous rows) cv::Mat-like view is accepted through `pitch`
+    wide = np.zeros((fs, fs + 40), np.uint8)
+    wide[:, 10:10 + fs] = seq[1]
+    out1b = fm.processImage(wide[:, 10:10 + fs])
+    assert np.allclose(out1b, out1, rtol=0, atol=0, equal_nan=True)
+
+
+def test_gating_constant_and_large_shift(gpu):
+    n = 64
+    const = np.full((n, n), 200, np.uint8)
+    fm = FftMethod(n, n, 80.0)
+    out = fm.process_batch_host(const[None], const[None])[0]
+    assert np.allclose(out, O.fft_process(const, const, O.fft_layout(n, n, n, 1, 1), 32)[0], rtol=0, atol=1e-6)
+    assert np.allclose(out, 1 - n / 2, rtol=0, atol=1e-4)  # same degenerate answer as the CPU path (see test_oracle_fft)
+    fm_small = FftMethod(n, n, 9.99)
+    prev = synth.canvas_np(3, n, n, False)[:n, :n].copy()
+    cur = np.roll(prev, (0, 10), axis=(0, 1))
+    assert np.isnan(fm_small.process_batch_host(cur[None], prev[None])).all()
+    assert np.allclose(FftMethod(n, n, 10.01).process_batch_host(cur[None], prev[None])[0], [[10.0, 0.0]], rtol=0, atol=1e-5)
+    fm128 = FftMethod(128, 128, 80.0)
+    c128 = np.full((128, 128), 9, np.uint8)
+    assert np.isnan(fm128.process_batch_host(c128[None], c128[None])).all()  # (-63,-63) exceeds 80 px
+
+
+def test_circular_shifts_are_exact(gpu):
+    n = 64
+    prev = synth.canvas_np(11, n, n, False)[:n, :n].copy()
+    shifts = [(5, -3), (-7, 2), (0, 11), (-1, -1), (13, 13), (-20, 6)]
+    cur = np.stack([np.roll(prev, (dy, dx), axis=(0, 1)) for dx, dy in shifts])
+    fm = FftMethod(n, n, 80.0)
+    got = fm.process_batch_host(cur, np.repeat(prev[None], len(shifts), 0))[:, 0]
+    assert np.allclose(got, np.array(shifts, float), rtol=0, atol=2e-5)
+
+
+def test_full_size_c2_batch_properties(gpu):
+    """BASELINE config c2 at full size (752x480, 8x8 x 64^2, batch 1024): size-independent properties
+    instead of 65k oracle calls -- planted translation recovered per pair, identical frames give ~0,
+    the batch result equals the per-pair result bit for bit, and a sample is checked against the oracle."""
+    B, h, w, n = 1024, 480, 752, 64
+    cur, prev, shifts, kinds = synth.batch_torch(B, h, w, n // 8, gpu)
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(8, 8), origin=(1, 1), stride=(98, 59))
+    out = fm.process_batch_device(cur, prev)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy()
+    sh = shifts.numpy()
+    for k in range(B):
+        if kinds[k] in ("shift", "noisy"):
+            assert np.isfinite(res[k]).all()
+            assert np.abs(np.median(res[k], axis=0) - sh[k]).max() < 0.3, (k, kinds[k])
+            assert np.abs(res[k] - sh[k]).max() < 1.0
+        elif kinds[k] == "identical":
+            assert np.abs(res[k]).max() < 1e-4
+        else:
+            assert np.allclose(res[k], 1 - n / 2, rtol=0, atol=1e-4)
+    # independence: pair k alone gives the same bits
+    for k in (0, 511, 1023):
+        alone = fm.process_batch_device(cur[k:k + 1], prev[k:k + 1]).cpu().numpy()[0]
+        assert np.array_equal(alone, res[k], equal_nan=True)
+    lay = O.fft_layout(w, h, n, 8, 8, (1, 1), (98, 59))
+    for k in (1, 500, 1011):
+        _compare(res[k], cur[k].cpu().numpy(), prev[k].cpu().numpy(), lay, f"full{k}")

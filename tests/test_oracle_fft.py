@@ -1,0 +1,146 @@
+"""CPU tests of the FFT-path oracle (oracle/pc_ref.c): analytic known answers, the numpy
+twin, the committed golden vectors. The reference has no tests of its own,
+so these pin the checker itself. Tolerances are written next to each assertion."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import twin
+from mrs_optic_flow_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _patch(k, n, blur=True):
+    return synth.canvas_np(k, n, n, blur)[synth.MARGIN:synth.MARGIN + n, synth.MARGIN:synth.MARGIN + n]
+
+
+@pytest.mark.parametrize("n", [32, 64, 120, 128])
+@pytest.mark.parametrize("precision", [32, 64])
+def test_identical_patches_give_zero(n, precision):
+    p = _patch(3, n)
+    (x, y), d = O.phase_correlate(p, p, precision)
+    assert d["peak"] == (n // 2, n // 2)
+    # peak height N^2 - 4: the 4 real-only CCS slots are zeroed by the F8 quirk
+    assert abs(d["peak_value"] - (n * n - 4)) < 1e-2 * n
+    assert abs(x) < 1e-5 and abs(y) < 1e-5
+
+
+@pytest.mark.parametrize("n", [32, 64, 128])
+@pytest.mark.parametrize("shift", [(5, -3), (-7, 2), (0, 11), (-1, -1)])
+def test_circular_shift_is_exact_delta(n, shift):
+    dx, dy = shift
+    prev = _patch(5, n, blur=False)
+    cur = np.roll(prev, (dy, dx), axis=(0, 1))  # content moves by (+dx, +dy)
+    for precision in (32, 64):
+        (x, y), d = O.phase_correlate(cur, prev, precision)
+        # cv::phaseCorrelate returns center - t; the reference negates it (FftMethod.cpp:1836)
+        assert abs(-x - dx) < 2e-5 and abs(-y - dy) < 2e-5, (precision, x, y)
+        assert d["peak"] == (n // 2 + dx, n // 2 + dy)
+        assert d["second_value"] < 1.0  # everything off-peak is rounding noise or the -4 comb
+
+
+def test_sign_convention_of_processimage():
+    h, w = 96, 160
+    cur, prev = synth.pair_np(2, h, w, 4, -3)
+    lay = O.fft_layout(w, h, 64, 2, 1, (3, 5), (80, 1))
+    out, ninv = O.fft_process(cur, prev, lay, 64)
+    assert ninv == 0
+    assert np.all(np.abs(out - np.array([4.0, -3.0])) < 0.35), out  # non-circular shift: biased centroid
+
+
+@pytest.mark.parametrize("n,expect_nan", [(64, False), (128, True)])
+def test_constant_patch(n, expect_nan):
+    f = np.full((n, n), 77, np.uint8)
+    lay = O.fft_layout(n, n, n, 1, 1)
+    out, ninv = O.fft_process(f, f, lay, 32)
+    if expect_nan:  # (-63,-63): 63^2*2 > 80^2 -> gated (FftMethod.cpp:1841)
+        assert ninv == 1 and np.isnan(out).all()
+    else:
+        # all-equal surface (~1e-11 everywhere) -> first maximum at (0,0) -> clamped 3x3 window -> t ~ (1,1)
+        # -> 1 - N/2; the +DBL_EPSILON in the centroid denominator (:1378) is worth ~1e-5 px at these magnitudes
+        assert ninv == 0 and np.allclose(out, 1 - n / 2, rtol=0, atol=1e-4)
+
+
+def test_gate_on_max_px_speed():
+    n = 64
+    prev = _patch(9, n, blur=False)
+    cur = np.roll(prev, (0, 10), axis=(0, 1))
+    ok, _ = O.fft_process(cur, prev, O.fft_layout(n, n, n, 1, 1, max_px_speed=10.01), 64)
+    bad, ninv = O.fft_process(cur, prev, O.fft_layout(n, n, n, 1, 1, max_px_speed=9.99), 64)
+    assert np.allclose(ok, [[10.0, 0.0]], rtol=0, atol=1e-6)
+    assert ninv == 1 and np.isnan(bad).all()
+
+
+def test_output_index_is_i_plus_j_times_grid_x():
+    n, gx, gy = 32, 3, 2
+    h, w = gy * n, gx * n
+    prev = synth.canvas_np(4, h, w, False)[:h, :w].copy()
+    cur = prev.copy()
+    i, j = 2, 1  # only this patch moves (circularly, inside its own tile)
+    tile = prev[j * n:(j + 1) * n, i * n:(i + 1) * n]
+    cur[j * n:(j + 1) * n, i * n:(i + 1) * n] = np.roll(tile, (2, 3), axis=(0, 1))
+    out, _ = O.fft_process(cur, prev, O.fft_layout(w, h, n, gx, gy), 64)
+    want = np.zeros((gx * gy, 2))
+    want[i + j * gx] = (3.0, 2.0)
+    assert np.allclose(out, want, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [32, 64, 120, 128])
+def test_f64_matches_numpy_twin(n):
+    for k in range(6):
+        dx, dy = synth.planted_shift(k + 1, n // 8)
+        cur, prev = synth.pair_np(k, n, n, dx, dy, blur=(k % 2 == 0), kind="noisy" if k == 5 else "shift")
+        (x, y), d = O.phase_correlate(cur, prev, 64)
+        (tx, ty), _, pk = twin.phase_correlate(cur, prev)
+        assert d["peak"] == pk
+        assert abs(x - tx) < 1e-9 and abs(y - ty) < 1e-9  # two independent fp64 restatements
+
+
+@pytest.mark.parametrize("n", [64, 128])
+def test_f32_within_1e5_of_f64_on_well_conditioned_patches(n):
+    worst = 0.0
+    for k in range(12):
+        dx, dy = synth.planted_shift(k + 3, n // 8)
+        cur, prev = synth.pair_np(100 + k, n, n, dx, dy)
+        (x32, y32), d32 = O.phase_correlate(cur, prev, 32)
+        (x64, y64), d64 = O.phase_correlate(cur, prev, 64)
+        assert d32["peak"] == d64["peak"]
+        worst = max(worst, abs(x32 - x64), abs(y32 - y64))
+    assert worst < 1e-5, worst  # SURVEY A.8 measured <= 5e-7; the north-star tolerance is 1e-4
+
+
+def test_quirk_moves_centroid_by_more_than_parity_tolerance():
+    """dropping the real-only-slot behaviour shifts the result by ~1e-4..4e-4 px at N=64,
+    i.e. the restatement must carry it to be meaningful at 1e-4."""
+    n, worst = 64, 0.0
+    for k in range(8):
+        cur, prev = synth.pair_np(40 + k, n, n, 5, -3, blur=False)
+        (a, b), _, _ = twin.phase_correlate(cur, prev, quirk=True)
+        (c, d), _, _ = twin.phase_correlate(cur, prev, quirk=False)
+        worst = max(worst, abs(a - c), abs(b - d))
+    assert worst > 1e-4
+
+
+def test_rejects_unsupported_sizes():
+    a = np.zeros((63, 63), np.float32)
+    with pytest.raises(ValueError):
+        O.phase_correlate(a, a, 32)
+
+
+def test_golden_vectors_reproduce():
+    """tests/golden/fft_*.npz were written by tests/golden/make_golden.py from the fp64 oracle."""
+    files = sorted(f for f in os.listdir(GOLDEN) if f.startswith("fft_") and f.endswith(".npz"))
+    assert files, "golden fixtures missing"
+    for f in files:
+        g = np.load(os.path.join(GOLDEN, f))
+        lay = O.fft_layout(*[int(v) for v in g["layout"][:5]], tuple(int(v) for v in g["layout"][5:7]),
+                           tuple(int(v) for v in g["layout"][7:9]), float(g["max_px_speed"]))
+        for k in range(g["cur"].shape[0]):
+            out64, _ = O.fft_process(g["cur"][k], g["prev"][k], lay, 64)
+            out32, _ = O.fft_process(g["cur"][k], g["prev"][k], lay, 32)
+            assert np.allclose(out64, g["expected"][k], rtol=0, atol=1e-9, equal_nan=True)
+            ok = g["well_conditioned"][k]
+            assert np.allclose(out32[ok], g["expected"][k][ok], rtol=0, atol=1e-5, equal_nan=True)
