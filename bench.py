@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one HBM-resident batch of synthetic frame pairs
+through the C ABI (mof_*_process_batch_device, ONE kernel launch per batch for the FFT path):
+
+  c2 (default)  FftMethod, 752x480, 8x8 grid of 64x64 patches, 1024 pairs per GPU   <- BASELINE metric
+  c3            FastSpacedBMMethod, 752x480, sps 16 / step 8 / radius 16, 1024 pairs per GPU
+  c4            FftMethod, 1920x1080, 16x16 grid of 128x128 patches, 1024 pairs per GPU (8192 over 8 GPUs)
+
+Multi-GPU (--gpus N under torch.distributed.run): frame pairs are independent, so every rank owns
+its own shard of the batch (weak scaling, no data-path collective); each step ends with the one
+RCCL all-gather of the per-pair flow vectors.
+
+Prints ONE JSON line on rank 0. `roofline.achieved` = algorithmic bytes per launch / average kernel
+duration measured with HIP events on the launch stream inside the timed region; `cpu_baseline` = the
+CPU oracle (a port of the reference's useOCL=false path; the reference itself cannot be built here)
+timed on this box's host cores over a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "c2": dict(kind="fft", h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=1024, s=8,
+               name="c2: FftMethod 752x480, 8x8 grid of 64x64 patches, batch=1024 frame pairs per GPU",
+               # min(2*Gx*Gy*N^2, 2*W*H) u8 in + Gx*Gy*2*4 B out
+               bytes_per_pair=min(2 * 64 * 64 * 64, 2 * 752 * 480) + 64 * 8),
+    "c4": dict(kind="fft", h=1080, w=1920, n=128, grid=(16, 16), origin=(0, 0), stride=(119, 63), batch=1024, s=16,
+               name="c4: FftMethod 1920x1080, 16x16 grid of 128x128 patches, batch=1024 frame pairs per GPU",
+               bytes_per_pair=min(2 * 256 * 128 * 128, 2 * 1920 * 1080) + 256 * 8),
+    # calibration of the FETCH_SIZE counter for this kernel's access pattern: the 64x64 patches tile the frame
+    # exactly, every frame byte is read exactly once per launch -> known HBM read bytes = 2*512*512 per pair
+    "cal": dict(kind="fft", h=512, w=512, n=64, grid=(8, 8), origin=(0, 0), stride=(64, 64), batch=1024, s=8,
+                name="cal: FftMethod 512x512 tiled exactly by 8x8 patches of 64x64 (counter calibration), batch=1024",
+                bytes_per_pair=2 * 512 * 512 + 64 * 8),
+    "c3": dict(kind="bm", h=480, w=752, block=16, step=8, radius=16, batch=1024, s=12,
+               name="c3: FastSpacedBMMethod 752x480, samplePointSize=16, stepSize=8, scanRadius=16, batch=1024 per GPU",
+               # blocks*sps^2 + window area + 2*blocks + 2
+               bytes_per_pair=540 * 256 + 744 * 456 + 2 * 540 + 2),
+}
+
+
+def cpu_baseline(wl, budget_s: float = 12.0):
+    """Time the CPU oracle (1 thread, like the reference's serial patch loop FftMethod.cpp:1829-1866)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from mrs_optic_flow_amd import synth
+
+    n_gen = 4
+    cur, prev, _, _ = synth.batch_np(n_gen, wl["h"], wl["w"], wl["s"], classes=False, k0=1)
+    if wl["kind"] == "fft":
+        lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
+        run = lambda k: O.fft_process(cur[k % n_gen], prev[k % n_gen], lay, 32)
+        what = "f32 oracle (oracle/pc_ref.c)"
+    else:
+        cfg = O.bm_config_fast_spaced(wl["w"], wl["h"], wl["block"], wl["step"], wl["radius"])
+        run = lambda k: O.bm_process(cur[k % n_gen], prev[k % n_gen], cfg)
+        what = "integer oracle (oracle/bm_ref.c)"
+    run(0)
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < budget_s:
+        run(done)
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{done} frame pairs of the same workload in {dt:.1f} s, {what}, 1 thread, gcc -O2"}
+
+
+def load_traffic(tag: str):
+    """HBM bytes per launch from a committed rocprofv3 --pmc run of this command (profiles/traffic_*.json)."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{tag}.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frame pairs per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from mrs_optic_flow_amd import FastSpacedBMMethod, FftMethod, sharding, synth
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    B = wl["batch"]
+    # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
+    cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
+    if wl["kind"] == "fft":
+        eng = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"],
+                        origin=wl["origin"], stride=wl["stride"], device=local_rank)
+        out = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
+
+        def launch():
+            eng.process_batch_device(cur, prev, out=out)
+            return out
+    else:
+        eng = FastSpacedBMMethod(wl["block"], wl["radius"], wl["step"], (wl["h"], wl["w"]), device=local_rank)
+
+        def launch():
+            return eng.process_batch_device(cur, prev)[2]
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev0[i].record()
+        res = launch()
+        if i is not None:
+            ev1[i].record()
+        if world > 1:  # the one collective of the batched-frames mode: gather of the flow vectors
+            res = sharding.gather_results(res, B * world)
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps  # HIP events on the launch stream
+    if rank == 0:
+        pairs = B * world * args.steps
+        bytes_per_launch = wl["bytes_per_pair"] * B
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "frame_pairs_per_s" + ("_fft_phase_corr" if wl["kind"] == "fft" else "_fast_spaced_bm"),
+            "value": pairs / elapsed,
+            "unit": "frame-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if wl["kind"] == "fft" else "u8",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "batch_per_gpu": B, "frame": f'{wl["w"]}x{wl["h"]} u8',
+                       "parallelism": f"frame-pair shards x{world}, all-gather of flow vectors" if world > 1 else "1 GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "binding": "LDS/VALU (fp32 FFT in LDS), not HBM -- see DESIGN.md" if wl["kind"] == "fft"
+                         else "integer VALU (v_qsad_pk_u16_u8), not HBM -- see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+// processors.hpp -- header-only C++ host side above the C ABI (include/mof.h).
+//
+// Mirrors the reference's processor classes for the hot path, same method names, argument
+// order/meaning and error behaviour, so that a maintainer can swap them in:
+//   class OpticFlowCalc                      /root/reference/include/OpticFlowCalc.h:6-22
+//   class FftMethod : OpticFlowCalc          /root/reference/include/FftMethod.h:434-441
+//   class BlockMethod : OpticFlowCalc        /root/reference/include/BlockMethod.h:40-42
+//   class FastSpacedBMMethod : OpticFlowCalc /root/reference/include/FastSpacedBMMethod_OCL.h:38-42
+//
+// Two layers:
+//   * mof::FftMethod / mof::BlockMethod / mof::FastSpacedBMMethod work on mof::ImageView
+//     (pointer + rows/cols/step, i.e. what a CV_8UC1 cv::Mat header carries) and need nothing but
+//     this header and libmof_hip.so;
+//   * when OpenCV and the reference's OpticFlowCalc.h are on the include path,
+//     MofFftMethod : public OpticFlowCalc is the literal drop-in for `FftMethod* fftProcessor_`
+//     (/root/reference/src/optic_flow.cpp:251, :1001-1002, :1685-1690).
+//
+// Error behaviour follows the reference: a re-entrant call returns an EMPTY vector
+// (FftMethod.cpp:1775-1776); invalid patches are (NaN, NaN) (:1853); constructor failures and
+// HIP errors throw std::runtime_error (the reference lets cv::Exception escape, :1393-1395).
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../mof.h"
+
+namespace mof {
+
+struct Point2d {
+  double x, y;
+};
+struct Point2i {
+  int x, y;
+};
+struct Point2f {
+  float x, y;
+};
+
+// What the engine needs of a CV_8UC1 cv::Mat: data pointer, size, row step in bytes.
+struct ImageView {
+  const uint8_t* data;
+  int rows, cols;
+  size_t step;
+};
+
+namespace detail {
+inline void check(int rc, const char* what) {
+  if (rc != MOF_OK) throw std::runtime_error(std::string(what) + ": " + mof_last_error());
+}
+}  // namespace detail
+
+class FftMethod {
+ public:
+  // Argument list of the reference constructor (FftMethod.h:434-435). storeVideo / videoPath /
+  // videoFPS / cl_file_name / useOCL and the three *_enable flags are accepted and ignored: the
+  // engine is headless and always runs the HIP path (SURVEY.md §8(b) "side effects not to reproduce").
+  FftMethod(int i_frameSize, int i_samplePointSize, double max_px_speed_t, bool /*i_storeVideo*/ = false,
+            bool /*i_raw_enable*/ = false, bool /*i_rot_corr_enable*/ = false, bool /*i_tilt_corr_enable*/ = false,
+            std::string* /*videoPath*/ = nullptr, int /*videoFPS*/ = 0, std::string /*i_cl_file_name*/ = "",
+            bool /*i_useOCL*/ = true, int device = 0) {
+    detail::check(mof_fft_config_reference(&cfg_, i_frameSize, i_samplePointSize, max_px_speed_t), "FftMethod geometry");
+    cfg_.device = device;
+    detail::check(mof_fft_create(&cfg_, &engine_), "mof_fft_create");
+  }
+  // Generalised patch layout (origin, stride, grid) -- BASELINE c2/c4 grids do not fit the square tiling.
+  explicit FftMethod(const mof_fft_config& cfg) : cfg_(cfg) { detail::check(mof_fft_create(&cfg_, &engine_), "mof_fft_create"); }
+  ~FftMethod() { mof_fft_destroy(engine_); }
+  FftMethod(const FftMethod&) = delete;
+  FftMethod& operator=(const FftMethod&) = delete;
+
+  // OpticFlowCalc::setImPrev (OpticFlowCalc.h:14-16)
+  void setImPrev(ImageView imPrev_t) { detail::check(mof_fft_set_prev(engine_, imPrev_t.data, imPrev_t.step), "setImPrev"); }
+
+  // FftMethod::processImage (FftMethod.cpp:1772-1903). midPoint_t, yaw_angle, rot_center and raw_output are
+  // ignored exactly as the reference ignores them; fx, fy are stored only (:1781-1782).
+  std::vector<Point2d> processImage(ImageView imCurr, bool /*gui*/, bool /*debug*/, Point2i /*midPoint_t*/,
+                                    double /*yaw_angle*/, Point2d /*rot_center*/, std::vector<Point2d>& /*raw_output*/,
+                                    double i_fx = 300, double i_fy = 300) {
+    fx_ = i_fx;
+    fy_ = i_fy;
+    if (imCurr.rows != cfg_.frame_height || imCurr.cols != cfg_.frame_width)
+      throw std::runtime_error("processImage: frame size does not match the engine geometry");
+    std::vector<Point2d> speeds((size_t)cfg_.grid_x * cfg_.grid_y);
+    const int rc = mof_fft_process(engine_, imCurr.data, imCurr.step, reinterpret_cast<double*>(speeds.data()), &last_invalid_);
+    if (rc == MOF_ERR_BUSY) return {};  // `if (running) return std::vector<cv::Point2d>();`
+    detail::check(rc, "mof_fft_process");
+    return speeds;
+  }
+
+  int sqNum() const { return cfg_.grid_x; }
+  int invalidPatches() const { return last_invalid_; }
+  const mof_fft_config& config() const { return cfg_; }
+  mof_fft_engine* handle() { return engine_; }
+
+ private:
+  mof_fft_config cfg_{};
+  mof_fft_engine* engine_ = nullptr;
+  double fx_ = 300, fy_ = 300;
+  int last_invalid_ = 0;
+};
+
+// Integer stage of both block matchers behind one engine.
+class BlockMatcherBase {
+ public:
+  ~BlockMatcherBase() { mof_bm_destroy(engine_); }
+  BlockMatcherBase(const BlockMatcherBase&) = delete;
+  BlockMatcherBase& operator=(const BlockMatcherBase&) = delete;
+  void setImPrev(ImageView imPrev_t) { detail::check(mof_bm_set_prev(engine_, imPrev_t.data, imPrev_t.step), "setImPrev"); }
+  // per-block integer shifts of the last processImage call, index by*grid_x + bx
+  const std::vector<int8_t>& flowX() const { return dx_; }
+  const std::vector<int8_t>& flowY() const { return dy_; }
+  const mof_bm_config& config() const { return cfg_; }
+
+ protected:
+  explicit BlockMatcherBase(const mof_bm_config& cfg) : cfg_(cfg) {
+    detail::check(mof_bm_create(&cfg_, &engine_), "mof_bm_create");
+    dx_.resize((size_t)cfg_.grid_x * cfg_.grid_y);
+    dy_.resize(dx_.size());
+  }
+  // returns false when the engine was busy
+  bool run(ImageView im, int8_t mode[2]) {
+    if (im.rows != cfg_.frame_height || im.cols != cfg_.frame_width)
+      throw std::runtime_error("processImage: frame size does not match the engine geometry");
+    const int rc = mof_bm_process(engine_, im.data, im.step, dx_.data(), dy_.data(), mode);
+    if (rc == MOF_ERR_BUSY) return false;
+    detail::check(rc, "mof_bm_process");
+    return true;
+  }
+  mof_bm_config cfg_{};
+  mof_bm_engine* engine_ = nullptr;
+  std::vector<int8_t> dx_, dy_;
+};
+
+class BlockMethod : public BlockMatcherBase {
+ public:
+  // BlockMethod(frameSize, samplePointSize, scanRadius, scanDiameter, scanCount, stepSize) -- BlockMethod.cpp:3
+  BlockMethod(int i_frameSize, int i_samplePointSize, int i_scanRadius, int /*i_scanDiameter*/ = 0, int /*i_scanCount*/ = 0,
+              int /*i_stepSize*/ = 0, int device = 0)
+      : BlockMatcherBase(make(i_frameSize, i_samplePointSize, i_scanRadius, device)) {}
+  // BlockMethod::processImage (BlockMethod.cpp:25-94): ONE vector = the per-axis histogram mode. The reference
+  // then runs Refine() (:79), whose second image is resized from the first; the integer mode is returned
+  // here un-refined.
+  std::vector<Point2d> processImage(ImageView imCurr, bool /*gui*/, bool /*debug*/, Point2i /*midPoint_t*/,
+                                    double /*yaw_angle*/, Point2d /*tiltCorr*/) {
+    int8_t mode[2] = {0, 0};
+    if (!run(imCurr, mode)) return {};
+    return {Point2d{(double)mode[0], (double)mode[1]}};
+  }
+
+ private:
+  static mof_bm_config make(int fs, int sps, int r, int device) {
+    mof_bm_config c{};
+    detail::check(mof_bm_config_block_method(&c, fs, sps, r), "BlockMethod geometry");
+    c.device = device;
+    return c;
+  }
+};
+
+class FastSpacedBMMethod : public BlockMatcherBase {
+ public:
+  // FastSpacedBMMethod(samplePointSize, scanRadius, stepSize, cx, cy, fx, fy, k1, k2, k3, p1, p2, storeVideo, videoPath)
+  // -- FastSpacedBMMethod_OCL.cpp:5-6; the camera parameters are stored-only there and dropped here. The frame
+  // size, which the reference takes from the first image, is fixed at construction.
+  FastSpacedBMMethod(int i_samplePointSize, int i_scanRadius, int i_stepSize, int frame_width, int frame_height, int device = 0)
+      : BlockMatcherBase(make(frame_width, frame_height, i_samplePointSize, i_stepSize, i_scanRadius, device)) {}
+  // FastSpacedBMMethod::processImage (FastSpacedBMMethod_OCL.cpp:71-184): one Point2f = (modeX, modeY) (:172-175)
+  std::vector<Point2f> processImage(ImageView imCurr, bool /*gui*/, bool /*debug*/, Point2i /*midPoint_t*/,
+                                    double /*yaw_angle*/, Point2d /*tiltCorr*/) {
+    int8_t mode[2] = {0, 0};
+    if (!run(imCurr, mode)) return {};
+    return {Point2f{(float)mode[0], (float)mode[1]}};
+  }
+
+ private:
+  static mof_bm_config make(int w, int h, int sps, int step, int r, int device) {
+    mof_bm_config c{};
+    detail::check(mof_bm_config_fast_spaced(&c, w, h, sps, step, r), "FastSpacedBM geometry");
+    c.device = device;
+    return c;
+  }
+};
+
+}  // namespace mof
+
+// ------------------------------------------------------------------------------------------------
+// Literal drop-in for the ROS node, compiled only where the reference's headers and OpenCV exist.
+// ------------------------------------------------------------------------------------------------
+#if defined(__has_include)
+#if __has_include(<opencv2/core.hpp>) && __has_include(<OpticFlowCalc.h>)
+#include <OpticFlowCalc.h>
+
+#include <opencv2/core.hpp>
+
+class MofFftMethod : public OpticFlowCalc {
+ public:
+  MofFftMethod(int i_frameSize, int i_samplePointSize, double max_px_speed_t, bool i_storeVideo, bool i_raw_enable,
+               bool i_rot_corr_enable, bool i_tilt_corr_enable, std::string* videoPath, int videoFPS,
+               std::string i_cl_file_name, bool i_useOCL)
+      : impl_(i_frameSize, i_samplePointSize, max_px_speed_t, i_storeVideo, i_raw_enable, i_rot_corr_enable,
+              i_tilt_corr_enable, videoPath, videoFPS, i_cl_file_name, i_useOCL) {
+    max_px_speed_sq = max_px_speed_t * max_px_speed_t;
+  }
+
+  std::vector<cv::Point2d> processImage(cv::Mat imCurr, bool gui, bool debug, cv::Point midPoint_t, double yaw_angle,
+                                        cv::Point2d rot_center, std::vector<cv::Point2d>& output_vectors_raw,
+                                        double i_fx = 300, double i_fy = 300) override {
+    CV_Assert(imCurr.type() == CV_8UC1);
+    std::vector<mof::Point2d> raw;
+    std::vector<mof::Point2d> r =
+        impl_.processImage(mof::ImageView{imCurr.data, imCurr.rows, imCurr.cols, imCurr.step}, gui, debug,
+                           mof::Point2i{midPoint_t.x, midPoint_t.y}, yaw_angle, mof::Point2d{rot_center.x, rot_center.y},
+                           raw, i_fx, i_fy);
+    (void)output_vectors_raw;  // untouched by the reference as well
+    std::vector<cv::Point2d> out(r.size());
+    for (size_t i = 0; i < r.size(); ++i) out[i] = cv::Point2d(r[i].x, r[i].y);
+    return out;
+  }
+  // hides OpticFlowCalc::setImPrev (non-virtual there): forwards the pixels to the device-resident previous frame
+  void setImPrev(cv::Mat imPrev_t) {
+    imPrev = imPrev_t;
+    impl_.setImPrev(mof::ImageView{imPrev_t.data, imPrev_t.rows, imPrev_t.cols, imPrev_t.step});
+  }
+
+ private:
+  mof::FftMethod impl_;
+};
+#endif
+#endif

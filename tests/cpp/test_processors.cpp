@@ -1,0 +1,77 @@
+// Host-side C++ test driver for include/mof/processors.hpp (the C++ mirror of the reference's
+// processor classes). Reads a raw u8 frame sequence, runs the stateful processImage() calls the ROS
+// node would make, prints the results; tests/test_gpu_cpp_host.py compares them with the oracle.
+//   usage: test_processors fft <frameSize> <sps> <max_px_speed> <nframes> <file>
+//          test_processors bm  <frameSize> <sps> <radius> <nframes> <file>
+//          test_processors fsbm <w> <h> <sps> <step> <radius> <nframes> <file>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "mof/processors.hpp"
+
+static std::vector<uint8_t> read_all(const char* path, size_t bytes) {
+  std::vector<uint8_t> buf(bytes);
+  FILE* f = std::fopen(path, "rb");
+  if (!f || std::fread(buf.data(), 1, bytes, f) != bytes) {
+    std::fprintf(stderr, "cannot read %zu bytes from %s\n", bytes, path);
+    std::exit(2);
+  }
+  std::fclose(f);
+  return buf;
+}
+
+int main(int argc, char** argv) {
+  try {
+    if (argc >= 7 && !std::strcmp(argv[1], "fft")) {
+      const int fs = std::atoi(argv[2]), sps = std::atoi(argv[3]), n = std::atoi(argv[5]);
+      const double mps = std::atof(argv[4]);
+      auto frames = read_all(argv[6], (size_t)fs * fs * n);
+      mof::FftMethod proc(fs, sps, mps, false, false, false, false, nullptr, 30, "unused.cl", true);
+      std::vector<uint8_t> zeros((size_t)fs * fs, 0);
+      proc.setImPrev(mof::ImageView{zeros.data(), fs, fs, (size_t)fs});  // optic_flow.cpp:1016-1018
+      std::vector<mof::Point2d> raw;
+      for (int t = 0; t < n; ++t) {
+        auto v = proc.processImage(mof::ImageView{frames.data() + (size_t)t * fs * fs, fs, fs, (size_t)fs}, false, false,
+                                   mof::Point2i{fs / 2, fs / 2}, 0.0, mof::Point2d{0, 0}, raw, 300, 300);
+        std::printf("frame %d n %zu", t, v.size());
+        for (auto& p : v) std::printf(" %.17g %.17g", p.x, p.y);
+        std::printf("\n");
+      }
+      return 0;
+    }
+    if (argc >= 7 && !std::strcmp(argv[1], "bm")) {
+      const int fs = std::atoi(argv[2]), sps = std::atoi(argv[3]), r = std::atoi(argv[4]), n = std::atoi(argv[5]);
+      auto frames = read_all(argv[6], (size_t)fs * fs * n);
+      mof::BlockMethod proc(fs, sps, r, 2 * r + 1, (2 * r + 1) * (2 * r + 1), 0);
+      for (int t = 0; t < n; ++t) {
+        auto v = proc.processImage(mof::ImageView{frames.data() + (size_t)t * fs * fs, fs, fs, (size_t)fs}, false, false,
+                                   mof::Point2i{fs / 2, fs / 2}, 0.0, mof::Point2d{0, 0});
+        std::printf("frame %d mode %g %g blocks", t, v.at(0).x, v.at(0).y);
+        for (size_t b = 0; b < proc.flowX().size(); ++b) std::printf(" %d %d", proc.flowX()[b], proc.flowY()[b]);
+        std::printf("\n");
+      }
+      return 0;
+    }
+    if (argc >= 9 && !std::strcmp(argv[1], "fsbm")) {
+      const int w = std::atoi(argv[2]), h = std::atoi(argv[3]), sps = std::atoi(argv[4]), step = std::atoi(argv[5]),
+                r = std::atoi(argv[6]), n = std::atoi(argv[7]);
+      auto frames = read_all(argv[8], (size_t)w * h * n);
+      mof::FastSpacedBMMethod proc(sps, r, step, w, h);
+      for (int t = 0; t < n; ++t) {
+        auto v = proc.processImage(mof::ImageView{frames.data() + (size_t)t * w * h, h, w, (size_t)w}, false, false,
+                                   mof::Point2i{w / 2, h / 2}, 0.0, mof::Point2d{0, 0});
+        std::printf("frame %d mode %g %g blocks", t, (double)v.at(0).x, (double)v.at(0).y);
+        for (size_t b = 0; b < proc.flowX().size(); ++b) std::printf(" %d %d", proc.flowX()[b], proc.flowY()[b]);
+        std::printf("\n");
+      }
+      return 0;
+    }
+    std::fprintf(stderr, "bad usage\n");
+    return 2;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 3;
+  }
+}

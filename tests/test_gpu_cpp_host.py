@@ -1,0 +1,63 @@
+"""GPU test of the C++ host mirror (include/mof/processors.hpp) through tests/cpp/test_processors:
+the stateful call sequence the ROS node makes (setImPrev(zeros), then processImage per frame)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from mrs_optic_flow_amd import synth
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(os.path.dirname(__file__), "cpp", "test_processors")
+
+
+def _run(args, frames, tmp_path):
+    assert os.path.exists(BIN), "tests/cpp/test_processors missing: run __graft_entry__.build()"
+    path = tmp_path / "frames.raw"
+    frames.tofile(path)
+    out = subprocess.run([BIN] + [str(a) for a in args] + [str(path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return [line.split() for line in out.stdout.strip().splitlines()]
+
+
+def test_fft_method_sequence(gpu, tmp_path):
+    fs, sps, n = 192, 64, 4
+    frames = np.stack([synth.pair_np(33, fs, fs, 2 * t, -3 * t)[0] for t in range(n)])
+    lines = _run(["fft", fs, sps, 80, n], frames, tmp_path)
+    lay = O.fft_layout(fs, fs, sps, 3, 3)
+    for t, tok in enumerate(lines):
+        assert tok[0] == "frame" and int(tok[1]) == t and int(tok[3]) == 9
+        got = np.array([float(v) for v in tok[4:]]).reshape(9, 2)
+        prev = frames[t] if t == 0 else frames[t - 1]  # `first`: the first frame correlates with itself
+        want, _ = O.fft_process(frames[t], prev, lay, 64)
+        assert np.allclose(got, want, rtol=0, atol=1e-4, equal_nan=True)
+
+
+def test_block_method_sequence(gpu, tmp_path):
+    fs, sps, r, n = 144, 32, 8, 3
+    frames = np.stack([synth.pair_np(34, fs, fs, 3 * t, t, blur=False)[0] for t in range(n)])
+    lines = _run(["bm", fs, sps, r, n], frames, tmp_path)
+    cfg = O.bm_config_block_method(fs, sps, r)
+    prev = np.zeros((fs, fs), np.uint8)  # BlockMethod.cpp:17-18
+    for t, tok in enumerate(lines):
+        dx, dy, mode = O.bm_process(frames[t], prev, cfg)
+        assert (float(tok[3]), float(tok[4])) == mode
+        got = np.array([int(v) for v in tok[6:]]).reshape(-1, 2)
+        assert (got[:, 0] == dx.ravel()).all() and (got[:, 1] == dy.ravel()).all()
+        prev = frames[t]
+
+
+def test_fast_spaced_bm_sequence(gpu, tmp_path):
+    w, h, sps, step, r, n = 168, 120, 16, 8, 10, 3
+    frames = np.stack([synth.pair_np(35, h, w, -2 * t, 3 * t)[0] for t in range(n)])
+    lines = _run(["fsbm", w, h, sps, step, r, n], frames, tmp_path)
+    cfg = O.bm_config_fast_spaced(w, h, sps, step, r)
+    prev = np.zeros((h, w), np.uint8)
+    for t, tok in enumerate(lines):
+        dx, dy, mode = O.bm_process(frames[t], prev, cfg)
+        assert (float(tok[3]), float(tok[4])) == mode
+        got = np.array([int(v) for v in tok[6:]]).reshape(-1, 2)
+        assert (got[:, 0] == dx.ravel()).all() and (got[:, 1] == dy.ravel()).all()
+        prev = frames[t]
