@@ -29,6 +29,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mof_kernels.h"
 
@@ -490,17 +491,26 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   }
 }
 
+// Diagnostic knob (occupancy experiments only): MOF_PC_EXTRA_LDS=<bytes> pads the dynamic LDS request.
+static size_t extra_lds() {
+  static const size_t v = [] {
+    const char* e = getenv("MOF_PC_EXTRA_LDS");
+    return e ? (size_t)atol(e) : (size_t)0;
+  }();
+  return v;
+}
+
 template <int N>
 static hipError_t configure_n() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)PcTraits<N>::LDS_BYTES);
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PcTraits<N>::LDS_BYTES + extra_lds()));
 }
 
 template <int N>
 static hipError_t launch_n(const PcArgs& a, int n_pairs, hipStream_t stream) {
   using Tr = PcTraits<N>;
   const unsigned blocks = (unsigned)n_pairs * (unsigned)(a.grid_x * a.grid_y);
-  hipLaunchKernelGGL(pc_field_kernel<N>, dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(pc_field_kernel<N>, dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
   return hipGetLastError();
 }
 
