@@ -19,6 +19,9 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "mof_kernels.h"
 
@@ -37,6 +40,15 @@ __device__ __forceinline__ Cand first_min(Cand a, Cand b) {
 }
 
 __device__ __forceinline__ int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// compile-time loop: guarantees full unrolling whatever the unroller's size thresholds say
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 }  // namespace
 
@@ -163,6 +175,173 @@ __global__ void __launch_bounds__(256) bm_mode_kernel(BmArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K2 fast path: 16x16 blocks, one workgroup per ROW of blocks, one lane per (block, group of 4
+// x-shifts). The lane keeps its block's 16x16 current pixels (64 VGPRs) and ALL its 2r+1 y-shift
+// accumulators (packed 4 x u16, exact: 255*256 < 65536) in registers and sweeps the previous-frame
+// window once, row by row: each window row (5 dwords from the LDS strip) feeds up to 16 (y-shift,
+// block-row) pairs x 4 v_qsad_pk_u16_u8. LDS traffic drops to 5 dwords per 64 SAD instructions and the
+// VALU stream is >80 % v_qsad. The strip of the previous frame shared by the whole block row is staged
+// in LDS once (windows of neighbouring blocks overlap by 50 %).
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(64) bm_scan16_kernel(BmArgs a, int strip_dwords, int bpw, int waves_per_row) {
+  // ONE wave per workgroup: `bpw` consecutive blocks of one block row; no workgroup barrier anywhere.
+  constexpr int SPS = 16, D = 2 * R + 1, XG = (D + 3) / 4, WW = SPS + 2 * R;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = threadIdx.x;
+  const int S = SPS + a.step;
+  const int gx = a.grid_x;
+  const int wr = blockIdx.x % waves_per_row;
+  const int by = (blockIdx.x / waves_per_row) % a.grid_y;
+  const int pair = blockIdx.x / (waves_per_row * a.grid_y);
+  const int b0 = wr * bpw;                               // first block of this wave
+  const int nb = (gx - b0 < bpw) ? gx - b0 : bpw;        // blocks of this wave (>= 1)
+  uint32_t* strip = lds;                                 // [WW][strip_dwords]
+  uint32_t* keys = strip + WW * strip_dwords;            // [64]
+  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + b0 * S;
+  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + R) * a.pitch + R + b0 * S;
+  const int strip_w = (nb - 1) * S + WW;  // bytes of the frame rows this wave needs
+
+  const int b = lane / XG, xg = lane % XG;      // block within the wave, group of four x-shifts
+  const bool active = b < nb;
+  const int bc = active ? b : nb - 1;           // idle lanes shadow the last block (never stored)
+
+  // the block's current pixels: 16 rows x 16 B straight from global memory into registers (issued first)
+  uint32_t cb[SPS][4];
+#pragma unroll
+  for (int j = 0; j < SPS; ++j) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t;
+    __builtin_memcpy(&t, cur + (size_t)j * a.pitch + bc * S, 16);  // one global_load_dwordx4, any alignment
+    cb[j][0] = t.x;
+    cb[j][1] = t.y;
+    cb[j][2] = t.z;
+    cb[j][3] = t.w;
+  }
+
+  // ---- stage the strip: 16-byte loads at any byte alignment (global_load_dwordx4 -> ds_write_b128);
+  //      strip_dwords is a multiple of 4; bytes beyond the strip are zero and never loaded
+  {
+    const int chunks = strip_dwords / 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (int i = lane; i < WW * chunks; i += 64) {
+      const int y = i / chunks, x = 16 * (i % chunks);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const uint8_t* src = prev + (size_t)y * a.pitch + x;
+      if (x + 16 <= strip_w) {
+        __builtin_memcpy(&v, src, 16);
+      } else {
+        uint32_t t[4] = {0u, 0u, 0u, 0u};
+        for (int q = 0; q < 16; ++q)
+          if (x + q < strip_w) t[q >> 2] |= (uint32_t)src[q] << (8 * (q & 3));
+        v = u32x4{t[0], t[1], t[2], t[3]};
+      }
+      *reinterpret_cast<u32x4*>(strip + (size_t)y * strip_dwords + 4 * (i % chunks)) = v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  uint64_t acc[D];
+#pragma unroll
+  for (int ys = 0; ys < D; ++ys) acc[ys] = 0;
+  const uint32_t* wbase = strip + (bc * S) / 4 + xg;
+  // straight-line sweep: wy, j, g are compile-time, so acc[] and cb[][] stay in registers. A y-shift is
+  // complete once window row ys + 15 has been consumed: it is folded into the running first-minimum key
+  // ((sad << 16) | row-major index) right away, so at most 16 accumulators are live.
+  uint32_t kmin = 0xffffffffu, centre = 0;
+  const bool last_group = (xg == XG - 1);
+  static_for<0, WW>([&](auto wy_c) {
+    constexpr int wy = decltype(wy_c)::value;
+    uint32_t w[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) w[g] = wbase[wy * strip_dwords + g];
+    static_for<0, SPS>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      constexpr int ys = wy - j;
+      if constexpr (ys >= 0 && ys < D) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[ys] = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w[g + 1] << 32) | w[g], cb[j][g], acc[ys]);
+      }
+    });
+    constexpr int done = wy - (SPS - 1);
+    if constexpr (done >= 0 && done < D) {
+      // key = (sad << 16) | index: v_lshl_or_b32 for the low halves, v_and_or_b32 for the high halves
+      const uint32_t lo = (uint32_t)acc[done], hi = (uint32_t)(acc[done] >> 32);
+      const uint32_t idx0 = (uint32_t)(done * D) + 4u * (uint32_t)xg;
+      uint32_t k0 = (lo << 16) | idx0;
+      uint32_t k1 = (lo & 0xffff0000u) | (idx0 + 1u);
+      uint32_t k2 = (hi << 16) | (idx0 + 2u);
+      uint32_t k3 = (hi & 0xffff0000u) | (idx0 + 3u);
+      if (last_group) {  // x-shifts beyond 2r exist only in the last group of four
+        if (4 * (XG - 1) + 1 >= D) k1 = 0xffffffffu;
+        if (4 * (XG - 1) + 2 >= D) k2 = 0xffffffffu;
+        if (4 * (XG - 1) + 3 >= D) k3 = 0xffffffffu;
+      }
+      kmin = min(kmin, min(min(k0, k1), min(k2, k3)));
+      if constexpr (done == R) centre = (uint32_t)(acc[R] >> (16 * (R % 4))) & 0xffffu;
+    }
+    // keep the scheduler from hoisting every row's LDS reads to the top (it would spill ~130 VGPRs)
+    __builtin_amdgcn_sched_barrier(0);
+  });
+
+  // ---- per block: first minimum over its XG lanes (wave-local through LDS), low-contrast rule, store
+  keys[lane] = kmin;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // the lane holding the centre SAD (x-shift group R/4, y-shift R) finishes its block
+  if (active && xg == R / 4) {
+    uint32_t km = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < XG; ++i) km = min(km, keys[b * XG + i]);
+    const int idx = (int)(km & 0xffffu), best = (int)(km >> 16);
+    int mx = idx % D, my = idx / D;
+    if (a.low_contrast_rule && (double)((int)centre - best) <= (double)(R * R) * 0.2) {
+      mx = R;
+      my = R;
+    }
+    const size_t o = (size_t)pair * (gx * a.grid_y) + (size_t)by * gx + b0 + b;
+    a.dx[o] = (int8_t)(mx - R);
+    a.dy[o] = (int8_t)(my - R);
+  }
+}
+
+template <int R>
+static void scan16_plan(const BmArgs& a, int* bpw, int* waves_per_row, int* strip_dwords, size_t* lds) {
+  constexpr int D = 2 * R + 1, XG = (D + 3) / 4, WW = 16 + 2 * R;
+  const int S = 16 + a.step;
+  const int cap = 64 / XG;                                 // blocks a wave can hold
+  *waves_per_row = (a.grid_x + cap - 1) / cap;
+  *bpw = (a.grid_x + *waves_per_row - 1) / *waves_per_row; // balanced
+  const int strip_w = (*bpw - 1) * S + WW;
+  *strip_dwords = (((strip_w + 3) / 4 + 1) + 3) & ~3;      // + over-read dword, rounded to 16 B
+  *lds = sizeof(uint32_t) * ((size_t)WW * *strip_dwords + 64);
+}
+
+template <int R>
+static hipError_t launch_scan16(const BmArgs& a, int n_pairs, hipStream_t stream) {
+  int bpw, wpr, sd;
+  size_t lds;
+  scan16_plan<R>(a, &bpw, &wpr, &sd, &lds);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bm_scan16_kernel<R>, dim3((unsigned)n_pairs * a.grid_y * wpr), dim3(64), lds, stream, a, sd, bpw, wpr);
+  return hipGetLastError();
+}
+
+static bool fast16_ok(const BmArgs& a) {
+  if (a.block != 16 || (a.step % 4) != 0 || !(a.radius == 8 || a.radius == 16)) return false;
+  int bpw, wpr, sd;
+  size_t lds;
+  if (a.radius == 16) scan16_plan<16>(a, &bpw, &wpr, &sd, &lds);
+  else scan16_plan<8>(a, &bpw, &wpr, &sd, &lds);
+  return lds <= 64 * 1024;
+}
+
 bool bm_config_supported(int block, int radius) {
   return block >= 4 && block <= 64 && (block % 4) == 0 && radius >= 1 && radius <= 48;
 }
@@ -174,6 +353,9 @@ static size_t bm_lds_bytes(const BmArgs& a) {
 }
 
 hipError_t launch_bm_scan(const BmArgs& a, int n_pairs, hipStream_t stream) {
+  if (fast16_ok(a) && !getenv("MOF_BM_GENERIC")) {
+    return a.radius == 16 ? launch_scan16<16>(a, n_pairs, stream) : launch_scan16<8>(a, n_pairs, stream);
+  }
   const size_t lds = bm_lds_bytes(a);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   const unsigned blocks = (unsigned)n_pairs * (unsigned)(a.grid_x * a.grid_y);
