@@ -89,6 +89,19 @@ int mof_fft_reset(mof_fft_engine* e);
  * (FftMethod.cpp:1872). n_invalid (optional) counts NaN patches. */
 int mof_fft_process(mof_fft_engine* e, const uint8_t* frame, size_t pitch, double* out_xy, int* n_invalid);
 
+/* processImageLongRange (FftMethod.cpp:1905-2007; LONG_RANGE_RATIO 4, :3): both frames are reduced to a quarter
+ * exactly as cv::resize(.., 1/4, 1/4) does for CV_8UC1 (rounded mean of the 2x2 centre of each 4x4 cell) -- on the
+ * fly inside the kernel -- and the same per-patch correlation runs on the (grid_x/4) x (grid_y/4) grid of patches of
+ * the SAME size (samplePointSize_lr, :1685; sqNum_lr, :1720). Shares `first` and the previous frame with
+ * mof_fft_process. Only for the reference tiling with frame sides divisible by 4 and sqNum >= 4
+ * (else MOF_ERR_UNSUPPORTED). out_xy: 2 * mof_fft_long_range_patches(e) doubles, in quarter-resolution pixels (the
+ * node multiplies by 4, optic_flow.cpp:472-476). */
+int mof_fft_long_range_patches(const mof_fft_engine* e);
+int mof_fft_process_long_range(mof_fft_engine* e, const uint8_t* frame, size_t pitch, double* out_xy, int* n_invalid);
+int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride,
+                                            const uint8_t* d_prev, size_t prev_stride, size_t pitch, int n_pairs,
+                                            double* d_out_xy, void* stream);
+
 /* Batched mode on DEVICE pointers: pair k correlates d_cur + k*cur_stride with
  * d_prev + k*prev_stride (strides in bytes; a video sequence is cur = frames + frame_bytes,
  * prev = frames, both strides frame_bytes). d_out_xy receives n_pairs*grid_x*grid_y*2 doubles.

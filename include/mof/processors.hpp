@@ -90,6 +90,24 @@ class FftMethod {
     return speeds;
   }
 
+  // FftMethod::processImageLongRange (FftMethod.cpp:1905-2007): sqNum/4 x sqNum/4 vectors in quarter-resolution
+  // pixels; throws when the geometry has no long-range form (sqNum < 4, sides not divisible by 4).
+  std::vector<Point2d> processImageLongRange(ImageView imCurr, bool /*gui*/, bool /*debug*/, Point2i /*midPoint_t*/,
+                                             double /*yaw_angle*/, Point2d /*rot_center*/,
+                                             std::vector<Point2d>& /*raw_output*/, double i_fx = 300, double i_fy = 300) {
+    fx_ = i_fx;
+    fy_ = i_fy;
+    if (imCurr.rows != cfg_.frame_height || imCurr.cols != cfg_.frame_width)
+      throw std::runtime_error("processImageLongRange: frame size does not match the engine geometry");
+    const int n = mof_fft_long_range_patches(engine_);
+    detail::check(n < 0 ? n : MOF_OK, "mof_fft_long_range_patches");
+    std::vector<Point2d> speeds((size_t)n);
+    const int rc = mof_fft_process_long_range(engine_, imCurr.data, imCurr.step, reinterpret_cast<double*>(speeds.data()), &last_invalid_);
+    if (rc == MOF_ERR_BUSY) return {};
+    detail::check(rc, "mof_fft_process_long_range");
+    return speeds;
+  }
+
   int sqNum() const { return cfg_.grid_x; }
   int invalidPatches() const { return last_invalid_; }
   const mof_fft_config& config() const { return cfg_; }
@@ -214,6 +232,20 @@ class MofFftMethod : public OpticFlowCalc {
                            mof::Point2i{midPoint_t.x, midPoint_t.y}, yaw_angle, mof::Point2d{rot_center.x, rot_center.y},
                            raw, i_fx, i_fy);
     (void)output_vectors_raw;  // untouched by the reference as well
+    std::vector<cv::Point2d> out(r.size());
+    for (size_t i = 0; i < r.size(); ++i) out[i] = cv::Point2d(r[i].x, r[i].y);
+    return out;
+  }
+  std::vector<cv::Point2d> processImageLongRange(cv::Mat imCurr, bool gui, bool debug, cv::Point midPoint_t,
+                                                 double yaw_angle, cv::Point2d rot_center,
+                                                 std::vector<cv::Point2d>& output_vectors_raw, double i_fx = 300,
+                                                 double i_fy = 300) {
+    CV_Assert(imCurr.type() == CV_8UC1);
+    std::vector<mof::Point2d> raw;
+    std::vector<mof::Point2d> r = impl_.processImageLongRange(
+        mof::ImageView{imCurr.data, imCurr.rows, imCurr.cols, imCurr.step}, gui, debug,
+        mof::Point2i{midPoint_t.x, midPoint_t.y}, yaw_angle, mof::Point2d{rot_center.x, rot_center.y}, raw, i_fx, i_fy);
+    (void)output_vectors_raw;
     std::vector<cv::Point2d> out(r.size());
     for (size_t i = 0; i < r.size(); ++i) out[i] = cv::Point2d(r[i].x, r[i].y);
     return out;

@@ -56,6 +56,9 @@ SYMBOLS = {
     "mof_fft_set_prev": (_I, [_VP, _VP, _SZ]),
     "mof_fft_reset": (_I, [_VP]),
     "mof_fft_process": (_I, [_VP, _VP, _SZ, _VP, C.POINTER(_I)]),
+    "mof_fft_long_range_patches": (_I, [_VP]),
+    "mof_fft_process_long_range": (_I, [_VP, _VP, _SZ, _VP, C.POINTER(_I)]),
+    "mof_fft_process_long_range_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_fft_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_fft_process_batch_host": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP]),
     "mof_fft_sync": (_I, [_VP]),

@@ -219,6 +219,7 @@ static mof::PcArgs fft_args(const mof_fft_engine* e, const uint8_t* cur, size_t 
   a.origin_y = e->cfg.origin_y;
   a.stride_x = e->cfg.stride_x;
   a.stride_y = e->cfg.stride_y;
+  a.downscale = 1;
   a.max_px_speed_sq = e->cfg.max_px_speed * e->cfg.max_px_speed;  // pow(max_px_speed_t, 2), FftMethod.cpp:1686
   a.twiddles = e->d_twiddles;
   a.out = out;
@@ -270,6 +271,73 @@ int mof_fft_process(mof_fft_engine* e, const uint8_t* frame, size_t pitch, doubl
   if (n_invalid) *n_invalid = bad;
   e->prev_slot = cur_slot;  // imPrev = imCurr.clone(), FftMethod.cpp:1872
   e->first = false;         // :1900
+  return MOF_OK;
+}
+
+// Long-range geometry (FftMethod.cpp:1685, :1720): same patch size on the quarter-resolution frame,
+// sqNum_lr = sqNum / 4 patches per side. Only defined for the reference's own tiling.
+static int long_range_args(const mof_fft_engine* e, mof::PcArgs* a) {
+  const mof_fft_config& c = e->cfg;
+  if (c.origin_x || c.origin_y || c.stride_x != c.patch_size || c.stride_y != c.patch_size)
+    return fail(MOF_ERR_UNSUPPORTED, "long-range mode needs the reference tiling (origin 0, stride = patch size)");
+  if ((c.frame_width & 3) || (c.frame_height & 3) || c.grid_x < 4 || c.grid_y < 4)
+    return fail(MOF_ERR_UNSUPPORTED, "long-range mode needs frame sides divisible by 4 and sqNum >= 4");
+  a->grid_x = c.grid_x / 4;
+  a->grid_y = c.grid_y / 4;
+  a->downscale = 4;
+  return MOF_OK;
+}
+
+int mof_fft_long_range_patches(const mof_fft_engine* e) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  mof::PcArgs a{};
+  int rc = long_range_args(e, &a);
+  return rc ? rc : a.grid_x * a.grid_y;
+}
+
+int mof_fft_process_long_range(mof_fft_engine* e, const uint8_t* frame, size_t pitch, double* out_xy, int* n_invalid) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!frame || !out_xy || pitch < (size_t)e->cfg.frame_width) return fail(MOF_ERR_BAD_ARG, "bad frame/pitch/out");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int cur_slot = 1 - e->prev_slot;
+  pack_frame(e->h_stage, frame, pitch, e->cfg.frame_width, e->cfg.frame_height);
+  HIP_TRY(hipMemcpyAsync(e->d_frames[cur_slot], e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+  const uint8_t* prev = e->first ? e->d_frames[cur_slot] : e->d_frames[e->prev_slot];  // FftMethod.cpp:1920-1922
+  mof::PcArgs a = fft_args(e, e->d_frames[cur_slot], 0, prev, 0, (size_t)e->cfg.frame_width, e->d_out);
+  int rc = long_range_args(e, &a);
+  if (rc) return rc;
+  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, 1, e->stream));
+  const size_t res = (size_t)a.grid_x * a.grid_y * 2;
+  HIP_TRY(hipMemcpyAsync(e->h_out, e->d_out, res * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  int bad = 0;
+  for (size_t i = 0; i < res; i += 2) {
+    out_xy[i] = e->h_out[i];
+    out_xy[i + 1] = e->h_out[i + 1];
+    if (std::isnan(e->h_out[i])) ++bad;
+  }
+  if (n_invalid) *n_invalid = bad;
+  e->prev_slot = cur_slot;  // imPrev = imCurr.clone(), FftMethod.cpp:1992
+  e->first = false;         // :2004
+  return MOF_OK;
+}
+
+int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride,
+                                            const uint8_t* d_prev, size_t prev_stride, size_t pitch, int n_pairs,
+                                            double* d_out_xy, void* stream) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!d_cur || !d_prev || !d_out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
+    return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if (n_pairs == 0) return MOF_OK;
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
+  int rc = long_range_args(e, &a);
+  if (rc) return rc;
+  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
 

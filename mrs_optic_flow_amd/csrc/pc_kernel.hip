@@ -349,7 +349,10 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
   return best;
 }
 
-template <int N>
+// DS = 1: patches are read from the frames as they are. DS = 4: long-range mode -- every patch pixel is the
+// quarter-resolution pixel cv::resize(.., 1/4, 1/4, INTER_LINEAR) would produce (FftMethod.cpp:1931-1932), i.e.
+// the rounded mean of the 2x2 centre of a 4x4 cell, formed on the fly from the full-resolution frame.
+template <int N, int DS>
 __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   using P = PcTraits<N>;
   constexpr int T = P::T, H = N / 2, R1 = P::R1, R2 = P::R2, LPW = P::LPW;
@@ -364,8 +367,9 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   const int pi = patch % a.grid_x, pj = patch / a.grid_x;
   const int x0 = a.origin_x + pi * a.stride_x;
   const int y0 = a.origin_y + pj * a.stride_y;
-  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)y0 * a.pitch + x0;
-  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)y0 * a.pitch + x0;
+  // (x0, y0) are in the units of the correlated image: full-res pixels, or quarter-res pixels when DS = 4
+  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(DS * y0) * a.pitch + DS * x0;
+  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(DS * y0) * a.pitch + DS * x0;
 
   // twiddles of the second Stockham stage, W_N^{k x}: x = lane % R1 in row passes, lane / (64/R1) in column passes
   cf tw_row[R2 - 1], tw_col[R2 - 1];
@@ -378,19 +382,39 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
     }
   }
 
-  // ---- load: the wave's own LPW rows, 16 B per lane per image, u8 -> f32 (exact), z = cur + i*prev
+  // ---- load: the wave's own LPW rows, 16 pixels per lane per image, u8 -> f32 (exact), z = cur + i*prev
   //      (convertTo, :1805-1806)
   {
-    constexpr int CPR = N / 16;  // 16-byte chunks per row
+    constexpr int CPR = N / 16;  // 16-pixel chunks per row
     const int row = wave * LPW + lane / CPR, col = (lane % CPR) * 16;
-    uint32_t cw[4], pw[4];
-    __builtin_memcpy(cw, cur + (size_t)row * a.pitch + col, 16);
-    __builtin_memcpy(pw, prev + (size_t)row * a.pitch + col, 16);
+    if constexpr (DS == 1) {
+      uint32_t cw[4], pw[4];
+      __builtin_memcpy(cw, cur + (size_t)row * a.pitch + col, 16);
+      __builtin_memcpy(pw, prev + (size_t)row * a.pitch + col, 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cw[q] >> (8 * b)) & 0xffu), (float)((pw[q] >> (8 * b)) & 0xffu)};
+        for (int b = 0; b < 4; ++b)
+          z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cw[q] >> (8 * b)) & 0xffu), (float)((pw[q] >> (8 * b)) & 0xffu)};
+    } else {
+      // pixel (row, col+i) <- (s(4r+1,4c+1) + s(4r+1,4c+2) + s(4r+2,4c+1) + s(4r+2,4c+2) + 2) >> 2 of the full-res frame
+      const uint8_t* c1 = cur + (size_t)(4 * row + 1) * a.pitch + 4 * col;
+      const uint8_t* p1 = prev + (size_t)(4 * row + 1) * a.pitch + 4 * col;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t ca[4], cb[4], pa[4], pb[4];
+        __builtin_memcpy(ca, c1 + 16 * q, 16);
+        __builtin_memcpy(cb, c1 + a.pitch + 16 * q, 16);
+        __builtin_memcpy(pa, p1 + 16 * q, 16);
+        __builtin_memcpy(pb, p1 + a.pitch + 16 * q, 16);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const uint32_t cs = ((ca[b] >> 8) & 0xffu) + ((ca[b] >> 16) & 0xffu) + ((cb[b] >> 8) & 0xffu) + ((cb[b] >> 16) & 0xffu);
+          const uint32_t ps = ((pa[b] >> 8) & 0xffu) + ((pa[b] >> 16) & 0xffu) + ((pb[b] >> 8) & 0xffu) + ((pb[b] >> 16) & 0xffu);
+          z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cs + 2u) >> 2), (float)((ps + 2u) >> 2)};
+        }
+      }
+    }
     wave_sync();
   }
 
@@ -502,7 +526,10 @@ static size_t extra_lds() {
 
 template <int N>
 static hipError_t configure_n() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PcTraits<N>::LDS_BYTES + extra_lds()));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 4>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PcTraits<N>::LDS_BYTES + extra_lds()));
 }
 
@@ -510,7 +537,10 @@ template <int N>
 static hipError_t launch_n(const PcArgs& a, int n_pairs, hipStream_t stream) {
   using Tr = PcTraits<N>;
   const unsigned blocks = (unsigned)n_pairs * (unsigned)(a.grid_x * a.grid_y);
-  hipLaunchKernelGGL(pc_field_kernel<N>, dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
+  if (a.downscale == 4)
+    hipLaunchKernelGGL((pc_field_kernel<N, 4>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
+  else
+    hipLaunchKernelGGL((pc_field_kernel<N, 1>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
   return hipGetLastError();
 }
 

@@ -90,6 +90,36 @@ class FftMethod:
         self.last_invalid = ninv.value
         return out
 
+    def processImageLongRange(self, imCurr, gui=False, debug=False, midPoint=None, yaw_angle=0.0, rot_center=None,
+                              raw_output=None, fx=300.0, fy=300.0) -> np.ndarray:
+        """FftMethod::processImageLongRange: [sqNum_lr^2, 2] shifts in quarter-resolution pixels."""
+        f = _np_u8(imCurr)
+        self._check_shape(f)
+        n = self._lib.mof_fft_long_range_patches(self._h)
+        if n < 0:
+            check(n)
+        out = np.empty((n, 2), np.float64)
+        ninv = C.c_int(0)
+        check(self._lib.mof_fft_process_long_range(self._h, f.ctypes.data, f.strides[0], out.ctypes.data, C.byref(ninv)))
+        self.last_invalid = ninv.value
+        return out
+
+    def process_long_range_batch_device(self, cur, prev, stream=None):
+        import torch
+
+        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and cur.shape == prev.shape
+        assert cur.stride(2) == 1 and prev.stride(2) == 1 and cur.stride(1) == prev.stride(1)
+        n_lr = self._lib.mof_fft_long_range_patches(self._h)
+        if n_lr < 0:
+            check(n_lr)
+        n = cur.shape[0]
+        out = torch.empty((n, n_lr, 2), dtype=torch.float64, device=cur.device)
+        s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        check(self._lib.mof_fft_process_long_range_batch_device(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
+                                                                prev.stride(0), cur.stride(1), n, out.data_ptr(),
+                                                                _stream_ptr(s)))
+        return out
+
     # -- batched --------------------------------------------------------------------------------
     def process_batch_host(self, cur: np.ndarray, prev: np.ndarray) -> np.ndarray:
         cur = np.ascontiguousarray(cur, dtype=np.uint8)

@@ -64,6 +64,22 @@ int oracle_phase_correlate_f64(const double* a, size_t a_stride, const double* b
 int oracle_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_fft_layout* layout,
                           int precision, double* out_xy, int* n_invalid, oracle_pc_diag* diag);
 
+/* cv::resize(src, dst, Size(), 1/4, 1/4) with the default INTER_LINEAR on CV_8UC1, as called by
+ * FftMethod::processImageLongRange (src/FftMethod.cpp:1931-1932, LONG_RANGE_RATIO :3). With scale 4 the
+ * source coordinate of destination x is 4x + 1.5, i.e. both taps weigh 1/2 in each axis, and OpenCV's
+ * fixed-point path (coefficients 1024, vertical pass ((b*(S>>4))>>16 ... + 2) >> 2) reduces exactly to
+ *   dst(y,x) = (src(4y+1,4x+1) + src(4y+1,4x+2) + src(4y+2,4x+1) + src(4y+2,4x+2) + 2) >> 2.
+ * [published OpenCV algorithm, unpinned]. w, h must be multiples of 4. dst is (h/4) x (w/4), tightly packed. */
+int oracle_resize_quarter_u8(const uint8_t* src, size_t pitch, int w, int h, uint8_t* dst);
+
+/* FftMethod::processImageLongRange, useOCL=false (src/FftMethod.cpp:1905-2007): both frames are reduced
+ * to a quarter, then the same per-patch correlation and gate run on the sqNum/4 x sqNum/4 grid of
+ * N x N patches (samplePointSize_lr = samplePointSize, :1685; sqNum_lr = sqNum/4, :1720).
+ * `layout` describes the FULL-resolution reference tiling (origin 0, stride = patch); out_xy receives
+ * 2*(grid_x/4)*(grid_y/4) doubles. */
+int oracle_fft_process_long_range_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch,
+                                     const oracle_fft_layout* layout, int precision, double* out_xy, int* n_invalid);
+
 /* Block geometry shared by both block-matching paths.
  * BlockMethod (src/BlockMethod.cpp:11, :45): step=0, threshold off,
  *   grid = (fs-2r)/sps squared.

@@ -89,4 +89,38 @@ int oracle_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch,
   return 0;
 }
 
+int oracle_resize_quarter_u8(const uint8_t* src, size_t pitch, int w, int h, uint8_t* dst) {
+  if (!src || !dst || w < 4 || h < 4 || (w & 3) || (h & 3)) return -1;
+  const int dw = w / 4;
+  for (int y = 0; y < h / 4; ++y)
+    for (int x = 0; x < dw; ++x) {
+      const uint8_t* r1 = src + (size_t)(4 * y + 1) * pitch + 4 * x;
+      const uint8_t* r2 = r1 + pitch;
+      dst[(size_t)y * dw + x] = (uint8_t)((r1[1] + r1[2] + r2[1] + r2[2] + 2) >> 2);
+    }
+  return 0;
+}
+
+int oracle_fft_process_long_range_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_fft_layout* L,
+                                     int precision, double* out_xy, int* n_invalid) {
+  if (!cur || !prev || !L || !out_xy) return -1;
+  if (L->origin_x || L->origin_y || L->stride_x != L->patch || L->stride_y != L->patch) return -1;
+  if ((L->width & 3) || (L->height & 3) || L->grid_x < 4 || L->grid_y < 4) return -1;
+  const int w = L->width / 4, h = L->height / 4;
+  uint8_t* c = (uint8_t*)malloc((size_t)w * h);
+  uint8_t* p = (uint8_t*)malloc((size_t)w * h);
+  if (!c || !p) { free(c); free(p); return -2; }
+  oracle_resize_quarter_u8(cur, pitch, L->width, L->height, c);   /* ref :1931 */
+  oracle_resize_quarter_u8(prev, pitch, L->width, L->height, p);  /* ref :1932 */
+  oracle_fft_layout lr = *L;
+  lr.width = w;
+  lr.height = h;
+  lr.grid_x = L->grid_x / 4; /* sqNum_lr = sqNum / LONG_RANGE_RATIO, ref :1720 */
+  lr.grid_y = L->grid_y / 4;
+  int rc = oracle_fft_process_u8(c, p, (size_t)w, &lr, precision, out_xy, n_invalid, NULL);
+  free(c);
+  free(p);
+  return rc;
+}
+
 const char* oracle_version(void) { return "mof-oracle 0.1 (parity unpinned: no reference fixtures, OpenCV absent)"; }

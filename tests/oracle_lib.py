@@ -58,6 +58,11 @@ def lib():
         L.oracle_fft_process_u8.restype = C.c_int
         L.oracle_fft_process_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FftLayout), C.c_int,
                                             C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+        L.oracle_resize_quarter_u8.restype = C.c_int
+        L.oracle_resize_quarter_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_fft_process_long_range_u8.restype = C.c_int
+        L.oracle_fft_process_long_range_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FftLayout), C.c_int,
+                                                       C.c_void_p, C.POINTER(C.c_int)]
         L.oracle_bm_config_block_method.argtypes = [C.POINTER(BmConfig), C.c_int, C.c_int, C.c_int]
         L.oracle_bm_config_fast_spaced.argtypes = [C.POINTER(BmConfig), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.oracle_bm_process_u8.restype = C.c_int
@@ -116,6 +121,30 @@ def fft_process(cur: np.ndarray, prev: np.ndarray, layout: FftLayout, precision:
         raise ValueError(f"oracle_fft_process_u8 rc={rc}")
     if want_diag:
         return out, ninv.value, diags
+    return out, ninv.value
+
+
+def resize_quarter(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros((h // 4, w // 4), np.uint8)
+    rc = lib().oracle_resize_quarter_u8(_ptr(img), w, w, h, _ptr(out))
+    if rc:
+        raise ValueError(f"oracle_resize_quarter_u8 rc={rc}")
+    return out
+
+
+def fft_process_long_range(cur: np.ndarray, prev: np.ndarray, layout: FftLayout, precision: int = 32):
+    """FftMethod::processImageLongRange on one uint8 frame pair -> [(gy/4)*(gx/4), 2] float64."""
+    cur = np.ascontiguousarray(cur)
+    prev = np.ascontiguousarray(prev)
+    g = (layout.grid_x // 4) * (layout.grid_y // 4)
+    out = np.zeros((g, 2), np.float64)
+    ninv = C.c_int(0)
+    rc = lib().oracle_fft_process_long_range_u8(_ptr(cur), _ptr(prev), cur.shape[1], C.byref(layout), precision,
+                                                _ptr(out), C.byref(ninv))
+    if rc:
+        raise ValueError(f"oracle_fft_process_long_range_u8 rc={rc}")
     return out, ninv.value
 
 

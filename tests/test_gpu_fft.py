@@ -164,3 +164,29 @@ def test_full_size_c2_batch_properties(gpu):
     lay = O.fft_layout(w, h, n, 8, 8, (1, 1), (98, 59))
     for k in (1, 500, 1011):
         _compare(res[k], cur[k].cpu().numpy(), prev[k].cpu().numpy(), lay, f"full{k}")
+
+
+def test_long_range_mode(gpu):
+    """processImageLongRange: quarter-resolution patches formed inside the kernel; shares `first`/prev with
+    processImage (FftMethod.cpp:1920-1922, :1992, :2004)."""
+    fs, n = 512, 64  # sqNum = 8 -> sqNum_lr = 2
+    seq = [synth.pair_np(41, fs, fs, 8 * t, -4 * t)[0] for t in range(3)]
+    lay = O.fft_layout(fs, fs, n, 8, 8)
+    fm = FftMethod(fs, n, 80.0)
+    out0 = fm.processImageLongRange(seq[0])
+    assert out0.shape == (4, 2)
+    assert np.allclose(out0, O.fft_process_long_range(seq[0], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    out1 = fm.processImageLongRange(seq[1])
+    assert np.allclose(out1, O.fft_process_long_range(seq[1], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    assert np.allclose(out1, [2.0, -1.0], rtol=0, atol=0.3)
+    out2 = fm.processImage(seq[2])  # the ordinary path continues from the same previous frame
+    assert np.allclose(out2, O.fft_process(seq[2], seq[1], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    cur = torch.from_numpy(np.stack(seq[1:])).to(gpu)
+    prev = torch.from_numpy(np.stack(seq[:-1])).to(gpu)
+    got = fm.process_long_range_batch_device(cur, prev).cpu().numpy()
+    for t in range(2):
+        want, _ = O.fft_process_long_range(seq[t + 1], seq[t], lay, 64)
+        assert np.allclose(got[t], want, rtol=0, atol=TOL, equal_nan=True)
+    from mrs_optic_flow_amd import MofError
+    with pytest.raises(MofError):  # sqNum < 4
+        FftMethod(128, 64, 80.0).processImageLongRange(np.zeros((128, 128), np.uint8))

@@ -144,3 +144,21 @@ def test_golden_vectors_reproduce():
             assert np.allclose(out64, g["expected"][k], rtol=0, atol=1e-9, equal_nan=True)
             ok = g["well_conditioned"][k]
             assert np.allclose(out32[ok], g["expected"][k][ok], rtol=0, atol=1e-5, equal_nan=True)
+
+
+def test_long_range_quarter_resize_and_grid():
+    """processImageLongRange (FftMethod.cpp:1905-2007): cv::resize by 1/4 == rounded mean of each 4x4 cell's 2x2
+    centre; the correlation then runs on sqNum/4 patches of the same size and reports quarter-resolution pixels."""
+    fs, n = 512, 128
+    cur, prev = synth.pair_np(3, fs, fs, 20, -12)
+    q = O.resize_quarter(cur)
+    c = cur.astype(np.int32)
+    assert (q == ((c[1::4, 1::4] + c[1::4, 2::4] + c[2::4, 1::4] + c[2::4, 2::4] + 2) >> 2)).all()
+    out, ninv = O.fft_process_long_range(cur, prev, O.fft_layout(fs, fs, n, 4, 4), 64)
+    assert out.shape == (1, 2) and ninv == 0
+    assert np.allclose(out, [[5.0, -3.0]], rtol=0, atol=0.2)  # (20,-12)/4
+    # identical to running the ordinary path on the reduced frames
+    want, _ = O.fft_process(q, O.resize_quarter(prev), O.fft_layout(fs // 4, fs // 4, n, 1, 1), 64)
+    assert np.array_equal(out, want)
+    with pytest.raises(ValueError):  # sqNum < 4: sqNum_lr would be 0
+        O.fft_process_long_range(cur[:256, :256], prev[:256, :256], O.fft_layout(256, 256, 128, 2, 2), 64)
