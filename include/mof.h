@@ -59,7 +59,7 @@ int mof_device_count(void);
 
 typedef struct mof_fft_config {
   int frame_width, frame_height; /* pixels                                                    */
-  int patch_size;                /* samplePointSize N: 32, 64 or 128                          */
+  int patch_size;                /* samplePointSize N: 32, 64, 120 (reference default) or 128 */
   int grid_x, grid_y;            /* patches per row / per column                              */
   int origin_x, origin_y;        /* top-left pixel of patch (0,0)                             */
   int stride_x, stride_y;        /* distance between patch origins                            */

@@ -127,7 +127,7 @@ static int validate_fft(const mof_fft_config* c) {
       c->origin_y < 0 || c->stride_x < 0 || c->stride_y < 0)
     return fail(MOF_ERR_BAD_ARG, "bad FFT geometry");
   if (!mof::pc_patch_size_supported(c->patch_size))
-    return fail(MOF_ERR_UNSUPPORTED, "patch_size %d not supported by the HIP kernel (32, 64, 128)", c->patch_size);
+    return fail(MOF_ERR_UNSUPPORTED, "patch_size %d not supported by the HIP kernel (32, 64, 120, 128)", c->patch_size);
   if (c->origin_x + (long)(c->grid_x - 1) * c->stride_x + c->patch_size > c->frame_width ||
       c->origin_y + (long)(c->grid_y - 1) * c->stride_y + c->patch_size > c->frame_height)
     return fail(MOF_ERR_BAD_ARG, "patch grid leaves the frame");

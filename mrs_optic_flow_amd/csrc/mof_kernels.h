@@ -26,6 +26,9 @@ struct PcArgs {
 bool pc_patch_size_supported(int n);
 hipError_t pc_configure(int patch_size);  // once per device before the first launch
 hipError_t launch_pc_field(const PcArgs& a, int patch_size, int n_pairs, hipStream_t stream);
+// N = 120 (15 x 8) lives in pc_kernel_mixed.hip
+hipError_t pc_configure_120();
+hipError_t launch_pc_field_120(const PcArgs& a, int n_pairs, hipStream_t stream);
 
 // ---- K2/K3: SAD block scan + histogram mode -------------------------------------------------
 struct BmArgs {

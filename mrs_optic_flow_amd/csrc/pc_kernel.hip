@@ -32,112 +32,11 @@
 #include <stdlib.h>
 
 #include "mof_kernels.h"
+#include "pc_common.hpp"
 
 namespace mof {
 
 namespace {
-
-struct cf {
-  float x, y;
-};
-
-__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-// multiply by -i (a quarter turn of the forward kernel e^{-2 pi i k/N})
-__device__ __forceinline__ cf mul_mi(cf a) { return {a.y, -a.x}; }
-
-template <int R>
-__device__ __forceinline__ void butterfly(cf* v);
-
-template <>
-__device__ __forceinline__ void butterfly<2>(cf* v) {
-  cf a = v[0], b = v[1];
-  v[0] = cadd(a, b);
-  v[1] = csub(a, b);
-}
-
-template <>
-__device__ __forceinline__ void butterfly<4>(cf* v) {
-  cf a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
-  cf c = cadd(v[1], v[3]), d = mul_mi(csub(v[1], v[3]));
-  v[0] = cadd(a, c);
-  v[1] = cadd(b, d);
-  v[2] = csub(a, c);
-  v[3] = csub(b, d);
-}
-
-template <>
-__device__ __forceinline__ void butterfly<8>(cf* v) {
-  const float h = 0.70710678118654752440f;
-  cf e[4] = {v[0], v[2], v[4], v[6]};
-  cf o[4] = {v[1], v[3], v[5], v[7]};
-  butterfly<4>(e);
-  butterfly<4>(o);
-  cf w1 = {h * (o[1].x + o[1].y), h * (o[1].y - o[1].x)};   // o1 * e^{-i pi/4}
-  cf w2 = mul_mi(o[2]);                                     // o2 * e^{-i pi/2}
-  cf w3 = {h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y)};  // o3 * e^{-3 i pi/4}
-  v[0] = cadd(e[0], o[0]);
-  v[4] = csub(e[0], o[0]);
-  v[1] = cadd(e[1], w1);
-  v[5] = csub(e[1], w1);
-  v[2] = cadd(e[2], w2);
-  v[6] = csub(e[2], w2);
-  v[3] = cadd(e[3], w3);
-  v[7] = csub(e[3], w3);
-}
-
-template <>
-__device__ __forceinline__ void butterfly<16>(cf* v) {
-  // 16 = 4 x 4: four radix-4 over n1 (stride 4), twiddle W16^{n2 k1}, four radix-4 over n2
-  const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
-  cf t[4][4];
-#pragma unroll
-  for (int n2 = 0; n2 < 4; ++n2) {
-    cf a[4] = {v[n2], v[n2 + 4], v[n2 + 8], v[n2 + 12]};
-    butterfly<4>(a);
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) t[n2][k1] = a[k1];
-  }
-  // W16^m = (cos(pi m/8), -sin(pi m/8))
-  const cf w[10] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}, {-1.f, 0.f},
-                    {-c1, s1}};
-#pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1) {
-    cf a[4];
-#pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) a[n2] = (n2 * k1 == 0) ? t[n2][k1] : cmul(t[n2][k1], w[n2 * k1]);
-    butterfly<4>(a);
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = a[k2];
-  }
-}
-
-// Orders the LDS traffic of the lanes of ONE wave (a wave's DS instructions execute in order);
-// emits no instruction, only stops the compiler from moving LDS accesses across it.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// 8-byte LDS read kept as ONE ds_read_b64: hipcc otherwise fuses neighbouring reads into ds_read2_b64 /
-// ds_read2st64_b64, which move half the bytes per LDS cycle on gfx950 (MI355X_MICROARCH.md, LDS table).
-__device__ __forceinline__ cf lds_read(const cf* p) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef const volatile f2 __attribute__((address_space(3))) * lds_f2_ptr;
-  const f2 t = *(lds_f2_ptr)(p);
-  return {t.x, t.y};
-}
-
-struct Best {
-  float v;
-  int idx;
-};
-__device__ __forceinline__ Best better(Best a, Best b) {
-  // first maximum in row-major order of the fft-shifted surface (cv::minMaxLoc)
-  return (b.v > a.v || (b.v == a.v && b.idx < a.idx)) ? b : a;
-}
 
 template <int N>
 struct Cfg;
@@ -429,36 +328,19 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   //      behaviour of :107-109 / :1127-1129). Only the half spectrum v < N/2 (+ row N/2 packed into the
   //      imaginary part of row 0) is kept, conjugated, for the Hermitian inverse.
   {
-    const float eps = 1.1920928955078125e-07f;  // FLT_EPSILON, :1117
-    auto cross = [&](cf zk, cf zm, bool real_only) -> cf {
-      // A[k] = (Z[k] + conj(Z[-k]))/2 ; B[k] = (Z[k] - conj(Z[-k]))/(2i)
-      const cf A = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
-      const cf B = {0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x)};
-      if (real_only) {
-        const float p = A.x * B.x;
-        return {p * __builtin_amdgcn_rcpf(p * p + eps), 0.f};
-      }
-      const float pr = A.x * B.x + A.y * B.y;
-      const float pim = A.y * B.x - A.x * B.y;
-      // C = P |P| / (|P|^2 + eps) with ONE hardware sqrt and ONE hardware reciprocal (1 ulp each): the
-      // IEEE divide/sqrt expansions were a fifth of the kernel's VALU work for no effect at 1e-4 px.
-      const float q = pr * pr + pim * pim;
-      const float s = __builtin_amdgcn_sqrtf(q) * __builtin_amdgcn_rcpf(q + eps);
-      return {pr * s, pim * s};
-    };
     // rows 1..H-1: every u; partner (N-v, N-u) lies in the untouched lower half
     for (int g = tid; g < (H - 1) * N; g += T) {
       const int v = 1 + g / N, u = g % N;
       const cf zk = z[zaddr<N>(v, u)], zm = z[zaddr<N>(N - v, (N - u) % N)];
-      const cf C = cross(zk, zm, false);
+      const cf C = cross_power(zk, zm, false);
       z[zaddr<N>(v, u)] = {C.x, -C.y};  // conj(C[v][u])
     }
     // rows 0 and H share row 0: G'[u] = conj(C[0][u]) + i conj(C[H][u]); partner of u is N-u in the same rows
     for (int u = tid; u <= H; u += T) {
       const int um = (N - u) % N;
       const bool self = (u == um);
-      const cf C0 = cross(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
-      const cf CH = cross(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
+      const cf C0 = cross_power(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
+      const cf CH = cross_power(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
       z[zaddr<N>(0, u)] = {C0.x + CH.y, CH.x - C0.y};
       if (!self) z[zaddr<N>(0, um)] = {C0.x - CH.y, CH.x + C0.y};
     }
@@ -479,39 +361,14 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   if (lane == 0) red[wave] = best;
   __syncthreads();
 
-  // ---- 5x5 weighted centroid in double + validity gate  (:1337-1383, :1838-1856): 25 lanes of wave 0 take one
-  //      window element each, three fp64 sums are reduced by shuffles
+  // ---- 5x5 weighted centroid in double + validity gate  (:1337-1383, :1838-1856), wave 0
   if (wave == 0) {
     for (int w = 1; w < P::WAVES; ++w) best = better(best, red[w]);
-    const int px = best.idx % N, py = best.idx / N;
-    const int ys = py - 2 + lane / 5, xs = px - 2 + lane % 5;
-    double cx = 0.0, cy = 0.0, sum = 0.0;
-    if (lane < 25 && ys >= 0 && ys <= N - 1 && xs >= 0 && xs <= N - 1) {  // window clamped to the patch
-      const int y = (ys + H) % N, x = (xs + H) % N;                        // un-shifted position
+    centroid_gate_store<N>(best, lane, a.max_px_speed_sq, a.out + 2 * ((size_t)pair * patches + patch), [&](int ys, int xs) {
+      const int y = (ys + H) % N, x = (xs + H) % N;  // un-shifted position
       const cf s = z[zaddr<N>(y, x % H)];
-      const double val = (double)(x < H ? s.x : s.y);
-      cx = (double)xs * val;
-      cy = (double)ys * val;
-      sum = val;
-    }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-      cx += __shfl_xor(cx, off, 64);
-      cy += __shfl_xor(cy, off, 64);
-      sum += __shfl_xor(sum, off, 64);
-    }
-    if (lane == 0) {
-      sum += 2.220446049250313e-16;  // DBL_EPSILON, :1378
-      // shift = -(center - t) = t - N/2   (:1836)
-      double sx = cx / sum - (double)N / 2.0;
-      double sy = cy / sum - (double)N / 2.0;
-      const bool bad = (sx * sx + sy * sy > a.max_px_speed_sq) || (fabs(sx) > (double)N / 2.0) ||
-                       (fabs(sy) > (double)N / 2.0) || (sx != sx) || (sy != sy);
-      if (bad) sx = sy = __builtin_nan("");
-      double* o = a.out + 2 * ((size_t)pair * patches + patch);
-      o[0] = sx;
-      o[1] = sy;
-    }
+      return x < H ? s.x : s.y;
+    });
   }
 }
 
@@ -549,6 +406,7 @@ hipError_t pc_configure(int patch_size) {
     case 32: return configure_n<32>();
     case 64: return configure_n<64>();
     case 128: return configure_n<128>();
+    case 120: return pc_configure_120();
     default: return hipErrorInvalidValue;
   }
 }
@@ -558,10 +416,11 @@ hipError_t launch_pc_field(const PcArgs& a, int patch_size, int n_pairs, hipStre
     case 32: return launch_n<32>(a, n_pairs, stream);
     case 64: return launch_n<64>(a, n_pairs, stream);
     case 128: return launch_n<128>(a, n_pairs, stream);
+    case 120: return launch_pc_field_120(a, n_pairs, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
-bool pc_patch_size_supported(int n) { return n == 32 || n == 64 || n == 128; }
+bool pc_patch_size_supported(int n) { return n == 32 || n == 64 || n == 128 || n == 120; }
 
 }  // namespace mof

@@ -1,0 +1,359 @@
+// pc_kernel_mixed.hip -- K1 for the reference's DEFAULT patch size, N = 120 = 15 x 8
+// (config/default.yaml:31-32: frame_size 480, sample_point_size 120 -> 4 x 4 patches; the reference's own
+// OpenCL plan for it is radix {8, 5, 3}, src/FftMethod.cpp:481-539).
+//
+// Same algorithm and structure as pc_kernel.hip (two-for-one packed forward transform, normalised
+// cross-power spectrum with the real-only-slot rule, Hermitian half-size inverse, arg-max from registers,
+// fp64 centroid + gate; wave-local passes, 5 workgroup barriers), with
+//   * two Stockham stages per 1-D transform: radix 15 (3 x 5 Cooley-Tukey in registers), then radix 8;
+//   * 15 waves (960 threads), wave w owns lines [8w, 8w+8); the radix-8 stage has 15 butterflies per line,
+//     which does not divide the wave, so lanes are predicated and the inter-stage twiddles W_120^{kx} are
+//     fetched from the (L1-resident, host-computed-in-double) table instead of living in registers;
+//   * tile pitch 121 complex, no skew: the stride-15 accesses are already conflict-free (30 dwords mod 32).
+// One workgroup per CU (113 KB of LDS).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mof_kernels.h"
+#include "pc_common.hpp"
+
+namespace mof {
+
+namespace {
+
+constexpr int N = 120, H = 60, R1 = 15, R2 = 8, LPW = 8, WAVES = N / LPW, T = WAVES * 64, PITCH = 121;
+constexpr size_t LDS_BYTES_120 = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best);
+
+__device__ __forceinline__ int za(int r, int c) { return r * PITCH + c; }
+
+__device__ __forceinline__ void butterfly3(cf* a) {
+  const float s3 = 0.86602540378443864676f;  // sin(2 pi / 3)
+  const cf s = cadd(a[1], a[2]), d = csub(a[1], a[2]);
+  const cf m = {a[0].x - 0.5f * s.x, a[0].y - 0.5f * s.y};
+  a[0] = cadd(a[0], s);
+  a[1] = {m.x + s3 * d.y, m.y - s3 * d.x};
+  a[2] = {m.x - s3 * d.y, m.y + s3 * d.x};
+}
+
+__device__ __forceinline__ void butterfly5(cf* a) {
+  const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;  // cos(2pi/5), cos(4pi/5)
+  const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;   // sin(2pi/5), sin(4pi/5)
+  const cf s14 = cadd(a[1], a[4]), d14 = csub(a[1], a[4]), s23 = cadd(a[2], a[3]), d23 = csub(a[2], a[3]);
+  const cf p1 = {a[0].x + c1 * s14.x + c2 * s23.x, a[0].y + c1 * s14.y + c2 * s23.y};
+  const cf p2 = {a[0].x + c2 * s14.x + c1 * s23.x, a[0].y + c2 * s14.y + c1 * s23.y};
+  const cf q1 = {s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y};
+  const cf q2 = {s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y};
+  a[0] = {a[0].x + s14.x + s23.x, a[0].y + s14.y + s23.y};
+  a[1] = {p1.x + q1.y, p1.y - q1.x};  // p1 - i q1
+  a[4] = {p1.x - q1.y, p1.y + q1.x};  // p1 + i q1
+  a[2] = {p2.x + q2.y, p2.y - q2.x};
+  a[3] = {p2.x - q2.y, p2.y + q2.x};
+}
+
+// 15-point DFT: n = 5 n1 + n2, k = k1 + 3 k2
+__device__ __forceinline__ void butterfly15(cf* v) {
+  // W15^m = (cos(2 pi m / 15), -sin(2 pi m / 15)), m = 1..8
+  const cf w15[9] = {{1.f, 0.f},
+                     {0.91354545764260089550f, -0.40673664307580020775f},
+                     {0.66913060635885821383f, -0.74314482547739423501f},
+                     {0.30901699437494742410f, -0.95105651629515357212f},
+                     {-0.10452846326765347140f, -0.99452189536827333692f},
+                     {-0.5f, -0.86602540378443864676f},
+                     {-0.80901699437494742410f, -0.58778525229247312917f},
+                     {-0.97814760073380563793f, -0.20791169081775933710f},
+                     {-0.97814760073380563793f, 0.20791169081775933710f}};
+  cf t[5][3];
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    cf a[3] = {v[n2], v[5 + n2], v[10 + n2]};
+    butterfly3(a);
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) t[n2][k1] = (n2 * k1 == 0) ? a[k1] : cmul(a[k1], w15[n2 * k1]);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    cf b[5] = {t[0][k1], t[1][k1], t[2][k1], t[3][k1], t[4][k1]};
+    butterfly5(b);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) v[k1 + 3 * k2] = b[k2];
+  }
+}
+
+__device__ __forceinline__ cf twiddle(const float* __restrict__ table, int idx) {  // W_120^idx, idx < 120
+  const float2 t = *reinterpret_cast<const float2*>(table + 2 * idx);
+  return {t.x, t.y};
+}
+
+// ---- row pass over lines [line0, line0 + 8) that are < nlines (wave-local) ----------------------------
+__device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int nlines, int lane, const float* tw) {
+  {  // stage 1: radix 15; 8 butterflies per line -> one per lane
+    const int line = line0 + lane / R2, x = lane % R2;
+    const bool on = line < nlines;
+    cf v[R1];
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < R1; ++k) v[k] = lds_read(&z[za(line, x + k * R2)]);
+      butterfly15(v);
+    }
+    wave_sync();
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < R1; ++k) z[za(line, x * R1 + k)] = v[k];
+    }
+    wave_sync();
+  }
+  {  // stage 2: radix 8; 15 butterflies per line -> 120 per wave over 2 x 64 lane slots
+    cf v[2][R2];
+    int line[2], x[2];
+    bool on[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int q = lane + 64 * b;
+      line[b] = line0 + q / R1;
+      x[b] = q % R1;
+      on[b] = q < LPW * R1 && line[b] < nlines;
+      if (on[b]) {
+#pragma unroll
+        for (int k = 0; k < R2; ++k) {
+          const cf a = lds_read(&z[za(line[b], x[b] + k * R1)]);
+          v[b][k] = (k == 0) ? a : cmul(a, twiddle(tw, k * x[b]));
+        }
+        butterfly<8>(v[b]);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      if (on[b]) {
+#pragma unroll
+        for (int k = 0; k < R2; ++k) z[za(line[b], x[b] + k * R1)] = v[b][k];
+      }
+    wave_sync();
+  }
+}
+
+// ---- forward column pass over columns [col0, col0 + 8) (wave-local) -----------------------------------
+__device__ __forceinline__ void col_pass_fwd(cf* __restrict__ z, int col0, int lane, const float* tw) {
+  {  // stage 1: lane -> (column lane % 8, x = lane / 8)
+    const int col = col0 + lane % LPW, x = lane / LPW;
+    cf v[R1];
+#pragma unroll
+    for (int k = 0; k < R1; ++k) v[k] = lds_read(&z[za(x + k * R2, col)]);
+    butterfly15(v);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < R1; ++k) z[za(x * R1 + k, col)] = v[k];
+    wave_sync();
+  }
+  {  // stage 2: x = q / 8 in 0..14
+    cf v[2][R2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int q = lane + 64 * b, col = col0 + q % LPW, x = q / LPW;
+      if (x < R1) {
+#pragma unroll
+        for (int k = 0; k < R2; ++k) {
+          const cf a = lds_read(&z[za(x + k * R1, col)]);
+          v[b][k] = (k == 0) ? a : cmul(a, twiddle(tw, k * x));
+        }
+        butterfly<8>(v[b]);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int q = lane + 64 * b, col = col0 + q % LPW, x = q / LPW;
+      if (x < R1) {
+#pragma unroll
+        for (int k = 0; k < R2; ++k) z[za(x + k * R1, col)] = v[b][k];
+      }
+    }
+    wave_sync();
+  }
+}
+
+// ---- inverse column pass on column pairs (col, col + H), col in [col0, col0 + 8) and < H (wave-local);
+//      see col_pass_inv in pc_kernel.hip for the data layout --------------------------------------------
+__device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int lane, const float* tw) {
+  {  // stage 1
+    const int col = col0 + lane % LPW, x = lane / LPW;
+    const bool on = col < H;
+    cf v[R1];
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < R1; ++k) {
+        const int r = x + k * R2;
+        const int rr = (r == 0 || r == H) ? 0 : (r < H ? r : N - r);
+        const cf a = lds_read(&z[za(rr, col)]), c = lds_read(&z[za(rr, col + H)]);
+        cf e;
+        if (r == 0) e = {a.x, c.x};
+        else if (r == H) e = {a.y, c.y};
+        else if (r < H) e = {a.x - c.y, a.y + c.x};
+        else e = {a.x + c.y, c.x - a.y};
+        v[k] = e;
+      }
+      butterfly15(v);
+    }
+    wave_sync();
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < R1; ++k) z[za(x * R1 + k, col)] = v[k];
+    }
+    wave_sync();
+  }
+  Best best = {-__builtin_huge_valf(), 0x7fffffff};
+  {  // stage 2 + arg-max from registers
+    cf v[2][R2];
+    bool on[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int q = lane + 64 * b, col = col0 + q % LPW, x = q / LPW;
+      on[b] = x < R1 && col < H;
+      if (on[b]) {
+#pragma unroll
+        for (int k = 0; k < R2; ++k) {
+          const cf a = lds_read(&z[za(x + k * R1, col)]);
+          v[b][k] = (k == 0) ? a : cmul(a, twiddle(tw, k * x));
+        }
+        butterfly<8>(v[b]);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int q = lane + 64 * b, col = col0 + q % LPW, x = q / LPW;
+      if (on[b]) {
+#pragma unroll
+        for (int k = 0; k < R2; ++k) {
+          const int y = x + k * R1;
+          z[za(y, col)] = v[b][k];
+          const int ys = (y + H) % N;
+          best = better(best, Best{v[b][k].x, ys * N + col + H});
+          best = better(best, Best{v[b][k].y, ys * N + col});
+        }
+      }
+    }
+  }
+  return best;
+}
+
+}  // namespace
+
+template <int DS>
+__global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cf* z = reinterpret_cast<cf*>(smem);
+  Best* red = reinterpret_cast<Best*>(z + N * PITCH);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int patches = a.grid_x * a.grid_y;
+  const int pair = blockIdx.x / patches;
+  const int patch = blockIdx.x % patches;
+  const int pi = patch % a.grid_x, pj = patch / a.grid_x;
+  const int x0 = a.origin_x + pi * a.stride_x;
+  const int y0 = a.origin_y + pj * a.stride_y;
+  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(DS * y0) * a.pitch + DS * x0;
+  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(DS * y0) * a.pitch + DS * x0;
+  const float* tw = a.twiddles;
+
+  // ---- load: the wave's own 8 rows in 8-pixel chunks (15 per row), u8 -> f32, z = cur + i*prev (:1805-1806)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int q = lane + 64 * b;
+    if (q < LPW * (N / 8)) {
+      const int row = wave * LPW + q / (N / 8), col = (q % (N / 8)) * 8;
+      uint32_t c[2], p[2];
+      if constexpr (DS == 1) {
+        __builtin_memcpy(c, cur + (size_t)row * a.pitch + col, 8);
+        __builtin_memcpy(p, prev + (size_t)row * a.pitch + col, 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          z[za(row, col + i)] = {(float)((c[i >> 2] >> (8 * (i & 3))) & 0xffu), (float)((p[i >> 2] >> (8 * (i & 3))) & 0xffu)};
+      } else {
+        // long-range mode: rounded mean of the 2x2 centre of each 4x4 cell (cv::resize 1/4, FftMethod.cpp:1931-1932)
+        const uint8_t* c1 = cur + (size_t)(4 * row + 1) * a.pitch + 4 * col;
+        const uint8_t* p1 = prev + (size_t)(4 * row + 1) * a.pitch + 4 * col;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          uint32_t ca[4], cb[4], pa[4], pb[4];
+          __builtin_memcpy(ca, c1 + 16 * h2, 16);
+          __builtin_memcpy(cb, c1 + a.pitch + 16 * h2, 16);
+          __builtin_memcpy(pa, p1 + 16 * h2, 16);
+          __builtin_memcpy(pb, p1 + a.pitch + 16 * h2, 16);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t cs = ((ca[i] >> 8) & 0xffu) + ((ca[i] >> 16) & 0xffu) + ((cb[i] >> 8) & 0xffu) + ((cb[i] >> 16) & 0xffu);
+            const uint32_t ps = ((pa[i] >> 8) & 0xffu) + ((pa[i] >> 16) & 0xffu) + ((pb[i] >> 8) & 0xffu) + ((pb[i] >> 16) & 0xffu);
+            z[za(row, col + 4 * h2 + i)] = {(float)((cs + 2u) >> 2), (float)((ps + 2u) >> 2)};
+          }
+        }
+      }
+    }
+  }
+  wave_sync();
+
+  // ---- forward 2-D transform: rows (wave-local), barrier, columns (wave-local)
+  row_pass(z, wave * LPW, N, lane, tw);
+  __syncthreads();
+  col_pass_fwd(z, wave * LPW, lane, tw);
+  __syncthreads();
+
+  // ---- normalised cross-power spectrum, half spectrum kept conjugated (see pc_kernel.hip)
+  for (int g = tid; g < (H - 1) * N; g += T) {
+    const int v = 1 + g / N, u = g % N;
+    const cf zk = z[za(v, u)], zm = z[za(N - v, (N - u) % N)];
+    const cf C = cross_power(zk, zm, false);
+    z[za(v, u)] = {C.x, -C.y};
+  }
+  for (int u = tid; u <= H; u += T) {
+    const int um = (N - u) % N;
+    const bool self = (u == um);
+    const cf C0 = cross_power(z[za(0, u)], z[za(0, um)], self);
+    const cf CH = cross_power(z[za(H, u)], z[za(H, um)], self);
+    z[za(0, u)] = {C0.x + CH.y, CH.x - C0.y};
+    if (!self) z[za(0, um)] = {C0.x - CH.y, CH.x + C0.y};
+  }
+  __syncthreads();
+
+  // ---- Hermitian inverse: rows 0..H-1, then column pairs (idft :1497)
+  if (wave * LPW < H) row_pass(z, wave * LPW, H, lane, tw);
+  __syncthreads();
+  Best best = {-__builtin_huge_valf(), 0x7fffffff};
+  if (wave * LPW < H) best = col_pass_inv(z, wave * LPW, lane, tw);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o = {__shfl_xor(best.v, off, 64), __shfl_xor(best.idx, off, 64)};
+    best = better(best, o);
+  }
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+
+  if (wave == 0) {
+    for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
+    centroid_gate_store<N>(best, lane, a.max_px_speed_sq, a.out + 2 * ((size_t)pair * patches + patch), [&](int ys, int xs) {
+      const int y = (ys + H) % N, x = (xs + H) % N;
+      const cf s = z[za(y, x % H)];
+      return x < H ? s.x : s.y;
+    });
+  }
+}
+
+hipError_t pc_configure_120() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_120);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<4>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_120);
+}
+
+hipError_t launch_pc_field_120(const PcArgs& a, int n_pairs, hipStream_t stream) {
+  const unsigned blocks = (unsigned)n_pairs * (unsigned)(a.grid_x * a.grid_y);
+  if (a.downscale == 4)
+    hipLaunchKernelGGL((pc_field_kernel_120<4>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
+  else
+    hipLaunchKernelGGL((pc_field_kernel_120<1>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace mof

@@ -60,5 +60,7 @@ if __name__ == "__main__":
     fft_case("fft_n64_unaligned.npz", 160, 224, 64, (3, 2), (1, 1), (79, 47), 12, 8, 0)
     fft_case("fft_n128.npz", 144, 272, 128, (2, 1), (5, 9), (139, 1), 12, 16, 0)
     fft_case("fft_n32_tiled.npz", 96, 96, 32, (3, 3), (0, 0), (32, 32), 12, 4, 0)
+    # the reference's default patch size (config/default.yaml:32): 120 = 15 x 8, on a 240^2 crop -> 2 x 2 patches
+    fft_case("fft_n120_reference_tiling.npz", 240, 240, 120, (2, 2), (0, 0), (120, 120), 8, 15, 0)
     bm_case("bm_fast_spaced_c3.npz", 120, 168, 16, 8, 16, True, 12, 12, 0)
     bm_case("bm_block_method_c1.npz", 112, 112, 32, 0, 8, False, 12, 6, 0)

@@ -35,7 +35,8 @@ def _compare(got, cur, prev, lay, label=""):
     return n_checked
 
 
-@pytest.mark.parametrize("name", ["fft_n64_unaligned.npz", "fft_n128.npz", "fft_n32_tiled.npz"])
+@pytest.mark.parametrize("name", ["fft_n64_unaligned.npz", "fft_n128.npz", "fft_n32_tiled.npz",
+                                  "fft_n120_reference_tiling.npz"])
 def test_golden_vectors(gpu, name):
     g = np.load(os.path.join(GOLDEN, name))
     w, h, n, gx, gy, ox, oy, sx, sy = (int(v) for v in g["layout"])
@@ -44,7 +45,10 @@ def test_golden_vectors(gpu, name):
     ok = g["well_conditioned"]
     assert ok.sum() > 0.8 * ok.size
     assert np.allclose(got[ok], g["expected"][ok], rtol=0, atol=TOL, equal_nan=True)
-    assert np.array_equal(np.isnan(got), np.isnan(g["expected"]))
+    # validity must agree wherever the arg-max is not decided by rounding noise (a constant patch at N = 120 has
+    # AC bins of pure rounding noise under radix-3/5 butterflies, in the oracle as on the GPU)
+    stable = ok | (g["kinds"][:, None] != "constant")
+    assert np.array_equal(np.isnan(got)[stable], np.isnan(g["expected"])[stable])
     # the host-pointer batch entry gives the same bits as the device-pointer one
     got_h = fm.process_batch_host(g["cur"], g["prev"])
     assert np.array_equal(got_h, got, equal_nan=True)
@@ -55,6 +59,8 @@ def test_golden_vectors(gpu, name):
     (128, (270, 480), (3, 2), (0, 0), (119, 63)),      # c4 patch/stride on a reduced frame
     (64, (448, 448), (7, 7), (0, 0), (64, 64)),        # the reference's own square tiling (sqNum = 7)
     (32, (70, 130), (3, 1), (2, 3), (33, 1)),
+    (120, (480, 480), (4, 4), (0, 0), (120, 120)),     # the reference's default geometry (default.yaml:31-32)
+    (120, (250, 380), (3, 2), (3, 1), (127, 129)),
 ])
 def test_seeded_batches_match_oracle(gpu, n, shape, grid, origin, stride):
     h, w = shape
@@ -190,3 +196,26 @@ def test_long_range_mode(gpu):
     from mrs_optic_flow_amd import MofError
     with pytest.raises(MofError):  # sqNum < 4
         FftMethod(128, 64, 80.0).processImageLongRange(np.zeros((128, 128), np.uint8))
+
+
+def test_reference_default_geometry_480_120(gpu):
+    """frame_size 480, sample_point_size 120 (config/default.yaml:31-32): the stateful path and long-range mode
+    (sqNum 4 -> sqNum_lr 1) on the patch size the reference actually ships with."""
+    fs, n = 480, 120
+    seq = [synth.pair_np(51, fs, fs, 8 * t, 4 * t)[0] for t in range(3)]
+    lay = O.fft_layout(fs, fs, n, 4, 4)
+    fm = FftMethod(fs, n, 80.0)
+    assert fm.sqNum == 4
+    fm.processImage(seq[0])
+    out1 = fm.processImage(seq[1])
+    assert np.allclose(out1, O.fft_process(seq[1], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    assert np.allclose(np.median(out1, axis=0), [8.0, 4.0], rtol=0, atol=0.3)
+    out2 = fm.processImageLongRange(seq[2])
+    assert out2.shape == (1, 2)
+    assert np.allclose(out2, O.fft_process_long_range(seq[2], seq[1], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    # circular shifts on a single 120x120 patch are exact
+    prev = synth.canvas_np(12, n, n, False)[:n, :n].copy()
+    shifts = [(7, -9), (-30, 11), (1, 0)]
+    cur = np.stack([np.roll(prev, (dy, dx), axis=(0, 1)) for dx, dy in shifts])
+    got = FftMethod(n, n, 80.0).process_batch_host(cur, np.repeat(prev[None], 3, 0))[:, 0]
+    assert np.allclose(got, np.array(shifts, float), rtol=0, atol=3e-5)
