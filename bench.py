@@ -7,6 +7,7 @@ through the C ABI (mof_*_process_batch_device, ONE kernel launch per batch for t
   c2 (default)  FftMethod, 752x480, 8x8 grid of 64x64 patches, 1024 pairs per GPU   <- BASELINE metric
   c3            FastSpacedBMMethod, 752x480, sps 16 / step 8 / radius 16, 1024 pairs per GPU
   c4            FftMethod, 1920x1080, 16x16 grid of 128x128 patches, 1024 pairs per GPU (8192 over 8 GPUs)
+  c5            c2 + scaleRotationEstimator (log-polar + whole-frame phase correlation of the 480^2 centre crop)
 
 Multi-GPU (--gpus N under torch.distributed.run): frame pairs are independent, so every rank owns
 its own shard of the batch (weak scaling, no data-path collective); each step ends with the one
@@ -43,6 +44,12 @@ WORKLOADS = {
     "cal": dict(kind="fft", h=512, w=512, n=64, grid=(8, 8), origin=(0, 0), stride=(64, 64), batch=1024, s=8,
                 name="cal: FftMethod 512x512 tiled exactly by 8x8 patches of 64x64 (counter calibration), batch=1024",
                 bytes_per_pair=2 * 512 * 512 + 64 * 8),
+    "c5": dict(kind="fft+sr", h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=1024, s=8,
+               sr_res=480, sr_m=49.9, sr_x0=136,
+               name="c5: FftMethod (c2) + scaleRotationEstimator on the 480x480 centre crop (log-polar M=49.9 + whole-frame "
+                    "phase correlation), 752x480, batch=1024 frame pairs per GPU",
+               # 2*W*H u8 in + flow vectors + (scale, rot)
+               bytes_per_pair=2 * 752 * 480 + 64 * 8 + 8),
     "c3": dict(kind="bm", h=480, w=752, block=16, step=8, radius=16, batch=1024, s=12,
                name="c3: FastSpacedBMMethod 752x480, samplePointSize=16, stepSize=8, scanRadius=16, batch=1024 per GPU",
                # blocks*sps^2 + window area + 2*blocks + 2
@@ -58,7 +65,17 @@ def cpu_baseline(wl, budget_s: float = 12.0):
 
     n_gen = 4
     cur, prev, _, _ = synth.batch_np(n_gen, wl["h"], wl["w"], wl["s"], classes=False, k0=1)
-    if wl["kind"] == "fft":
+    if wl["kind"] == "fft+sr":
+        lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
+        x0, r = wl["sr_x0"], wl["sr_res"]
+
+        def run(k):
+            O.fft_process(cur[k % n_gen], prev[k % n_gen], lay, 32)
+            est = O.ScaleRotationEstimator(r, wl["sr_m"], 32)
+            est.processImage(prev[k % n_gen][:r, x0:x0 + r])
+            est.processImage(cur[k % n_gen][:r, x0:x0 + r])
+        what = "f32 oracle (oracle/pc_ref.c + lp_ref.c)"
+    elif wl["kind"] == "fft":
         lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
         run = lambda k: O.fft_process(cur[k % n_gen], prev[k % n_gen], lay, 32)
         what = "f32 oracle (oracle/pc_ref.c)"
@@ -100,7 +117,7 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    from mrs_optic_flow_amd import FastSpacedBMMethod, FftMethod, sharding, synth
+    from mrs_optic_flow_amd import FastSpacedBMMethod, FftMethod, ScaleRotationEstimator, sharding, synth
 
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -120,14 +137,23 @@ def main() -> None:
     B = wl["batch"]
     # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
     cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
-    if wl["kind"] == "fft":
+    if wl["kind"] in ("fft", "fft+sr"):
         eng = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"],
                         origin=wl["origin"], stride=wl["stride"], device=local_rank)
         out = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
+        if wl["kind"] == "fft+sr":
+            sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank)
+            x0, r = wl["sr_x0"], wl["sr_res"]
+            cur_c, prev_c = cur[:, :r, x0:x0 + r], prev[:, :r, x0:x0 + r]
 
-        def launch():
-            eng.process_batch_device(cur, prev, out=out)
-            return out
+            def launch():
+                eng.process_batch_device(cur, prev, out=out)
+                srout = sr.process_batch_device(cur_c, prev_c)
+                return torch.cat([out.reshape(B, -1), srout], dim=1)
+        else:
+            def launch():
+                eng.process_batch_device(cur, prev, out=out)
+                return out
     else:
         eng = FastSpacedBMMethod(wl["block"], wl["radius"], wl["step"], (wl["h"], wl["w"]), device=local_rank)
 
@@ -172,7 +198,8 @@ def main() -> None:
         bytes_per_launch = wl["bytes_per_pair"] * B
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         line = {
-            "metric": "frame_pairs_per_s" + ("_fft_phase_corr" if wl["kind"] == "fft" else "_fast_spaced_bm"),
+            "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fft+sr": "_fft_phase_corr_plus_scale_rotation",
+                                             "bm": "_fast_spaced_bm"}[wl["kind"]],
             "value": pairs / elapsed,
             "unit": "frame-pairs/s",
             "n_gpus": world,
@@ -182,15 +209,15 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if wl["kind"] == "fft" else "u8",
+            "dtype": "u8" if wl["kind"] == "bm" else "f32",
             "data": "synthetic",
             "config": {"workload": wl["name"], "batch_per_gpu": B, "frame": f'{wl["w"]}x{wl["h"]} u8',
                        "parallelism": f"frame-pair shards x{world}, all-gather of flow vectors" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "binding": "LDS/VALU (fp32 FFT in LDS), not HBM -- see DESIGN.md" if wl["kind"] == "fft"
-                         else "integer VALU (v_qsad_pk_u16_u8), not HBM -- see DESIGN.md"},
+                         "binding": "integer VALU (v_qsad_pk_u16_u8), not HBM -- see DESIGN.md" if wl["kind"] == "bm"
+                         else "LDS/VALU (fp32 FFT in LDS), not HBM -- see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)

@@ -7,6 +7,7 @@
  *                                                /root/reference/src/FftMethod.cpp:1680-1766, :1772-1903
  *   BlockMethod::BlockMethod / processImage      /root/reference/src/BlockMethod.cpp:3-22, :25-94
  *   FastSpacedBMMethod::processImage             /root/reference/src/FastSpacedBMMethod_OCL.cpp:71-184
+ *   scaleRotationEstimator::processImage         /root/reference/src/scaleRotationEstimator.cpp:34-148
  *
  * Plain pointers and sizes only; no C++/torch/OpenCV types; no exceptions cross
  * this boundary. Every entry point returns a status (0 ok, <0 error) and the text
@@ -159,6 +160,37 @@ int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t c
 int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
                               size_t prev_stride, size_t pitch, int n_pairs, int8_t* dx, int8_t* dy, int8_t* mode);
 int mof_bm_sync(mof_bm_engine* e);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Scale / rotation estimator (scaleRotationEstimator, BASELINE config c5)                    */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct mof_sr_config {
+  int resolution;   /* side of the square image (scaleRotationEstimator.cpp:5): 240, 256 or 480       */
+  double magnitude; /* log-polar magnitude M (scale_rot_magnitude, config/default.yaml:13: 49.9)      */
+  int device;
+} mof_sr_config;
+
+typedef struct mof_sr_engine mof_sr_engine;
+
+/* scaleRotationEstimator::scaleRotationEstimator (scaleRotationEstimator.cpp:3-32). */
+int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out);
+void mof_sr_destroy(mof_sr_engine* e);
+/* Re-arms `first` and clears tempIm (scaleRotationEstimator.cpp:27, :31). */
+int mof_sr_reset(mof_sr_engine* e);
+
+/* scaleRotationEstimator::processImage (scaleRotationEstimator.cpp:34-148), synchronous. frame: resolution^2
+ * CV_8UC1. out_scale_rot[2] = (scale, rotation in rad): first call -> log-polar (INTER_CUBIC) kept as the previous
+ * image, returns (1, 0) (:36-74); later calls -> log-polar (INTER_LANCZOS4, :112), pt = cv::phaseCorrelate(current,
+ * previous) (:117), |pt.x| > resolution/2 -> (1, 0) without updating the previous image (:119-121), else
+ * scale = exp(pt.x / M), rot = (pt.y / (resolution/360)) * pi/180 (:123-124) and previous <- current (:128). */
+int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double* out_scale_rot);
+
+/* Batched mode on DEVICE pointers; each pair (prev, cur) is processed as the two-call sequence of a fresh estimator.
+ * d_cur / d_prev point at the top-left pixel of the resolution^2 crop inside each frame (pitch bytes per row).
+ * d_out receives n_pairs * 4 doubles: scale, rot, pt.x, pt.y. Asynchronous on `stream`. */
+int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                size_t prev_stride, size_t pitch, int n_pairs, double* d_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -201,6 +201,31 @@ class FastSpacedBMMethod : public BlockMatcherBase {
   }
 };
 
+// scaleRotationEstimator(resolution, m, storeVideo, videoPath, videoFPS) -- scaleRotationEstimator.cpp:3-32;
+// processImage returns (scale, rotation [rad]) as the reference's cv::Point2d(scale, rotat) (:126).
+class scaleRotationEstimator {
+ public:
+  scaleRotationEstimator(int res, double m, bool /*i_storeVideo*/ = false, std::string* /*videoPath*/ = nullptr,
+                         int /*videoFPS*/ = 0, int device = 0) {
+    mof_sr_config c{res, m, device};
+    detail::check(mof_sr_create(&c, &engine_), "mof_sr_create");
+    res_ = res;
+  }
+  ~scaleRotationEstimator() { mof_sr_destroy(engine_); }
+  scaleRotationEstimator(const scaleRotationEstimator&) = delete;
+  scaleRotationEstimator& operator=(const scaleRotationEstimator&) = delete;
+  Point2d processImage(ImageView imCurr, bool /*gui*/, bool /*debug*/) {
+    if (imCurr.rows != res_ || imCurr.cols != res_) throw std::runtime_error("scaleRotationEstimator: accepts only res x res images");
+    double out[2] = {1.0, 0.0};
+    detail::check(mof_sr_process(engine_, imCurr.data, imCurr.step, out), "mof_sr_process");
+    return Point2d{out[0], out[1]};
+  }
+
+ private:
+  mof_sr_engine* engine_ = nullptr;
+  int res_ = 0;
+};
+
 }  // namespace mof
 
 // ------------------------------------------------------------------------------------------------

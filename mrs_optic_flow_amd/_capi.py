@@ -38,6 +38,10 @@ class FftConfig(C.Structure):
                 ("stride_x", C.c_int), ("stride_y", C.c_int), ("max_px_speed", C.c_double), ("device", C.c_int)]
 
 
+class SrConfig(C.Structure):
+    _fields_ = [("resolution", C.c_int), ("magnitude", C.c_double), ("device", C.c_int)]
+
+
 class BmConfig(C.Structure):
     _fields_ = [("frame_width", C.c_int), ("frame_height", C.c_int), ("block_size", C.c_int),
                 ("step_size", C.c_int), ("scan_radius", C.c_int), ("grid_x", C.c_int), ("grid_y", C.c_int),
@@ -72,6 +76,11 @@ SYMBOLS = {
     "mof_bm_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP, _VP, _VP]),
     "mof_bm_process_batch_host": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP, _VP]),
     "mof_bm_sync": (_I, [_VP]),
+    "mof_sr_create": (_I, [C.POINTER(SrConfig), C.POINTER(_VP)]),
+    "mof_sr_destroy": (None, [_VP]),
+    "mof_sr_reset": (_I, [_VP]),
+    "mof_sr_process": (_I, [_VP, _VP, _SZ, _VP]),
+    "mof_sr_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
 }
 
 _lib = None

@@ -30,6 +30,21 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+
+namespace mof {
+// shared with mof_sr.hip: records the calling thread's last error text, returns `code`
+int capi_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace mof
+
+namespace {
+
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
     hipError_t _e = (expr);                                                                    \

@@ -47,4 +47,40 @@ bool bm_config_supported(int block, int radius);
 hipError_t launch_bm_scan(const BmArgs& a, int n_pairs, hipStream_t stream);
 hipError_t launch_bm_mode(const BmArgs& a, int n_pairs, hipStream_t stream);
 
+// ---- K4..K8: scale / rotation estimator (log-polar remap + whole-frame phase correlation) ----
+struct SrMapEntry {
+  int16_t ax, ay;   // anchor pixel (map coordinate >> 5), saturated to int16
+  uint16_t widx;    // (fy & 31) * 32 + (fx & 31): row of the 2-D weight table
+  uint16_t valid;   // anchor inside the source (BORDER_TRANSPARENT otherwise)
+};
+
+struct SrLpArgs {
+  const uint8_t* src;   // image i at src + i*src_stride, `pitch` bytes per row, res x res pixels
+  size_t src_stride, pitch;
+  uint8_t* dst;         // image i at dst + i*dst_stride, tightly packed res*res
+  size_t dst_stride;
+  const SrMapEntry* map;   // res*res
+  const int16_t* weights;  // [1024][K*K]
+  int res;
+};
+
+struct SrPcArgs {
+  const uint8_t* lp_cur;   // pair k at + k*lp_stride, res*res u8 each
+  const uint8_t* lp_prev;
+  size_t lp_stride;
+  const float* twiddles;   // res (cos, -sin) pairs
+  float* Z;                // scratch [pairs][res][res] complex
+  float* D;                // scratch [pairs][res][res/2+1] complex
+  float* S;                // scratch [pairs][res][res] real surface (un-shifted)
+  float2* cand;            // scratch [pairs][n_cand] (value, shifted index)
+  int n_cand;
+  double M;                // log-polar magnitude
+  double* out;             // [pairs][4] = scale, rot, pt.x, pt.y
+};
+
+bool sr_resolution_supported(int res);
+int sr_candidates(int res);
+hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp /*2 cubic, 4 lanczos4*/, int n_images, hipStream_t stream);
+hipError_t launch_sr_phase_correlate(const SrPcArgs& a, int res, int n_pairs, hipStream_t stream);
+
 }  // namespace mof

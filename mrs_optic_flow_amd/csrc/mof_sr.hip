@@ -1,0 +1,353 @@
+// mof_sr.hip -- host side of the scale/rotation estimator behind the C ABI (mof_sr_* in include/mof.h).
+//
+// Mirrors scaleRotationEstimator (/root/reference/src/scaleRotationEstimator.cpp:3-32 ctor, :34-148
+// processImage): state = the persistent log-polar image `tempIm` (:27), the previous log-polar image
+// `prevIm_F32` (:48, :128) and `first` (:31). What cv::logPolar / cv::remap would compute on the host for
+// every frame -- the float maps, their 1/32-px fixed-point form and the 2^15-scaled kernel tables -- depends
+// only on (resolution, M), so it is built ONCE here and kept on the device; per frame the GPU does one gather
+// (K4) and the whole-frame phase correlation (K5..K8). No CPU compute path.
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mof.h"
+#include "mof_kernels.h"
+
+namespace mof {
+int capi_fail(int code, const char* fmt, ...);  // mof_capi.hip: records the thread's last error
+}
+
+namespace {
+
+constexpr int kTab = 32;            // INTER_TAB_SIZE
+constexpr int kCoefScale = 1 << 15; // INTER_REMAP_COEF_SCALE
+constexpr int kChunk = 32;          // frame pairs per pipeline pass (keeps ~150 MB of scratch cache-resident)
+
+#define SR_TRY(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess) return mof::capi_fail(MOF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+void kernel_1d(int ksize, float x, float* c) {
+  if (ksize == 4) {  // bicubic, A = -0.75
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+    return;
+  }
+  // Lanczos4: sin(pi x) sin(pi x / 4) / (pi^2 x^2 / 4) evaluated through the angle-sum table OpenCV uses
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+  if (x < FLT_EPSILON) {
+    for (int i = 0; i < 8; ++i) c[i] = 0.f;
+    c[3] = 1.f;
+    return;
+  }
+  float sum = 0.f;
+  const double y0 = -(x + 3) * 3.14159265358979323846 * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+  for (int i = 0; i < 8; ++i) {
+    const double y = -(x + 3 - i) * 3.14159265358979323846 * 0.25;
+    c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    sum += c[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; ++i) c[i] *= sum;
+}
+
+// [fy][fx][ksize^2] fixed-point weights, each set corrected to sum to 2^15 on one of the four centre taps
+std::vector<int16_t> weight_table(int ksize) {
+  std::vector<float> t1((size_t)kTab * ksize);
+  for (int i = 0; i < kTab; ++i) kernel_1d(ksize, (float)i * (1.f / kTab), &t1[(size_t)i * ksize]);
+  std::vector<int16_t> tab((size_t)kTab * kTab * ksize * ksize);
+  for (int fy = 0; fy < kTab; ++fy)
+    for (int fx = 0; fx < kTab; ++fx) {
+      int16_t* w = &tab[((size_t)fy * kTab + fx) * ksize * ksize];
+      int isum = 0;
+      for (int r = 0; r < ksize; ++r)
+        for (int c = 0; c < ksize; ++c) {
+          long q = std::lrintf(t1[(size_t)fy * ksize + r] * t1[(size_t)fx * ksize + c] * (float)kCoefScale);
+          q = q > 32767 ? 32767 : (q < -32768 ? -32768 : q);
+          w[r * ksize + c] = (int16_t)q;
+          isum += (int)q;
+        }
+      if (isum != kCoefScale) {
+        const int diff = isum - kCoefScale, h = ksize / 2;
+        int big = h * ksize + h, small = h * ksize + h;
+        for (int r = h; r < h + 2; ++r)
+          for (int c = h; c < h + 2; ++c) {
+            const int i = r * ksize + c;
+            if (w[i] < w[small]) small = i;
+            else if (w[i] > w[big]) big = i;
+          }
+        if (diff < 0) w[big] = (int16_t)(w[big] - diff);
+        else w[small] = (int16_t)(w[small] - diff);
+      }
+    }
+  return tab;
+}
+
+// cv::logPolar's maps in remap's fixed-point form: x = (exp(rho/M) - 1) cos(phi) + cx (float), rows = phi
+std::vector<mof::SrMapEntry> logpolar_map(int res, double M) {
+  std::vector<mof::SrMapEntry> map((size_t)res * res);
+  std::vector<float> rhos((size_t)res);
+  for (int rho = 0; rho < res; ++rho) rhos[(size_t)rho] = (float)(std::exp((double)rho / M) - 1.0);
+  const float cx = (float)(res / 2), cy = (float)(res / 2);  // cv::Point2f(resolution / 2, resolution / 2)
+  const double kangle = 2.0 * 3.14159265358979323846 / (double)res;
+  for (int phi = 0; phi < res; ++phi) {
+    const double cp = std::cos(phi * kangle), sp = std::sin(phi * kangle);
+    for (int rho = 0; rho < res; ++rho) {
+      const double r = (double)rhos[(size_t)rho];
+      const float fx = (float)(r * cp + (double)cx) * (float)kTab, fy = (float)(r * sp + (double)cy) * (float)kTab;
+      mof::SrMapEntry e{0, 0, 0, 0};
+      if (std::fabs(fx) < 1.0e9f && std::fabs(fy) < 1.0e9f) {
+        const long ix = std::lrintf(fx), iy = std::lrintf(fy);
+        long ax = ix >> 5, ay = iy >> 5;
+        ax = ax > 32767 ? 32767 : (ax < -32768 ? -32768 : ax);
+        ay = ay > 32767 ? 32767 : (ay < -32768 ? -32768 : ay);
+        e.ax = (int16_t)ax;
+        e.ay = (int16_t)ay;
+        e.widx = (uint16_t)((iy & (kTab - 1)) * kTab + (ix & (kTab - 1)));
+        e.valid = (ax >= 0 && ax < res && ay >= 0 && ay < res) ? 1 : 0;
+      }
+      map[(size_t)phi * res + rho] = e;
+    }
+  }
+  return map;
+}
+
+struct BusyGuard {
+  std::atomic<bool>& flag;
+  bool owned;
+  explicit BusyGuard(std::atomic<bool>& f) : flag(f), owned(!f.exchange(true)) {}
+  ~BusyGuard() {
+    if (owned) flag.store(false);
+  }
+};
+
+}  // namespace
+
+struct mof_sr_engine {
+  mof_sr_config cfg{};
+  hipStream_t stream = nullptr;
+  mof::SrMapEntry* d_map = nullptr;
+  int16_t* d_w_cubic = nullptr;
+  int16_t* d_w_lanczos = nullptr;
+  float* d_twiddles = nullptr;
+  uint8_t* d_frame = nullptr;    // staging for the stateful path (res*res)
+  uint8_t* d_temp_im = nullptr;  // tempIm, :27
+  uint8_t* d_prev_lp = nullptr;  // prevIm_F32 (kept as the u8 image it was converted from)
+  uint8_t* d_lp = nullptr;       // batch: [kChunk][2][res*res] log-polar images (cur, prev)
+  float *d_Z = nullptr, *d_D = nullptr, *d_S = nullptr;
+  float2* d_cand = nullptr;
+  double* d_out = nullptr;       // [kChunk][4]
+  uint8_t* h_stage = nullptr;
+  double* h_out = nullptr;
+  bool first = true;             // :31
+  std::atomic<bool> busy{false};
+};
+
+extern "C" {
+
+void mof_sr_destroy(mof_sr_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  void* dev[] = {e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_twiddles, e->d_frame, e->d_temp_im, e->d_prev_lp,
+                 e->d_lp,  e->d_Z,       e->d_D,         e->d_S,        e->d_cand,  e->d_out};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
+  if (e->h_out) (void)hipHostFree(e->h_out);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) {
+  if (!out) return mof::capi_fail(MOF_ERR_BAD_ARG, "null out");
+  *out = nullptr;
+  if (!cfg || !(cfg->magnitude > 0.0)) return mof::capi_fail(MOF_ERR_BAD_ARG, "bad scale/rotation config");
+  if (!mof::sr_resolution_supported(cfg->resolution))
+    return mof::capi_fail(MOF_ERR_UNSUPPORTED, "resolution %d not supported by the HIP pipeline (240, 256, 480)", cfg->resolution);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return mof::capi_fail(MOF_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) return mof::capi_fail(MOF_ERR_BAD_ARG, "device %d out of range", cfg->device);
+  SR_TRY(hipSetDevice(cfg->device));
+  mof_sr_engine* e = new (std::nothrow) mof_sr_engine();
+  if (!e) return mof::capi_fail(MOF_ERR_NO_MEMORY, "out of host memory");
+  e->cfg = *cfg;
+  const int res = cfg->resolution;
+  const size_t nn = (size_t)res * res;
+  const std::vector<mof::SrMapEntry> map = logpolar_map(res, cfg->magnitude);
+  const std::vector<int16_t> wc = weight_table(4), wl = weight_table(8);
+  std::vector<float> tw(2 * (size_t)res);
+  for (int k = 0; k < res; ++k) {
+    double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)res;
+    double c = std::cos(ang), s = std::sin(ang);
+    if ((4 * k) % res == 0) {
+      const int q = (4 * k) / res;
+      c = (q == 0) ? 1.0 : (q == 2) ? -1.0 : 0.0;
+      s = (q == 1) ? -1.0 : (q == 3) ? 1.0 : 0.0;
+    }
+    tw[2 * (size_t)k] = (float)c;
+    tw[2 * (size_t)k + 1] = (float)s;
+  }
+#define CREATE_TRY(expr)                                                                  \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      mof::capi_fail(MOF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));                \
+      mof_sr_destroy(e);                                                                  \
+      return MOF_ERR_HIP;                                                                 \
+    }                                                                                     \
+  } while (0)
+  CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipMalloc(&e->d_map, map.size() * sizeof(mof::SrMapEntry)));
+  CREATE_TRY(hipMemcpy(e->d_map, map.data(), map.size() * sizeof(mof::SrMapEntry), hipMemcpyHostToDevice));
+  CREATE_TRY(hipMalloc(&e->d_w_cubic, wc.size() * sizeof(int16_t)));
+  CREATE_TRY(hipMemcpy(e->d_w_cubic, wc.data(), wc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  CREATE_TRY(hipMalloc(&e->d_w_lanczos, wl.size() * sizeof(int16_t)));
+  CREATE_TRY(hipMemcpy(e->d_w_lanczos, wl.data(), wl.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  CREATE_TRY(hipMalloc(&e->d_twiddles, tw.size() * sizeof(float)));
+  CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+  CREATE_TRY(hipMalloc(&e->d_frame, nn));
+  CREATE_TRY(hipMalloc(&e->d_temp_im, nn));
+  CREATE_TRY(hipMalloc(&e->d_prev_lp, nn));
+  CREATE_TRY(hipMemset(e->d_temp_im, 0, nn));  // tempIm = cv::Mat::zeros, :27
+  CREATE_TRY(hipMemset(e->d_prev_lp, 0, nn));
+  CREATE_TRY(hipMalloc(&e->d_lp, (size_t)kChunk * 2 * nn));
+  CREATE_TRY(hipMalloc(&e->d_Z, (size_t)kChunk * nn * 2 * sizeof(float)));
+  CREATE_TRY(hipMalloc(&e->d_D, (size_t)kChunk * res * (res / 2 + 1) * 2 * sizeof(float)));
+  CREATE_TRY(hipMalloc(&e->d_S, (size_t)kChunk * nn * sizeof(float)));
+  CREATE_TRY(hipMalloc(&e->d_cand, (size_t)kChunk * mof::sr_candidates(res) * sizeof(float2)));
+  CREATE_TRY(hipMalloc(&e->d_out, (size_t)kChunk * 4 * sizeof(double)));
+  CREATE_TRY(hipHostMalloc(&e->h_stage, nn, hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc(&e->h_out, 4 * sizeof(double), hipHostMallocDefault));
+#undef CREATE_TRY
+  *out = e;
+  return MOF_OK;
+}
+
+int mof_sr_reset(mof_sr_engine* e) {
+  if (!e) return mof::capi_fail(MOF_ERR_NOT_INIT, "null engine");
+  BusyGuard g(e->busy);
+  if (!g.owned) return mof::capi_fail(MOF_ERR_BUSY, "engine busy");
+  SR_TRY(hipSetDevice(e->cfg.device));
+  SR_TRY(hipMemsetAsync(e->d_temp_im, 0, (size_t)e->cfg.resolution * e->cfg.resolution, e->stream));
+  SR_TRY(hipStreamSynchronize(e->stream));
+  e->first = true;
+  return MOF_OK;
+}
+
+static mof::SrPcArgs pc_args(const mof_sr_engine* e, const uint8_t* lp_cur, const uint8_t* lp_prev, size_t lp_stride,
+                             double* out) {
+  mof::SrPcArgs a{};
+  a.lp_cur = lp_cur;
+  a.lp_prev = lp_prev;
+  a.lp_stride = lp_stride;
+  a.twiddles = e->d_twiddles;
+  a.Z = e->d_Z;
+  a.D = e->d_D;
+  a.S = e->d_S;
+  a.cand = e->d_cand;
+  a.n_cand = mof::sr_candidates(e->cfg.resolution);
+  a.M = e->cfg.magnitude;
+  a.out = out;
+  return a;
+}
+
+int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double* out_scale_rot) {
+  if (!e) return mof::capi_fail(MOF_ERR_NOT_INIT, "null engine");
+  const int res = e->cfg.resolution;
+  if (!frame || !out_scale_rot || pitch < (size_t)res) return mof::capi_fail(MOF_ERR_BAD_ARG, "bad frame/pitch/out");
+  BusyGuard g(e->busy);
+  if (!g.owned) return mof::capi_fail(MOF_ERR_BUSY, "engine busy");
+  SR_TRY(hipSetDevice(e->cfg.device));
+  const size_t nn = (size_t)res * res;
+  for (int y = 0; y < res; ++y) std::memcpy(e->h_stage + (size_t)y * res, frame + (size_t)y * pitch, (size_t)res);
+  SR_TRY(hipMemcpyAsync(e->d_frame, e->h_stage, nn, hipMemcpyHostToDevice, e->stream));
+  mof::SrLpArgs lp{};
+  lp.src = e->d_frame;
+  lp.src_stride = 0;
+  lp.pitch = (size_t)res;
+  lp.dst = e->d_temp_im;
+  lp.dst_stride = 0;
+  lp.map = e->d_map;
+  lp.res = res;
+  if (e->first) {
+    lp.weights = e->d_w_cubic;
+    SR_TRY(mof::launch_sr_logpolar(lp, 2, 1, e->stream));  // INTER_CUBIC, :45
+    SR_TRY(hipMemcpyAsync(e->d_prev_lp, e->d_temp_im, nn, hipMemcpyDeviceToDevice, e->stream));  // :48
+    SR_TRY(hipStreamSynchronize(e->stream));
+    e->first = false;  // :73
+    out_scale_rot[0] = 1.0;
+    out_scale_rot[1] = 0.0;  // :74
+    return MOF_OK;
+  }
+  lp.weights = e->d_w_lanczos;
+  SR_TRY(mof::launch_sr_logpolar(lp, 4, 1, e->stream));  // INTER_LANCZOS4, :112
+  mof::SrPcArgs a = pc_args(e, e->d_temp_im, e->d_prev_lp, 0, e->d_out);
+  SR_TRY(mof::launch_sr_phase_correlate(a, res, 1, e->stream));  // :117
+  SR_TRY(hipMemcpyAsync(e->h_out, e->d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  SR_TRY(hipStreamSynchronize(e->stream));
+  out_scale_rot[0] = e->h_out[0];
+  out_scale_rot[1] = e->h_out[1];
+  // the reference returns early on the gate, BEFORE prevIm_F32 = tempIm_F32.clone() (:119-121 vs :128)
+  if (!(std::fabs(e->h_out[2]) > (double)(res / 2))) {
+    SR_TRY(hipMemcpyAsync(e->d_prev_lp, e->d_temp_im, nn, hipMemcpyDeviceToDevice, e->stream));
+    SR_TRY(hipStreamSynchronize(e->stream));
+  }
+  return MOF_OK;
+}
+
+int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                size_t prev_stride, size_t pitch, int n_pairs, double* d_out, void* stream) {
+  if (!e) return mof::capi_fail(MOF_ERR_NOT_INIT, "null engine");
+  const int res = e->cfg.resolution;
+  if (!d_cur || !d_prev || !d_out || n_pairs < 0 || pitch < (size_t)res) return mof::capi_fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if (n_pairs == 0) return MOF_OK;
+  BusyGuard g(e->busy);
+  if (!g.owned) return mof::capi_fail(MOF_ERR_BUSY, "engine busy");
+  SR_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nn = (size_t)res * res;
+  for (int k0 = 0; k0 < n_pairs; k0 += kChunk) {
+    const int n = (n_pairs - k0 < kChunk) ? n_pairs - k0 : kChunk;
+    // every pair is the two-call sequence of a fresh estimator: prev -> INTER_CUBIC (:45), cur -> INTER_LANCZOS4
+    // (:112) onto the same zero-initialised tempIm (the transparent pixels are the same for both maps)
+    SR_TRY(hipMemsetAsync(e->d_lp, 0, (size_t)n * 2 * nn, s));
+    mof::SrLpArgs lp{};
+    lp.pitch = pitch;
+    lp.map = e->d_map;
+    lp.res = res;
+    lp.dst_stride = 2 * nn;
+    lp.src = d_prev + (size_t)k0 * prev_stride;
+    lp.src_stride = prev_stride;
+    lp.dst = e->d_lp + nn;
+    lp.weights = e->d_w_cubic;
+    SR_TRY(mof::launch_sr_logpolar(lp, 2, n, s));
+    lp.src = d_cur + (size_t)k0 * cur_stride;
+    lp.src_stride = cur_stride;
+    lp.dst = e->d_lp;
+    lp.weights = e->d_w_lanczos;
+    SR_TRY(mof::launch_sr_logpolar(lp, 4, n, s));
+    mof::SrPcArgs a = pc_args(e, e->d_lp, e->d_lp + nn, 2 * nn, d_out + 4 * (size_t)k0);
+    SR_TRY(mof::launch_sr_phase_correlate(a, res, n, s));
+  }
+  return MOF_OK;
+}
+
+}  // extern "C"

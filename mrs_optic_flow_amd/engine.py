@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import BmConfig, FftConfig, check
+from ._capi import BmConfig, FftConfig, SrConfig, check
 
 
 def _np_u8(frame) -> np.ndarray:
@@ -267,3 +267,51 @@ class FastSpacedBMMethod(_BmBase):
         h, w = frame_shape
         check(_capi.load().mof_bm_config_fast_spaced(C.byref(cfg), w, h, samplePointSize, stepSize, scanRadius))
         super().__init__(cfg, device)
+
+
+class ScaleRotationEstimator:
+    """scaleRotationEstimator(resolution, m, ...) -- /root/reference/src/scaleRotationEstimator.cpp:3-32; processImage
+    returns (scale, rotation [rad]) like :34-148."""
+
+    def __init__(self, resolution: int, m: float = 49.9, storeVideo: bool = False, videoPath=None, videoFPS: int = 30,
+                 device: int = 0):
+        self._lib = _capi.load()
+        self.cfg = SrConfig(resolution, float(m), device)
+        self._h = C.c_void_p()
+        check(self._lib.mof_sr_create(C.byref(self.cfg), C.byref(self._h)))
+
+    def reset(self) -> None:
+        check(self._lib.mof_sr_reset(self._h))
+
+    def processImage(self, imCurr, gui=False, debug=False):
+        f = _np_u8(imCurr)
+        if f.shape != (self.cfg.resolution, self.cfg.resolution):
+            raise ValueError("scaleRotationEstimator accepts only square images of its resolution")
+        out = np.zeros(2, np.float64)
+        check(self._lib.mof_sr_process(self._h, f.ctypes.data, f.strides[0], out.ctypes.data))
+        return float(out[0]), float(out[1])
+
+    def process_batch_device(self, cur, prev, stream=None):
+        """cur, prev: torch uint8 [n, res, res] views (any pitch/stride) -> float64 [n, 4] = scale, rot, pt.x, pt.y."""
+        import torch
+
+        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and cur.shape == prev.shape
+        assert cur.shape[1] == cur.shape[2] == self.cfg.resolution
+        assert cur.stride(2) == 1 and prev.stride(2) == 1 and cur.stride(1) == prev.stride(1)
+        n = cur.shape[0]
+        out = torch.empty((n, 4), dtype=torch.float64, device=cur.device)
+        s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        check(self._lib.mof_sr_process_batch_device(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
+                                                    prev.stride(0), cur.stride(1), n, out.data_ptr(), _stream_ptr(s)))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.mof_sr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

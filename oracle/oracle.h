@@ -80,6 +80,20 @@ int oracle_resize_quarter_u8(const uint8_t* src, size_t pitch, int w, int h, uin
 int oracle_fft_process_long_range_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch,
                                      const oracle_fft_layout* layout, int precision, double* out_xy, int* n_invalid);
 
+/* cv::logPolar(src, dst, Point2f(res/2, res/2), M, interp) on a res x res CV_8UC1 image, dst pre-existing
+ * (pixels mapped outside the source keep their content: BORDER_TRANSPARENT). interp: 2 = INTER_CUBIC,
+ * 4 = INTER_LANCZOS4. See lp_ref.c for the restated OpenCV semantics (unpinned). */
+int oracle_logpolar_u8(const uint8_t* src, size_t pitch, int res, double M, int interp, uint8_t* dst);
+
+/* scaleRotationEstimator::processImage (src/scaleRotationEstimator.cpp:34-148), one call:
+ * first != 0: temp_im <- logPolar(frame, INTER_CUBIC), prev_lp <- float(temp_im), out = (1, 0)      (:36-74)
+ * else: temp_im <- logPolar(frame, INTER_LANCZOS4) (:112); pt = cv::phaseCorrelate(cur_lp, prev_lp) (:117);
+ *       |pt.x| > res/2 -> (1, 0) (:119-121, pt.y is never checked); scale = exp(pt.x / M),
+ *       rot = (pt.y / Ky) * pi / 180 with Ky = res / 360 (:123-124, :26); prev_lp <- cur_lp (:128).
+ * temp_im (res*res u8) and prev_lp (res*res float) are the estimator's state; pt_xy (optional) gets pt. */
+int oracle_scale_rotation_step(const uint8_t* frame, size_t pitch, int res, double M, int first, uint8_t* temp_im,
+                               float* prev_lp, int precision, double* out_scale_rot, double* pt_xy);
+
 /* Block geometry shared by both block-matching paths.
  * BlockMethod (src/BlockMethod.cpp:11, :45): step=0, threshold off,
  *   grid = (fs-2r)/sps squared.

@@ -63,6 +63,11 @@ def lib():
         L.oracle_fft_process_long_range_u8.restype = C.c_int
         L.oracle_fft_process_long_range_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FftLayout), C.c_int,
                                                        C.c_void_p, C.POINTER(C.c_int)]
+        L.oracle_logpolar_u8.restype = C.c_int
+        L.oracle_logpolar_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.oracle_scale_rotation_step.restype = C.c_int
+        L.oracle_scale_rotation_step.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_bm_config_block_method.argtypes = [C.POINTER(BmConfig), C.c_int, C.c_int, C.c_int]
         L.oracle_bm_config_fast_spaced.argtypes = [C.POINTER(BmConfig), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.oracle_bm_process_u8.restype = C.c_int
@@ -146,6 +151,44 @@ def fft_process_long_range(cur: np.ndarray, prev: np.ndarray, layout: FftLayout,
     if rc:
         raise ValueError(f"oracle_fft_process_long_range_u8 rc={rc}")
     return out, ninv.value
+
+
+def logpolar(src: np.ndarray, M: float, interp: int, dst: np.ndarray | None = None) -> np.ndarray:
+    """cv::logPolar(src, dst, (res/2, res/2), M, interp) on a square uint8 image; dst is updated in place."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    res = src.shape[0]
+    assert src.shape == (res, res)
+    if dst is None:
+        dst = np.zeros((res, res), np.uint8)
+    assert dst.flags.c_contiguous and dst.dtype == np.uint8 and dst.shape == (res, res)
+    rc = lib().oracle_logpolar_u8(_ptr(src), res, res, float(M), int(interp), _ptr(dst))
+    if rc:
+        raise ValueError(f"oracle_logpolar_u8 rc={rc}")
+    return dst
+
+
+class ScaleRotationEstimator:
+    """scaleRotationEstimator restated (state: tempIm, prevIm_F32, first)."""
+
+    def __init__(self, res: int, M: float, precision: int = 32):
+        self.res, self.M, self.precision = res, float(M), precision
+        self.temp_im = np.zeros((res, res), np.uint8)
+        self.prev_lp = np.zeros((res, res), np.float32)
+        self.first = True
+        self.pt = (0.0, 0.0)
+
+    def processImage(self, frame: np.ndarray):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert frame.shape == (self.res, self.res)
+        out = np.zeros(2)
+        pt = np.zeros(2)
+        rc = lib().oracle_scale_rotation_step(_ptr(frame), self.res, self.res, self.M, int(self.first), _ptr(self.temp_im),
+                                              _ptr(self.prev_lp), self.precision, _ptr(out), _ptr(pt))
+        if rc:
+            raise ValueError(f"oracle_scale_rotation_step rc={rc}")
+        self.first = False
+        self.pt = (float(pt[0]), float(pt[1]))
+        return float(out[0]), float(out[1])
 
 
 def bm_config_block_method(frame_size, block, radius) -> BmConfig:
