@@ -112,6 +112,9 @@ def main() -> None:
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frame pairs per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus > 1 (nccl == RCCL; gloo only to rehearse several ranks on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -129,10 +132,15 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     B = wl["batch"]
     # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
@@ -162,19 +170,31 @@ def main() -> None:
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # the one collective of the batched-frames mode: all-gather of the flow vectors. With RCCL it is issued
+    # non-blocking and double-buffered, so it overlaps the next batch's kernels (it is ~1 MB per rank).
+    ag = None
+    if world > 1 and args.backend == "nccl" and wl["kind"] == "fft":
+        ag = sharding.AsyncGather((B, eng.n_patches, 2), torch.float64, dev, B * world)
 
     def step(i=None):
+        nonlocal out
+        if ag is not None:
+            out = ag.slot()
         if i is not None:
             ev0[i].record()
         res = launch()
         if i is not None:
             ev1[i].record()
-        if world > 1:  # the one collective of the batched-frames mode: gather of the flow vectors
+        if ag is not None:
+            return ag.submit()
+        if world > 1:
             res = sharding.gather_results(res, B * world)
         return res
 
     for _ in range(args.warmup):
         step()
+    if ag is not None:
+        ag.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -182,6 +202,8 @@ def main() -> None:
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    if ag is not None:
+        ag.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -51,6 +51,47 @@ def gather_results(local, n_pairs: int, group=None):
     return out[:n_pairs]
 
 
+class AsyncGather:
+    """Double-buffered, non-blocking gather for back-to-back batches: the all-gather of batch i (RCCL, its own
+    stream) overlaps the kernels of batch i+1; a buffer is waited for only right before it is reused."""
+
+    def __init__(self, shard_shape, dtype, device, n_pairs: int, group=None, depth: int = 2):
+        import torch
+        import torch.distributed as dist
+
+        self.group, self.n_pairs, self.depth = group, n_pairs, depth
+        self.world = dist.get_world_size(group)
+        self.per = -(-n_pairs // self.world)
+        assert shard_shape[0] == self.per, "AsyncGather needs equal shards (pad the last one)"
+        self.local = [torch.empty(shard_shape, dtype=dtype, device=device) for _ in range(depth)]
+        self.full = [torch.empty((self.world * self.per,) + tuple(shard_shape[1:]), dtype=dtype, device=device)
+                     for _ in range(depth)]
+        self.work = [None] * depth
+        self.i = 0
+
+    def slot(self):
+        """Local result buffer for the next batch (waits for the gather that last read it)."""
+        k = self.i % self.depth
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+        return self.local[k]
+
+    def submit(self):
+        import torch.distributed as dist
+
+        k = self.i % self.depth
+        self.work[k] = dist.all_gather_into_tensor(self.full[k], self.local[k], group=self.group, async_op=True)
+        self.i += 1
+        return self.full[k]
+
+    def drain(self):
+        for k in range(self.depth):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+
+
 def run_sharded(process_shard: Callable, n_pairs: int, rank: int, world: int, group=None):
     """``process_shard(lo, hi) -> tensor [hi-lo, ...]`` on this rank's shard, then gather."""
     lo, hi = shard_bounds(n_pairs, rank, world)
