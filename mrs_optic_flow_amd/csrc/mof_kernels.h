@@ -17,6 +17,8 @@ struct PcArgs {
   int grid_x, grid_y;     // patches per frame
   int origin_x, origin_y;
   int stride_x, stride_y;
+  int total;              // n_pairs * grid_x * grid_y (set by the launcher)
+  int stagger_div, stagger_units;  // start-up stagger of co-resident workgroups (set by the launcher)
   int downscale;          // 1, or 4 = long-range mode (quarter-resolution patches formed on the fly)
   double max_px_speed_sq; // FftMethod.cpp:1686
   const float* twiddles;  // device, N (cos, -sin) pairs, computed in double on the host

@@ -43,6 +43,9 @@ __device__ __forceinline__ void butterfly<4>(cf* v) {
 
 template <>
 __device__ __forceinline__ void butterfly<8>(cf* v) {
+#ifdef MOF_ABLATE_NOBFLY
+  return;  // diagnostic build: keeps the LDS traffic, drops the butterfly arithmetic
+#endif
   const float h = 0.70710678118654752440f;
   cf e[4] = {v[0], v[2], v[4], v[6]};
   cf o[4] = {v[1], v[3], v[5], v[7]};
@@ -135,20 +138,24 @@ __device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
   return {pr * s, pim * s};
 }
 
-// 5x5 weighted centroid in double + validity gate (:1337-1383, :1838-1856), executed by ONE wave: 25 lanes take
-// one window element each (`surface(ys, xs)` returns the fft-shifted correlation value), three fp64 sums are
-// reduced by shuffles, lane 0 stores (x, y) or (NaN, NaN).
+// 5x5 weighted centroid in double + validity gate (:1337-1383, :1838-1856), executed by ONE wave in two steps so
+// that the tile can be recycled in between: (1) 25 lanes fetch one window element each (`surface(ys, xs)` returns the
+// fft-shifted correlation value; 0 outside the clamped window), (2) three fp64 sums are reduced by shuffles and lane 0
+// stores (x, y) or (NaN, NaN).
 template <int N, class Surface>
-__device__ __forceinline__ void centroid_gate_store(Best best, int lane, double max_px_speed_sq, double* out, Surface surface) {
+__device__ __forceinline__ float centroid_window_value(Best best, int lane, Surface surface) {
   const int px = best.idx % N, py = best.idx / N;
   const int ys = py - 2 + lane / 5, xs = px - 2 + lane % 5;
-  double cx = 0.0, cy = 0.0, sum = 0.0;
-  if (lane < 25 && ys >= 0 && ys <= N - 1 && xs >= 0 && xs <= N - 1) {  // window clamped to the patch
-    const double val = (double)surface(ys, xs);
-    cx = (double)xs * val;
-    cy = (double)ys * val;
-    sum = val;
-  }
+  if (lane < 25 && ys >= 0 && ys <= N - 1 && xs >= 0 && xs <= N - 1) return surface(ys, xs);  // window clamped to the patch
+  return 0.f;
+}
+
+template <int N>
+__device__ __forceinline__ void centroid_gate_store(Best best, float wval, int lane, double max_px_speed_sq, double* out) {
+  const int px = best.idx % N, py = best.idx / N;
+  const int ys = py - 2 + lane / 5, xs = px - 2 + lane % 5;
+  const double val = (double)wval;  // 0 for lanes outside the window
+  double cx = (double)xs * val, cy = (double)ys * val, sum = val;
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) {
     cx += __shfl_xor(cx, off, 64);

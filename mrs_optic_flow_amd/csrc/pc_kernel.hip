@@ -113,7 +113,11 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
         cf a = lds_read(&z[zaddr<N>(line, x + k * R1)]);
+#ifdef MOF_ABLATE_NOBFLY
+        v[b][k] = a;
+#else
         v[b][k] = (k == 0) ? a : cmul(a, tw_row[k - 1]);
+#endif
       }
       butterfly<R2>(v[b]);
     }
@@ -162,7 +166,11 @@ __device__ __forceinline__ void col_pass_fwd(cf* __restrict__ z, int col0, int l
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
         cf a = lds_read(&z[zaddr<N>(x + k * R1, col)]);
+#ifdef MOF_ABLATE_NOBFLY
+        v[b][k] = a;
+#else
         v[b][k] = (k == 0) ? a : cmul(a, tw_col[k - 1]);
+#endif
       }
       butterfly<R2>(v[b]);
     }
@@ -227,7 +235,11 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
         cf a = lds_read(&z[zaddr<N>(x + k * R1, col)]);
+#ifdef MOF_ABLATE_NOBFLY
+        v[b][k] = a;
+#else
         v[b][k] = (k == 0) ? a : cmul(a, tw_col[k - 1]);
+#endif
       }
       butterfly<R2>(v[b]);
     }
@@ -259,21 +271,22 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   cf* z = reinterpret_cast<cf*>(smem);
   Best* red = reinterpret_cast<Best*>(z + N * P::PITCH);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
   const int patches = a.grid_x * a.grid_y;
-  const int pair = blockIdx.x / patches;
-  const int patch = blockIdx.x % patches;
-  const int pi = patch % a.grid_x, pj = patch / a.grid_x;
-  const int x0 = a.origin_x + pi * a.stride_x;
-  const int y0 = a.origin_y + pj * a.stride_y;
-  // (x0, y0) are in the units of the correlated image: full-res pixels, or quarter-res pixels when DS = 4
-  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(DS * y0) * a.pitch + DS * x0;
-  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(DS * y0) * a.pitch + DS * x0;
+  constexpr int CPR = N / 16;  // 16-pixel chunks per row
+  const int lrow = wave0 * LPW + lane0 / CPR, lcol = (lane0 % CPR) * 16;  // this lane's 16 pixels of the patch
+
+  // (x0, y0) of a patch are in the units of the correlated image: full-res pixels, or quarter-res when DS = 4
+  auto patch_base = [&](int p, const uint8_t* frames, size_t frame_stride) -> const uint8_t* {
+    const int pr = p / patches, pt = p % patches;
+    const int px0 = a.origin_x + (pt % a.grid_x) * a.stride_x, py0 = a.origin_y + (pt / a.grid_x) * a.stride_y;
+    return frames + (size_t)pr * frame_stride + (size_t)(DS * py0) * a.pitch + DS * px0;
+  };
 
   // twiddles of the second Stockham stage, W_N^{k x}: x = lane % R1 in row passes, lane / (64/R1) in column passes
   cf tw_row[R2 - 1], tw_col[R2 - 1];
   {
-    const int xr = lane % R1, xc = lane / (64 / R1);
+    const int xr = lane0 % R1, xc = lane0 / (64 / R1);
 #pragma unroll
     for (int k = 1; k < R2; ++k) {
       tw_row[k - 1] = {a.twiddles[2 * (k * xr)], a.twiddles[2 * (k * xr) + 1]};
@@ -281,24 +294,46 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
     }
   }
 
-  // ---- load: the wave's own LPW rows, 16 pixels per lane per image, u8 -> f32 (exact), z = cur + i*prev
-  //      (convertTo, :1805-1806)
+  // ---- persistent workgroup: patches p = blockIdx.x, + gridDim.x, ...; the 2 x 16 B of the NEXT patch are
+  //      requested from HBM before the current one is transformed, so the ~2 us load latency is off the critical path
+  uint32_t cw[4] = {0u, 0u, 0u, 0u}, pw[4] = {0u, 0u, 0u, 0u};
+  int p = blockIdx.x;
+  if (DS == 1 && p < a.total) {
+    __builtin_memcpy(cw, patch_base(p, a.cur, a.cur_stride) + (size_t)lrow * a.pitch + lcol, 16);
+    __builtin_memcpy(pw, patch_base(p, a.prev, a.prev_stride) + (size_t)lrow * a.pitch + lcol, 16);
+  }
+  // Co-resident workgroups would otherwise run the same phase at the same time (all of them LDS-bound, then all
+  // VALU-bound): delay the k-th workgroup of a CU by k quarter-patches so their phases interleave.
   {
-    constexpr int CPR = N / 16;  // 16-pixel chunks per row
+    const int slot = (blockIdx.x / a.stagger_div) & 3;
+    for (int i = 0; i < slot * a.stagger_units; ++i) __builtin_amdgcn_s_sleep(100);
+  }
+  for (; p < a.total; p += gridDim.x) {
+  // The lane / wave indices are laundered once per patch: otherwise LICM hoists every LDS address of the body out
+  // of the persistent loop (+70 VGPRs), which costs a whole workgroup of occupancy per CU.
+  int lane = lane0, wave = wave0;
+  asm volatile("" : "+v"(lane), "+v"(wave));
+  lane &= 63;             // give the value ranges back to the optimiser (they fold the skew and the
+  wave &= P::WAVES - 1;   // Hermitian row cases at compile time)
+  const int tid = wave * 64 + lane;
+  // ---- the wave's own LPW rows: u8 -> f32 (exact), z = cur + i*prev  (convertTo, :1805-1806)
+  {
     const int row = wave * LPW + lane / CPR, col = (lane % CPR) * 16;
     if constexpr (DS == 1) {
-      uint32_t cw[4], pw[4];
-      __builtin_memcpy(cw, cur + (size_t)row * a.pitch + col, 16);
-      __builtin_memcpy(pw, prev + (size_t)row * a.pitch + col, 16);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cw[q] >> (8 * b)) & 0xffu), (float)((pw[q] >> (8 * b)) & 0xffu)};
+      const int pn = p + gridDim.x;
+      if (pn < a.total) {
+        __builtin_memcpy(cw, patch_base(pn, a.cur, a.cur_stride) + (size_t)lrow * a.pitch + lcol, 16);
+        __builtin_memcpy(pw, patch_base(pn, a.prev, a.prev_stride) + (size_t)lrow * a.pitch + lcol, 16);
+      }
     } else {
       // pixel (row, col+i) <- (s(4r+1,4c+1) + s(4r+1,4c+2) + s(4r+2,4c+1) + s(4r+2,4c+2) + 2) >> 2 of the full-res frame
-      const uint8_t* c1 = cur + (size_t)(4 * row + 1) * a.pitch + 4 * col;
-      const uint8_t* p1 = prev + (size_t)(4 * row + 1) * a.pitch + 4 * col;
+      const uint8_t* c1 = patch_base(p, a.cur, a.cur_stride) + (size_t)(4 * row + 1) * a.pitch + 4 * col;
+      const uint8_t* p1 = patch_base(p, a.prev, a.prev_stride) + (size_t)(4 * row + 1) * a.pitch + 4 * col;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         uint32_t ca[4], cb[4], pa[4], pb[4];
@@ -318,15 +353,18 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   }
 
   // ---- forward 2-D transform of z: rows (wave-local), barrier, columns (wave-local)  (dft x2, :1491-1493)
+#ifndef MOF_ABLATE_NOFWD
   row_pass<N, LPW>(z, wave * LPW, lane, tw_row);
   __syncthreads();
   col_pass_fwd<N>(z, wave * LPW, lane, tw_col);
+#endif
   __syncthreads();
 
   // ---- untangle A = FFT(cur), B = FFT(prev); P = A conj(B); C = P|P| / (|P|^2 + eps)
   //      (mulSpectrums :1494, magSpectrums :70-168, divSpectrums :1086-1251, incl. the real-only-slot
   //      behaviour of :107-109 / :1127-1129). Only the half spectrum v < N/2 (+ row N/2 packed into the
   //      imaginary part of row 0) is kept, conjugated, for the Hermitian inverse.
+#ifndef MOF_ABLATE_NOPW
   {
     // rows 1..H-1: every u; partner (N-v, N-u) lies in the untouched lower half
     for (int g = tid; g < (H - 1) * N; g += T) {
@@ -345,14 +383,21 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       if (!self) z[zaddr<N>(0, um)] = {C0.x - CH.y, CH.x + C0.y};
     }
   }
+#endif
   __syncthreads();
 
   // ---- inverse (unscaled) of the Hermitian spectrum: forward transforms of conj(C); rows 0..H-1 only,
   //      then column pairs  (idft :1497)
+#ifndef MOF_ABLATE_NOINV
   if (wave < P::WI) row_pass<N, P::LI>(z, wave * P::LI, lane, tw_row);
+#endif
   __syncthreads();
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
+#ifndef MOF_ABLATE_NOINV
   if (wave < P::WI) best = col_pass_inv<N>(z, wave * P::LI, lane, tw_col);
+#else
+  best = Best{z[zaddr<N>(lane, wave)].x, lane * N + wave};
+#endif
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     Best o = {__shfl_xor(best.v, off, 64), __shfl_xor(best.idx, off, 64)};
@@ -361,15 +406,24 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   if (lane == 0) red[wave] = best;
   __syncthreads();
 
-  // ---- 5x5 weighted centroid in double + validity gate  (:1337-1383, :1838-1856), wave 0
+  // ---- 5x5 weighted centroid in double + validity gate  (:1337-1383, :1838-1856), wave 0. The window is read
+  //      before a second barrier releases the other waves to overwrite the tile with the next patch.
+  float wval = 0.f;
+#ifdef MOF_ABLATE_NOTAIL
+  if (wave == 0 && lane == 0) { a.out[2 * (size_t)p] = best.v; a.out[2 * (size_t)p + 1] = (double)best.idx; }
+  continue;
+#endif
   if (wave == 0) {
     for (int w = 1; w < P::WAVES; ++w) best = better(best, red[w]);
-    centroid_gate_store<N>(best, lane, a.max_px_speed_sq, a.out + 2 * ((size_t)pair * patches + patch), [&](int ys, int xs) {
+    wval = centroid_window_value<N>(best, lane, [&](int ys, int xs) {
       const int y = (ys + H) % N, x = (xs + H) % N;  // un-shifted position
       const cf s = z[zaddr<N>(y, x % H)];
       return x < H ? s.x : s.y;
     });
   }
+  __syncthreads();
+  if (wave == 0) centroid_gate_store<N>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p);
+  }  // persistent loop
 }
 
 // Diagnostic knob (occupancy experiments only): MOF_PC_EXTRA_LDS=<bytes> pads the dynamic LDS request.
@@ -390,10 +444,28 @@ static hipError_t configure_n() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PcTraits<N>::LDS_BYTES + extra_lds()));
 }
 
+static int g_cu_count = 0;  // set by pc_configure()
+
 template <int N>
-static hipError_t launch_n(const PcArgs& a, int n_pairs, hipStream_t stream) {
+static hipError_t launch_n(const PcArgs& a_in, int n_pairs, hipStream_t stream) {
   using Tr = PcTraits<N>;
-  const unsigned blocks = (unsigned)n_pairs * (unsigned)(a.grid_x * a.grid_y);
+  PcArgs a = a_in;
+  a.total = n_pairs * a.grid_x * a.grid_y;
+  a.stagger_div = g_cu_count > 0 ? g_cu_count : 256;
+  {
+    static const int units = [] { const char* e = getenv("MOF_PC_STAGGER"); return e ? atoi(e) : 0; }();
+    a.stagger_units = units;
+  }
+  // persistent grid: as many workgroups as are resident at once (LDS-limited), each loops over patches
+  const int per_cu = (int)((160u * 1024u) / (Tr::LDS_BYTES + extra_lds()));
+  int resident = (g_cu_count > 0 ? g_cu_count : 256) * (per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu));
+  // N = 128 (one 1024-thread workgroup per CU) gains from the persistent loop + prefetch (c4: +9 %); the small
+  // tiles run better as one workgroup per patch (c2: +6 %; the hardware dispatcher balances 4 workgroups per CU
+  // better than a static stride does). MOF_PC_PERSISTENT=0/1 overrides (diagnostics).
+  static const int force = [] { const char* e = getenv("MOF_PC_PERSISTENT"); return e ? atoi(e) : -1; }();
+  const bool persistent = force >= 0 ? force != 0 : (N >= 128);
+  if (!persistent) resident = a.total;
+  const unsigned blocks = (unsigned)(a.total < resident ? a.total : resident);
   if (a.downscale == 4)
     hipLaunchKernelGGL((pc_field_kernel<N, 4>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
   else
@@ -402,6 +474,9 @@ static hipError_t launch_n(const PcArgs& a, int n_pairs, hipStream_t stream) {
 }
 
 hipError_t pc_configure(int patch_size) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cu_count = prop.multiProcessorCount;
   switch (patch_size) {
     case 32: return configure_n<32>();
     case 64: return configure_n<64>();

@@ -331,11 +331,12 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
 
   if (wave == 0) {
     for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
-    centroid_gate_store<N>(best, lane, a.max_px_speed_sq, a.out + 2 * ((size_t)pair * patches + patch), [&](int ys, int xs) {
+    const float wval = centroid_window_value<N>(best, lane, [&](int ys, int xs) {
       const int y = (ys + H) % N, x = (xs + H) % N;
       const cf s = z[za(y, x % H)];
       return x < H ? s.x : s.y;
     });
+    centroid_gate_store<N>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * ((size_t)pair * patches + patch));
   }
 }
 
