@@ -12,7 +12,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for g in "${GROUPS_[@]}"; do
-  rocprofv3 --pmc $g --output-format csv -d $OUT/pmc_g$i -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/pmc_g$i.log 2>&1 || { tail -5 $OUT/pmc_g$i.log; exit 1; }
+  rocprofv3 --pmc $g --kernel-include-regex "mof::" --output-format csv -d $OUT/pmc_g$i -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/pmc_g$i.log 2>&1 || { tail -5 $OUT/pmc_g$i.log; exit 1; }
   i=$((i+1))
 done
 echo "pmc groups done: $i"
