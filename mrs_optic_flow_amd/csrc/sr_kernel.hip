@@ -160,11 +160,18 @@ __global__ void __launch_bounds__(256) sr_logpolar_kernel(SrLpArgs a) {
   const int sx = m.ax - HALF, sy = m.ay - HALF;
   int sum = 0;
   if (sx >= 0 && sy >= 0 && sx + K <= res && sy + K <= res) {
+    // interior footprint: one K-byte pixel load (any alignment) and one 2K-byte weight load (aligned) per tap row
 #pragma unroll
     for (int k1 = 0; k1 < K; ++k1) {
-      const uint8_t* row = src + (size_t)(sy + k1) * a.pitch + sx;
+      uint32_t px[K / 4], wq[K / 2];
+      __builtin_memcpy(px, src + (size_t)(sy + k1) * a.pitch + sx, K);
+      __builtin_memcpy(wq, __builtin_assume_aligned(w + k1 * K, 2 * K), 2 * K);
 #pragma unroll
-      for (int k2 = 0; k2 < K; ++k2) sum += (int)row[k2] * (int)w[k1 * K + k2];
+      for (int k2 = 0; k2 < K; ++k2) {
+        const int pv = (int)((px[k2 >> 2] >> (8 * (k2 & 3))) & 0xffu);
+        const int wv = (int)(int16_t)(wq[k2 >> 1] >> (16 * (k2 & 1)));
+        sum += pv * wv;
+      }
     }
   } else {
     for (int k1 = 0; k1 < K; ++k1) {
