@@ -39,6 +39,10 @@ WORKLOADS = {
     "c4": dict(kind="fft", h=1080, w=1920, n=128, grid=(16, 16), origin=(0, 0), stride=(119, 63), batch=1024, s=16,
                name="c4: FftMethod 1920x1080, 16x16 grid of 128x128 patches, batch=1024 frame pairs per GPU",
                bytes_per_pair=min(2 * 256 * 128 * 128, 2 * 1920 * 1080) + 256 * 8),
+    # the reference's own default geometry (config/default.yaml:31-32): 480x480 crop, 4x4 patches of 120x120
+    "ref": dict(kind="fft", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
+                name="ref: FftMethod 480x480, 4x4 grid of 120x120 patches (reference default.yaml), batch=1024 per GPU",
+                bytes_per_pair=2 * 480 * 480 + 16 * 8),
     # calibration of the FETCH_SIZE counter for this kernel's access pattern: the 64x64 patches tile the frame
     # exactly, every frame byte is read exactly once per launch -> known HBM read bytes = 2*512*512 per pair
     "cal": dict(kind="fft", h=512, w=512, n=64, grid=(8, 8), origin=(0, 0), stride=(64, 64), batch=1024, s=8,

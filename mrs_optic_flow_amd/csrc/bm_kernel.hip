@@ -188,7 +188,10 @@ __global__ void __launch_bounds__(256) bm_mode_kernel(BmArgs a) {
 template <int R>
 __global__ void __launch_bounds__(64) bm_scan16_kernel(BmArgs a, int strip_dwords, int bpw, int waves_per_row) {
   // ONE wave per workgroup: `bpw` consecutive blocks of one block row; no workgroup barrier anywhere.
-  constexpr int SPS = 16, D = 2 * R + 1, XG = (D + 3) / 4, WW = SPS + 2 * R;
+  // 2R+1 = 4*(R/2) + 1 x-shifts: R/2 lanes per block take four each through v_qsad, the last x-shift (2R) is
+  // shared out over the same lanes by y-shift and done with v_sad_u8 (same 1 byte-difference / lane / cycle rate)
+  static_assert(R % 2 == 0, "fast path needs an even scan radius");
+  constexpr int SPS = 16, D = 2 * R + 1, XG = R / 2, WW = SPS + 2 * R;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = threadIdx.x;
   const int S = SPS + a.step;
@@ -253,7 +256,6 @@ __global__ void __launch_bounds__(64) bm_scan16_kernel(BmArgs a, int strip_dword
   // complete once window row ys + 15 has been consumed: it is folded into the running first-minimum key
   // ((sad << 16) | row-major index) right away, so at most 16 accumulators are live.
   uint32_t kmin = 0xffffffffu, centre = 0;
-  const bool last_group = (xg == XG - 1);
   static_for<0, WW>([&](auto wy_c) {
     constexpr int wy = decltype(wy_c)::value;
     uint32_t w[5];
@@ -277,17 +279,25 @@ __global__ void __launch_bounds__(64) bm_scan16_kernel(BmArgs a, int strip_dword
       uint32_t k1 = (lo & 0xffff0000u) | (idx0 + 1u);
       uint32_t k2 = (hi << 16) | (idx0 + 2u);
       uint32_t k3 = (hi & 0xffff0000u) | (idx0 + 3u);
-      if (last_group) {  // x-shifts beyond 2r exist only in the last group of four
-        if (4 * (XG - 1) + 1 >= D) k1 = 0xffffffffu;
-        if (4 * (XG - 1) + 2 >= D) k2 = 0xffffffffu;
-        if (4 * (XG - 1) + 3 >= D) k3 = 0xffffffffu;
-      }
       kmin = min(kmin, min(min(k0, k1), min(k2, k3)));
       if constexpr (done == R) centre = (uint32_t)(acc[R] >> (16 * (R % 4))) & 0xffffu;
     }
     // keep the scheduler from hoisting every row's LDS reads to the top (it would spill ~130 VGPRs)
     __builtin_amdgcn_sched_barrier(0);
   });
+
+  // ---- the last x-shift (xs = 2R): lane xg of the block takes y-shifts xg, xg + XG, ...
+  for (int ys = xg; ys < D; ys += XG) {
+    uint32_t acc1 = 0;
+    const uint32_t* wcol = strip + (bc * S) / 4 + (2 * R) / 4 + ys * strip_dwords;
+#pragma unroll
+    for (int j = 0; j < SPS; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc1 = __builtin_amdgcn_sad_u8(wcol[j * strip_dwords + g], cb[j][g], acc1);
+    }
+    const uint32_t key = (acc1 << 16) | (uint32_t)(ys * D + 2 * R);
+    kmin = min(kmin, key);
+  }
 
   // ---- per block: first minimum over its XG lanes (wave-local through LDS), low-contrast rule, store
   keys[lane] = kmin;
@@ -313,7 +323,7 @@ __global__ void __launch_bounds__(64) bm_scan16_kernel(BmArgs a, int strip_dword
 
 template <int R>
 static void scan16_plan(const BmArgs& a, int* bpw, int* waves_per_row, int* strip_dwords, size_t* lds) {
-  constexpr int D = 2 * R + 1, XG = (D + 3) / 4, WW = 16 + 2 * R;
+  constexpr int XG = R / 2, WW = 16 + 2 * R;
   const int S = 16 + a.step;
   const int cap = 64 / XG;                                 // blocks a wave can hold
   *waves_per_row = (a.grid_x + cap - 1) / cap;

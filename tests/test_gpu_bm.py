@@ -111,3 +111,27 @@ def test_full_size_c3_batch_properties(gpu):
     for k in (11, 531):  # noisy pairs against the oracle
         wdx, wdy, wmode = O.bm_process(cur[k].cpu().numpy(), prev[k].cpu().numpy(), cfg)
         assert (dx[k] == wdx).all() and (dy[k] == wdy).all() and tuple(mode[k, :2]) == wmode
+
+
+def test_random_geometries_bit_exact(gpu):
+    """Seeded sweep over block sizes / steps / radii / frame sizes (fast 16x16 path and the generic kernel)."""
+    rng = np.random.default_rng(20261003)
+    for trial in range(14):
+        block = int(rng.choice([4, 8, 12, 16, 16, 16, 20, 32]))
+        radius = int(rng.choice([2, 5, 8, 8, 16, 16, 21])) if block != 16 else int(rng.choice([8, 16, 16, 5]))
+        step = int(rng.choice([0, 4, 8, 3])) if block != 16 else int(rng.choice([0, 4, 8, 12]))
+        gx, gy = int(rng.integers(1, 9)), int(rng.integers(1, 5))
+        S = block + step
+        w = gx * S + 2 * radius + int(rng.integers(0, S))  # reference grid maths: (w - 2r) / S = gx
+        h = gy * S + 2 * radius + int(rng.integers(0, S))
+        cur = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+        prev = np.roll(cur, (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), axis=(1, 2))
+        prev = np.clip(prev.astype(np.int32) + rng.integers(-6, 7, prev.shape), 0, 255).astype(np.uint8)
+        eng = FastSpacedBMMethod(block, radius, step, (h, w))
+        cfg = O.bm_config_fast_spaced(w, h, block, step, radius)
+        assert (eng.cfg.grid_x, eng.cfg.grid_y) == (cfg.grid_x, cfg.grid_y)
+        dx, dy, mode = eng.process_batch_host(cur, prev)
+        for k in range(2):
+            wdx, wdy, wmode = O.bm_process(cur[k], prev[k], cfg)
+            assert (dx[k] == wdx).all() and (dy[k] == wdy).all(), (trial, block, step, radius, w, h)
+            assert tuple(mode[k, :2]) == wmode
