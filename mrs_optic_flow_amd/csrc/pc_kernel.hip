@@ -48,9 +48,15 @@ template <>
 struct Cfg<64> {
   static constexpr int R1 = 8, R2 = 8, SK = 3, PITCH = 72;
 };
+#ifndef MOF_SK128
+#define MOF_SK128 4
+#endif
+#ifndef MOF_PITCH128
+#define MOF_PITCH128 136
+#endif
 template <>
 struct Cfg<128> {
-  static constexpr int R1 = 16, R2 = 8, SK = 4, PITCH = 136;
+  static constexpr int R1 = 16, R2 = 8, SK = MOF_SK128, PITCH = MOF_PITCH128;
 };
 
 }  // namespace
@@ -244,6 +250,14 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
       butterfly<R2>(v[b]);
     }
     wave_sync();
+    // lane-local first maximum in two steps (max value, then the smallest shifted index that attains it): half the
+    // instructions of a running (value, index) compare per candidate
+    float m = -__builtin_huge_valf();
+#pragma unroll
+    for (int b = 0; b < PER; ++b)
+#pragma unroll
+      for (int k = 0; k < R2; ++k) m = fmaxf(m, fmaxf(v[b][k].x, v[b][k].y));
+    int mi = 0x7fffffff;
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int col = col0 + lane % CW + CW * b, x = lane / CW;
@@ -251,11 +265,12 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
       for (int k = 0; k < R2; ++k) {
         const int y = x + k * R1;
         z[zaddr<N>(y, col)] = v[b][k];
-        const int ys = (y + H) % N;
-        best = better(best, Best{v[b][k].x, ys * N + col + H});  // column col      -> shifted col + H
-        best = better(best, Best{v[b][k].y, ys * N + col});      // column col + H  -> shifted col
+        const int base = ((y + H) % N) * N + col;
+        mi = min(mi, v[b][k].x == m ? base + H : 0x7fffffff);  // column col      -> shifted col + H
+        mi = min(mi, v[b][k].y == m ? base : 0x7fffffff);      // column col + H  -> shifted col
       }
     }
+    best = Best{m, mi};
   }
   return best;
 }
