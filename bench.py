@@ -43,6 +43,10 @@ WORKLOADS = {
     "ref": dict(kind="fft", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
                 name="ref: FftMethod 480x480, 4x4 grid of 120x120 patches (reference default.yaml), batch=1024 per GPU",
                 bytes_per_pair=2 * 480 * 480 + 16 * 8),
+    # c2 with the node's front end fused in: interleaved BGR8 frames, CV_RGB2GRAY inside the load
+    "c2bgr": dict(kind="fft", bgr=True, h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=512, s=8,
+                  name="c2bgr: c2 on interleaved BGR8 frames, CV_RGB2GRAY fused into the load, batch=512 per GPU",
+                  bytes_per_pair=3 * min(2 * 64 * 64 * 64, 2 * 752 * 480) + 64 * 8),
     # calibration of the FETCH_SIZE counter for this kernel's access pattern: the 64x64 patches tile the frame
     # exactly, every frame byte is read exactly once per launch -> known HBM read bytes = 2*512*512 per pair
     "cal": dict(kind="fft", h=512, w=512, n=64, grid=(8, 8), origin=(0, 0), stride=(64, 64), batch=1024, s=8,
@@ -162,6 +166,15 @@ def main() -> None:
                 eng.process_batch_device(cur, prev, out=out)
                 srout = sr.process_batch_device(cur_c, prev_c)
                 return torch.cat([out.reshape(B, -1), srout], dim=1)
+        elif wl.get("bgr"):
+            # synthetic colour frames: three different affine maps of the gray texture (data stays u8)
+            def colour(g):
+                g16 = g.to(torch.int16)
+                return torch.stack([g, (255 - g16 // 2).to(torch.uint8), (g16 * 3 // 4 + 20).to(torch.uint8)], dim=-1).contiguous()
+            cur3, prev3 = colour(cur), colour(prev)
+
+            def launch():
+                return eng.process_batch_device_bgr(cur3, prev3)
         else:
             def launch():
                 eng.process_batch_device(cur, prev, out=out)

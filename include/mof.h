@@ -110,6 +110,13 @@ int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_
  * the caller synchronises. The engine's stateful previous frame is not touched. */
 int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                  size_t prev_stride, size_t pitch, int n_pairs, double* d_out_xy, void* stream);
+/* Front-end fusion: the frames are interleaved BGR8 as the node receives them
+ * (cv_bridge::toCvCopy(msg, BGR8), optic_flow.cpp:1465) and cv::cvtColor(crop, gray, CV_RGB2GRAY) (:1622) -- applied to
+ * BGR data, i.e. gray = (B*4899 + G*9617 + R*1868 + 8192) >> 14 -- happens inside the kernel's load. d_cur / d_prev
+ * point at the first byte of the frame_width x frame_height crop (the cropping rectangle of :1609-1616), pitch is
+ * in BYTES (3 per pixel). Otherwise as mof_fft_process_batch_device. */
+int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                     size_t prev_stride, size_t pitch, int n_pairs, double* d_out_xy, void* stream);
 /* Same on HOST pointers (upload, run, download, synchronous). */
 int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
                                size_t prev_stride, size_t pitch, int n_pairs, double* out_xy);

@@ -235,6 +235,7 @@ static mof::PcArgs fft_args(const mof_fft_engine* e, const uint8_t* cur, size_t 
   a.stride_x = e->cfg.stride_x;
   a.stride_y = e->cfg.stride_y;
   a.downscale = 1;
+  a.channels = 1;
   a.max_px_speed_sq = e->cfg.max_px_speed * e->cfg.max_px_speed;  // pow(max_px_speed_t, 2), FftMethod.cpp:1686
   a.twiddles = e->d_twiddles;
   a.out = out;
@@ -368,6 +369,23 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
   if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
   HIP_TRY(hipSetDevice(e->cfg.device));
   mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
+  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
+  return MOF_OK;
+}
+
+int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                     size_t prev_stride, size_t pitch, int n_pairs, double* d_out_xy, void* stream) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!d_cur || !d_prev || !d_out_xy || n_pairs < 0 || pitch < 3 * (size_t)e->cfg.frame_width)
+    return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if (n_pairs == 0) return MOF_OK;
+  if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
+    return fail(MOF_ERR_BAD_ARG, "batch too large for one launch");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
+  a.channels = 3;
   HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }

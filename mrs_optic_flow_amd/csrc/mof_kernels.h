@@ -19,6 +19,7 @@ struct PcArgs {
   int stride_x, stride_y;
   int total;              // n_pairs * grid_x * grid_y (set by the launcher)
   int stagger_div, stagger_units;  // start-up stagger of co-resident workgroups (set by the launcher)
+  int channels;           // 1 = gray frames; 3 = interleaved BGR8, CV_RGB2GRAY fused into the load
   int downscale;          // 1, or 4 = long-range mode (quarter-resolution patches formed on the fly)
   double max_px_speed_sq; // FftMethod.cpp:1686
   const float* twiddles;  // device, N (cos, -sin) pairs, computed in double on the host

@@ -117,6 +117,32 @@ __device__ __forceinline__ Best better(Best a, Best b) {
 }
 
 
+// cv::cvtColor(.., CV_RGB2GRAY) on 8-bit data (fixed point, yuv_shift 14): gray = (c0*R2Y + c1*G2Y + c2*B2Y + 2^13) >> 14
+// with R2Y 4899, G2Y 9617, B2Y 1868. The node feeds it BGR8 data (optic_flow.cpp:1465 toCvCopy(BGR8), :1622
+// CV_RGB2GRAY), so the blue byte gets the red weight -- reproduced as is.
+__device__ __forceinline__ uint32_t rgb2gray_fixed(uint32_t c0, uint32_t c1, uint32_t c2) {
+  return (c0 * 4899u + c1 * 9617u + c2 * 1868u + 8192u) >> 14;
+}
+
+// 16 gray pixels from 48 interleaved bytes (12 dwords, any alignment)
+__device__ __forceinline__ void gray16_from_bgr48(const uint8_t* p, uint32_t* g /*[4] packed u8x4*/) {
+  uint32_t w[12];
+  __builtin_memcpy(w, p, 48);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t packed = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = 3 * (4 * q + b);  // byte index of pixel 4q+b
+      const uint32_t c0 = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+      const uint32_t c1 = (w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xffu;
+      const uint32_t c2 = (w[(i + 2) >> 2] >> (8 * ((i + 2) & 3))) & 0xffu;
+      packed |= rgb2gray_fixed(c0, c1, c2) << (8 * b);
+    }
+    g[q] = packed;
+  }
+}
+
 // One bin of the normalised cross-power spectrum from the packed transform Z = FFT(cur + i prev):
 //   A[k] = (Z[k] + conj(Z[-k]))/2 ; B[k] = (Z[k] - conj(Z[-k]))/(2i) ; P = A conj(B)        (mulSpectrums :1494)
 //   C = P |P| / (|P|^2 + eps)                                   (magSpectrums :70-168, divSpectrums :1086-1251)

@@ -278,8 +278,11 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
 // DS = 1: patches are read from the frames as they are. DS = 4: long-range mode -- every patch pixel is the
 // quarter-resolution pixel cv::resize(.., 1/4, 1/4, INTER_LINEAR) would produce (FftMethod.cpp:1931-1932), i.e.
 // the rounded mean of the 2x2 centre of a 4x4 cell, formed on the fly from the full-resolution frame.
-template <int N, int DS>
+// CH = 3: the frames are interleaved BGR8 and the CV_RGB2GRAY conversion of the node's front end
+// (optic_flow.cpp:1622) is fused into the load, so raw camera frames are read from HBM exactly once.
+template <int N, int DS, int CH>
 __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
+  static_assert(CH == 1 || (CH == 3 && DS == 1), "BGR front end only for the full-resolution path");
   using P = PcTraits<N>;
   constexpr int T = P::T, H = N / 2, R1 = P::R1, R2 = P::R2, LPW = P::LPW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   auto patch_base = [&](int p, const uint8_t* frames, size_t frame_stride) -> const uint8_t* {
     const int pr = p / patches, pt = p % patches;
     const int px0 = a.origin_x + (pt % a.grid_x) * a.stride_x, py0 = a.origin_y + (pt / a.grid_x) * a.stride_y;
-    return frames + (size_t)pr * frame_stride + (size_t)(DS * py0) * a.pitch + DS * px0;
+    return frames + (size_t)pr * frame_stride + (size_t)(DS * py0) * a.pitch + (size_t)(CH * DS * px0);
   };
 
   // twiddles of the second Stockham stage, W_N^{k x}: x = lane % R1 in row passes, lane / (64/R1) in column passes
@@ -313,10 +316,18 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   //      requested from HBM before the current one is transformed, so the ~2 us load latency is off the critical path
   uint32_t cw[4] = {0u, 0u, 0u, 0u}, pw[4] = {0u, 0u, 0u, 0u};
   int p = blockIdx.x;
-  if (DS == 1 && p < a.total) {
-    __builtin_memcpy(cw, patch_base(p, a.cur, a.cur_stride) + (size_t)lrow * a.pitch + lcol, 16);
-    __builtin_memcpy(pw, patch_base(p, a.prev, a.prev_stride) + (size_t)lrow * a.pitch + lcol, 16);
-  }
+  auto fetch16 = [&](int pp, uint32_t* c, uint32_t* q) {
+    const uint8_t* cs = patch_base(pp, a.cur, a.cur_stride) + (size_t)lrow * a.pitch + CH * lcol;
+    const uint8_t* ps = patch_base(pp, a.prev, a.prev_stride) + (size_t)lrow * a.pitch + CH * lcol;
+    if constexpr (CH == 1) {
+      __builtin_memcpy(c, cs, 16);
+      __builtin_memcpy(q, ps, 16);
+    } else {
+      gray16_from_bgr48(cs, c);
+      gray16_from_bgr48(ps, q);
+    }
+  };
+  if (DS == 1 && p < a.total) fetch16(p, cw, pw);
   // Co-resident workgroups would otherwise run the same phase at the same time (all of them LDS-bound, then all
   // VALU-bound): delay the k-th workgroup of a CU by k quarter-patches so their phases interleave.
   {
@@ -341,10 +352,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
         for (int b = 0; b < 4; ++b)
           z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cw[q] >> (8 * b)) & 0xffu), (float)((pw[q] >> (8 * b)) & 0xffu)};
       const int pn = p + gridDim.x;
-      if (pn < a.total) {
-        __builtin_memcpy(cw, patch_base(pn, a.cur, a.cur_stride) + (size_t)lrow * a.pitch + lcol, 16);
-        __builtin_memcpy(pw, patch_base(pn, a.prev, a.prev_stride) + (size_t)lrow * a.pitch + lcol, 16);
-      }
+      if (pn < a.total) fetch16(pn, cw, pw);
     } else {
       // pixel (row, col+i) <- (s(4r+1,4c+1) + s(4r+1,4c+2) + s(4r+2,4c+1) + s(4r+2,4c+2) + 2) >> 2 of the full-res frame
       const uint8_t* c1 = patch_base(p, a.cur, a.cur_stride) + (size_t)(4 * row + 1) * a.pitch + 4 * col;
@@ -393,9 +401,9 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       const int um = (N - u) % N;
       const bool self = (u == um);
       const cf C0 = cross_power(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
-      const cf CH = cross_power(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
-      z[zaddr<N>(0, u)] = {C0.x + CH.y, CH.x - C0.y};
-      if (!self) z[zaddr<N>(0, um)] = {C0.x - CH.y, CH.x + C0.y};
+      const cf Ch = cross_power(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
+      z[zaddr<N>(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
+      if (!self) z[zaddr<N>(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
     }
   }
 #endif
@@ -452,11 +460,15 @@ static size_t extra_lds() {
 
 template <int N>
 static hipError_t configure_n() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PcTraits<N>::LDS_BYTES + extra_lds()));
+  const int lds = (int)(PcTraits<N>::LDS_BYTES + extra_lds());
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 1, 1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 4>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PcTraits<N>::LDS_BYTES + extra_lds()));
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 1, 3>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 4, 1>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 static int g_cu_count = 0;  // set by pc_configure()
@@ -481,10 +493,13 @@ static hipError_t launch_n(const PcArgs& a_in, int n_pairs, hipStream_t stream) 
   const bool persistent = force >= 0 ? force != 0 : (N >= 128);
   if (!persistent) resident = a.total;
   const unsigned blocks = (unsigned)(a.total < resident ? a.total : resident);
+  if (a.downscale == 4 && a.channels == 3) return hipErrorInvalidValue;
   if (a.downscale == 4)
-    hipLaunchKernelGGL((pc_field_kernel<N, 4>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
+    hipLaunchKernelGGL((pc_field_kernel<N, 4, 1>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
+  else if (a.channels == 3)
+    hipLaunchKernelGGL((pc_field_kernel<N, 1, 3>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
   else
-    hipLaunchKernelGGL((pc_field_kernel<N, 1>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
+    hipLaunchKernelGGL((pc_field_kernel<N, 1, 1>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
   return hipGetLastError();
 }
 

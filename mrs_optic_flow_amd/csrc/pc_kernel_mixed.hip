@@ -240,7 +240,7 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
 
 }  // namespace
 
-template <int DS>
+template <int DS, int CH>
 __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* z = reinterpret_cast<cf*>(smem);
@@ -253,8 +253,8 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   const int pi = patch % a.grid_x, pj = patch / a.grid_x;
   const int x0 = a.origin_x + pi * a.stride_x;
   const int y0 = a.origin_y + pj * a.stride_y;
-  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(DS * y0) * a.pitch + DS * x0;
-  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(DS * y0) * a.pitch + DS * x0;
+  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(DS * y0) * a.pitch + (size_t)(CH * DS * x0);
+  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(DS * y0) * a.pitch + (size_t)(CH * DS * x0);
   const float* tw = a.twiddles;
 
   // ---- load: the wave's own 8 rows in 8-pixel chunks (15 per row), u8 -> f32, z = cur + i*prev (:1805-1806)
@@ -265,8 +265,20 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
       const int row = wave * LPW + q / (N / 8), col = (q % (N / 8)) * 8;
       uint32_t c[2], p[2];
       if constexpr (DS == 1) {
-        __builtin_memcpy(c, cur + (size_t)row * a.pitch + col, 8);
-        __builtin_memcpy(p, prev + (size_t)row * a.pitch + col, 8);
+        if constexpr (CH == 1) {
+          __builtin_memcpy(c, cur + (size_t)row * a.pitch + col, 8);
+          __builtin_memcpy(p, prev + (size_t)row * a.pitch + col, 8);
+        } else {  // BGR8 front end (optic_flow.cpp:1622): 8 pixels = 24 bytes
+          uint8_t cb[24], pb[24];
+          __builtin_memcpy(cb, cur + (size_t)row * a.pitch + 3 * col, 24);
+          __builtin_memcpy(pb, prev + (size_t)row * a.pitch + 3 * col, 24);
+          c[0] = c[1] = p[0] = p[1] = 0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            c[i >> 2] |= rgb2gray_fixed(cb[3 * i], cb[3 * i + 1], cb[3 * i + 2]) << (8 * (i & 3));
+            p[i >> 2] |= rgb2gray_fixed(pb[3 * i], pb[3 * i + 1], pb[3 * i + 2]) << (8 * (i & 3));
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           z[za(row, col + i)] = {(float)((c[i >> 2] >> (8 * (i & 3))) & 0xffu), (float)((p[i >> 2] >> (8 * (i & 3))) & 0xffu)};
@@ -310,9 +322,9 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
     const int um = (N - u) % N;
     const bool self = (u == um);
     const cf C0 = cross_power(z[za(0, u)], z[za(0, um)], self);
-    const cf CH = cross_power(z[za(H, u)], z[za(H, um)], self);
-    z[za(0, u)] = {C0.x + CH.y, CH.x - C0.y};
-    if (!self) z[za(0, um)] = {C0.x - CH.y, CH.x + C0.y};
+    const cf Ch = cross_power(z[za(H, u)], z[za(H, um)], self);
+    z[za(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
+    if (!self) z[za(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
   }
   __syncthreads();
 
@@ -341,19 +353,25 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
 }
 
 hipError_t pc_configure_120() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<1>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<1, 1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_120);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<4>),
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<1, 3>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_120);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<4, 1>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_120);
 }
 
 hipError_t launch_pc_field_120(const PcArgs& a, int n_pairs, hipStream_t stream) {
   const unsigned blocks = (unsigned)n_pairs * (unsigned)(a.grid_x * a.grid_y);
+  if (a.downscale == 4 && a.channels == 3) return hipErrorInvalidValue;
   if (a.downscale == 4)
-    hipLaunchKernelGGL((pc_field_kernel_120<4>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
+    hipLaunchKernelGGL((pc_field_kernel_120<4, 1>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
+  else if (a.channels == 3)
+    hipLaunchKernelGGL((pc_field_kernel_120<1, 3>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
   else
-    hipLaunchKernelGGL((pc_field_kernel_120<1>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
+    hipLaunchKernelGGL((pc_field_kernel_120<1, 1>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
   return hipGetLastError();
 }
 

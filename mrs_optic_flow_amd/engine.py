@@ -152,6 +152,23 @@ class FftMethod:
                                                      prev.stride(0), cur.stride(1), n, out.data_ptr(), _stream_ptr(s)))
         return out
 
+    def process_batch_device_bgr(self, cur, prev, stream=None):
+        """cur, prev: torch uint8 [n, H, W, 3] BGR8 views (crop of the camera frames; W-stride 3, any row pitch):
+        CV_RGB2GRAY (as the node applies it to BGR data) is fused into the kernel's load."""
+        import torch
+
+        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and cur.shape == prev.shape
+        assert cur.dim() == 4 and cur.shape[3] == 3 and cur.stride(3) == 1 and cur.stride(2) == 3
+        assert prev.stride(3) == 1 and prev.stride(2) == 3 and cur.stride(1) == prev.stride(1)
+        self._check_shape(cur[0, :, :, 0])
+        n = cur.shape[0]
+        out = torch.empty((n, self.n_patches, 2), dtype=torch.float64, device=cur.device)
+        s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        check(self._lib.mof_fft_process_batch_device_bgr(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
+                                                         prev.stride(0), cur.stride(1), n, out.data_ptr(),
+                                                         _stream_ptr(s)))
+        return out
+
     def _check_shape(self, f) -> None:
         if tuple(f.shape[-2:]) != (self.cfg.frame_height, self.cfg.frame_width):
             raise ValueError(f"frame is {tuple(f.shape[-2:])}, engine expects "

@@ -80,6 +80,11 @@ int oracle_resize_quarter_u8(const uint8_t* src, size_t pitch, int w, int h, uin
 int oracle_fft_process_long_range_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch,
                                      const oracle_fft_layout* layout, int precision, double* out_xy, int* n_invalid);
 
+/* cv::cvtColor(src, dst, CV_RGB2GRAY) on interleaved 8-bit 3-channel data, as the node's front end applies it to BGR8
+ * frames (/root/reference/src/optic_flow.cpp:1465, :1622): dst = (c0*4899 + c1*9617 + c2*1868 + 8192) >> 14
+ * (OpenCV's fixed-point RGB2Gray, yuv_shift 14; published algorithm, unpinned). dst is w*h, tightly packed. */
+int oracle_rgb2gray_u8(const uint8_t* src, size_t pitch_bytes, int w, int h, uint8_t* dst);
+
 /* cv::logPolar(src, dst, Point2f(res/2, res/2), M, interp) on a res x res CV_8UC1 image, dst pre-existing
  * (pixels mapped outside the source keep their content: BORDER_TRANSPARENT). interp: 2 = INTER_CUBIC,
  * 4 = INTER_LANCZOS4. See lp_ref.c for the restated OpenCV semantics (unpinned). */

@@ -123,4 +123,14 @@ int oracle_fft_process_long_range_u8(const uint8_t* cur, const uint8_t* prev, si
   return rc;
 }
 
+int oracle_rgb2gray_u8(const uint8_t* src, size_t pitch_bytes, int w, int h, uint8_t* dst) {
+  if (!src || !dst || w < 1 || h < 1) return -1;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const uint8_t* p = src + (size_t)y * pitch_bytes + 3 * (size_t)x;
+      dst[(size_t)y * w + x] = (uint8_t)((p[0] * 4899 + p[1] * 9617 + p[2] * 1868 + (1 << 13)) >> 14);
+    }
+  return 0;
+}
+
 const char* oracle_version(void) { return "mof-oracle 0.1 (parity unpinned: no reference fixtures, OpenCV absent)"; }

@@ -63,6 +63,8 @@ def lib():
         L.oracle_fft_process_long_range_u8.restype = C.c_int
         L.oracle_fft_process_long_range_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FftLayout), C.c_int,
                                                        C.c_void_p, C.POINTER(C.c_int)]
+        L.oracle_rgb2gray_u8.restype = C.c_int
+        L.oracle_rgb2gray_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.oracle_logpolar_u8.restype = C.c_int
         L.oracle_logpolar_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_void_p]
         L.oracle_scale_rotation_step.restype = C.c_int
@@ -151,6 +153,18 @@ def fft_process_long_range(cur: np.ndarray, prev: np.ndarray, layout: FftLayout,
     if rc:
         raise ValueError(f"oracle_fft_process_long_range_u8 rc={rc}")
     return out, ninv.value
+
+
+def rgb2gray(img: np.ndarray) -> np.ndarray:
+    """cv::cvtColor(img, CV_RGB2GRAY) on an [H, W, 3] uint8 array (whatever its channel order really is)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, c = img.shape
+    assert c == 3
+    out = np.zeros((h, w), np.uint8)
+    rc = lib().oracle_rgb2gray_u8(_ptr(img), 3 * w, w, h, _ptr(out))
+    if rc:
+        raise ValueError(f"oracle_rgb2gray_u8 rc={rc}")
+    return out
 
 
 def logpolar(src: np.ndarray, M: float, interp: int, dst: np.ndarray | None = None) -> np.ndarray:

@@ -219,3 +219,29 @@ def test_reference_default_geometry_480_120(gpu):
     cur = np.stack([np.roll(prev, (dy, dx), axis=(0, 1)) for dx, dy in shifts])
     got = FftMethod(n, n, 80.0).process_batch_host(cur, np.repeat(prev[None], 3, 0))[:, 0]
     assert np.allclose(got, np.array(shifts, float), rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize("n,fs", [(64, 256), (120, 240)])
+def test_bgr_front_end_fused_into_the_load(gpu, n, fs):
+    """BGR8 camera frames, crop at (xi, yi) and CV_RGB2GRAY (optic_flow.cpp:1609-1622) fused into K1."""
+    B, H, W, xi, yi = 3, fs + 17, fs + 40, 23, 9
+    rng = np.random.default_rng(77)
+    base = [synth.pair_np(60 + k, H, W, 3 + k, -2 * k) for k in range(B)]
+    # colour frames whose gray conversion is non-trivial: channels = texture scaled/offset differently + noise
+    def colour(g):
+        g = g.astype(np.int32)
+        ch = np.stack([g, 255 - g // 2, (g * 3 // 4 + 20)], axis=-1) + rng.integers(-2, 3, g.shape + (3,))
+        return np.clip(ch, 0, 255).astype(np.uint8)
+    cur = np.stack([colour(c) for c, _ in base])
+    prev = np.stack([colour(p) for _, p in base])
+    fm = FftMethod(fs, n, 80.0)
+    tc, tp = torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)
+    got = fm.process_batch_device_bgr(tc[:, yi:yi + fs, xi:xi + fs], tp[:, yi:yi + fs, xi:xi + fs]).cpu().numpy()
+    lay = O.fft_layout(fs, fs, n, fs // n, fs // n)
+    for k in range(B):
+        gc = O.rgb2gray(cur[k, yi:yi + fs, xi:xi + fs])
+        gp = O.rgb2gray(prev[k, yi:yi + fs, xi:xi + fs])
+        _compare(got[k], gc, gp, lay, f"bgr{k}")
+        # identical bits to running the gray path on the converted crop
+        ref = fm.process_batch_device(torch.from_numpy(gc[None]).to(gpu), torch.from_numpy(gp[None]).to(gpu)).cpu().numpy()[0]
+        assert np.array_equal(ref, got[k], equal_nan=True)

@@ -162,3 +162,12 @@ def test_long_range_quarter_resize_and_grid():
     assert np.array_equal(out, want)
     with pytest.raises(ValueError):  # sqNum < 4: sqNum_lr would be 0
         O.fft_process_long_range(cur[:256, :256], prev[:256, :256], O.fft_layout(256, 256, 128, 2, 2), 64)
+
+
+def test_rgb2gray_fixed_point():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (9, 13, 3), dtype=np.uint8)
+    g = O.rgb2gray(img)
+    c = img.astype(np.int64)
+    assert (g == ((c[..., 0] * 4899 + c[..., 1] * 9617 + c[..., 2] * 1868 + 8192) >> 14)).all()
+    assert (O.rgb2gray(np.full((2, 2, 3), 255, np.uint8)) == 255).all()  # the three weights sum to 2^14
