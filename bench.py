@@ -190,8 +190,12 @@ def main() -> None:
     # the one collective of the batched-frames mode: all-gather of the flow vectors. With RCCL it is issued
     # non-blocking and double-buffered, so it overlaps the next batch's kernels (it is ~1 MB per rank).
     ag = None
-    if world > 1 and args.backend == "nccl" and wl["kind"] == "fft":
-        ag = sharding.AsyncGather((B, eng.n_patches, 2), torch.float64, dev, B * world)
+    if world > 1 and args.backend == "nccl" and wl["kind"] == "fft" and not wl.get("bgr"):
+        try:
+            ag = sharding.AsyncGather((B, eng.n_patches, 2), torch.float64, dev, B * world)
+        except Exception as exc:  # fall back to the blocking gather rather than lose the run
+            print(f"[bench] async gather unavailable ({exc}); using the blocking all-gather", file=sys.stderr)
+            ag = None
 
     def step(i=None):
         nonlocal out
