@@ -344,9 +344,9 @@ int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_
                                             const uint8_t* d_prev, size_t prev_stride, size_t pitch, int n_pairs,
                                             double* d_out_xy, void* stream) {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_pairs == 0) return MOF_OK;  // an empty batch carries no pointers to check
   if (!d_cur || !d_prev || !d_out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
-  if (n_pairs == 0) return MOF_OK;
   BusyGuard g(e->busy);
   if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -360,9 +360,9 @@ int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_
 int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                  size_t prev_stride, size_t pitch, int n_pairs, double* d_out_xy, void* stream) {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_pairs == 0) return MOF_OK;  // an empty batch carries no pointers to check
   if (!d_cur || !d_prev || !d_out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
-  if (n_pairs == 0) return MOF_OK;
   if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
     return fail(MOF_ERR_BAD_ARG, "batch too large for one launch");
   BusyGuard g(e->busy);
@@ -376,9 +376,9 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
 int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                      size_t prev_stride, size_t pitch, int n_pairs, double* d_out_xy, void* stream) {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_pairs == 0) return MOF_OK;  // an empty batch carries no pointers to check
   if (!d_cur || !d_prev || !d_out_xy || n_pairs < 0 || pitch < 3 * (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
-  if (n_pairs == 0) return MOF_OK;
   if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
     return fail(MOF_ERR_BAD_ARG, "batch too large for one launch");
   BusyGuard g(e->busy);
@@ -393,9 +393,9 @@ int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, si
 int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
                                size_t prev_stride, size_t pitch, int n_pairs, double* out_xy) {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_pairs == 0) return MOF_OK;  // an empty batch carries no pointers to check
   if (!cur || !prev || !out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
-  if (n_pairs == 0) return MOF_OK;
   HIP_TRY(hipSetDevice(e->cfg.device));
   const size_t fb = e->frame_bytes, res = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
   uint8_t *d_c = nullptr, *d_p = nullptr;
@@ -604,9 +604,9 @@ int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t c
                                 size_t prev_stride, size_t pitch, int n_pairs, int8_t* d_dx, int8_t* d_dy,
                                 int8_t* d_mode, void* stream) {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_pairs == 0) return MOF_OK;  // an empty batch carries no pointers to check
   if (!d_cur || !d_prev || !d_dx || !d_dy || !d_mode || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
-  if (n_pairs == 0) return MOF_OK;
   if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
     return fail(MOF_ERR_BAD_ARG, "batch too large for one launch");
   BusyGuard g(e->busy);
@@ -622,9 +622,9 @@ int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t c
 int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
                               size_t prev_stride, size_t pitch, int n_pairs, int8_t* dx, int8_t* dy, int8_t* mode) {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_pairs == 0) return MOF_OK;  // an empty batch carries no pointers to check
   if (!cur || !prev || !dx || !dy || !mode || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
-  if (n_pairs == 0) return MOF_OK;
   HIP_TRY(hipSetDevice(e->cfg.device));
   const size_t fb = e->frame_bytes, nb = (size_t)e->cfg.grid_x * e->cfg.grid_y;
   std::vector<uint8_t> pc(fb * n_pairs), pp(fb * n_pairs);

@@ -125,7 +125,7 @@ class FftMethod:
         cur = np.ascontiguousarray(cur, dtype=np.uint8)
         prev = np.ascontiguousarray(prev, dtype=np.uint8)
         assert cur.shape == prev.shape and cur.ndim == 3
-        self._check_shape(cur[0])
+        self._check_shape(cur)
         n = cur.shape[0]
         out = np.empty((n, self.n_patches, 2), np.float64)
         fb = cur.shape[1] * cur.shape[2]
@@ -142,7 +142,7 @@ class FftMethod:
         assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and prev.is_cuda
         assert cur.dim() == 3 and cur.shape == prev.shape and cur.stride(2) == 1 and prev.stride(2) == 1
         assert cur.stride(1) == prev.stride(1)
-        self._check_shape(cur[0])
+        self._check_shape(cur)
         n = cur.shape[0]
         if out is None:
             out = torch.empty((n, self.n_patches, 2), dtype=torch.float64, device=cur.device)

@@ -245,3 +245,30 @@ def test_bgr_front_end_fused_into_the_load(gpu, n, fs):
         # identical bits to running the gray path on the converted crop
         ref = fm.process_batch_device(torch.from_numpy(gc[None]).to(gpu), torch.from_numpy(gp[None]).to(gpu)).cpu().numpy()[0]
         assert np.array_equal(ref, got[k], equal_nan=True)
+
+
+def test_edge_cases_and_error_paths(gpu):
+    """Empty batches, shape mismatches, unsupported geometry, engine reuse across many calls."""
+    from mrs_optic_flow_amd import MofError, _capi
+    import ctypes as C
+
+    fm = FftMethod(128, 64, 80.0)
+    empty = torch.zeros((0, 128, 128), dtype=torch.uint8, device=gpu)
+    assert fm.process_batch_device(empty, empty).shape == (0, 4, 2)
+    assert fm.process_batch_host(np.zeros((0, 128, 128), np.uint8), np.zeros((0, 128, 128), np.uint8)).shape == (0, 4, 2)
+    with pytest.raises(ValueError):
+        fm.processImage(np.zeros((64, 64), np.uint8))
+    with pytest.raises(MofError) as exc:
+        FftMethod(sample_point_size=48, frame_shape=(96, 96))  # 48 is not a supported patch size
+    assert exc.value.code == _capi.MOF_ERR_UNSUPPORTED
+    lib = _capi.load()
+    assert lib.mof_fft_process_batch_device(fm._h, None, 0, None, 0, 128, 1, None, None) == _capi.MOF_ERR_BAD_ARG
+    assert b"bad batch" in lib.mof_last_error()
+    # an engine is reusable: alternate stateful and batched calls, results stay those of a fresh engine
+    f = [synth.pair_np(70, 128, 128, 2 * t, t)[0] for t in range(3)]
+    fresh = FftMethod(128, 64, 80.0)
+    fresh.processImage(f[0]); want = fresh.processImage(f[1])
+    for _ in range(3):
+        fm.reset(); fm.processImage(f[0])
+        fm.process_batch_host(np.stack(f), np.stack(f[::-1]))
+        assert np.array_equal(fm.processImage(f[1]), want, equal_nan=True)
