@@ -150,17 +150,22 @@ __device__ __forceinline__ void gray16_from_bgr48(const uint8_t* p, uint32_t* g 
 // ONE hardware sqrt and ONE hardware reciprocal (1 ulp each): the IEEE divide/sqrt expansions were a fifth of the
 // kernel's VALU work for no effect at 1e-4 px.
 __device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
-  const float eps = 1.1920928955078125e-07f;  // FLT_EPSILON, :1117
-  const cf A = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
-  const cf B = {0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x)};
+  // Worked on 2A = Z[k] + conj(Z[-k]) and 2B = -i (Z[k] - conj(Z[-k])): P' = 2A conj(2B) = 4P, and
+  //   P |P| / (|P|^2 + eps)  ==  P' |P'| / (|P'|^2 + 16 eps)   exactly (powers of two), four multiplies fewer per bin.
+  const float eps16 = 16.f * 1.1920928955078125e-07f;  // 16 * FLT_EPSILON, :1117
+  const cf A = {zk.x + zm.x, zk.y - zm.y};
+  const cf B = {zk.y + zm.y, zm.x - zk.x};
   if (real_only) {
-    const float p = A.x * B.x;
-    return {p * __builtin_amdgcn_rcpf(p * p + eps), 0.f};
+    // P = A.x B.x / 4 ; C = P / (P^2 + eps) = 4 P' / (P'^2 + 16 eps)
+    const float p4 = A.x * B.x;
+    return {4.f * p4 * __builtin_amdgcn_rcpf(p4 * p4 + eps16), 0.f};
   }
   const float pr = A.x * B.x + A.y * B.y;
   const float pim = A.y * B.x - A.x * B.y;
   const float q = pr * pr + pim * pim;
-  const float s = __builtin_amdgcn_sqrtf(q) * __builtin_amdgcn_rcpf(q + eps);
+  // |P'|^2 >= 2^10: 16 eps / q < 2^-30 is below half an ulp of the unit-magnitude result, so C = P' rsq(q) (one
+  // transcendental); the general form only runs for (numerically) empty bins such as constant patches
+  const float s = (q >= 1024.f) ? __builtin_amdgcn_rsqf(q) : __builtin_amdgcn_sqrtf(q) * __builtin_amdgcn_rcpf(q + eps16);
   return {pr * s, pim * s};
 }
 

@@ -389,12 +389,27 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   //      imaginary part of row 0) is kept, conjugated, for the Hermitian inverse.
 #ifndef MOF_ABLATE_NOPW
   {
-    // rows 1..H-1: every u; partner (N-v, N-u) lies in the untouched lower half
-    for (int g = tid; g < (H - 1) * N; g += T) {
-      const int v = 1 + g / N, u = g % N;
-      const cf zk = z[zaddr<N>(v, u)], zm = z[zaddr<N>(N - v, (N - u) % N)];
-      const cf C = cross_power(zk, zm, false);
-      z[zaddr<N>(v, u)] = {C.x, -C.y};  // conj(C[v][u])
+    // rows 1..H-1: every u; partner (N-v, N-u) lies in the untouched lower half. Fixed trip count, so every
+    // address is a base plus a compile-time offset.
+    {
+      constexpr int UPW = (N < 64) ? N : 64;          // columns covered by one wave
+      constexpr int RPI = T / UPW;                     // rows covered per iteration
+      const int u = tid % UPW, vr = tid / UPW;
+      const int um = (N - u) % N;
+#pragma unroll
+      for (int i = 0; i < (H - 1 + RPI - 1) / RPI; ++i) {
+#pragma unroll
+        for (int uu = 0; uu < N / UPW; ++uu) {
+          const int v = 1 + vr + i * RPI;
+          if (v < H) {
+            const int uc = u + uu * UPW, umc = (N - uc) % N;
+            (void)um;
+            const cf zk = z[zaddr<N>(v, uc)], zm = z[zaddr<N>(N - v, umc)];
+            const cf C = cross_power(zk, zm, false);
+            z[zaddr<N>(v, uc)] = {C.x, -C.y};  // conj(C[v][u])
+          }
+        }
+      }
     }
     // rows 0 and H share row 0: G'[u] = conj(C[0][u]) + i conj(C[H][u]); partner of u is N-u in the same rows
     for (int u = tid; u <= H; u += T) {

@@ -136,8 +136,14 @@ __device__ __forceinline__ void lds_fft(cf* z, int nlines, const float* tw, int 
   }
 }
 
-constexpr int ROWS_L = 8;   // rows per workgroup in K5
-constexpr int COLS_CW = 4;  // columns (plus their mirrors) per workgroup in K6
+#ifndef MOF_SR_ROWS
+#define MOF_SR_ROWS 8
+#endif
+constexpr int ROWS_L = MOF_SR_ROWS;   // rows per workgroup in K5
+#ifndef MOF_SR_CW
+#define MOF_SR_CW 4
+#endif
+constexpr int COLS_CW = MOF_SR_CW;  // columns (plus their mirrors) per workgroup in K6
 constexpr int INV_L = 8;    // row PAIRS per workgroup in K7
 
 }  // namespace
