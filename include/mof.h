@@ -158,6 +158,13 @@ int mof_bm_reset(mof_bm_engine* e);
  * starts as zeros (BlockMethod.cpp:17-18) unless set_prev was called. */
 int mof_bm_process(mof_bm_engine* e, const uint8_t* frame, size_t pitch, int8_t* dx, int8_t* dy, int8_t* mode_xy);
 
+/* BlockMethod::Refine(imCurr, imPrev, fullpixFlow, passes) (BlockMethod.cpp:96-147) on the two frames of the LAST
+ * mof_bm_process call (the reference calls it with passes = 2 on the histogram mode, :79). faithful != 0 reproduces
+ * the reference literally -- the "previous" 2x image is resized from the CURRENT one (:110) -- while
+ * faithful == 0 resizes it from the previous frame; everything else (cv::resize x2 in OpenCV's 8-bit fixed point, the
+ * cut-out rectangles of :113-123, nine SADs, first minimum, offset / 2^passes) is the same. Synchronous. */
+int mof_bm_refine(mof_bm_engine* e, int fullpix_x, int fullpix_y, int passes, int faithful, double* out_xy);
+
 /* Batched mode on DEVICE pointers. d_dx, d_dy: n_pairs*grid_x*grid_y int8; d_mode: n_pairs*8 int8
  * = {modeX, modeY, 2nd X, 2nd Y, 3rd X, 3rd Y, 0, 0} (the TestDepth=3 list of
  * FastSpacedBMMethod_OCL.cpp:97 per axis). Asynchronous on `stream`. */

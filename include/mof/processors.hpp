@@ -158,17 +158,26 @@ class BlockMethod : public BlockMatcherBase {
   BlockMethod(int i_frameSize, int i_samplePointSize, int i_scanRadius, int /*i_scanDiameter*/ = 0, int /*i_scanCount*/ = 0,
               int /*i_stepSize*/ = 0, int device = 0)
       : BlockMatcherBase(make(i_frameSize, i_samplePointSize, i_scanRadius, device)) {}
-  // BlockMethod::processImage (BlockMethod.cpp:25-94): ONE vector = the per-axis histogram mode. The reference
-  // then runs Refine() (:79), whose second image is resized from the first; the integer mode is returned
-  // here un-refined.
+  enum RefineMode { kNoRefine = 0, kFaithful = 1, kRepaired = 2 };
+  // BlockMethod::processImage (BlockMethod.cpp:25-94): ONE vector = Refine(histogram mode, 2) (:79). kFaithful
+  // (default) reproduces Refine literally, including that its "previous" image is resized from the current one
+  // (SURVEY F9); kRepaired resizes it from the previous frame; kNoRefine returns the integer mode.
+  void setRefine(RefineMode m) { refine_ = m; }
   std::vector<Point2d> processImage(ImageView imCurr, bool /*gui*/, bool /*debug*/, Point2i /*midPoint_t*/,
                                     double /*yaw_angle*/, Point2d /*tiltCorr*/) {
     int8_t mode[2] = {0, 0};
     if (!run(imCurr, mode)) return {};
-    return {Point2d{(double)mode[0], (double)mode[1]}};
+    mode_ = Point2i{mode[0], mode[1]};
+    if (refine_ == kNoRefine) return {Point2d{(double)mode[0], (double)mode[1]}};
+    double r[2] = {0, 0};
+    detail::check(mof_bm_refine(engine_, mode[0], mode[1], 2, refine_ == kFaithful ? 1 : 0, r), "mof_bm_refine");
+    return {Point2d{r[0], r[1]}};
   }
+  Point2i mode() const { return mode_; }
 
  private:
+  RefineMode refine_ = kFaithful;
+  Point2i mode_{0, 0};
   static mof_bm_config make(int fs, int sps, int r, int device) {
     mof_bm_config c{};
     detail::check(mof_bm_config_block_method(&c, fs, sps, r), "BlockMethod geometry");

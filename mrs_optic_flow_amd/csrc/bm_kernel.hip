@@ -352,6 +352,84 @@ static bool fast16_ok(const BmArgs& a) {
   return lds <= 64 * 1024;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K9/K10: BlockMethod::Refine (/root/reference/src/BlockMethod.cpp:96-147)
+// K9: cv::resize(src, dst, 2x) for CV_8UC1, INTER_LINEAR, in OpenCV's fixed point (coefficients 512/1536 of 2048,
+//     vertical pass ((b*(S>>4))>>16 ... + 2) >> 2; weights reset at the left/right border, row indices clipped
+//     at the top/bottom) -- one thread per destination pixel, integer, bit-exact against the oracle.
+// K10: the nine SADs of one refinement pass between the cut-out of A at (1,1) and B at (spx+n, spy+m), n,m in
+//     {-1,0,1}: per-thread partial sums, wave shuffle + LDS reduction, one 64-bit atomic per workgroup and shift.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bm_resize2x_kernel(const uint8_t* __restrict__ src, size_t pitch, int w, int h,
+                                                          uint8_t* __restrict__ dst) {
+  const int dw = 2 * w, dh = 2 * h;
+  const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+  if (dx >= dw || dy >= dh) return;
+  int sx = (dx >> 1) - ((dx & 1) ? 0 : 1);
+  int a0 = (dx & 1) ? 1536 : 512, a1 = 2048 - a0;
+  if (sx < 0) { sx = 0; a0 = 2048; a1 = 0; }
+  int sx1 = sx + 1;
+  if (sx1 >= w) { sx = w - 1; sx1 = w - 1; a0 = 2048; a1 = 0; }
+  int sy = (dy >> 1) - ((dy & 1) ? 0 : 1);
+  const int b0 = (dy & 1) ? 1536 : 512, b1 = 2048 - b0;
+  int sy1 = sy + 1;
+  if (sy < 0) sy = 0;
+  if (sy1 > h - 1) sy1 = h - 1;
+  const uint8_t* r0 = src + (size_t)sy * pitch;
+  const uint8_t* r1 = src + (size_t)sy1 * pitch;
+  const int S0 = (int)r0[sx] * a0 + (int)r0[sx1] * a1;
+  const int S1 = (int)r1[sx] * a0 + (int)r1[sx1] * a1;
+  dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+}
+
+__global__ void __launch_bounds__(256) bm_refine_sad_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                            int W2, int spx, int spy, int cw, int ch,
+                                                            unsigned long long* __restrict__ out9) {
+  __shared__ unsigned int red[4][9];
+  const int tid = threadIdx.x;
+  unsigned int acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0;
+  // 16 cut-out rows per workgroup; a thread's partial sum stays below 2^32 (16 * ceil(cw/256) * 255)
+  const int y0 = blockIdx.x * 16;
+  for (int y = y0; y < y0 + 16 && y < ch; ++y) {
+    const uint8_t* a = A + (size_t)(1 + y) * W2 + 1;
+    for (int x = tid; x < cw; x += 256) {
+      const int av = a[x];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const uint8_t* b = B + (size_t)(spy + m - 1 + y) * W2 + spx - 1 + x;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          const int d = av - (int)b[n];
+          acc[m * 3 + n] += (unsigned int)(d < 0 ? -d : d);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    unsigned int v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (unsigned int)__shfl_xor((int)v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  if (tid < 9) atomicAdd(&out9[tid], (unsigned long long)red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+hipError_t launch_bm_resize2x(const uint8_t* src, size_t pitch, int w, int h, uint8_t* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(bm_resize2x_kernel, dim3((unsigned)((2 * w + 255) / 256), (unsigned)(2 * h)), dim3(256), 0, stream, src,
+                     pitch, w, h, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_bm_refine_sad(const uint8_t* A, const uint8_t* B, int W2, int spx, int spy, int cw, int ch,
+                                unsigned long long* out9, hipStream_t stream) {
+  hipLaunchKernelGGL(bm_refine_sad_kernel, dim3((unsigned)((ch + 15) / 16)), dim3(256), 0, stream, A, B, W2, spx, spy, cw, ch, out9);
+  return hipGetLastError();
+}
+
 bool bm_config_supported(int block, int radius) {
   return block >= 4 && block <= 64 && (block % 4) == 0 && radius >= 1 && radius <= 48;
 }

@@ -99,6 +99,11 @@ struct mof_bm_engine {
   int8_t* d_mode = nullptr;
   int8_t* h_res = nullptr;     // pinned: dx | dy | mode
   uint8_t* h_stage = nullptr;
+  // BlockMethod::Refine scratch (allocated on first use): the two 2x images, nine SADs
+  uint8_t* d_up[2] = {nullptr, nullptr};
+  unsigned long long* d_sad9 = nullptr;
+  unsigned long long* h_sad9 = nullptr;
+  bool have_pair = false;      // a processImage call has been made (both frame slots are meaningful)
   std::atomic<bool> busy{false};
 };
 
@@ -546,6 +551,10 @@ void mof_bm_destroy(mof_bm_engine* e) {
   if (e->d_mode) (void)hipFree(e->d_mode);
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
+  if (e->d_up[0]) (void)hipFree(e->d_up[0]);
+  if (e->d_up[1]) (void)hipFree(e->d_up[1]);
+  if (e->d_sad9) (void)hipFree(e->d_sad9);
+  if (e->h_sad9) (void)hipHostFree(e->h_sad9);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -597,6 +606,57 @@ int mof_bm_process(mof_bm_engine* e, const uint8_t* frame, size_t pitch, int8_t*
     mode_xy[1] = e->h_res[2 * nb + 1];
   }
   e->prev_slot = cur_slot;  // imPrev = imCurr.clone(), BlockMethod.cpp:89
+  e->have_pair = true;
+  return MOF_OK;
+}
+
+int mof_bm_refine(mof_bm_engine* e, int fullpix_x, int fullpix_y, int passes, int faithful, double* out_xy) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (!out_xy || passes < 1 || passes > 4) return fail(MOF_ERR_BAD_ARG, "bad refine arguments");
+  if (!e->have_pair) return fail(MOF_ERR_NOT_INIT, "mof_bm_refine needs a preceding mof_bm_process call");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int w = e->cfg.frame_width, h = e->cfg.frame_height, W2 = 2 * w, H2 = 2 * h;
+  if (!e->d_up[0]) {
+    HIP_TRY(hipMalloc(&e->d_up[0], (size_t)W2 * H2));
+    HIP_TRY(hipMalloc(&e->d_up[1], (size_t)W2 * H2));
+    HIP_TRY(hipMalloc(&e->d_sad9, 9 * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(&e->h_sad9, 9 * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  // after mof_bm_process the frame just processed sits in the "previous" slot, its predecessor in the other one
+  const uint8_t* cur = e->d_frames[e->prev_slot];
+  const uint8_t* prev = e->d_frames[1 - e->prev_slot];
+  int tx = fullpix_x, ty = fullpix_y, scale = 1;
+  for (int i = 1; i <= passes; ++i) {
+    scale *= 2;
+    tx *= 2;
+    ty *= 2;  // BlockMethod.cpp:106-107
+    if (i == 1) {
+      // :110-111 -- both images go to twice the ORIGINAL size; the reference resizes the "previous" one from the
+      // CURRENT image. Later passes resize to the same 2x size, i.e. copy.
+      HIP_TRY(mof::launch_bm_resize2x(cur, (size_t)w, w, h, e->d_up[0], e->stream));
+      HIP_TRY(mof::launch_bm_resize2x(faithful ? cur : prev, (size_t)w, w, h, e->d_up[1], e->stream));
+    }
+    int spx, spy;  // :113-121
+    if (tx < 0 && ty < 0) { spx = -tx + 1; spy = -ty + 1; }
+    else if (tx < 0 && ty >= 0) { spx = -tx + 1; spy = 1; }
+    else if (tx >= 0 && ty < 0) { spx = 1; spy = -ty + 1; }
+    else { spx = 1; spy = 1; }
+    const int cw = W2 - ((tx < 0 ? -tx : tx) + 2), ch = H2 - ((ty < 0 ? -ty : ty) + 2);  // :123
+    if (cw <= 0 || ch <= 0) return fail(MOF_ERR_BAD_ARG, "refine: offset (%d, %d) leaves no cut-out", tx, ty);
+    HIP_TRY(hipMemsetAsync(e->d_sad9, 0, 9 * sizeof(unsigned long long), e->stream));
+    HIP_TRY(mof::launch_bm_refine_sad(e->d_up[0], e->d_up[1], W2, spx, spy, cw, ch, e->d_sad9, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_sad9, e->d_sad9, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int best = 0;  // cv::minMaxLoc: first minimum, row-major over (m, n)  (:140)
+    for (int k = 1; k < 9; ++k)
+      if ((int)e->h_sad9[k] < (int)e->h_sad9[best]) best = k;  // absDiffsMatSubpix is CV_32S
+    tx += best % 3 - 1;
+    ty += best / 3 - 1;  // :142
+  }
+  out_xy[0] = (double)((float)tx / (float)scale);  // :144
+  out_xy[1] = (double)((float)ty / (float)scale);
   return MOF_OK;
 }
 

@@ -49,6 +49,10 @@ struct BmArgs {
 bool bm_config_supported(int block, int radius);
 hipError_t launch_bm_scan(const BmArgs& a, int n_pairs, hipStream_t stream);
 hipError_t launch_bm_mode(const BmArgs& a, int n_pairs, hipStream_t stream);
+// BlockMethod::Refine building blocks (K9 2x resize, K10 nine cut-out SADs)
+hipError_t launch_bm_resize2x(const uint8_t* src, size_t pitch, int w, int h, uint8_t* dst, hipStream_t stream);
+hipError_t launch_bm_refine_sad(const uint8_t* A, const uint8_t* B, int W2, int spx, int spy, int cw, int ch,
+                                unsigned long long* out9, hipStream_t stream);
 
 // ---- K4..K8: scale / rotation estimator (log-polar remap + whole-frame phase correlation) ----
 struct SrMapEntry {

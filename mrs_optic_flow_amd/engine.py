@@ -218,11 +218,19 @@ class _BmBase:
         g = (self.cfg.grid_y, self.cfg.grid_x)
         return dx.reshape(g), dy.reshape(g), (int(mode[0]), int(mode[1]))
 
-    def processImage(self, imCurr, gui=False, debug=False, midPoint=None, yaw_angle=0.0, tiltCorr=None):
-        """One output vector = the histogram mode, like both reference classes
-        (BlockMethod.cpp:75-92 before Refine; FastSpacedBMMethod_OCL.cpp:172-175)."""
+    def refine(self, fullpix, passes: int = 2, faithful: bool = True):
+        """BlockMethod::Refine on the frames of the last processImage/processBlocks call (BlockMethod.cpp:96-147)."""
+        out = np.zeros(2, np.float64)
+        check(self._lib.mof_bm_refine(self._h, int(fullpix[0]), int(fullpix[1]), passes, int(faithful), out.ctypes.data))
+        return float(out[0]), float(out[1])
+
+    def processImage(self, imCurr, gui=False, debug=False, midPoint=None, yaw_angle=0.0, tiltCorr=None, refine=None):
+        """One output vector. refine=None: the histogram mode (FastSpacedBMMethod_OCL.cpp:172-175; BlockMethod before
+        :79). refine="faithful"/"fixed": BlockMethod's full return value, Refine(mode, 2) (BlockMethod.cpp:79)."""
         _, _, mode = self.processBlocks(imCurr)
-        return np.array([[float(mode[0]), float(mode[1])]])
+        if refine is None:
+            return np.array([[float(mode[0]), float(mode[1])]])
+        return np.array([self.refine(mode, 2, refine == "faithful")])
 
     def process_batch_host(self, cur: np.ndarray, prev: np.ndarray):
         cur = np.ascontiguousarray(cur, dtype=np.uint8)

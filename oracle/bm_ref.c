@@ -132,3 +132,85 @@ int oracle_bm_histogram_top(const int8_t* d, int count, int radius, int depth, i
   for (int i = 0; i < depth; ++i) top[i] = (int8_t)idx[i];
   return 0;
 }
+
+int oracle_resize_2x_u8(const uint8_t* src, size_t pitch, int w, int h, uint8_t* dst) {
+  if (!src || !dst || w < 2 || h < 2) return -1;
+  const int dw = 2 * w, dh = 2 * h;
+  int* rows = (int*)malloc(sizeof(int) * (size_t)dw * 2);
+  if (!rows) return -2;
+  for (int dy = 0; dy < dh; ++dy) {
+    /* vertical taps: fy = dy/2 - 0.25 */
+    /* vertically OpenCV keeps the weights and clips the ROW INDICES (rows -1 and h read rows 0 and h-1) */
+    int sy = (dy >> 1) - ((dy & 1) ? 0 : 1);
+    const int b0 = (dy & 1) ? 1536 : 512, b1 = 2048 - b0;
+    int sy1 = sy + 1;
+    if (sy < 0) sy = 0;
+    if (sy1 > h - 1) sy1 = h - 1;
+    for (int t = 0; t < 2; ++t) {
+      const uint8_t* S = src + (size_t)(t ? sy1 : sy) * pitch;
+      int* D = rows + t * dw;
+      for (int dx = 0; dx < dw; ++dx) {
+        int sx = (dx >> 1) - ((dx & 1) ? 0 : 1);
+        int a0 = (dx & 1) ? 1536 : 512, a1 = 2048 - a0;
+        if (sx < 0) { sx = 0; a0 = 2048; a1 = 0; }
+        int sx1 = sx + 1;
+        if (sx1 >= w) { sx1 = w - 1; a0 = 2048; a1 = 0; sx = w - 1; }
+        D[dx] = S[sx] * a0 + S[sx1] * a1;
+      }
+    }
+    for (int dx = 0; dx < dw; ++dx)
+      dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (rows[dx] >> 4)) >> 16) + ((b1 * (rows[dw + dx] >> 4)) >> 16) + 2) >> 2);
+  }
+  free(rows);
+  return 0;
+}
+
+int oracle_bm_refine_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, int w, int h, int fullpix_x, int fullpix_y,
+                        int passes, int faithful, double* out_xy, int32_t* sads) {
+  if (!cur || !prev || !out_xy || passes < 1 || passes > 4) return -1;
+  const int W2 = 2 * w, H2 = 2 * h;
+  uint8_t* c2 = (uint8_t*)malloc((size_t)W2 * H2);
+  uint8_t* p2 = (uint8_t*)malloc((size_t)W2 * H2);
+  if (!c2 || !p2) { free(c2); free(p2); return -2; }
+  int tx = fullpix_x, ty = fullpix_y, scale = 1, rc = 0;
+  for (int i = 1; i <= passes && !rc; ++i) {
+    scale *= 2;
+    tx *= 2;
+    ty *= 2; /* :106-107 */
+    if (i == 1) {
+      /* :110-111 -- first pass: both are 2x up-samples (of the CURRENT image when faithful) */
+      oracle_resize_2x_u8(cur, pitch, w, h, c2);
+      if (faithful) memcpy(p2, c2, (size_t)W2 * H2);
+      else oracle_resize_2x_u8(prev, pitch, w, h, p2);
+    } /* later passes: resize to the same 2x size == copy; faithful: imPrev2x <- imCurr2x (already equal) */
+    int spx, spy; /* :113-121 */
+    if (tx < 0 && ty < 0) { spx = -tx + 1; spy = -ty + 1; }
+    else if (tx < 0 && ty >= 0) { spx = -tx + 1; spy = 1; }
+    else if (tx >= 0 && ty < 0) { spx = 1; spy = -ty + 1; }
+    else { spx = 1; spy = 1; }
+    const int cw = W2 - ((tx < 0 ? -tx : tx) + 2), ch = H2 - ((ty < 0 ? -ty : ty) + 2); /* :123 */
+    if (cw <= 0 || ch <= 0) { rc = -3; break; }
+    int32_t best = 0;
+    int bn = 0, bm = 0, first = 1;
+    for (int m = -1; m <= 1; ++m)
+      for (int n = -1; n <= 1; ++n) { /* :127-136; stored at (1+n, 1+m): row-major scan == this loop order */
+        int64_t acc = 0;
+        for (int y = 0; y < ch; ++y) {
+          const uint8_t* a = c2 + (size_t)(1 + y) * W2 + 1;
+          const uint8_t* b = p2 + (size_t)(spy + m + y) * W2 + spx + n;
+          for (int x = 0; x < cw; ++x) acc += a[x] > b[x] ? a[x] - b[x] : b[x] - a[x];
+        }
+        if (sads) sads[(i - 1) * 9 + (m + 1) * 3 + (n + 1)] = (int32_t)acc;
+        if (first || (int32_t)acc < best) { best = (int32_t)acc; bn = n; bm = m; first = 0; }
+      }
+    tx += bn;
+    ty += bm; /* :142 totalOffset + min_loc - (1,1) */
+  }
+  if (!rc) {
+    out_xy[0] = (double)((float)tx / (float)scale); /* :144 */
+    out_xy[1] = (double)((float)ty / (float)scale);
+  }
+  free(c2);
+  free(p2);
+  return rc;
+}

@@ -124,6 +124,24 @@ void oracle_bm_config_fast_spaced(oracle_bm_config* c, int width, int height, in
 int oracle_bm_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_bm_config* cfg,
                          int8_t* dx, int8_t* dy, int8_t* mode_xy, int32_t* sad_min, int32_t* sad_all);
 
+/* cv::resize(src, dst, Size(2w, 2h)) with the default INTER_LINEAR on CV_8UC1 (BlockMethod::Refine,
+ * src/BlockMethod.cpp:110-111): source coordinate of destination x is x/2 - 0.25, i.e. taps (k-1, k) weighted
+ * (1/4, 3/4) for x = 2k and (k, k+1) weighted (3/4, 1/4) for x = 2k+1, clamped at the borders; OpenCV's fixed point:
+ * horizontal sums with coefficients 512/1536 (of 2048), vertical ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+ * [published OpenCV algorithm, unpinned]. dst is 2h x 2w, tightly packed. */
+int oracle_resize_2x_u8(const uint8_t* src, size_t pitch, int w, int h, uint8_t* dst);
+
+/* BlockMethod::Refine(imCurr, imPrev, fullpixFlow, passes) -- src/BlockMethod.cpp:96-147 -- restated literally,
+ * including (faithful != 0) its two defects: the "previous" image of every pass is resized from the CURRENT one
+ * (:110) and non-negative offsets never move the previous-image cut-out (:116-123). With faithful == 0
+ * the previous image is resized from the previous image (the evident intent); everything else is unchanged.
+ * Per pass: both images are brought to twice the ORIGINAL size (:110-111; the second pass therefore copies), the
+ * offset is doubled, nine SADs between the cut-out of the current image at (1,1) and the previous image at
+ * startpoint + (n,m) are taken, and the first minimum moves the offset by (n,m). Returns offset / 2^passes in
+ * out_xy. Fails (-3) when a cut-out would be empty. */
+int oracle_bm_refine_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, int w, int h, int fullpix_x, int fullpix_y,
+                        int passes, int faithful, double* out_xy, int32_t* sads /* optional, passes*9 */);
+
 /* Histogram_C1_D0 top-TestDepth output (src/FastSpacedBMMethod.cl:155-167):
  * sorted shift indices per axis (stable descending by count), first `depth`. */
 int oracle_bm_histogram_top(const int8_t* d, int count, int radius, int depth, int8_t* top);

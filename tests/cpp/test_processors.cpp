@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
       for (int t = 0; t < n; ++t) {
         auto v = proc.processImage(mof::ImageView{frames.data() + (size_t)t * fs * fs, fs, fs, (size_t)fs}, false, false,
                                    mof::Point2i{fs / 2, fs / 2}, 0.0, mof::Point2d{0, 0});
-        std::printf("frame %d mode %g %g blocks", t, v.at(0).x, v.at(0).y);
+        std::printf("frame %d mode %d %d refined %.9g %.9g blocks", t, proc.mode().x, proc.mode().y, v.at(0).x, v.at(0).y);
         for (size_t b = 0; b < proc.flowX().size(); ++b) std::printf(" %d %d", proc.flowX()[b], proc.flowY()[b]);
         std::printf("\n");
       }

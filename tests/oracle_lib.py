@@ -75,6 +75,11 @@ def lib():
         L.oracle_bm_process_u8.restype = C.c_int
         L.oracle_bm_process_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(BmConfig),
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_resize_2x_u8.restype = C.c_int
+        L.oracle_resize_2x_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_bm_refine_u8.restype = C.c_int
+        L.oracle_bm_refine_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_bm_histogram_top.restype = C.c_int
         L.oracle_bm_histogram_top.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_version.restype = C.c_char_p
@@ -243,3 +248,27 @@ def bm_histogram_top(d: np.ndarray, radius: int, depth: int = 3) -> np.ndarray:
     if rc:
         raise ValueError(f"oracle_bm_histogram_top rc={rc}")
     return top
+
+
+def resize_2x(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros((2 * h, 2 * w), np.uint8)
+    rc = lib().oracle_resize_2x_u8(_ptr(img), w, w, h, _ptr(out))
+    if rc:
+        raise ValueError(f"oracle_resize_2x_u8 rc={rc}")
+    return out
+
+
+def bm_refine(cur: np.ndarray, prev: np.ndarray, fullpix, passes: int = 2, faithful: bool = True, want_sads: bool = False):
+    """BlockMethod::Refine restated -> (x, y)[, sads[passes, 3, 3]]."""
+    cur = np.ascontiguousarray(cur, dtype=np.uint8)
+    prev = np.ascontiguousarray(prev, dtype=np.uint8)
+    h, w = cur.shape
+    out = np.zeros(2)
+    sads = np.zeros((passes, 3, 3), np.int32)
+    rc = lib().oracle_bm_refine_u8(_ptr(cur), _ptr(prev), w, w, h, int(fullpix[0]), int(fullpix[1]), passes, int(faithful),
+                                   _ptr(out), _ptr(sads))
+    if rc:
+        raise ValueError(f"oracle_bm_refine_u8 rc={rc}")
+    return ((float(out[0]), float(out[1])), sads) if want_sads else (float(out[0]), float(out[1]))

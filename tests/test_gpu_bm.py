@@ -135,3 +135,20 @@ def test_random_geometries_bit_exact(gpu):
             wdx, wdy, wmode = O.bm_process(cur[k], prev[k], cfg)
             assert (dx[k] == wdx).all() and (dy[k] == wdy).all(), (trial, block, step, radius, w, h)
             assert tuple(mode[k, :2]) == wmode
+
+
+def test_refine_matches_oracle(gpu):
+    """mof_bm_refine (BlockMethod::Refine, faithful and repaired) on the frames of the last processImage call."""
+    fs = 144
+    seq = [synth.pair_np(81, fs, fs, -3 * t, 2 * t)[0] for t in range(3)]
+    eng = BlockMethod(fs, 32, 8)
+    eng.processBlocks(seq[0])
+    for t in (1, 2):
+        dx, dy, mode = eng.processBlocks(seq[t])
+        for faithful in (True, False):
+            for fp in (mode, (0, 0), (-2, -1), (3, -4)):
+                want = O.bm_refine(seq[t], seq[t - 1], fp, 2, faithful)
+                assert eng.refine(fp, 2, faithful) == want, (t, faithful, fp)
+    from mrs_optic_flow_amd import MofError
+    with pytest.raises(MofError):
+        eng.refine((400, 0))

@@ -43,8 +43,10 @@ def test_block_method_sequence(gpu, tmp_path):
     prev = np.zeros((fs, fs), np.uint8)  # BlockMethod.cpp:17-18
     for t, tok in enumerate(lines):
         dx, dy, mode = O.bm_process(frames[t], prev, cfg)
-        assert (float(tok[3]), float(tok[4])) == mode
-        got = np.array([int(v) for v in tok[6:]]).reshape(-1, 2)
+        assert (int(tok[3]), int(tok[4])) == mode
+        # BlockMethod::processImage returns Refine(mode, 2) (BlockMethod.cpp:79), reproduced literally by default
+        assert (float(tok[6]), float(tok[7])) == O.bm_refine(frames[t], prev, mode, 2, True)
+        got = np.array([int(v) for v in tok[9:]]).reshape(-1, 2)
         assert (got[:, 0] == dx.ravel()).all() and (got[:, 1] == dy.ravel()).all()
         prev = frames[t]
 

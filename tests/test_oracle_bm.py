@@ -101,3 +101,34 @@ def test_golden_vectors_reproduce():
         for k in range(g["cur"].shape[0]):
             dx, dy, mode = O.bm_process(g["cur"][k], g["prev"][k], cfg)
             assert (dx == g["dx"][k]).all() and (dy == g["dy"][k]).all() and mode == tuple(g["mode"][k])
+
+
+def test_resize_2x_fixed_point():
+    """cv::resize x2 (INTER_LINEAR, CV_8UC1): interior = (1/4, 3/4) taps in both axes, borders replicate."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (7, 9), dtype=np.uint8)
+    up = O.resize_2x(img)
+    assert up.shape == (14, 18)
+    f = img.astype(np.float64)
+    # interior destination (2k, 2l): 1/16 * (a(k-1,l-1) + 3 a(k-1,l) + 3 a(k,l-1) + 9 a(k,l)), within fixed-point rounding
+    for k, l in [(2, 3), (4, 5), (1, 1)]:
+        ref = (f[k - 1, l - 1] + 3 * f[k - 1, l] + 3 * f[k, l - 1] + 9 * f[k, l]) / 16
+        assert abs(float(up[2 * k, 2 * l]) - ref) <= 1.0
+    assert up[0, 0] == img[0, 0] and up[-1, -1] == img[-1, -1]        # corners replicate
+    assert (O.resize_2x(np.full((5, 5), 200, np.uint8)) == 200).all()  # weights sum to one
+
+
+def test_refine_follows_the_reference_text():
+    """BlockMethod::Refine, literally (BlockMethod.cpp:96-147): with the F9 defect both 2x images are the current
+    frame, so a non-negative offset is returned unchanged while a negative one drifts."""
+    cur, prev = synth.pair_np(13, 96, 96, 3, -2)
+    assert O.bm_refine(cur, prev, (0, 0), 2, True) == (0.0, 0.0)
+    assert O.bm_refine(cur, prev, (2, 3), 2, True) == (2.0, 3.0)
+    (x, y), sads = O.bm_refine(cur, prev, (-3, 2), 2, True, want_sads=True)
+    # a negative offset shifts the cut-out of the (self-)"previous" image: every candidate compares the image with a
+    # shifted copy of itself and the offset drifts (known answer of this restatement)
+    assert (x, y) == (-3.25, 1.75) and sads.shape == (2, 3, 3) and sads[0, 1, 1] > 0
+    # repaired variant: previous image really is the previous frame; identical frames refine to exactly zero offset
+    assert O.bm_refine(cur, cur, (0, 0), 2, False) == (0.0, 0.0)
+    with pytest.raises(ValueError):
+        O.bm_refine(cur, prev, (200, 0), 2, True)  # cut-out would be empty
