@@ -58,6 +58,10 @@ WORKLOADS = {
                     "phase correlation), 752x480, batch=1024 frame pairs per GPU",
                # 2*W*H u8 in + flow vectors + (scale, rot)
                bytes_per_pair=2 * 752 * 480 + 64 * 8 + 8),
+    # BASELINE c1 geometry (the CPU plumbing config) on the GPU: BlockMethod, 272x272 crop, 8x8 blocks of 32x32, +-8 px
+    "c1": dict(kind="bm", block_method=True, h=272, w=272, block=32, step=0, radius=8, batch=1024, s=6,
+               name="c1: BlockMethod 272x272 crop, 8x8 grid of 32x32 blocks, scanRadius=8, batch=1024 per GPU",
+               bytes_per_pair=65536 + 73984 + 130),
     "c3": dict(kind="bm", h=480, w=752, block=16, step=8, radius=16, batch=1024, s=12,
                name="c3: FastSpacedBMMethod 752x480, samplePointSize=16, stepSize=8, scanRadius=16, batch=1024 per GPU",
                # blocks*sps^2 + window area + 2*blocks + 2
@@ -88,7 +92,8 @@ def cpu_baseline(wl, budget_s: float = 12.0):
         run = lambda k: O.fft_process(cur[k % n_gen], prev[k % n_gen], lay, 32)
         what = "f32 oracle (oracle/pc_ref.c)"
     else:
-        cfg = O.bm_config_fast_spaced(wl["w"], wl["h"], wl["block"], wl["step"], wl["radius"])
+        cfg = (O.bm_config_block_method(wl["h"], wl["block"], wl["radius"]) if wl.get("block_method")
+               else O.bm_config_fast_spaced(wl["w"], wl["h"], wl["block"], wl["step"], wl["radius"]))
         run = lambda k: O.bm_process(cur[k % n_gen], prev[k % n_gen], cfg)
         what = "integer oracle (oracle/bm_ref.c)"
     run(0)
@@ -180,7 +185,11 @@ def main() -> None:
                 eng.process_batch_device(cur, prev, out=out)
                 return out
     else:
-        eng = FastSpacedBMMethod(wl["block"], wl["radius"], wl["step"], (wl["h"], wl["w"]), device=local_rank)
+        if wl.get("block_method"):
+            from mrs_optic_flow_amd import BlockMethod
+            eng = BlockMethod(wl["h"], wl["block"], wl["radius"], device=local_rank)
+        else:
+            eng = FastSpacedBMMethod(wl["block"], wl["radius"], wl["step"], (wl["h"], wl["w"]), device=local_rank)
 
         def launch():
             return eng.process_batch_device(cur, prev)[2]
@@ -242,7 +251,7 @@ def main() -> None:
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fft+sr": "_fft_phase_corr_plus_scale_rotation",
-                                             "bm": "_fast_spaced_bm"}[wl["kind"]],
+                                             "bm": "_block_method" if wl.get("block_method") else "_fast_spaced_bm"}[wl["kind"]],
             "value": pairs / elapsed,
             "unit": "frame-pairs/s",
             "n_gpus": world,
