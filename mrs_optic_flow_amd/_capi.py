@@ -96,6 +96,14 @@ def load():
             raise MofLibraryError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # ROCm PyTorch wheels bundle their own libamdhip64. If this library pulled in /opt/rocm's copy first, the
+        # process would hold two HIP runtimes and the second one to initialise sees no device. Letting torch load
+        # first (when it is installed) makes the order of imports irrelevant for every Python user of the ABI.
+        if not os.environ.get("MOF_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:  # torch is optional plumbing
+                pass
         try:
             lib = C.CDLL(LIB_PATH)
         except OSError as exc:  # pragma: no cover - depends on the host
