@@ -128,6 +128,8 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl == RCCL; gloo only to rehearse several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step into a HIP graph and replay it (helps the multi-launch c5 pipeline)")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +195,20 @@ def main() -> None:
 
         def launch():
             return eng.process_batch_device(cur, prev)[2]
+
+    if args.graph and world == 1:
+        eager_launch = launch
+        eager_launch()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                graph_result = eager_launch()
+
+        def launch():
+            graph.replay()
+            return graph_result
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -264,7 +280,8 @@ def main() -> None:
             "dtype": "u8" if wl["kind"] == "bm" else "f32",
             "data": "synthetic",
             "config": {"workload": wl["name"], "batch_per_gpu": B, "frame": f'{wl["w"]}x{wl["h"]} u8',
-                       "parallelism": f"frame-pair shards x{world}, all-gather of flow vectors" if world > 1 else "1 GPU"},
+                       "parallelism": f"frame-pair shards x{world}, all-gather of flow vectors" if world > 1 else "1 GPU",
+                       "hip_graph": bool(args.graph and world == 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,

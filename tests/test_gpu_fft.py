@@ -272,3 +272,29 @@ def test_edge_cases_and_error_paths(gpu):
         fm.reset(); fm.processImage(f[0])
         fm.process_batch_host(np.stack(f), np.stack(f[::-1]))
         assert np.array_equal(fm.processImage(f[1]), want, equal_nan=True)
+
+
+def test_batch_entry_points_are_hip_graph_capturable(gpu):
+    """No allocation, synchronisation or host read-back inside the batched entry points: they can be captured into a
+    HIP graph on the caller's stream and replayed (launch-bound pipelines such as c5 benefit)."""
+    from mrs_optic_flow_amd import ScaleRotationEstimator
+
+    B, fs = 4, 256
+    cur, prev, _, _ = synth.batch_np(B, fs, fs, 6, classes=False, k0=3)
+    tc, tp = torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)
+    fm, sr = FftMethod(fs, 64, 80.0), ScaleRotationEstimator(fs, 45.0)
+    out = torch.empty((B, fm.n_patches, 2), dtype=torch.float64, device=gpu)
+    want = fm.process_batch_device(tc, tp).clone()
+    want_sr = sr.process_batch_device(tc, tp).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            fm.process_batch_device(tc, tp, out=out)
+            sr_out = sr.process_batch_device(tc, tp)
+    out.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.equal(sr_out, want_sr)
