@@ -154,9 +154,15 @@ constexpr int INV_L = 8;    // row PAIRS per workgroup in K7
 // border take BORDER_REFLECT_101 taps. dst = (sum + 2^14) >> 15 saturated: integer, bit-exact.
 template <int K>
 __global__ void __launch_bounds__(256) sr_logpolar_kernel(SrLpArgs a) {
-  const int pix = blockIdx.x * 256 + threadIdx.x;
+  // a wave covers an 8 (phi) x 8 (rho) tile of the destination: its 64 footprints then share a compact patch of the
+  // source instead of lying along a ray (the kernel is bound by L1 line look-ups: 26 -> ~10 per wave-load)
   const int res = a.res;
-  if (pix >= res * res) return;
+  const int tiles_rho = (res + 31) / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rho = (blockIdx.x % tiles_rho) * 32 + wave * 8 + (lane & 7);
+  const int phi = (blockIdx.x / tiles_rho) * 8 + (lane >> 3);
+  if (rho >= res || phi >= res) return;
+  const int pix = phi * res + rho;
   const int img = blockIdx.y;
   const SrMapEntry m = a.map[pix];
   if (!m.valid) return;
@@ -337,7 +343,7 @@ __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
 bool sr_resolution_supported(int res) { return res == 240 || res == 256 || res == 480; }
 
 hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipStream_t stream) {
-  const dim3 grid((unsigned)((a.res * a.res + 255) / 256), (unsigned)n_images);
+  const dim3 grid((unsigned)(((a.res + 31) / 32) * ((a.res + 7) / 8)), (unsigned)n_images);
   if (interp == 2)
     hipLaunchKernelGGL(sr_logpolar_kernel<4>, grid, dim3(256), 0, stream, a);
   else
