@@ -63,7 +63,10 @@ struct Cfg<128> {
 
 template <int N>
 struct PcTraits {
-  static constexpr int T = N * N / 16;
+#ifndef MOF_K1_T64
+#define MOF_K1_T64 256
+#endif
+  static constexpr int T = (N == 64) ? MOF_K1_T64 : N * N / 16;
   static constexpr int WAVES = T / 64;
   static constexpr int LPW = N / WAVES;  // lines (rows or columns) owned by a wave
   static constexpr int R1 = Cfg<N>::R1, R2 = Cfg<N>::R2, SK = Cfg<N>::SK, PITCH = Cfg<N>::PITCH;
@@ -293,6 +296,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   const int patches = a.grid_x * a.grid_y;
   constexpr int CPR = N / 16;  // 16-pixel chunks per row
   const int lrow = wave0 * LPW + lane0 / CPR, lcol = (lane0 % CPR) * 16;  // this lane's 16 pixels of the patch
+  const bool ld_on = lane0 < LPW * CPR;  // (all lanes unless the workgroup has more than N*N/16 threads)
 
   // (x0, y0) of a patch are in the units of the correlated image: full-res pixels, or quarter-res when DS = 4
   auto patch_base = [&](int p, const uint8_t* frames, size_t frame_stride) -> const uint8_t* {
@@ -327,7 +331,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       gray16_from_bgr48(ps, q);
     }
   };
-  if (DS == 1 && p < a.total) fetch16(p, cw, pw);
+  if (DS == 1 && p < a.total && ld_on) fetch16(p, cw, pw);
   // Co-resident workgroups would otherwise run the same phase at the same time (all of them LDS-bound, then all
   // VALU-bound): delay the k-th workgroup of a CU by k quarter-patches so their phases interleave.
   {
@@ -346,14 +350,16 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   {
     const int row = wave * LPW + lane / CPR, col = (lane % CPR) * 16;
     if constexpr (DS == 1) {
+      if (ld_on) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-          z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cw[q] >> (8 * b)) & 0xffu), (float)((pw[q] >> (8 * b)) & 0xffu)};
-      const int pn = p + gridDim.x;
-      if (pn < a.total) fetch16(pn, cw, pw);
-    } else {
+          for (int b = 0; b < 4; ++b)
+            z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cw[q] >> (8 * b)) & 0xffu), (float)((pw[q] >> (8 * b)) & 0xffu)};
+        const int pn = p + gridDim.x;
+        if (pn < a.total) fetch16(pn, cw, pw);
+      }
+    } else if (ld_on) {
       // pixel (row, col+i) <- (s(4r+1,4c+1) + s(4r+1,4c+2) + s(4r+2,4c+1) + s(4r+2,4c+2) + 2) >> 2 of the full-res frame
       const uint8_t* c1 = patch_base(p, a.cur, a.cur_stride) + (size_t)(4 * row + 1) * a.pitch + 4 * col;
       const uint8_t* p1 = patch_base(p, a.prev, a.prev_stride) + (size_t)(4 * row + 1) * a.pitch + 4 * col;
