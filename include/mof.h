@@ -66,7 +66,23 @@ typedef struct mof_fft_config {
   int stride_x, stride_y;        /* distance between patch origins                            */
   double max_px_speed;           /* gate on |shift| (FftMethod.cpp:1686, :1841)               */
   int device;                    /* HIP device ordinal                                        */
+  int peak_model;                /* MOF_PEAK_OPENCV (0, useOCL=false) or MOF_PEAK_OCL (useOCL=true) */
+  int search_radius;             /* MOF_PEAK_OCL only: SEARCH_RADIUS, 55 (FftMethod.cpp:820)  */
 } mof_fft_config;
+
+/* Which of the reference's two peak models turns a patch pair into a shift:
+ *   MOF_PEAK_OPENCV  the live path, shift = -cv::phaseCorrelate(cur, prev) (FftMethod.cpp:1836): P|P|/(|P|^2+eps)
+ *                    normalisation, 5x5 centroid over every value, in double.
+ *   MOF_PEAK_OCL     what FftMethod computes with useOCL=true (FftMethod.cpp:1824-1825, :1833 -> cl/FftMethod.cl):
+ *                    P rsqrt(|P|^2 + eps) normalisation (cl:971-982; 1/(a b) in the four real-only slots, :1029),
+ *                    inverse scaled by 1/N^2, rows and columns with search_radius < index < N - search_radius of the
+ *                    un-shifted surface zeroed (cl:737-746, :823-826), first maximum, 7x7 centroid over the values > 0
+ *                    with the sum seeded by FLT_EPSILON (cl:1315-1379). The OpenCL kernel orders its work-groups with
+ *                    barrier(), which OpenCL does not guarantee, so its literal output is not defined; this is its
+ *                    race-free reading. Its centroid sums floats over absolute frame coordinates (~1e-4 px of rounding
+ *                    noise); the engine sums patch-local doubles.
+ * The gate (FftMethod.cpp:1838-1856) is the same for both. */
+enum { MOF_PEAK_OPENCV = 0, MOF_PEAK_OCL = 1 };
 
 /* Geometry exactly as FftMethod's constructor derives it (FftMethod.cpp:1706-1720):
  * frameSize forced even; if it is not a multiple of samplePointSize the patch becomes

@@ -57,12 +57,16 @@ class FftMethod {
   // Argument list of the reference constructor (FftMethod.h:434-435). storeVideo / videoPath /
   // videoFPS / cl_file_name / useOCL and the three *_enable flags are accepted and ignored: the
   // engine is headless and always runs the HIP path (SURVEY.md §8(b) "side effects not to reproduce").
+  // useOCL in particular does NOT pick the arithmetic: the default is cv::phaseCorrelate's peak model, the
+  // reference's live CPU path; pass peak_model = MOF_PEAK_OCL to get what its OpenCL kernel computes instead
+  // (include/mof.h).
   FftMethod(int i_frameSize, int i_samplePointSize, double max_px_speed_t, bool /*i_storeVideo*/ = false,
             bool /*i_raw_enable*/ = false, bool /*i_rot_corr_enable*/ = false, bool /*i_tilt_corr_enable*/ = false,
             std::string* /*videoPath*/ = nullptr, int /*videoFPS*/ = 0, std::string /*i_cl_file_name*/ = "",
-            bool /*i_useOCL*/ = true, int device = 0) {
+            bool /*i_useOCL*/ = true, int device = 0, int peak_model = MOF_PEAK_OPENCV) {
     detail::check(mof_fft_config_reference(&cfg_, i_frameSize, i_samplePointSize, max_px_speed_t), "FftMethod geometry");
     cfg_.device = device;
+    cfg_.peak_model = peak_model;
     detail::check(mof_fft_create(&cfg_, &engine_), "mof_fft_create");
   }
   // Generalised patch layout (origin, stride, grid) -- BASELINE c2/c4 grids do not fit the square tiling.

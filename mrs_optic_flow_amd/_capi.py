@@ -35,7 +35,8 @@ class MofError(RuntimeError):
 class FftConfig(C.Structure):
     _fields_ = [("frame_width", C.c_int), ("frame_height", C.c_int), ("patch_size", C.c_int),
                 ("grid_x", C.c_int), ("grid_y", C.c_int), ("origin_x", C.c_int), ("origin_y", C.c_int),
-                ("stride_x", C.c_int), ("stride_y", C.c_int), ("max_px_speed", C.c_double), ("device", C.c_int)]
+                ("stride_x", C.c_int), ("stride_y", C.c_int), ("max_px_speed", C.c_double), ("device", C.c_int),
+                ("peak_model", C.c_int), ("search_radius", C.c_int)]
 
 
 class SrConfig(C.Structure):

@@ -138,6 +138,8 @@ int mof_fft_config_reference(mof_fft_config* cfg, int frame_size, int sample_poi
   cfg->stride_x = cfg->stride_y = sample_point_size;
   cfg->max_px_speed = max_px_speed;
   cfg->device = 0;
+  cfg->peak_model = MOF_PEAK_OPENCV;  // useOCL = false, the live path
+  cfg->search_radius = 55;            // SEARCH_RADIUS, FftMethod.cpp:820 (only read by MOF_PEAK_OCL)
   return MOF_OK;
 }
 
@@ -153,6 +155,9 @@ static int validate_fft(const mof_fft_config* c) {
     return fail(MOF_ERR_BAD_ARG, "patch grid leaves the frame");
   if ((long)c->grid_x * c->grid_y > (1 << 20)) return fail(MOF_ERR_BAD_ARG, "too many patches");
   if (!(c->max_px_speed >= 0.0)) return fail(MOF_ERR_BAD_ARG, "max_px_speed must be >= 0");
+  if (c->peak_model != MOF_PEAK_OPENCV && c->peak_model != MOF_PEAK_OCL)
+    return fail(MOF_ERR_BAD_ARG, "peak_model must be MOF_PEAK_OPENCV or MOF_PEAK_OCL");
+  if (c->peak_model == MOF_PEAK_OCL && c->search_radius < 0) return fail(MOF_ERR_BAD_ARG, "search_radius must be >= 0");
   return MOF_OK;
 }
 
@@ -241,6 +246,8 @@ static mof::PcArgs fft_args(const mof_fft_engine* e, const uint8_t* cur, size_t 
   a.stride_y = e->cfg.stride_y;
   a.downscale = 1;
   a.channels = 1;
+  a.peak_model = e->cfg.peak_model;
+  a.search_radius = e->cfg.search_radius;
   a.max_px_speed_sq = e->cfg.max_px_speed * e->cfg.max_px_speed;  // pow(max_px_speed_t, 2), FftMethod.cpp:1686
   a.twiddles = e->d_twiddles;
   a.out = out;

@@ -21,6 +21,8 @@ struct PcArgs {
   int stagger_div, stagger_units;  // start-up stagger of co-resident workgroups (set by the launcher)
   int channels;           // 1 = gray frames; 3 = interleaved BGR8, CV_RGB2GRAY fused into the load
   int downscale;          // 1, or 4 = long-range mode (quarter-resolution patches formed on the fly)
+  int peak_model;         // 0 = cv::phaseCorrelate (useOCL=false), 1 = the OpenCL kernel's model (useOCL=true)
+  int search_radius;      // peak_model 1: SEARCH_RADIUS (FftMethod.cpp:820)
   double max_px_speed_sq; // FftMethod.cpp:1686
   const float* twiddles;  // device, N (cos, -sin) pairs, computed in double on the host
   double* out;            // device, [pair][patch] (x, y)

@@ -149,6 +149,10 @@ __device__ __forceinline__ void gray16_from_bgr48(const uint8_t* p, uint32_t* g 
 //   real-only CCS slots: C = P / (P^2 + eps)                                   (:107-109 / :1127-1129)
 // ONE hardware sqrt and ONE hardware reciprocal (1 ulp each): the IEEE divide/sqrt expansions were a fifth of the
 // kernel's VALU work for no effect at 1e-4 px.
+//
+// PK = 1 is the useOCL=true normalisation (cl/FftMethod.cl:971-982, :1024-1031): C = P rsqrt(|P|^2 + eps)
+// for every pair and 1 / (a b) in the four real-only slots.
+template <int PK = 0>
 __device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
   // Worked on 2A = Z[k] + conj(Z[-k]) and 2B = -i (Z[k] - conj(Z[-k])): P' = 2A conj(2B) = 4P, and
   //   P |P| / (|P|^2 + eps)  ==  P' |P'| / (|P'|^2 + 16 eps)   exactly (powers of two), four multiplies fewer per bin.
@@ -158,44 +162,66 @@ __device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
   if (real_only) {
     // P = A.x B.x / 4 ; C = P / (P^2 + eps) = 4 P' / (P'^2 + 16 eps)
     const float p4 = A.x * B.x;
+    if constexpr (PK == 1) return {4.f * __builtin_amdgcn_rcpf(p4), 0.f};  // 1 / (a b), cl:1029
     return {4.f * p4 * __builtin_amdgcn_rcpf(p4 * p4 + eps16), 0.f};
   }
   const float pr = A.x * B.x + A.y * B.y;
   const float pim = A.y * B.x - A.x * B.y;
   const float q = pr * pr + pim * pim;
+  if constexpr (PK == 1) {
+    // P rsqrt(|P|^2 + eps) == P' rsqrt(|P'|^2 + 16 eps)
+    const float s = __builtin_amdgcn_rsqf(q + eps16);
+    return {pr * s, pim * s};
+  }
   // |P'|^2 >= 2^10: 16 eps / q < 2^-30 is below half an ulp of the unit-magnitude result, so C = P' rsq(q) (one
   // transcendental); the general form only runs for (numerically) empty bins such as constant patches
   const float s = (q >= 1024.f) ? __builtin_amdgcn_rsqf(q) : __builtin_amdgcn_sqrtf(q) * __builtin_amdgcn_rcpf(q + eps16);
   return {pr * s, pim * s};
 }
 
-// 5x5 weighted centroid in double + validity gate (:1337-1383, :1838-1856), executed by ONE wave in two steps so
-// that the tile can be recycled in between: (1) 25 lanes fetch one window element each (`surface(ys, xs)` returns the
-// fft-shifted correlation value; 0 outside the clamped window), (2) three fp64 sums are reduced by shuffles and lane 0
-// stores (x, y) or (NaN, NaN).
-template <int N, class Surface>
+// Weighted centroid in double + validity gate, executed by ONE wave in two steps so that the tile can be recycled in
+// between: (1) (2 RAD + 1)^2 lanes fetch one window element each (`surface(ys, xs)` returns the fft-shifted correlation
+// value; 0 outside the clamped window), (2) three fp64 sums are reduced by shuffles and lane 0 stores (x, y) or
+// (NaN, NaN).
+//   PK = 0: cv::phaseCorrelate's weightedCentroid, 5x5, every value, sum + DBL_EPSILON      (:1337-1383, :1838-1856)
+//   PK = 1: the OpenCL kernel's refine(), 7x7, values > 0 only, sum seeded with FLT_EPSILON     (cl:1315-1379, :1478)
+//           (the kernel sums floats over absolute frame coordinates; here patch-local doubles -- same value, without
+//           the ~1e-4 px of rounding noise that representation adds)
+template <int PK>
+struct PeakModel {
+  static constexpr int RAD = PK == 1 ? 3 : 2;
+  static constexpr int W = 2 * RAD + 1;
+};
+
+template <int N, int PK = 0, class Surface>
 __device__ __forceinline__ float centroid_window_value(Best best, int lane, Surface surface) {
+  constexpr int RAD = PeakModel<PK>::RAD, W = PeakModel<PK>::W;
   const int px = best.idx % N, py = best.idx / N;
-  const int ys = py - 2 + lane / 5, xs = px - 2 + lane % 5;
-  if (lane < 25 && ys >= 0 && ys <= N - 1 && xs >= 0 && xs <= N - 1) return surface(ys, xs);  // window clamped to the patch
+  const int ys = py - RAD + lane / W, xs = px - RAD + lane % W;
+  if (lane < W * W && ys >= 0 && ys <= N - 1 && xs >= 0 && xs <= N - 1) {  // window clamped to the patch
+    const float v = surface(ys, xs);
+    if constexpr (PK == 1) return v > 0.f ? v : 0.f;
+    return v;
+  }
   return 0.f;
 }
 
-template <int N>
+template <int N, int PK = 0>
 __device__ __forceinline__ void centroid_gate_store(Best best, float wval, int lane, double max_px_speed_sq, double* out) {
+  constexpr int RAD = PeakModel<PK>::RAD, W = PeakModel<PK>::W;
   const int px = best.idx % N, py = best.idx / N;
-  const int ys = py - 2 + lane / 5, xs = px - 2 + lane % 5;
+  const int ys = py - RAD + lane / W, xs = px - RAD + lane % W;
   const double val = (double)wval;  // 0 for lanes outside the window
   double cx = (double)xs * val, cy = (double)ys * val, sum = val;
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
+  for (int off = 32; off > 0; off >>= 1) {
     cx += __shfl_xor(cx, off, 64);
     cy += __shfl_xor(cy, off, 64);
     sum += __shfl_xor(sum, off, 64);
   }
   if (lane == 0) {
-    sum += 2.220446049250313e-16;  // DBL_EPSILON, :1378
-    // shift = -(center - t) = t - N/2   (:1836)
+    sum += PK == 1 ? 1.1920928955078125e-07 : 2.220446049250313e-16;  // FLT_EPSILON cl:1342 / DBL_EPSILON :1378
+    // shift = -(center - t) = t - N/2   (:1836); the OpenCL branch returns centroid - N/2 un-negated (cl:1370, :1833)
     double sx = cx / sum - (double)N / 2.0;
     double sy = cy / sum - (double)N / 2.0;
     const bool bad = (sx * sx + sy * sy > max_px_speed_sq) || (fabs(sx) > (double)N / 2.0) ||
@@ -204,6 +230,14 @@ __device__ __forceinline__ void centroid_gate_store(Best best, float wval, int l
     out[0] = sx;
     out[1] = sy;
   }
+}
+
+// PK = 1 only: value (y, x) of the UN-shifted surface after the kernel's scaling and +-search_radius mask
+// (cl:733, :737-746, :823-826): rows / columns with search_radius < index < N - search_radius read as 0.
+template <int N>
+__device__ __forceinline__ float ocl_scale_mask(float v, int y, int x, int sr) {
+  const bool masked = (y > sr && y < N - sr) || (x > sr && x < N - sr);
+  return masked ? 0.f : v * (1.0f / (float)(N * N));
 }
 
 }  // namespace

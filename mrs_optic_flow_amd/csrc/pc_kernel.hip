@@ -200,8 +200,8 @@ __device__ __forceinline__ void col_pass_fwd(cf* __restrict__ z, int col0, int l
 // columns ride one complex transform: E[v] = F1[v][x1] + i F1[v][x2]; Re/Im of its transform are the
 // correlation surface at columns x1 / x2. Output: z(y, x1) = (c[y][x1], c[y][x1 + N/2]); returns the
 // lane's best (value, shifted index).
-template <int N>
-__device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int lane, const cf* tw_col) {
+template <int N, int PK>
+__device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int lane, const cf* tw_col, int search_radius) {
   using P = PcTraits<N>;
   constexpr int R1 = P::R1, R2 = P::R2, LI = P::LI, H = N / 2;
   {  // stage 1
@@ -251,6 +251,14 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
 #endif
       }
       butterfly<R2>(v[b]);
+      if constexpr (PK == 1) {  // OpenCL-kernel model: 1/N^2 scaling and the +-search_radius mask (cl:733, :737-746, :823-826)
+#pragma unroll
+        for (int k = 0; k < R2; ++k) {
+          const int y = x + k * R1;
+          v[b][k].x = ocl_scale_mask<N>(v[b][k].x, y, col, search_radius);
+          v[b][k].y = ocl_scale_mask<N>(v[b][k].y, y, col + H, search_radius);
+        }
+      }
     }
     wave_sync();
     // lane-local first maximum in two steps (max value, then the smallest shifted index that attains it): half the
@@ -283,7 +291,8 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
 // the rounded mean of the 2x2 centre of a 4x4 cell, formed on the fly from the full-resolution frame.
 // CH = 3: the frames are interleaved BGR8 and the CV_RGB2GRAY conversion of the node's front end
 // (optic_flow.cpp:1622) is fused into the load, so raw camera frames are read from HBM exactly once.
-template <int N, int DS, int CH>
+// PK = 1: the peak model of the reference's useOCL=true branch (cl/FftMethod.cl) instead of cv::phaseCorrelate's.
+template <int N, int DS, int CH, int PK>
 __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   static_assert(CH == 1 || (CH == 3 && DS == 1), "BGR front end only for the full-resolution path");
   using P = PcTraits<N>;
@@ -411,7 +420,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
             const int uc = u + uu * UPW, umc = (N - uc) % N;
             (void)um;
             const cf zk = z[zaddr<N>(v, uc)], zm = z[zaddr<N>(N - v, umc)];
-            const cf C = cross_power(zk, zm, false);
+            const cf C = cross_power<PK>(zk, zm, false);
             z[zaddr<N>(v, uc)] = {C.x, -C.y};  // conj(C[v][u])
           }
         }
@@ -421,8 +430,8 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
     for (int u = tid; u <= H; u += T) {
       const int um = (N - u) % N;
       const bool self = (u == um);
-      const cf C0 = cross_power(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
-      const cf Ch = cross_power(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
+      const cf C0 = cross_power<PK>(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
+      const cf Ch = cross_power<PK>(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
       z[zaddr<N>(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
       if (!self) z[zaddr<N>(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
     }
@@ -438,7 +447,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   __syncthreads();
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
 #ifndef MOF_ABLATE_NOINV
-  if (wave < P::WI) best = col_pass_inv<N>(z, wave * P::LI, lane, tw_col);
+  if (wave < P::WI) best = col_pass_inv<N, PK>(z, wave * P::LI, lane, tw_col, a.search_radius);
 #else
   best = Best{z[zaddr<N>(lane, wave)].x, lane * N + wave};
 #endif
@@ -459,14 +468,14 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
 #endif
   if (wave == 0) {
     for (int w = 1; w < P::WAVES; ++w) best = better(best, red[w]);
-    wval = centroid_window_value<N>(best, lane, [&](int ys, int xs) {
+    wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
       const int y = (ys + H) % N, x = (xs + H) % N;  // un-shifted position
       const cf s = z[zaddr<N>(y, x % H)];
       return x < H ? s.x : s.y;
     });
   }
   __syncthreads();
-  if (wave == 0) centroid_gate_store<N>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p);
+  if (wave == 0) centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p);
   }  // persistent loop
 }
 
@@ -479,17 +488,22 @@ static size_t extra_lds() {
   return v;
 }
 
+template <int N, int DS, int CH, int PK>
+static hipError_t configure_one(int lds) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, DS, CH, PK>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
 template <int N>
 static hipError_t configure_n() {
   const int lds = (int)(PcTraits<N>::LDS_BYTES + extra_lds());
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 1, 1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 1, 3>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel<N, 4, 1>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e;
+  if ((e = configure_one<N, 1, 1, 0>(lds)) != hipSuccess) return e;
+  if ((e = configure_one<N, 1, 3, 0>(lds)) != hipSuccess) return e;
+  if ((e = configure_one<N, 4, 1, 0>(lds)) != hipSuccess) return e;
+  if ((e = configure_one<N, 1, 1, 1>(lds)) != hipSuccess) return e;
+  if ((e = configure_one<N, 1, 3, 1>(lds)) != hipSuccess) return e;
+  return configure_one<N, 4, 1, 1>(lds);
 }
 
 static int g_cu_count = 0;  // set by pc_configure()
@@ -515,12 +529,17 @@ static hipError_t launch_n(const PcArgs& a_in, int n_pairs, hipStream_t stream) 
   if (!persistent) resident = a.total;
   const unsigned blocks = (unsigned)(a.total < resident ? a.total : resident);
   if (a.downscale == 4 && a.channels == 3) return hipErrorInvalidValue;
-  if (a.downscale == 4)
-    hipLaunchKernelGGL((pc_field_kernel<N, 4, 1>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
-  else if (a.channels == 3)
-    hipLaunchKernelGGL((pc_field_kernel<N, 1, 3>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
-  else
-    hipLaunchKernelGGL((pc_field_kernel<N, 1, 1>), dim3(blocks), dim3(Tr::T), Tr::LDS_BYTES + extra_lds(), stream, a);
+  const dim3 g(blocks), b(Tr::T);
+  const size_t lds = Tr::LDS_BYTES + extra_lds();
+  if (a.peak_model == 1) {
+    if (a.downscale == 4) hipLaunchKernelGGL((pc_field_kernel<N, 4, 1, 1>), g, b, lds, stream, a);
+    else if (a.channels == 3) hipLaunchKernelGGL((pc_field_kernel<N, 1, 3, 1>), g, b, lds, stream, a);
+    else hipLaunchKernelGGL((pc_field_kernel<N, 1, 1, 1>), g, b, lds, stream, a);
+  } else {
+    if (a.downscale == 4) hipLaunchKernelGGL((pc_field_kernel<N, 4, 1, 0>), g, b, lds, stream, a);
+    else if (a.channels == 3) hipLaunchKernelGGL((pc_field_kernel<N, 1, 3, 0>), g, b, lds, stream, a);
+    else hipLaunchKernelGGL((pc_field_kernel<N, 1, 1, 0>), g, b, lds, stream, a);
+  }
   return hipGetLastError();
 }
 

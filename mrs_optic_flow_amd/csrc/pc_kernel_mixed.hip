@@ -175,7 +175,8 @@ __device__ __forceinline__ void col_pass_fwd(cf* __restrict__ z, int col0, int l
 
 // ---- inverse column pass on column pairs (col, col + H), col in [col0, col0 + 8) and < H (wave-local);
 //      see col_pass_inv in pc_kernel.hip for the data layout --------------------------------------------
-__device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int lane, const float* tw) {
+template <int PK>
+__device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int lane, const float* tw, int search_radius) {
   {  // stage 1
     const int col = col0 + lane % LPW, x = lane / LPW;
     const bool on = col < H;
@@ -217,6 +218,14 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
           v[b][k] = (k == 0) ? a : cmul(a, twiddle(tw, k * x));
         }
         butterfly<8>(v[b]);
+        if constexpr (PK == 1) {  // OpenCL-kernel model: 1/N^2 scaling, +-search_radius mask (cl:733, :737-746, :823-826)
+#pragma unroll
+          for (int k = 0; k < R2; ++k) {
+            const int y = x + k * R1;
+            v[b][k].x = ocl_scale_mask<N>(v[b][k].x, y, col, search_radius);
+            v[b][k].y = ocl_scale_mask<N>(v[b][k].y, y, col + H, search_radius);
+          }
+        }
       }
     }
     wave_sync();
@@ -240,7 +249,7 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
 
 }  // namespace
 
-template <int DS, int CH>
+template <int DS, int CH, int PK>
 __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* z = reinterpret_cast<cf*>(smem);
@@ -315,14 +324,14 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   for (int g = tid; g < (H - 1) * N; g += T) {
     const int v = 1 + g / N, u = g % N;
     const cf zk = z[za(v, u)], zm = z[za(N - v, (N - u) % N)];
-    const cf C = cross_power(zk, zm, false);
+    const cf C = cross_power<PK>(zk, zm, false);
     z[za(v, u)] = {C.x, -C.y};
   }
   for (int u = tid; u <= H; u += T) {
     const int um = (N - u) % N;
     const bool self = (u == um);
-    const cf C0 = cross_power(z[za(0, u)], z[za(0, um)], self);
-    const cf Ch = cross_power(z[za(H, u)], z[za(H, um)], self);
+    const cf C0 = cross_power<PK>(z[za(0, u)], z[za(0, um)], self);
+    const cf Ch = cross_power<PK>(z[za(H, u)], z[za(H, um)], self);
     z[za(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
     if (!self) z[za(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
   }
@@ -332,7 +341,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   if (wave * LPW < H) row_pass(z, wave * LPW, H, lane, tw);
   __syncthreads();
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
-  if (wave * LPW < H) best = col_pass_inv(z, wave * LPW, lane, tw);
+  if (wave * LPW < H) best = col_pass_inv<PK>(z, wave * LPW, lane, tw, a.search_radius);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     Best o = {__shfl_xor(best.v, off, 64), __shfl_xor(best.idx, off, 64)};
@@ -343,35 +352,44 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
 
   if (wave == 0) {
     for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
-    const float wval = centroid_window_value<N>(best, lane, [&](int ys, int xs) {
+    const float wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
       const int y = (ys + H) % N, x = (xs + H) % N;
       const cf s = z[za(y, x % H)];
       return x < H ? s.x : s.y;
     });
-    centroid_gate_store<N>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * ((size_t)pair * patches + patch));
+    centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * ((size_t)pair * patches + patch));
   }
 }
 
-hipError_t pc_configure_120() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<1, 1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_120);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<1, 3>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_120);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<4, 1>),
+template <int DS, int CH, int PK>
+static hipError_t configure_one_120() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_field_kernel_120<DS, CH, PK>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_120);
+}
+
+hipError_t pc_configure_120() {
+  hipError_t e;
+  if ((e = configure_one_120<1, 1, 0>()) != hipSuccess) return e;
+  if ((e = configure_one_120<1, 3, 0>()) != hipSuccess) return e;
+  if ((e = configure_one_120<4, 1, 0>()) != hipSuccess) return e;
+  if ((e = configure_one_120<1, 1, 1>()) != hipSuccess) return e;
+  if ((e = configure_one_120<1, 3, 1>()) != hipSuccess) return e;
+  return configure_one_120<4, 1, 1>();
 }
 
 hipError_t launch_pc_field_120(const PcArgs& a, int n_pairs, hipStream_t stream) {
   const unsigned blocks = (unsigned)n_pairs * (unsigned)(a.grid_x * a.grid_y);
   if (a.downscale == 4 && a.channels == 3) return hipErrorInvalidValue;
-  if (a.downscale == 4)
-    hipLaunchKernelGGL((pc_field_kernel_120<4, 1>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
-  else if (a.channels == 3)
-    hipLaunchKernelGGL((pc_field_kernel_120<1, 3>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
-  else
-    hipLaunchKernelGGL((pc_field_kernel_120<1, 1>), dim3(blocks), dim3(T), LDS_BYTES_120, stream, a);
+  const dim3 g(blocks), b(T);
+  if (a.peak_model == 1) {
+    if (a.downscale == 4) hipLaunchKernelGGL((pc_field_kernel_120<4, 1, 1>), g, b, LDS_BYTES_120, stream, a);
+    else if (a.channels == 3) hipLaunchKernelGGL((pc_field_kernel_120<1, 3, 1>), g, b, LDS_BYTES_120, stream, a);
+    else hipLaunchKernelGGL((pc_field_kernel_120<1, 1, 1>), g, b, LDS_BYTES_120, stream, a);
+  } else {
+    if (a.downscale == 4) hipLaunchKernelGGL((pc_field_kernel_120<4, 1, 0>), g, b, LDS_BYTES_120, stream, a);
+    else if (a.channels == 3) hipLaunchKernelGGL((pc_field_kernel_120<1, 3, 0>), g, b, LDS_BYTES_120, stream, a);
+    else hipLaunchKernelGGL((pc_field_kernel_120<1, 1, 0>), g, b, LDS_BYTES_120, stream, a);
+  }
   return hipGetLastError();
 }
 

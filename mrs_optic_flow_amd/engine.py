@@ -34,14 +34,20 @@ def _stream_ptr(stream):
     return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
 
 
+PEAK_OPENCV, PEAK_OCL = 0, 1  # include/mof.h
+
+
 class FftMethod:
     """FftMethod behind the C ABI. ``layout`` generalises the reference's square tiling
     (origin, stride, grid); without it the constructor normalises the geometry exactly
-    as /root/reference/src/FftMethod.cpp:1706-1720 does."""
+    as /root/reference/src/FftMethod.cpp:1706-1720 does. ``peak_model`` selects which of the reference's two
+    peak models runs (include/mof.h): PEAK_OPENCV = cv::phaseCorrelate's (useOCL=false, the default and the path
+    BASELINE.json names), PEAK_OCL = its OpenCL kernel's (useOCL=true; ``search_radius`` = SEARCH_RADIUS, 55)."""
 
     def __init__(self, frame_size: int | None = None, sample_point_size: int = 64, max_px_speed: float = 80.0, *,
                  frame_shape: tuple[int, int] | None = None, grid: tuple[int, int] | None = None,
-                 origin: tuple[int, int] = (0, 0), stride: tuple[int, int] | None = None, device: int = 0):
+                 origin: tuple[int, int] = (0, 0), stride: tuple[int, int] | None = None, device: int = 0,
+                 peak_model: int = 0, search_radius: int = 55):
         lib = _capi.load()
         cfg = FftConfig()
         if frame_shape is None:
@@ -54,8 +60,10 @@ class FftMethod:
             grid = grid or ((w - origin[0] - sample_point_size) // stride[0] + 1,
                             (h - origin[1] - sample_point_size) // stride[1] + 1)
             cfg = FftConfig(w, h, sample_point_size, grid[0], grid[1], origin[0], origin[1], stride[0], stride[1],
-                            float(max_px_speed), 0)
+                            float(max_px_speed), 0, 0, 55)
         cfg.device = device
+        cfg.peak_model = int(peak_model)
+        cfg.search_radius = int(search_radius)
         self.cfg = cfg
         self._lib = lib
         self._h = C.c_void_p()

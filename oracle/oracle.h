@@ -64,6 +64,20 @@ int oracle_phase_correlate_f64(const double* a, size_t a_stride, const double* b
 int oracle_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_fft_layout* layout,
                           int precision, double* out_xy, int* n_invalid, oracle_pc_diag* diag);
 
+/* The useOCL=true peak model (cl/FftMethod.cl:971-982 rsqrt normalisation, :737-746/:823-826
+ * +-SEARCH_RADIUS mask, :1164-1313 arg-max, :1315-1379 7x7 positive-only float centroid over absolute coordinates),
+ * restated as the race-free maths the kernel chain intends -- see pc_ref_impl.h. (x0, y0) is the patch origin in the
+ * frame (the centroid is accumulated in absolute coordinates, which costs float precision exactly as in the kernel).
+ * out_xy is the SHIFT itself (the host does not negate this branch, src/FftMethod.cpp:1833). */
+int oracle_phase_correlate_ocl_f32(const float* a, size_t a_stride, const float* b, size_t b_stride, int n, int x0,
+                                   int y0, int search_radius, double* out_xy, oracle_pc_diag* diag, float* surface);
+int oracle_phase_correlate_ocl_f64(const double* a, size_t a_stride, const double* b, size_t b_stride, int n, int x0,
+                                   int y0, int search_radius, double* out_xy, oracle_pc_diag* diag, double* surface);
+/* FftMethod::processImage with useOCL=true under that model (src/FftMethod.cpp:1824-1825, :1833, :1840-1856;
+ * SEARCH_RADIUS 55, :820). Same layout/outputs as oracle_fft_process_u8. */
+int oracle_fft_process_ocl_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_fft_layout* layout,
+                              int search_radius, int precision, double* out_xy, int* n_invalid, oracle_pc_diag* diag);
+
 /* cv::resize(src, dst, Size(), 1/4, 1/4) with the default INTER_LINEAR on CV_8UC1, as called by
  * FftMethod::processImageLongRange (src/FftMethod.cpp:1931-1932, LONG_RANGE_RATIO :3). With scale 4 the
  * source coordinate of destination x is 4x + 1.5, i.e. both taps weigh 1/2 in each axis, and OpenCV's

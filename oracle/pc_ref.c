@@ -23,15 +23,23 @@ static int largest_prime_factor(int n) {
 
 #define R float
 #define SUFFIX _f32
+#define FMA_R fmaf
+#define SQRT_R sqrtf
 #include "pc_ref_impl.h"
 #undef R
 #undef SUFFIX
+#undef FMA_R
+#undef SQRT_R
 
 #define R double
 #define SUFFIX _f64
+#define FMA_R fma
+#define SQRT_R sqrt
 #include "pc_ref_impl.h"
 #undef R
 #undef SUFFIX
+#undef FMA_R
+#undef SQRT_R
 
 int oracle_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_fft_layout* L,
                           int precision, double* out_xy, int* n_invalid, oracle_pc_diag* diag) {
@@ -81,6 +89,58 @@ int oracle_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch,
         ++invalid;
       }
       out_xy[2 * (i + j * L->grid_x) + 0] = sx; /* ref :1855 index i + j*sqNum */
+      out_xy[2 * (i + j * L->grid_x) + 1] = sy;
+    }
+  if (n_invalid) *n_invalid = invalid;
+  free(af);
+  free(ad);
+  return 0;
+}
+
+int oracle_fft_process_ocl_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_fft_layout* L,
+                              int search_radius, int precision, double* out_xy, int* n_invalid, oracle_pc_diag* diag) {
+  if (!cur || !prev || !L || !out_xy) return -1;
+  const int n = L->patch;
+  if (n < 8 || (n & 1) || largest_prime_factor(n) > 61) return -1;
+  if (L->grid_x < 1 || L->grid_y < 1 || L->origin_x < 0 || L->origin_y < 0) return -1;
+  if (L->origin_x + (L->grid_x - 1) * L->stride_x + n > L->width) return -1;
+  if (L->origin_y + (L->grid_y - 1) * L->stride_y + n > L->height) return -1;
+  if (precision != 32 && precision != 64) return -1;
+  const size_t nn = (size_t)n * n;
+  float* af = (float*)malloc(sizeof(float) * nn * 2);
+  double* ad = (double*)malloc(sizeof(double) * nn * 2);
+  if (!af || !ad) { free(af); free(ad); return -2; }
+  int invalid = 0;
+  const double max_sq = L->max_px_speed * L->max_px_speed;
+  for (int j = 0; j < L->grid_y; ++j)
+    for (int i = 0; i < L->grid_x; ++i) {
+      const int xi = L->origin_x + i * L->stride_x, yi = L->origin_y + j * L->stride_y;
+      for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) {
+          uint8_t c = cur[(size_t)(yi + y) * pitch + xi + x];
+          uint8_t p = prev[(size_t)(yi + y) * pitch + xi + x];
+          af[(size_t)y * n + x] = (float)c;
+          af[nn + (size_t)y * n + x] = (float)p;
+          ad[(size_t)y * n + x] = (double)c;
+          ad[nn + (size_t)y * n + x] = (double)p;
+        }
+      double s[2];
+      oracle_pc_diag* d = diag ? &diag[i + j * L->grid_x] : NULL;
+      int rc = (precision == 32)
+                   ? oracle_phase_correlate_ocl_f32(af, (size_t)n, af + nn, (size_t)n, n, xi, yi, search_radius, s, d, NULL)
+                   : oracle_phase_correlate_ocl_f64(ad, (size_t)n, ad + nn, (size_t)n, n, xi, yi, search_radius, s, d, NULL);
+      if (rc) { free(af); free(ad); return rc; }
+      /* shift = speeds[i + sqNum*j], not negated (ref :1833); same gate (ref :1840-1856) */
+      double sx = s[0], sy = s[1];
+      int valid = 1;
+      if (sx * sx + sy * sy > max_sq || fabs(sx) > (double)n / 2 || fabs(sy) > (double)n / 2) valid = 0;
+      if (isnan(sx) || isnan(sy)) valid = 0;
+      if (!valid) {
+        sx = NAN;
+        sy = NAN;
+        ++invalid;
+      }
+      out_xy[2 * (i + j * L->grid_x) + 0] = sx;
       out_xy[2 * (i + j * L->grid_x) + 1] = sy;
     }
   if (n_invalid) *n_invalid = invalid;

@@ -252,6 +252,135 @@ int FN(oracle_phase_correlate)(const R* a, size_t a_stride, const R* b, size_t b
   return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * The useOCL=true peak model, restated from /root/reference/cl/FftMethod.cl as
+ * the maths its kernel chain intends (the kernel synchronises work-groups with barrier(), which
+ * OpenCL does not guarantee, so its literal output is not defined; this is the race-free reading):
+ *   cross-power   v = A*conj(B) * rsqrt(|A*conj(B)|^2 + FLT_EPSILON), products as mad()   cl:971-982, :1041, :1080
+ *                 the four real-only CCS slots get 1/(a*b)                                 cl:1024-1031
+ *   inverse       scaled by 1/(N*N)                                                        cl:733, :826
+ *   search mask   rows/columns with SEARCH_RADIUS < index < N - SEARCH_RADIUS (unshifted)
+ *                 are written as 0                                                         cl:737-746, :823-826
+ *   fft shift     index +- N/2 on write                                                    cl:738, :819-826
+ *   arg-max       first maximum in row-major order, from -FLT_MAX                          cl:1164-1313
+ *   refine        radius 3 (cl:1478): window clipped to the patch, only values > 0, float sums
+ *                 over ABSOLUTE frame coordinates, sum seeded with FLT_EPSILON; result
+ *                 centroid - (origin + N/2)                                                cl:1315-1379
+ * The host takes that value as the shift without negating it (FftMethod.cpp:1544, :1833).
+ * out_xy receives the shift (NOT center - t as the OpenCV-model function above). */
+int FN(oracle_phase_correlate_ocl)(const R* a, size_t a_stride, const R* b, size_t b_stride, int n, int x0, int y0,
+                                   int search_radius, double* out_xy, oracle_pc_diag* diag, R* surface) {
+  if (!a || !b || !out_xy || n < 8 || (n & 1) || largest_prime_factor(n) > 61 || search_radius < 0) return -1;
+  const size_t nn = (size_t)n * n;
+  FN(cpx)* A = (FN(cpx)*)malloc(sizeof(FN(cpx)) * nn);
+  FN(cpx)* B = (FN(cpx)*)malloc(sizeof(FN(cpx)) * nn);
+  FN(cpx)* C = (FN(cpx)*)malloc(sizeof(FN(cpx)) * nn);
+  FN(cpx)* tw = (FN(cpx)*)malloc(sizeof(FN(cpx)) * (size_t)n);
+  FN(cpx)* scratch = (FN(cpx)*)malloc(sizeof(FN(cpx)) * (size_t)n);
+  R* S = (R*)malloc(sizeof(R) * nn);
+  if (!A || !B || !C || !tw || !scratch || !S) {
+    free(A); free(B); free(C); free(tw); free(scratch); free(S);
+    return -2;
+  }
+  FN(make_twiddles)(tw, n);
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      A[(size_t)y * n + x].re = a[(size_t)y * a_stride + x];
+      A[(size_t)y * n + x].im = (R)0;
+      B[(size_t)y * n + x].re = b[(size_t)y * b_stride + x];
+      B[(size_t)y * n + x].im = (R)0;
+    }
+  FN(fft2d)(A, n, tw, 0, scratch);
+  FN(fft2d)(B, n, tw, 0, scratch);
+
+  const int h = n / 2;
+  const R eps = (R)FLT_EPSILON;
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c <= h; ++c) {
+      const int edge_col = (c == 0 || c == h);
+      if (edge_col && r > h) continue;
+      FN(cpx) av = A[(size_t)r * n + c], bv = B[(size_t)r * n + c], v;
+      if (edge_col && (r == 0 || r == h)) {
+        v.re = (R)1 / (av.re * bv.re); /* cl:1029 */
+        v.im = (R)0;
+      } else {
+        /* cmulnormf(a, conjf(b)): conj b, then mad(a.x,b.x,-a.y*b.y), mad(a.x,b.y,a.y*b.x)  cl:976-982 */
+        const R bx = bv.re, by = -bv.im;
+        const R mx = FMA_R(av.re, bx, -(av.im * by));
+        const R my = FMA_R(av.re, by, av.im * bx);
+        const R den = (R)1 / SQRT_R(FMA_R(mx, mx, my * my + eps));
+        v.re = mx * den;
+        v.im = my * den;
+      }
+      C[(size_t)r * n + c] = v;
+    }
+  for (int c = 0; c <= h; c += h)
+    for (int r = h + 1; r < n; ++r) {
+      C[(size_t)r * n + c].re = C[(size_t)(n - r) * n + c].re;
+      C[(size_t)r * n + c].im = -C[(size_t)(n - r) * n + c].im;
+    }
+  for (int r = 0; r < n; ++r)
+    for (int c = h + 1; c < n; ++c) {
+      FN(cpx) v = C[(size_t)((n - r) % n) * n + (n - c)];
+      C[(size_t)r * n + c].re = v.re;
+      C[(size_t)r * n + c].im = -v.im;
+    }
+  FN(fft2d)(C, n, tw, 1, scratch);
+
+  const R scale = (R)1 / (R)(n * n);
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      const int masked = (y > search_radius && y < n - search_radius) || (x > search_radius && x < n - search_radius);
+      const int sy = y < h ? y + h : y - h, sx = x < h ? x + h : x - h;
+      S[(size_t)sy * n + sx] = masked ? (R)0 : C[(size_t)y * n + x].re * scale;
+    }
+
+  int px = 0, py = 0;
+  R best = -(R)FLT_MAX;
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x)
+      if (best < S[(size_t)y * n + x]) {
+        best = S[(size_t)y * n + x];
+        px = x;
+        py = y;
+      }
+
+  const int radius = 3;
+  const int xmin = px - radius >= 0 ? px - radius : 0, xmax = px + radius < n ? px + radius : n - 1;
+  const int ymin = py - radius >= 0 ? py - radius : 0, ymax = py + radius < n ? py + radius : n - 1;
+  R cx = (R)0, cy = (R)0, sum = eps;
+  for (int y = ymin; y <= ymax; ++y)
+    for (int x = xmin; x <= xmax; ++x) {
+      const R v = S[(size_t)y * n + x];
+      if (v > (R)0) {
+        cx += (R)(x0 + x) * v;
+        cy += (R)(y0 + y) * v;
+        sum += v;
+      }
+    }
+  cx /= sum;
+  cy /= sum;
+  out_xy[0] = (double)(R)(cx - (R)(x0 + h));
+  out_xy[1] = (double)(R)(cy - (R)(y0 + h));
+
+  if (diag) {
+    double second = -HUGE_VAL;
+    for (int y = 0; y < n; ++y)
+      for (int x = 0; x < n; ++x) {
+        if (y >= ymin && y <= ymax && x >= xmin && x <= xmax) continue;
+        if ((double)S[(size_t)y * n + x] > second) second = (double)S[(size_t)y * n + x];
+      }
+    diag->peak_x = px;
+    diag->peak_y = py;
+    diag->peak_value = (double)best;
+    diag->second_value = second;
+    diag->response = (double)sum;
+  }
+  if (surface) memcpy(surface, S, sizeof(R) * nn);
+  free(A); free(B); free(C); free(tw); free(scratch); free(S);
+  return 0;
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

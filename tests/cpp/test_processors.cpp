@@ -2,6 +2,7 @@
 // processor classes). Reads a raw u8 frame sequence, runs the stateful processImage() calls the ROS
 // node would make, prints the results; tests/test_gpu_cpp_host.py compares them with the oracle.
 //   usage: test_processors fft <frameSize> <sps> <max_px_speed> <nframes> <file>
+//          test_processors fftocl ...same...   (peak_model = MOF_PEAK_OCL)
 //          test_processors bm  <frameSize> <sps> <radius> <nframes> <file>
 //          test_processors fsbm <w> <h> <sps> <step> <radius> <nframes> <file>
 #include <cstdio>
@@ -24,11 +25,12 @@ static std::vector<uint8_t> read_all(const char* path, size_t bytes) {
 
 int main(int argc, char** argv) {
   try {
-    if (argc >= 7 && !std::strcmp(argv[1], "fft")) {
+    if (argc >= 7 && (!std::strcmp(argv[1], "fft") || !std::strcmp(argv[1], "fftocl"))) {
       const int fs = std::atoi(argv[2]), sps = std::atoi(argv[3]), n = std::atoi(argv[5]);
       const double mps = std::atof(argv[4]);
       auto frames = read_all(argv[6], (size_t)fs * fs * n);
-      mof::FftMethod proc(fs, sps, mps, false, false, false, false, nullptr, 30, "unused.cl", true);
+      const int peak = !std::strcmp(argv[1], "fftocl") ? MOF_PEAK_OCL : MOF_PEAK_OPENCV;
+      mof::FftMethod proc(fs, sps, mps, false, false, false, false, nullptr, 30, "unused.cl", true, 0, peak);
       std::vector<uint8_t> zeros((size_t)fs * fs, 0);
       proc.setImPrev(mof::ImageView{zeros.data(), fs, fs, (size_t)fs});  // optic_flow.cpp:1016-1018
       std::vector<mof::Point2d> raw;

@@ -58,6 +58,14 @@ def lib():
         L.oracle_fft_process_u8.restype = C.c_int
         L.oracle_fft_process_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FftLayout), C.c_int,
                                             C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+        L.oracle_phase_correlate_ocl_f32.restype = C.c_int
+        L.oracle_phase_correlate_ocl_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                                      C.c_int, C.c_int, C.c_void_p, C.POINTER(PcDiag), C.c_void_p]
+        L.oracle_phase_correlate_ocl_f64.restype = C.c_int
+        L.oracle_phase_correlate_ocl_f64.argtypes = L.oracle_phase_correlate_ocl_f32.argtypes
+        L.oracle_fft_process_ocl_u8.restype = C.c_int
+        L.oracle_fft_process_ocl_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FftLayout), C.c_int, C.c_int,
+                                                C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         L.oracle_resize_quarter_u8.restype = C.c_int
         L.oracle_resize_quarter_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.oracle_fft_process_long_range_u8.restype = C.c_int
@@ -131,6 +139,48 @@ def fft_process(cur: np.ndarray, prev: np.ndarray, layout: FftLayout, precision:
                                      C.byref(ninv), diags)
     if rc:
         raise ValueError(f"oracle_fft_process_u8 rc={rc}")
+    if want_diag:
+        return out, ninv.value, diags
+    return out, ninv.value
+
+
+def phase_correlate_ocl(a: np.ndarray, b: np.ndarray, origin=(0, 0), search_radius: int = 55, precision: int = 32,
+                        want_surface: bool = False):
+    """The useOCL=true peak model on one patch pair. Returns ((sx, sy), diag dict[, surface]) -- the SHIFT itself."""
+    n = a.shape[0]
+    assert a.shape == (n, n) and b.shape == (n, n)
+    dt = np.float32 if precision == 32 else np.float64
+    a = np.ascontiguousarray(a, dtype=dt)
+    b = np.ascontiguousarray(b, dtype=dt)
+    out = np.zeros(2, np.float64)
+    diag = PcDiag()
+    surf = np.zeros((n, n), dt) if want_surface else None
+    fn = lib().oracle_phase_correlate_ocl_f32 if precision == 32 else lib().oracle_phase_correlate_ocl_f64
+    rc = fn(_ptr(a), n, _ptr(b), n, n, int(origin[0]), int(origin[1]), int(search_radius), _ptr(out), C.byref(diag),
+            _ptr(surf) if want_surface else None)
+    if rc:
+        raise ValueError(f"oracle_phase_correlate_ocl rc={rc}")
+    d = dict(peak=(diag.peak_x, diag.peak_y), peak_value=diag.peak_value, second_value=diag.second_value,
+             response=diag.response)
+    if want_surface:
+        return (out[0], out[1]), d, surf
+    return (out[0], out[1]), d
+
+
+def fft_process_ocl(cur: np.ndarray, prev: np.ndarray, layout: FftLayout, search_radius: int = 55, precision: int = 32,
+                    want_diag: bool = False):
+    """FftMethod::processImage under the useOCL=true peak model -> [gy*gx, 2] float64."""
+    assert cur.dtype == np.uint8 and prev.dtype == np.uint8 and cur.shape == prev.shape
+    cur = np.ascontiguousarray(cur)
+    prev = np.ascontiguousarray(prev)
+    g = layout.grid_x * layout.grid_y
+    out = np.zeros((g, 2), np.float64)
+    ninv = C.c_int(0)
+    diags = (PcDiag * g)() if want_diag else None
+    rc = lib().oracle_fft_process_ocl_u8(_ptr(cur), _ptr(prev), cur.shape[1], C.byref(layout), int(search_radius),
+                                         precision, _ptr(out), C.byref(ninv), diags)
+    if rc:
+        raise ValueError(f"oracle_fft_process_ocl_u8 rc={rc}")
     if want_diag:
         return out, ninv.value, diags
     return out, ninv.value

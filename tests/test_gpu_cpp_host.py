@@ -35,6 +35,19 @@ def test_fft_method_sequence(gpu, tmp_path):
         assert np.allclose(got, want, rtol=0, atol=1e-4, equal_nan=True)
 
 
+def test_fft_method_ocl_peak_model_sequence(gpu, tmp_path):
+    """The constructor's trailing peak_model argument selects the OpenCL kernel's peak model (MOF_PEAK_OCL)."""
+    fs, sps, n = 192, 64, 3
+    frames = np.stack([synth.pair_np(35, fs, fs, 3 * t, -2 * t)[0] for t in range(n)])
+    lines = _run(["fftocl", fs, sps, 80, n], frames, tmp_path)
+    lay = O.fft_layout(fs, fs, sps, 3, 3)
+    for t, tok in enumerate(lines):
+        got = np.array([float(v) for v in tok[4:]]).reshape(9, 2)
+        prev = frames[t] if t == 0 else frames[t - 1]
+        want, _ = O.fft_process_ocl(frames[t], prev, lay, 55, 64)
+        assert np.allclose(got, want, rtol=0, atol=1e-4, equal_nan=True)
+
+
 def test_block_method_sequence(gpu, tmp_path):
     fs, sps, r, n = 144, 32, 8, 3
     frames = np.stack([synth.pair_np(34, fs, fs, 3 * t, t, blur=False)[0] for t in range(n)])

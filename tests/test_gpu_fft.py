@@ -298,3 +298,86 @@ def test_batch_entry_points_are_hip_graph_capturable(gpu):
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want) and torch.equal(sr_out, want_sr)
+
+
+# ---- the useOCL=true peak model (MOF_PEAK_OCL) ----------------------------------------------
+# Tolerances: 1e-4 px against the oracle's double evaluation of the model; 5e-4 px against its faithful float
+# evaluation, whose centroid sums floats over ABSOLUTE frame coordinates and so carries up to ~2e-4 px of rounding
+# noise of its own (tests/test_oracle_fft.py::test_ocl_model_f32_noise_floor) -- the engine sums patch-local doubles.
+TOL_OCL_F32 = 5e-4
+
+
+def _compare_ocl(got, cur, prev, lay, sr=55, label=""):
+    want64, _, diags = O.fft_process_ocl(cur, prev, lay, sr, 64, want_diag=True)
+    want32, _ = O.fft_process_ocl(cur, prev, lay, sr, 32)
+    n_checked = 0
+    for p in range(want64.shape[0]):
+        d = diags[p]
+        if np.isfinite(d.peak_value) and d.second_value < 0.5 * d.peak_value:
+            assert np.allclose(got[p], want64[p], rtol=0, atol=TOL, equal_nan=True), (label, p, got[p], want64[p])
+            assert np.allclose(got[p], want32[p], rtol=0, atol=TOL_OCL_F32, equal_nan=True), (label, p, got[p], want32[p])
+            n_checked += 1
+    return n_checked
+
+
+@pytest.mark.parametrize("n,shape,grid,origin,stride", [
+    (64, (480, 752), (8, 8), (1, 1), (98, 59)),
+    (128, (270, 480), (3, 2), (0, 0), (119, 63)),
+    (32, (70, 130), (3, 1), (2, 3), (33, 1)),
+    (120, (480, 480), (4, 4), (0, 0), (120, 120)),   # the geometry the OpenCL kernel is launched with (SEARCH_RADIUS 55 < 60)
+])
+def test_ocl_peak_model_matches_oracle(gpu, n, shape, grid, origin, stride):
+    from mrs_optic_flow_amd.engine import PEAK_OCL
+    h, w = shape
+    B = 6
+    cur, prev, shifts, kinds = synth.batch_np(B, h, w, n // 8, k0=100)
+    fm = FftMethod(sample_point_size=n, frame_shape=shape, grid=grid, origin=origin, stride=stride, peak_model=PEAK_OCL)
+    got = fm.process_batch_device(torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)).cpu().numpy()
+    lay = O.fft_layout(w, h, n, grid[0], grid[1], origin, stride)
+    checked = sum(_compare_ocl(got[k], cur[k], prev[k], lay, 55, f"pair{k}/{kinds[k]}") for k in range(B))
+    assert checked > 0.6 * B * grid[0] * grid[1]
+    # the two peak models are different estimators: same motion, different sub-pixel value
+    cv = FftMethod(sample_point_size=n, frame_shape=shape, grid=grid, origin=origin, stride=stride)
+    got_cv = cv.process_batch_device(torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)).cpu().numpy()
+    for k in range(B):
+        if kinds[k] == "shift":
+            assert np.allclose(np.nanmedian(got[k], axis=0), shifts[k], rtol=0, atol=0.5)
+            assert np.nanmax(np.abs(got[k] - got_cv[k])) > 10 * TOL
+
+
+def test_ocl_peak_model_mask_constant_and_modes(gpu):
+    from mrs_optic_flow_amd.engine import PEAK_OCL
+    n = 64
+    prev = synth.canvas_np(7, n, n, False)[:n, :n].copy()
+    cur = np.roll(prev, (0, 9), axis=(0, 1))
+    lay = O.fft_layout(n, n, n, 1, 1)
+    wide = FftMethod(n, n, 80.0, peak_model=PEAK_OCL, search_radius=12).process_batch_host(cur[None], prev[None])[0]
+    assert np.allclose(wide, [[9.0, 0.0]], rtol=0, atol=2e-5)
+    # search radius 5: the true peak is masked. What is left is rounding noise of ~1e-8, far below the FLT_EPSILON the
+    # centroid's sum is seeded with, so the estimate collapses towards -N/2 (cl:1342, :1366): anything but (9, 0).
+    narrow = FftMethod(n, n, 80.0, peak_model=PEAK_OCL, search_radius=5).process_batch_host(cur[None], prev[None])[0]
+    assert np.all(np.isnan(narrow) | (narrow < -n / 4)), narrow
+    # constant patches: the real-only slots are 1/0 (cl:1029) -> (NaN, NaN), unlike the cv::phaseCorrelate model
+    const = np.full((n, n), 200, np.uint8)
+    fm = FftMethod(n, n, 80.0, peak_model=PEAK_OCL)
+    assert np.isnan(fm.process_batch_host(const[None], const[None])).all()
+    assert np.isnan(O.fft_process_ocl(const, const, lay)[0]).all()
+    # stateful + long-range entry points run the same model
+    fs = 512
+    seq = [synth.pair_np(43, fs, fs, 8 * t, -4 * t)[0] for t in range(3)]
+    lay8 = O.fft_layout(fs, fs, n, 8, 8)
+    fm = FftMethod(fs, n, 80.0, peak_model=PEAK_OCL)
+    fm.processImage(seq[0])
+    out1 = fm.processImage(seq[1])
+    assert _compare_ocl(out1, seq[1], seq[0], lay8, 55, "stateful") > 40
+    out2 = fm.processImageLongRange(seq[2])
+    q1, q2 = O.resize_quarter(seq[1]), O.resize_quarter(seq[2])
+    assert _compare_ocl(out2, q2, q1, O.fft_layout(fs // 4, fs // 4, n, 2, 2), 55, "long-range") >= 3
+    # BGR front end
+    col = lambda g: np.stack([g, 255 - g // 2, g // 4 * 3 + 20], axis=-1).astype(np.uint8)
+    c3, p3 = col(seq[2]), col(seq[1])
+    got = fm.process_batch_device_bgr(torch.from_numpy(c3[None]).to(gpu), torch.from_numpy(p3[None]).to(gpu)).cpu().numpy()[0]
+    assert _compare_ocl(got, O.rgb2gray(c3), O.rgb2gray(p3), lay8, 55, "bgr") > 40
+    from mrs_optic_flow_amd import MofError
+    with pytest.raises(MofError):
+        FftMethod(n, n, 80.0, peak_model=7)

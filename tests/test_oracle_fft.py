@@ -171,3 +171,97 @@ def test_rgb2gray_fixed_point():
     c = img.astype(np.int64)
     assert (g == ((c[..., 0] * 4899 + c[..., 1] * 9617 + c[..., 2] * 1868 + 8192) >> 14)).all()
     assert (O.rgb2gray(np.full((2, 2, 3), 255, np.uint8)) == 255).all()  # the three weights sum to 2^14
+
+
+# ---- the useOCL=true peak model ------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [32, 64, 120, 128])
+def test_ocl_model_identical_patches(n):
+    p = _patch(3, n)
+    (x, y), d = O.phase_correlate_ocl(p, p, origin=(n, 2 * n))
+    assert d["peak"] == (n // 2, n // 2)
+    # unit-magnitude spectrum, inverse scaled by 1/N^2: the peak is 1 minus the four real-only slots (1/(ab) ~ 0)
+    assert abs(d["peak_value"] - (1.0 - 4.0 / (n * n))) < 1e-4
+    assert abs(x) < 2e-4 and abs(y) < 2e-4  # float sums over absolute coordinates (origin != 0): ~1e-4 px of noise
+
+
+@pytest.mark.parametrize("n", [32, 64, 128])
+@pytest.mark.parametrize("shift", [(5, -3), (-7, 2), (0, 11), (-1, -1)])
+def test_ocl_model_circular_shift_has_the_sign_of_the_cpu_branch(n, shift):
+    dx, dy = shift
+    prev = _patch(5, n, blur=False)
+    cur = np.roll(prev, (dy, dx), axis=(0, 1))
+    (x, y), d = O.phase_correlate_ocl(cur, prev)
+    (cx, cy), _ = O.phase_correlate(cur, prev)
+    assert abs(x - dx) < 1e-4 and abs(y - dy) < 1e-4, (x, y)      # un-negated by the host (FftMethod.cpp:1833) ...
+    assert abs(x + cx) < 1e-4 and abs(y + cy) < 1e-4               # ... and equal to -cv::phaseCorrelate (:1836)
+    assert d["peak"] == (n // 2 + dx, n // 2 + dy)
+
+
+def test_ocl_model_search_radius_masks_larger_shifts():
+    n = 64
+    prev = _patch(7, n, blur=False)
+    cur = np.roll(prev, (0, 9), axis=(0, 1))
+    (x, _), d = O.phase_correlate_ocl(cur, prev, search_radius=12)
+    assert d["peak"] == (n // 2 + 9, n // 2) and abs(x - 9) < 1e-4
+    # radius 5: column 9 of the un-shifted surface is zeroed (cl:823-826); what is left is rounding noise around 0
+    (x, y), d, surf = O.phase_correlate_ocl(cur, prev, search_radius=5, want_surface=True)
+    assert d["peak"] != (n // 2 + 9, n // 2) and d["peak_value"] < 1e-3
+    un = np.fft.ifftshift(surf)
+    assert np.all(un[6:n - 5, :] == 0) and np.all(un[:, 6:n - 5] == 0)
+    assert np.any(un[:6, :6] != 0)
+    # reference sizes: SEARCH_RADIUS 55 masks nothing for N <= 111 and a 9-wide band for N = 120
+    _, _, s64 = O.phase_correlate_ocl(cur, prev, search_radius=55, want_surface=True)
+    assert np.count_nonzero(s64 == 0) == 0
+    p120 = _patch(9, 120)
+    _, _, s120 = O.phase_correlate_ocl(p120, p120, search_radius=55, want_surface=True)
+    un = np.fft.ifftshift(s120)
+    assert np.all(un[56:65, :] == 0) and np.all(un[:, 56:65] == 0) and np.all(un[:56, :56] != 0)
+
+
+@pytest.mark.parametrize("n", [64, 120])
+def test_ocl_model_f64_matches_numpy_twin(n):
+    cur, prev = synth.pair_np(11, n, n, 3, -2)
+    (x, y), d = O.phase_correlate_ocl(cur, prev, precision=64)
+    (tx, ty), _, peak = twin.phase_correlate_ocl(cur.astype(np.float64), prev.astype(np.float64))
+    assert d["peak"] == peak
+    assert abs(x - tx) < 1e-9 and abs(y - ty) < 1e-9
+
+
+@pytest.mark.parametrize("n", [32, 64, 120, 128])
+def test_ocl_model_f32_noise_floor(n):
+    """The faithful float centroid over ABSOLUTE coordinates carries ~1e-4 px of rounding noise at frame offsets of a
+    few hundred pixels; with the origin at 0 it is an order of magnitude closer to the double evaluation."""
+    worst_abs, worst_loc = 0.0, 0.0
+    for k in range(6):
+        cur, prev = synth.pair_np(20 + k, n, n, (k % 5) - 2, (k % 3) - 1)
+        (x64, y64), d64 = O.phase_correlate_ocl(cur, prev, origin=(360, 360), precision=64)
+        (xa, ya), da = O.phase_correlate_ocl(cur, prev, origin=(360, 360), precision=32)
+        (xl, yl), dl = O.phase_correlate_ocl(cur, prev, origin=(0, 0), precision=32)
+        assert d64["peak"] == da["peak"] == dl["peak"]
+        worst_abs = max(worst_abs, abs(xa - x64), abs(ya - y64))
+        worst_loc = max(worst_loc, abs(xl - x64), abs(yl - y64))
+    assert worst_abs < 5e-4, worst_abs
+    assert worst_loc < 5e-5, worst_loc
+
+
+def test_ocl_model_constant_patch_is_nan():
+    # a constant patch has exactly-zero Nyquist sums: the real-only slots become 1/0 and poison the surface
+    # (cl:1029); the gate then reports (NaN, NaN) (FftMethod.cpp:1844-1847). The CPU branch survives this case.
+    n = 64
+    f = np.full((n, n), 77, np.uint8)
+    out, ninv = O.fft_process_ocl(f, f, O.fft_layout(n, n, n, 1, 1))
+    assert ninv == 1 and np.isnan(out).all()
+
+
+def test_ocl_model_processimage_gate_and_index():
+    h, w = 128, 192
+    cur, prev = synth.pair_np(4, h, w, 6, -2)
+    cur = cur.copy()
+    cur[:64, 128:] = np.roll(prev[:64, 128:], (0, 30), axis=(0, 1))  # patch (i=2, j=0): 30 px to the right
+    lay = O.fft_layout(w, h, 64, 3, 2, max_px_speed=20.0)
+    out, ninv = O.fft_process_ocl(cur, prev, lay)
+    assert ninv == 1 and np.isnan(out[2]).all()          # 30^2 > 20^2 -> gated; index i + j*grid_x
+    keep = np.ones(6, bool)
+    keep[2] = False
+    assert np.all(np.abs(out[keep] - np.array([6.0, -2.0])) < 0.35), out

@@ -45,6 +45,47 @@ def phase_correlate(a: np.ndarray, b: np.ndarray, quirk: bool = True):
     return (n / 2.0 - cx / tot, n / 2.0 - cy / tot), s, (px, py)
 
 
+def phase_correlate_ocl(a: np.ndarray, b: np.ndarray, search_radius: int = 55):
+    """The useOCL=true peak model in float64: rsqrt normalisation, 1/(ab) in the real-only slots, scaled
+    inverse, +-search_radius mask, first maximum, 7x7 positive-only centroid seeded with FLT_EPSILON.
+    Returns ((sx, sy), surface, (px, py)) -- the shift itself."""
+    n = a.shape[0]
+    assert a.shape == (n, n) == b.shape and n % 2 == 0
+    A = np.fft.fft2(a.astype(np.float64))
+    B = np.fft.fft2(b.astype(np.float64))
+    P = A * np.conj(B)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        Cs = P / np.sqrt(np.abs(P) ** 2 + FLT_EPS)
+        h = n // 2
+        for r in (0, h):
+            for c in (0, h):
+                Cs[r, c] = 1.0 / (A[r, c].real * B[r, c].real)
+        c = np.fft.ifft2(Cs).real  # scaled by 1/N^2, as the kernel does
+    idx = np.arange(n)
+    masked = (idx > search_radius) & (idx < n - search_radius)
+    c = np.where(masked[:, None] | masked[None, :], 0.0, c)
+    s = np.fft.fftshift(c)
+    best, px, py = -np.finfo(np.float32).max, 0, 0
+    flat = s.ravel()
+    if not np.all(np.isnan(flat)):
+        m = np.nanmax(flat)
+        if m > best:
+            k = int(np.flatnonzero(flat == m)[0])
+            py, px = divmod(k, n)
+    y0, y1 = max(py - 3, 0), min(py + 3, n - 1)
+    x0, x1 = max(px - 3, 0), min(px + 3, n - 1)
+    cx = cy = 0.0
+    tot = FLT_EPS
+    for y in range(y0, y1 + 1):
+        for x in range(x0, x1 + 1):
+            v = float(s[y, x])
+            if v > 0.0:
+                cx += x * v
+                cy += y * v
+                tot += v
+    return (cx / tot - n // 2, cy / tot - n // 2), s, (px, py)
+
+
 def fft_process(cur: np.ndarray, prev: np.ndarray, patch: int, grid, origin=(0, 0), stride=None,
                 max_px_speed: float = 80.0) -> np.ndarray:
     """FftMethod::processImage restated: [gy*gx, 2] float64 with NaN gating."""
