@@ -299,7 +299,8 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "binding": "integer VALU (v_qsad_pk_u16_u8), not HBM -- see DESIGN.md" if wl["kind"] == "bm"
-                         else "LDS/VALU (fp32 FFT in LDS), not HBM -- see DESIGN.md"},
+                         else "VALU issue (fp32 FFT butterflies; SQ_ACTIVE_INST_VALU 91 % of SIMD cycles), LDS pipe second, "
+                              "not HBM -- see DESIGN.md section 5"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)

@@ -92,6 +92,9 @@ int mof_fft_config_reference(mof_fft_config* cfg, int frame_size, int sample_poi
 typedef struct mof_fft_engine mof_fft_engine;
 
 int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out);
+/* Diagnostics: name of the kernel formulation the engine launches ("stockham" -- pc_kernel.hip / pc_kernel_mixed.hip --
+ * or "quad", pc_kernel_quad.hip, selected for 64 x 64 patches by the environment variable MOF_PC_QUAD=1 at load time). */
+const char* mof_fft_kernel_variant(const mof_fft_engine* e);
 void mof_fft_destroy(mof_fft_engine* e);
 
 /* setImPrev (OpticFlowCalc.h:14-16): host frame copied to the device-resident previous frame.

@@ -57,6 +57,7 @@ SYMBOLS = {
     "mof_device_count": (_I, []),
     "mof_fft_config_reference": (_I, [C.POINTER(FftConfig), _I, _I, C.c_double]),
     "mof_fft_create": (_I, [C.POINTER(FftConfig), C.POINTER(_VP)]),
+    "mof_fft_kernel_variant": (C.c_char_p, [_VP]),
     "mof_fft_destroy": (None, [_VP]),
     "mof_fft_set_prev": (_I, [_VP, _VP, _SZ]),
     "mof_fft_reset": (_I, [_VP]),

@@ -212,6 +212,8 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) {
   return MOF_OK;
 }
 
+const char* mof_fft_kernel_variant(const mof_fft_engine* e) { return e ? mof::pc_kernel_variant(e->cfg.patch_size) : ""; }
+
 void mof_fft_destroy(mof_fft_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);

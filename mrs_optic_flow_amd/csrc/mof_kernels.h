@@ -29,8 +29,12 @@ struct PcArgs {
 };
 
 bool pc_patch_size_supported(int n);
+const char* pc_kernel_variant(int patch_size);
 hipError_t pc_configure(int patch_size);  // once per device before the first launch
 hipError_t launch_pc_field(const PcArgs& a, int patch_size, int n_pairs, hipStream_t stream);
+// N = 64, quad-per-line formulation (pc_kernel_quad.hip)
+hipError_t pc_configure_quad64();
+hipError_t launch_pc_field_quad64(const PcArgs& a, int n_pairs, hipStream_t stream);
 // N = 120 (15 x 8) lives in pc_kernel_mixed.hip
 hipError_t pc_configure_120();
 hipError_t launch_pc_field_120(const PcArgs& a, int n_pairs, hipStream_t stream);

@@ -175,7 +175,11 @@ __device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
   }
   // |P'|^2 >= 2^10: 16 eps / q < 2^-30 is below half an ulp of the unit-magnitude result, so C = P' rsq(q) (one
   // transcendental); the general form only runs for (numerically) empty bins such as constant patches
-  const float s = (q >= 1024.f) ? __builtin_amdgcn_rsqf(q) : __builtin_amdgcn_sqrtf(q) * __builtin_amdgcn_rcpf(q + eps16);
+  // -- taken as a wave-uniform branch: a per-lane one costs exec-mask juggling around every bin and, in the quad
+  // kernel, 48 spilled VGPRs.
+  float s = __builtin_amdgcn_rsqf(q);
+  if (__builtin_amdgcn_ballot_w64(!(q >= 1024.f)) != 0)
+    s = (q >= 1024.f) ? s : __builtin_amdgcn_sqrtf(q) * __builtin_amdgcn_rcpf(q + eps16);
   return {pr * s, pim * s};
 }
 
@@ -224,8 +228,10 @@ __device__ __forceinline__ void centroid_gate_store(Best best, float wval, int l
     // shift = -(center - t) = t - N/2   (:1836); the OpenCL branch returns centroid - N/2 un-negated (cl:1370, :1833)
     double sx = cx / sum - (double)N / 2.0;
     double sy = cy / sum - (double)N / 2.0;
+    // best.idx == 0x7fffffff: no value compared equal to the maximum, i.e. the whole surface is NaN (a patch whose
+    // spectrum holds infinities, e.g. 1/0 in a real-only slot under the OpenCL model) -> invalid, as a NaN centroid is
     const bool bad = (sx * sx + sy * sy > max_px_speed_sq) || (fabs(sx) > (double)N / 2.0) ||
-                     (fabs(sy) > (double)N / 2.0) || (sx != sx) || (sy != sy);
+                     (fabs(sy) > (double)N / 2.0) || (sx != sx) || (sy != sy) || best.idx == 0x7fffffff;
     if (bad) sx = sy = __builtin_nan("");
     out[0] = sx;
     out[1] = sy;

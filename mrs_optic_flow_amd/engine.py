@@ -69,6 +69,11 @@ class FftMethod:
         self._h = C.c_void_p()
         check(lib.mof_fft_create(C.byref(cfg), C.byref(self._h)))
 
+    @property
+    def kernel_variant(self) -> str:
+        """'stockham' or 'quad' (diagnostics, include/mof.h)."""
+        return self._lib.mof_fft_kernel_variant(self._h).decode()
+
     # -- reference surface --------------------------------------------------------------------
     @property
     def sqNum(self) -> int:

@@ -381,3 +381,22 @@ def test_ocl_peak_model_mask_constant_and_modes(gpu):
     from mrs_optic_flow_amd import MofError
     with pytest.raises(MofError):
         FftMethod(n, n, 80.0, peak_model=7)
+
+
+def test_quad_formulation_of_k1_passes_the_same_parity_tests(gpu):
+    """pc_kernel_quad.hip (MOF_PC_QUAD=1, read once at load time) is an opt-in alternative formulation for 64 x 64
+    patches; it has to stay correct. One child process re-runs this file's N = 64 parity cases with it selected."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MOF_PC_QUAD="1", MOF_EXPECT_VARIANT="quad")
+    sel = "golden or seeded or ocl_peak or bgr or long_range or gating or circular or expected_variant"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel,
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
+def test_expected_variant(gpu):
+    want = os.environ.get("MOF_EXPECT_VARIANT", "stockham")
+    assert FftMethod(64, 64, 80.0).kernel_variant == want
+    assert FftMethod(128, 128, 80.0).kernel_variant == "stockham"

@@ -36,6 +36,11 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint32_t seed) {
       if (OP == 10) u[i] = (u[i] & a1) | a2;                 // v_and_or
       if (OP == 11) f[i] = __builtin_amdgcn_rcpf(f[i]);
       if (OP == 12) u[i] = __builtin_amdgcn_alignbyte(u[i], a1, 1);
+      if (OP == 13) u[i] = __builtin_amdgcn_update_dpp(0, u[i], 0x4E, 0xf, 0xf, true) + a1;   // v_mov_b32_dpp quad_perm + v_add
+      if (OP == 14) f[i] = (u[i] & 1) ? f[i] : g[i] + f[i];                                     // v_add + v_cndmask
+      if (OP == 15) f[i] = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f[i]), 0xB1, 0xf, 0xf, true)), g[i], f[i]);  // mov_dpp + fmac
+      if (OP == 16) u[i] = __builtin_amdgcn_ds_swizzle(u[i], 0x8000 | 0x4E) + a1;              // ds_swizzle + v_add
+      if (OP == 17) u[i] = __builtin_amdgcn_update_dpp(0, u[i], 0x128, 0xf, 0xf, true) + a1;  // row_ror:8
     }
   }
   uint32_t r = 0;
@@ -80,5 +85,10 @@ int main() {
   run<10>("v_and_or_b32", d, cus, ghz);
   run<11>("v_rcp_f32", d, cus, ghz);
   run<12>("v_alignbyte_b32", d, cus, ghz);
+  run<13>("mov_dpp quad + add (2)", d, cus, ghz);
+  run<14>("add + cndmask (2)", d, cus, ghz);
+  run<15>("mov_dpp + fmac (2)", d, cus, ghz);
+  run<16>("ds_swizzle + add (1+1)", d, cus, ghz);
+  run<17>("mov_dpp row_ror + add (2)", d, cus, ghz);
   return 0;
 }
