@@ -22,7 +22,14 @@ namespace mof {
 
 namespace {
 
-constexpr int N = 120, H = 60, R1 = 15, R2 = 8, LPW = 8, WAVES = N / LPW, T = WAVES * 64, PITCH = 121;
+constexpr int N = 120, H = 60, R1 = 15, R2 = 8, LPW = 8, WAVES = N / LPW, T = WAVES * 64;
+// Row pitch 136 = 8 (mod 32) complex elements: with the lane maps below every ds_read_b64 group (32 lanes, 64 banks)
+// and every ds_write_b64 group (16 lanes, 32 banks) of the transform passes hits distinct banks
+// (tools/design/lds_conflicts_120.py; pitch 121 cost 2.3x the conflict-free LDS cycles, SQ_LDS_BANK_CONFLICT = 53 %).
+#ifndef MOF_PITCH120
+#define MOF_PITCH120 136
+#endif
+constexpr int PITCH = MOF_PITCH120;
 constexpr size_t LDS_BYTES_120 = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best);
 
 __device__ __forceinline__ int za(int r, int c) { return r * PITCH + c; }
@@ -103,16 +110,16 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int nlin
     }
     wave_sync();
   }
-  {  // stage 2: radix 8; 15 butterflies per line -> 120 per wave over 2 x 64 lane slots
+  {  // stage 2: radix 8; 15 butterflies per line: x = 0..7 of the wave's 8 lines, then x = 8..14 (lane map as in
+     // stage 1: 8 consecutive x of 4 lines per 32-lane group -- conflict-free with the pitch above)
     cf v[2][R2];
     int line[2], x[2];
     bool on[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int q = lane + 64 * b;
-      line[b] = line0 + q / R1;
-      x[b] = q % R1;
-      on[b] = q < LPW * R1 && line[b] < nlines;
+      line[b] = line0 + lane / 8;
+      x[b] = 8 * b + lane % 8;
+      on[b] = x[b] < R1 && line[b] < nlines;
       if (on[b]) {
 #pragma unroll
         for (int k = 0; k < R2; ++k) {
@@ -288,9 +295,6 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
             p[i >> 2] |= rgb2gray_fixed(pb[3 * i], pb[3 * i + 1], pb[3 * i + 2]) << (8 * (i & 3));
           }
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          z[za(row, col + i)] = {(float)((c[i >> 2] >> (8 * (i & 3))) & 0xffu), (float)((p[i >> 2] >> (8 * (i & 3))) & 0xffu)};
       } else {
         // long-range mode: rounded mean of the 2x2 centre of each 4x4 cell (cv::resize 1/4, FftMethod.cpp:1931-1932)
         const uint8_t* c1 = cur + (size_t)(4 * row + 1) * a.pitch + 4 * col;
@@ -302,14 +306,24 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
           __builtin_memcpy(cb, c1 + a.pitch + 16 * h2, 16);
           __builtin_memcpy(pa, p1 + 16 * h2, 16);
           __builtin_memcpy(pb, p1 + a.pitch + 16 * h2, 16);
+          c[h2] = p[h2] = 0;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const uint32_t cs = ((ca[i] >> 8) & 0xffu) + ((ca[i] >> 16) & 0xffu) + ((cb[i] >> 8) & 0xffu) + ((cb[i] >> 16) & 0xffu);
             const uint32_t ps = ((pa[i] >> 8) & 0xffu) + ((pa[i] >> 16) & 0xffu) + ((pb[i] >> 8) & 0xffu) + ((pb[i] >> 16) & 0xffu);
-            z[za(row, col + 4 * h2 + i)] = {(float)((cs + 2u) >> 2), (float)((ps + 2u) >> 2)};
+            c[h2] |= ((cs + 2u) >> 2) << (8 * i);
+            p[h2] |= ((ps + 2u) >> 2) << (8 * i);
           }
         }
       }
+      // The 8 pixels of a chunk are stored in a per-lane rotated order: straight order puts the 16 lanes of a
+      // ds_write_b64 group on two banks (chunks are 8 elements apart), an 8-way conflict on every store.
+      const int rot = ((q % (N / 8)) >> 1) & 7;
+      const uint64_t cr = __builtin_rotateright64(((uint64_t)c[1] << 32) | c[0], 8 * rot);
+      const uint64_t pr = __builtin_rotateright64(((uint64_t)p[1] << 32) | p[0], 8 * rot);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)  // byte i of the rotated word is pixel (i + rot) & 7
+        z[za(row, col + ((i + rot) & 7))] = {(float)((uint32_t)(cr >> (8 * i)) & 0xffu), (float)((uint32_t)(pr >> (8 * i)) & 0xffu)};
     }
   }
   wave_sync();
