@@ -262,16 +262,47 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   cf* z = reinterpret_cast<cf*>(smem);
   Best* red = reinterpret_cast<Best*>(z + N * PITCH);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
   const int patches = a.grid_x * a.grid_y;
-  const int pair = blockIdx.x / patches;
-  const int patch = blockIdx.x % patches;
-  const int pi = patch % a.grid_x, pj = patch / a.grid_x;
-  const int x0 = a.origin_x + pi * a.stride_x;
-  const int y0 = a.origin_y + pj * a.stride_y;
-  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(DS * y0) * a.pitch + (size_t)(CH * DS * x0);
-  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(DS * y0) * a.pitch + (size_t)(CH * DS * x0);
   const float* tw = a.twiddles;
+  auto patch_ptr = [&](int pp, const uint8_t* frames, size_t frame_stride) -> const uint8_t* {
+    const int pair = pp / patches, patch = pp % patches;
+    const int x0 = a.origin_x + (patch % a.grid_x) * a.stride_x, y0 = a.origin_y + (patch / a.grid_x) * a.stride_y;
+    return frames + (size_t)pair * frame_stride + (size_t)(DS * y0) * a.pitch + (size_t)(CH * DS * x0);
+  };
+
+  // ---- persistent workgroup (one per CU: the tile is 128 KB): patches p = blockIdx.x, + gridDim.x, ... With a single
+  //      workgroup on the CU nothing else hides the HBM latency of the patch load, so the raw pixels of the NEXT patch
+  //      are requested before the current one is transformed (full-resolution paths; 8 or 24 VGPRs).
+  constexpr int PFW = (DS == 1) ? (CH == 1 ? 2 : 6) : 1;  // dwords per image and chunk held in flight
+  uint32_t pfc[2][PFW], pfp[2][PFW];
+  auto prefetch = [&](int pp) {
+    if constexpr (DS == 1) {
+      const uint8_t* cb = patch_ptr(pp, a.cur, a.cur_stride);
+      const uint8_t* pb = patch_ptr(pp, a.prev, a.prev_stride);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int q = lane0 + 64 * b;
+        if (q < LPW * (N / 8)) {
+          const size_t off = (size_t)(wave0 * LPW + q / (N / 8)) * a.pitch + (size_t)CH * ((q % (N / 8)) * 8);
+          __builtin_memcpy(pfc[b], cb + off, 4 * PFW);
+          __builtin_memcpy(pfp[b], pb + off, 4 * PFW);
+        }
+      }
+    }
+  };
+  int p = blockIdx.x;
+  if (p < a.total) prefetch(p);
+  for (; p < a.total; p += gridDim.x) {
+  // lane / wave laundered once per patch: keeps LICM from hoisting every LDS address of the body out of the loop
+  int lane = lane0, wave = wave0;
+  asm volatile("" : "+v"(lane), "+v"(wave));
+  lane &= 63;
+  wave &= 15;
+  const int tid = wave * 64 + lane;
+  const uint8_t* cur = patch_ptr(p, a.cur, a.cur_stride);
+  const uint8_t* prev = patch_ptr(p, a.prev, a.prev_stride);
+  (void)cur; (void)prev;
 
   // ---- load: the wave's own 8 rows in 8-pixel chunks (15 per row), u8 -> f32, z = cur + i*prev (:1805-1806)
 #pragma unroll
@@ -279,20 +310,18 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
     const int q = lane + 64 * b;
     if (q < LPW * (N / 8)) {
       const int row = wave * LPW + q / (N / 8), col = (q % (N / 8)) * 8;
-      uint32_t c[2], p[2];
+      uint32_t c[2], pv[2];
       if constexpr (DS == 1) {
         if constexpr (CH == 1) {
-          __builtin_memcpy(c, cur + (size_t)row * a.pitch + col, 8);
-          __builtin_memcpy(p, prev + (size_t)row * a.pitch + col, 8);
-        } else {  // BGR8 front end (optic_flow.cpp:1622): 8 pixels = 24 bytes
-          uint8_t cb[24], pb[24];
-          __builtin_memcpy(cb, cur + (size_t)row * a.pitch + 3 * col, 24);
-          __builtin_memcpy(pb, prev + (size_t)row * a.pitch + 3 * col, 24);
-          c[0] = c[1] = p[0] = p[1] = 0;
+          c[0] = pfc[b][0]; c[1] = pfc[b][1];
+          pv[0] = pfp[b][0]; pv[1] = pfp[b][1];
+        } else {  // BGR8 front end (optic_flow.cpp:1622): 8 pixels = 24 bytes = 6 dwords
+          auto byte_of = [](const uint32_t* w, int i) -> uint32_t { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
+          c[0] = c[1] = pv[0] = pv[1] = 0;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            c[i >> 2] |= rgb2gray_fixed(cb[3 * i], cb[3 * i + 1], cb[3 * i + 2]) << (8 * (i & 3));
-            p[i >> 2] |= rgb2gray_fixed(pb[3 * i], pb[3 * i + 1], pb[3 * i + 2]) << (8 * (i & 3));
+            c[i >> 2] |= rgb2gray_fixed(byte_of(pfc[b], 3 * i), byte_of(pfc[b], 3 * i + 1), byte_of(pfc[b], 3 * i + 2)) << (8 * (i & 3));
+            pv[i >> 2] |= rgb2gray_fixed(byte_of(pfp[b], 3 * i), byte_of(pfp[b], 3 * i + 1), byte_of(pfp[b], 3 * i + 2)) << (8 * (i & 3));
           }
         }
       } else {
@@ -306,13 +335,13 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
           __builtin_memcpy(cb, c1 + a.pitch + 16 * h2, 16);
           __builtin_memcpy(pa, p1 + 16 * h2, 16);
           __builtin_memcpy(pb, p1 + a.pitch + 16 * h2, 16);
-          c[h2] = p[h2] = 0;
+          c[h2] = pv[h2] = 0;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const uint32_t cs = ((ca[i] >> 8) & 0xffu) + ((ca[i] >> 16) & 0xffu) + ((cb[i] >> 8) & 0xffu) + ((cb[i] >> 16) & 0xffu);
             const uint32_t ps = ((pa[i] >> 8) & 0xffu) + ((pa[i] >> 16) & 0xffu) + ((pb[i] >> 8) & 0xffu) + ((pb[i] >> 16) & 0xffu);
             c[h2] |= ((cs + 2u) >> 2) << (8 * i);
-            p[h2] |= ((ps + 2u) >> 2) << (8 * i);
+            pv[h2] |= ((ps + 2u) >> 2) << (8 * i);
           }
         }
       }
@@ -320,12 +349,13 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
       // ds_write_b64 group on two banks (chunks are 8 elements apart), an 8-way conflict on every store.
       const int rot = ((q % (N / 8)) >> 1) & 7;
       const uint64_t cr = __builtin_rotateright64(((uint64_t)c[1] << 32) | c[0], 8 * rot);
-      const uint64_t pr = __builtin_rotateright64(((uint64_t)p[1] << 32) | p[0], 8 * rot);
+      const uint64_t pr = __builtin_rotateright64(((uint64_t)pv[1] << 32) | pv[0], 8 * rot);
 #pragma unroll
       for (int i = 0; i < 8; ++i)  // byte i of the rotated word is pixel (i + rot) & 7
         z[za(row, col + ((i + rot) & 7))] = {(float)((uint32_t)(cr >> (8 * i)) & 0xffu), (float)((uint32_t)(pr >> (8 * i)) & 0xffu)};
     }
   }
+  if (p + (int)gridDim.x < a.total) prefetch(p + (int)gridDim.x);
   wave_sync();
 
   // ---- forward 2-D transform: rows (wave-local), barrier, columns (wave-local)
@@ -364,15 +394,19 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   if (lane == 0) red[wave] = best;
   __syncthreads();
 
+  // wave 0 reads the centroid window, then a barrier releases the others to overwrite the tile with the next patch
+  float wval = 0.f;
   if (wave == 0) {
     for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
-    const float wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
+    wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
       const int y = (ys + H) % N, x = (xs + H) % N;
       const cf s = z[za(y, x % H)];
       return x < H ? s.x : s.y;
     });
-    centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * ((size_t)pair * patches + patch));
   }
+  __syncthreads();
+  if (wave == 0) centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p);
+  }  // persistent loop
 }
 
 template <int DS, int CH, int PK>
@@ -391,8 +425,18 @@ hipError_t pc_configure_120() {
   return configure_one_120<4, 1, 1>();
 }
 
-hipError_t launch_pc_field_120(const PcArgs& a, int n_pairs, hipStream_t stream) {
-  const unsigned blocks = (unsigned)n_pairs * (unsigned)(a.grid_x * a.grid_y);
+static int g_cu_count_120 = 0;
+
+hipError_t launch_pc_field_120(const PcArgs& a_in, int n_pairs, hipStream_t stream) {
+  PcArgs a = a_in;
+  a.total = n_pairs * a.grid_x * a.grid_y;
+  if (g_cu_count_120 == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    g_cu_count_120 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                         ? prop.multiProcessorCount : 256;
+  }
+  const unsigned blocks = (unsigned)(a.total < g_cu_count_120 ? a.total : g_cu_count_120);  // one resident workgroup per CU
   if (a.downscale == 4 && a.channels == 3) return hipErrorInvalidValue;
   const dim3 g(blocks), b(T);
   if (a.peak_model == 1) {
