@@ -161,21 +161,21 @@ static int validate_fft(const mof_fft_config* c) {
   return MOF_OK;
 }
 
-int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) {
+int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   if (!out) return fail(MOF_ERR_BAD_ARG, "null out");
   *out = nullptr;
   int rc = validate_fft(cfg);
   if (rc) return rc;
   rc = select_device(cfg->device);
   if (rc) return rc;
-  mof_fft_engine* e = new (std::nothrow) mof_fft_engine();
-  if (!e) return fail(MOF_ERR_NO_MEMORY, "out of host memory");
-  e->cfg = *cfg;
-  e->frame_bytes = (size_t)cfg->frame_width * cfg->frame_height;
   const int n = cfg->patch_size;
   const size_t res = (size_t)cfg->grid_x * cfg->grid_y * 2;
   // twiddles W_N^k = exp(-2 pi i k / N), double -> float, axis values exact
   std::vector<float> tw(2 * (size_t)n);
+  mof_fft_engine* e = new (std::nothrow) mof_fft_engine();
+  if (!e) return fail(MOF_ERR_NO_MEMORY, "out of host memory");
+  e->cfg = *cfg;
+  e->frame_bytes = (size_t)cfg->frame_width * cfg->frame_height;
   for (int k = 0; k < n; ++k) {
     double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)n;
     double c = std::cos(ang), s = std::sin(ang);
@@ -210,6 +210,8 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) {
 #undef CREATE_TRY
   *out = e;
   return MOF_OK;
+} catch (const std::bad_alloc&) {
+  return fail(MOF_ERR_NO_MEMORY, "mof_fft_create: out of host memory");
 }
 
 const char* mof_fft_kernel_variant(const mof_fft_engine* e) { return e ? mof::pc_kernel_variant(e->cfg.patch_size) : ""; }
@@ -361,6 +363,8 @@ int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_
   if (n_pairs == 0) return MOF_OK;  // an empty batch carries no pointers to check
   if (!d_cur || !d_prev || !d_out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
+    return fail(MOF_ERR_BAD_ARG, "batch too large for one launch");
   BusyGuard g(e->busy);
   if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -405,7 +409,7 @@ int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, si
 }
 
 int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
-                               size_t prev_stride, size_t pitch, int n_pairs, double* out_xy) {
+                               size_t prev_stride, size_t pitch, int n_pairs, double* out_xy) try {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
   if (n_pairs == 0) return MOF_OK;  // an empty batch carries no pointers to check
   if (!cur || !prev || !out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
@@ -436,6 +440,8 @@ int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur
   if (d_p) (void)hipFree(d_p);
   if (d_o) (void)hipFree(d_o);
   return rc;
+} catch (const std::bad_alloc&) {
+  return fail(MOF_ERR_NO_MEMORY, "mof_fft_process_batch_host: out of host memory");
 }
 
 int mof_fft_sync(mof_fft_engine* e) {
@@ -689,7 +695,7 @@ int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t c
 }
 
 int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
-                              size_t prev_stride, size_t pitch, int n_pairs, int8_t* dx, int8_t* dy, int8_t* mode) {
+                              size_t prev_stride, size_t pitch, int n_pairs, int8_t* dx, int8_t* dy, int8_t* mode) try {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
   if (n_pairs == 0) return MOF_OK;  // an empty batch carries no pointers to check
   if (!cur || !prev || !dx || !dy || !mode || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
@@ -724,6 +730,8 @@ int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_s
   if (d_y) (void)hipFree(d_y);
   if (d_m) (void)hipFree(d_m);
   return rc;
+} catch (const std::bad_alloc&) {
+  return fail(MOF_ERR_NO_MEMORY, "mof_bm_process_batch_host: out of host memory");
 }
 
 int mof_bm_sync(mof_bm_engine* e) {

@@ -176,7 +176,7 @@ void mof_sr_destroy(mof_sr_engine* e) {
   delete e;
 }
 
-int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) {
+int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   if (!out) return mof::capi_fail(MOF_ERR_BAD_ARG, "null out");
   *out = nullptr;
   if (!cfg || !(cfg->magnitude > 0.0)) return mof::capi_fail(MOF_ERR_BAD_ARG, "bad scale/rotation config");
@@ -189,14 +189,14 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) {
   }
   if (cfg->device < 0 || cfg->device >= ndev) return mof::capi_fail(MOF_ERR_BAD_ARG, "device %d out of range", cfg->device);
   SR_TRY(hipSetDevice(cfg->device));
-  mof_sr_engine* e = new (std::nothrow) mof_sr_engine();
-  if (!e) return mof::capi_fail(MOF_ERR_NO_MEMORY, "out of host memory");
-  e->cfg = *cfg;
   const int res = cfg->resolution;
   const size_t nn = (size_t)res * res;
   const std::vector<mof::SrMapEntry> map = logpolar_map(res, cfg->magnitude);
   const std::vector<int16_t> wc = weight_table(4), wl = weight_table(8);
   std::vector<float> tw(2 * (size_t)res);
+  mof_sr_engine* e = new (std::nothrow) mof_sr_engine();
+  if (!e) return mof::capi_fail(MOF_ERR_NO_MEMORY, "out of host memory");
+  e->cfg = *cfg;
   for (int k = 0; k < res; ++k) {
     double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)res;
     double c = std::cos(ang), s = std::sin(ang);
@@ -242,6 +242,8 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) {
 #undef CREATE_TRY
   *out = e;
   return MOF_OK;
+} catch (const std::bad_alloc&) {
+  return mof::capi_fail(MOF_ERR_NO_MEMORY, "mof_sr_create: out of host memory");
 }
 
 int mof_sr_reset(mof_sr_engine* e) {

@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mof_kernels.h"
 #include "pc_common.hpp"
@@ -137,7 +138,7 @@ __device__ __forceinline__ void lds_fft(cf* z, int nlines, const float* tw, int 
 }
 
 #ifndef MOF_SR_ROWS
-#define MOF_SR_ROWS 8
+#define MOF_SR_ROWS 4
 #endif
 constexpr int ROWS_L = MOF_SR_ROWS;   // rows per workgroup in K5
 #ifndef MOF_SR_CW
@@ -167,7 +168,11 @@ __global__ void __launch_bounds__(256) sr_logpolar_kernel(SrLpArgs a) {
   const SrMapEntry m = a.map[pix];
   if (!m.valid) return;
   const uint8_t* src = a.src + (size_t)img * a.src_stride;
+#ifdef MOF_SR_ABL_W  // diagnostic build: every lane reads weight row 0 (results wrong by design)
+  const int16_t* w = a.weights;
+#else
   const int16_t* w = a.weights + (size_t)m.widx * (K * K);
+#endif
   constexpr int HALF = K / 2 - 1;
   const int sx = m.ax - HALF, sy = m.ay - HALF;
   int sum = 0;
@@ -199,6 +204,73 @@ __global__ void __launch_bounds__(256) sr_logpolar_kernel(SrLpArgs a) {
   int v = (sum + (1 << 14)) >> 15;
   v = v < 0 ? 0 : (v > 255 ? 255 : v);
   a.dst[(size_t)img * a.dst_stride + pix] = (uint8_t)v;
+}
+
+
+// Same remap with the whole 2-D weight table resident in LDS. In sr_logpolar_kernel every lane fetches its own
+// K*K-short weight row from the 128-KB (Lanczos4) table: 128 B per destination pixel out of L2, 8 TB/s chip-wide at the
+// measured rate -- the L2, not the arithmetic, set that kernel's time (an all-lanes-one-row build ran 2x faster).
+// Here one persistent 16-wave workgroup per CU copies the table once (rows padded to 144 / 40 B so that random rows
+// spread over the banks) and then walks 8 x 8 destination tiles; only the source pixels still come through L1.
+template <int K>
+struct LpLds {
+  static constexpr int ROW_B = (K == 8) ? 144 : 40;  // padded row, bytes (K*K*2 = 128 / 32 payload)
+  static constexpr size_t BYTES = (size_t)1024 * ROW_B;
+};
+
+template <int K>
+__global__ void __launch_bounds__(1024) sr_logpolar_lds_kernel(SrLpArgs a, int n_images) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
+  constexpr int ROW_B = LpLds<K>::ROW_B, PARTS = (K * K * 2) / (2 * K);  // one part = one tap row = 2K bytes
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < 1024 * PARTS; c += 1024) {
+    uint32_t v[K / 2];
+    __builtin_memcpy(v, reinterpret_cast<const unsigned char*>(a.weights) + (size_t)c * 2 * K, 2 * K);
+    __builtin_memcpy(wl + (c / PARTS) * ROW_B + (c % PARTS) * 2 * K, v, 2 * K);
+  }
+  __syncthreads();
+  const int res = a.res, tiles = (res + 7) / 8, per_img = tiles * tiles, total = n_images * per_img;
+  constexpr int HALF = K / 2 - 1;
+  for (int t = blockIdx.x * 16 + wave; t < total; t += gridDim.x * 16) {
+    const int img = t / per_img, r = t % per_img;
+    const int rho = (r % tiles) * 8 + (lane & 7), phi = (r / tiles) * 8 + (lane >> 3);
+    if (rho >= res || phi >= res) continue;
+    const int pix = phi * res + rho;
+    const SrMapEntry m = a.map[pix];
+    if (!m.valid) continue;
+    const uint8_t* src = a.src + (size_t)img * a.src_stride;
+    const unsigned char* w = wl + (int)m.widx * ROW_B;
+    const int sx = m.ax - HALF, sy = m.ay - HALF;
+    int sum = 0;
+    if (sx >= 0 && sy >= 0 && sx + K <= res && sy + K <= res) {
+#pragma unroll
+      for (int k1 = 0; k1 < K; ++k1) {
+        uint32_t px[K / 4], wq[K / 2];
+        __builtin_memcpy(px, src + (size_t)(sy + k1) * a.pitch + sx, K);
+        __builtin_memcpy(wq, __builtin_assume_aligned(w + k1 * 2 * K, 8), 2 * K);
+#pragma unroll
+        for (int k2 = 0; k2 < K; ++k2) {
+          const int pv = (int)((px[k2 >> 2] >> (8 * (k2 & 3))) & 0xffu);
+          const int wv = (int)(int16_t)(wq[k2 >> 1] >> (16 * (k2 & 1)));
+          sum += pv * wv;
+        }
+      }
+    } else {
+      const int16_t* ws = reinterpret_cast<const int16_t*>(w);
+      for (int k1 = 0; k1 < K; ++k1) {
+        int yy = sy + k1;
+        while (yy < 0 || yy >= res) yy = yy < 0 ? -yy : 2 * res - 2 - yy;
+        for (int k2 = 0; k2 < K; ++k2) {
+          int xx = sx + k2;
+          while (xx < 0 || xx >= res) xx = xx < 0 ? -xx : 2 * res - 2 - xx;
+          sum += (int)src[(size_t)yy * a.pitch + xx] * (int)ws[k1 * K + k2];
+        }
+      }
+    }
+    int v = (sum + (1 << 14)) >> 15;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    a.dst[(size_t)img * a.dst_stride + pix] = (uint8_t)v;
+  }
 }
 
 // ---- K5: forward row transforms of z = cur_lp + i prev_lp ------------------------------------------------
@@ -342,7 +414,29 @@ __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
 
 bool sr_resolution_supported(int res) { return res == 240 || res == 256 || res == 480; }
 
+template <int K>
+static hipError_t launch_lp_lds(const SrLpArgs& a, int n_images, hipStream_t stream) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_logpolar_lds_kernel<K>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LpLds<K>::BYTES);
+  if (e != hipSuccess) return e;
+  const int tiles = (a.res + 7) / 8;
+  const long total = (long)n_images * tiles * tiles;
+  const unsigned blocks = (unsigned)((total + 15) / 16 < cus ? (total + 15) / 16 : cus);
+  hipLaunchKernelGGL(sr_logpolar_lds_kernel<K>, dim3(blocks), dim3(1024), LpLds<K>::BYTES, stream, a, n_images);
+  return hipGetLastError();
+}
+
 hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipStream_t stream) {
+  // MOF_SR_LP_GLOBAL=1: the first formulation (weights fetched from L2 per pixel), kept for A/B measurements; it also
+  // serves single images, where staging the table would cost more than it saves
+  static const bool global_w = [] { const char* e = getenv("MOF_SR_LP_GLOBAL"); return e && atoi(e) != 0; }();
+  if (!global_w && n_images >= 4) return interp == 2 ? launch_lp_lds<4>(a, n_images, stream) : launch_lp_lds<8>(a, n_images, stream);
   const dim3 grid((unsigned)(((a.res + 31) / 32) * ((a.res + 7) / 8)), (unsigned)n_images);
   if (interp == 2)
     hipLaunchKernelGGL(sr_logpolar_kernel<4>, grid, dim3(256), 0, stream, a);
