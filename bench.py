@@ -236,7 +236,7 @@ def main() -> None:
             ag = None
 
     def step(i=None):
-        nonlocal out
+        nonlocal out, ag
         if ag is not None:
             out = ag.slot()
         if i is not None:
@@ -250,10 +250,19 @@ def main() -> None:
             res = sharding.gather_results(res, B * world)
         return res
 
-    for _ in range(args.warmup):
-        step()
-    if ag is not None:
-        ag.drain()
+    try:
+        for _ in range(args.warmup):
+            step()
+        if ag is not None:
+            ag.drain()
+    except Exception as exc:  # the non-blocking gather failed at run time: redo the warm-up with the blocking one
+        if ag is None:
+            raise
+        print(f"[bench] async gather failed in warm-up ({exc}); using the blocking all-gather", file=sys.stderr)
+        ag = None
+        out = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
+        for _ in range(args.warmup):
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
