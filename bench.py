@@ -30,6 +30,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X vector fp32 peak (all-FMA; an add-dominated FFT can reach about half of it)
+
+
+def fft_flops_per_pair(n: int, patches: int) -> float:
+    """fp32 work of one frame pair on the FFT path, BASELINE.md section 3 convention: per patch pair one complex 2-D
+    forward transform (the two real images ride one complex transform) and half of one for the Hermitian inverse,
+    5 N^2 log2(N^2) flop per complex 2-D transform, plus ~22 flop per bin of the half cross-power spectrum."""
+    import math
+    fft2 = 5.0 * n * n * math.log2(n * n)
+    return patches * (1.5 * fft2 + 22.0 * n * n / 2)
+
 
 WORKLOADS = {
     "c2": dict(kind="fft", h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=1024, s=8,
@@ -311,6 +322,13 @@ def main() -> None:
                          else "VALU issue (fp32 FFT butterflies; SQ_ACTIVE_INST_VALU 91 % of SIMD cycles), LDS pipe second, "
                               "not HBM -- see DESIGN.md section 5"},
         }
+        if wl["kind"] == "fft":
+            # the resource that actually binds K1: vector fp32. Informational, next to the HBM figure.
+            fl = fft_flops_per_pair(wl["n"], wl["grid"][0] * wl["grid"][1]) * B
+            line["roofline"]["compute"] = {"unit": "TFLOP/s", "achieved": fl / (kern_ms * 1e-3) / 1e12,
+                                           "peak": VALU_FP32_PEAK_TFLOPS,
+                                           "frac": fl / (kern_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
+                                           "flop_per_launch": fl, "pipe": "VALU fp32 (no MFMA form of this FFT)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)
