@@ -320,10 +320,10 @@ def main() -> None:
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "binding": "integer VALU (v_qsad_pk_u16_u8), not HBM -- see DESIGN.md" if wl["kind"] == "bm"
                          else "VALU issue (fp32 FFT butterflies; SQ_ACTIVE_INST_VALU 91 % of SIMD cycles), LDS pipe second, "
-                              "not HBM -- see DESIGN.md section 5"},
+                              "not HBM -- see DESIGN.md section 4 (K1)"},
         }
         if wl["kind"] == "fft":
-            # the resource that actually binds K1 (DESIGN.md section 5): vector fp32. Informational, next to the HBM figure.
+            # the resource that actually binds K1 (DESIGN.md section 4 (K1)): vector fp32. Informational, next to the HBM figure.
             fl = fft_flops_per_pair(wl["n"], wl["grid"][0] * wl["grid"][1]) * B
             line["roofline"]["compute"] = {"unit": "TFLOP/s", "achieved": fl / (kern_ms * 1e-3) / 1e12,
                                            "peak": VALU_FP32_PEAK_TFLOPS,

@@ -544,7 +544,7 @@ static hipError_t launch_n(const PcArgs& a_in, int n_pairs, hipStream_t stream) 
 }
 
 // MOF_PC_QUAD=1 routes N = 64 to the quad-per-line formulation of pc_kernel_quad.hip (an evaluated alternative: a third
-// of the LDS traffic, 35 % more VALU instructions, 8 % slower on MI355X because K1 is VALU-bound -- DESIGN.md §5).
+// of the LDS traffic, 35 % more VALU instructions, 8 % slower on MI355X because K1 is VALU-bound -- DESIGN.md §4, K1).
 static bool classic64() {
   static const bool v = [] { const char* e = getenv("MOF_PC_QUAD"); return !(e && atoi(e) != 0); }();
   return v;
