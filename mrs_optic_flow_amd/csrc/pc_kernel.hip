@@ -34,6 +34,10 @@
 #include "mof_kernels.h"
 #include "pc_common.hpp"
 
+#ifndef MOF_FUSED_TW
+#define MOF_FUSED_TW 1  // twiddles of the radix-8 second stage fused into its first layer (butterfly8_tw)
+#endif
+
 namespace mof {
 
 namespace {
@@ -125,10 +129,11 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
 #ifdef MOF_ABLATE_NOBFLY
         v[b][k] = a;
 #else
-        v[b][k] = (k == 0) ? a : cmul(a, tw_row[k - 1]);
+        v[b][k] = (k == 0 || (R2 == 8 && MOF_FUSED_TW)) ? a : cmul(a, tw_row[k - 1]);
 #endif
       }
-      butterfly<R2>(v[b]);
+      if constexpr (R2 == 8 && MOF_FUSED_TW) butterfly8_tw(v[b], tw_row);
+      else butterfly<R2>(v[b]);
     }
     wave_sync();
 #pragma unroll
@@ -178,10 +183,11 @@ __device__ __forceinline__ void col_pass_fwd(cf* __restrict__ z, int col0, int l
 #ifdef MOF_ABLATE_NOBFLY
         v[b][k] = a;
 #else
-        v[b][k] = (k == 0) ? a : cmul(a, tw_col[k - 1]);
+        v[b][k] = (k == 0 || (R2 == 8 && MOF_FUSED_TW)) ? a : cmul(a, tw_col[k - 1]);
 #endif
       }
-      butterfly<R2>(v[b]);
+      if constexpr (R2 == 8 && MOF_FUSED_TW) butterfly8_tw(v[b], tw_col);
+      else butterfly<R2>(v[b]);
     }
     wave_sync();
 #pragma unroll
@@ -247,10 +253,11 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
 #ifdef MOF_ABLATE_NOBFLY
         v[b][k] = a;
 #else
-        v[b][k] = (k == 0) ? a : cmul(a, tw_col[k - 1]);
+        v[b][k] = (k == 0 || (R2 == 8 && MOF_FUSED_TW)) ? a : cmul(a, tw_col[k - 1]);
 #endif
       }
-      butterfly<R2>(v[b]);
+      if constexpr (R2 == 8 && MOF_FUSED_TW) butterfly8_tw(v[b], tw_col);
+      else butterfly<R2>(v[b]);
       if constexpr (PK == 1) {  // OpenCL-kernel model: 1/N^2 scaling and the +-search_radius mask (cl:733, :737-746, :823-826)
 #pragma unroll
         for (int k = 0; k < R2; ++k) {

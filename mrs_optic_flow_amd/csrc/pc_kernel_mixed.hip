@@ -121,12 +121,13 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int nlin
       x[b] = 8 * b + lane % 8;
       on[b] = x[b] < R1 && line[b] < nlines;
       if (on[b]) {
+        cf t[R2 - 1];
 #pragma unroll
         for (int k = 0; k < R2; ++k) {
-          const cf a = lds_read(&z[za(line[b], x[b] + k * R1)]);
-          v[b][k] = (k == 0) ? a : cmul(a, twiddle(tw, k * x[b]));
+          v[b][k] = lds_read(&z[za(line[b], x[b] + k * R1)]);
+          if (k > 0) t[k - 1] = twiddle(tw, k * x[b]);
         }
-        butterfly<8>(v[b]);
+        butterfly8_tw(v[b], t);  // twiddle products fused into the first radix-2 layer
       }
     }
     wave_sync();
@@ -159,12 +160,13 @@ __device__ __forceinline__ void col_pass_fwd(cf* __restrict__ z, int col0, int l
     for (int b = 0; b < 2; ++b) {
       const int q = lane + 64 * b, col = col0 + q % LPW, x = q / LPW;
       if (x < R1) {
+        cf t[R2 - 1];
 #pragma unroll
         for (int k = 0; k < R2; ++k) {
-          const cf a = lds_read(&z[za(x + k * R1, col)]);
-          v[b][k] = (k == 0) ? a : cmul(a, twiddle(tw, k * x));
+          v[b][k] = lds_read(&z[za(x + k * R1, col)]);
+          if (k > 0) t[k - 1] = twiddle(tw, k * x);
         }
-        butterfly<8>(v[b]);
+        butterfly8_tw(v[b], t);
       }
     }
     wave_sync();
@@ -219,12 +221,13 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
       const int q = lane + 64 * b, col = col0 + q % LPW, x = q / LPW;
       on[b] = x < R1 && col < H;
       if (on[b]) {
+        cf t[R2 - 1];
 #pragma unroll
         for (int k = 0; k < R2; ++k) {
-          const cf a = lds_read(&z[za(x + k * R1, col)]);
-          v[b][k] = (k == 0) ? a : cmul(a, twiddle(tw, k * x));
+          v[b][k] = lds_read(&z[za(x + k * R1, col)]);
+          if (k > 0) t[k - 1] = twiddle(tw, k * x);
         }
-        butterfly<8>(v[b]);
+        butterfly8_tw(v[b], t);
         if constexpr (PK == 1) {  // OpenCL-kernel model: 1/N^2 scaling, +-search_radius mask (cl:733, :737-746, :823-826)
 #pragma unroll
           for (int k = 0; k < R2; ++k) {
