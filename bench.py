@@ -319,8 +319,8 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "binding": "integer VALU (v_qsad_pk_u16_u8), not HBM -- see DESIGN.md" if wl["kind"] == "bm"
-                         else "VALU issue (fp32 FFT butterflies; SQ_ACTIVE_INST_VALU 91 % of SIMD cycles), LDS pipe second, "
-                              "not HBM -- see DESIGN.md section 4 (K1)"},
+                         else "latency of the per-patch phase chain at 4 workgroups/CU (LDS-capacity limit); VALU 91 % active, "
+                              "LDS pipe 57-66 %; not HBM -- see DESIGN.md section 4 (K1)"},
         }
         if wl["kind"] == "fft":
             # the resource that actually binds K1: vector fp32. Informational, next to the HBM figure.

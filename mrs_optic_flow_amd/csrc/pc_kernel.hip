@@ -79,6 +79,7 @@ struct PcTraits {
   static constexpr int LI = (LPW / 2 > 64 / BMIN) ? LPW / 2 : 64 / BMIN;
   static constexpr int WI = (N / 2) / LI;
   static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best);
+  static constexpr bool PERSIST = N >= 128;  // see pc_field_kernel
   static_assert(R1 * R2 == N && T % 64 == 0 && 64 % R1 == 0 && 64 % R2 == 0, "bad plan");
 };
 
@@ -217,16 +218,23 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int col = col0 + lane % CW + CW * b, x = lane / CW;
+      // r = x + k R2 with x < R2: r < H exactly for k < R1/2, so the four Hermitian cases are decided at compile time
+      // per k, except for the lanes with x == 0 at k = 0 (r = 0) and k = R1/2 (r = H), which read the packed row 0
+      static_assert(R1 % 2 == 0 && 64 / CW == R2, "row classes below assume x < R2 and an even R1");
+      const bool x0 = x == 0;
 #pragma unroll
       for (int k = 0; k < R1; ++k) {
         const int r = x + k * R2;  // 0..N-1
-        const int rr = (r == 0 || r == H) ? 0 : (r < H ? r : N - r);
+        const int rr = (k < R1 / 2) ? r : ((k == R1 / 2 && x0) ? 0 : N - r);
         const cf a = lds_read(&z[zaddr<N>(rr, col)]), c = lds_read(&z[zaddr<N>(rr, col + H)]);
         cf e;
-        if (r == 0) e = {a.x, c.x};
-        else if (r == H) e = {a.y, c.y};
-        else if (r < H) e = {a.x - c.y, a.y + c.x};
-        else e = {a.x + c.y, c.x - a.y};
+        if (k < R1 / 2) {
+          e = {a.x - c.y, a.y + c.x};
+          if (k == 0 && x0) e = {a.x, c.x};
+        } else {
+          e = {a.x + c.y, c.x - a.y};
+          if (k == R1 / 2 && x0) e = {a.y, c.y};
+        }
         v[b][k] = e;
       }
       butterfly<R1>(v[b]);
@@ -314,10 +322,26 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   const int lrow = wave0 * LPW + lane0 / CPR, lcol = (lane0 % CPR) * 16;  // this lane's 16 pixels of the patch
   const bool ld_on = lane0 < LPW * CPR;  // (all lanes unless the workgroup has more than N*N/16 threads)
 
+  // N >= 128: persistent workgroups (one per CU) walking a linear patch index. Smaller tiles: one workgroup per
+  // patch on a 3-D grid (patch column, patch row, pair) -- the hardware dispatcher balances 4 workgroups per CU better
+  // than a static stride does, and the patch coordinates come from blockIdx without the integer divisions that
+  // otherwise cost ~5 % of the kernel's VALU instructions.
+  constexpr bool PERSIST = P::PERSIST;
+  (void)patches;
   // (x0, y0) of a patch are in the units of the correlated image: full-res pixels, or quarter-res when DS = 4
   auto patch_base = [&](int p, const uint8_t* frames, size_t frame_stride) -> const uint8_t* {
-    const int pr = p / patches, pt = p % patches;
-    const int px0 = a.origin_x + (pt % a.grid_x) * a.stride_x, py0 = a.origin_y + (pt / a.grid_x) * a.stride_y;
+    int pr, bx, by;
+    if constexpr (PERSIST) {
+      const int pt = p % patches;
+      pr = p / patches;
+      bx = pt % a.grid_x;
+      by = pt / a.grid_x;
+    } else {
+      pr = blockIdx.z;
+      bx = blockIdx.x;
+      by = blockIdx.y;
+    }
+    const int px0 = a.origin_x + bx * a.stride_x, py0 = a.origin_y + by * a.stride_y;
     return frames + (size_t)pr * frame_stride + (size_t)(DS * py0) * a.pitch + (size_t)(CH * DS * px0);
   };
 
@@ -335,7 +359,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   // ---- persistent workgroup: patches p = blockIdx.x, + gridDim.x, ...; the 2 x 16 B of the NEXT patch are
   //      requested from HBM before the current one is transformed, so the ~2 us load latency is off the critical path
   uint32_t cw[4] = {0u, 0u, 0u, 0u}, pw[4] = {0u, 0u, 0u, 0u};
-  int p = blockIdx.x;
+  int p = PERSIST ? (int)blockIdx.x : (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
   auto fetch16 = [&](int pp, uint32_t* c, uint32_t* q) {
     const uint8_t* cs = patch_base(pp, a.cur, a.cur_stride) + (size_t)lrow * a.pitch + CH * lcol;
     const uint8_t* ps = patch_base(pp, a.prev, a.prev_stride) + (size_t)lrow * a.pitch + CH * lcol;
@@ -350,11 +374,11 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   if (DS == 1 && p < a.total && ld_on) fetch16(p, cw, pw);
   // Co-resident workgroups would otherwise run the same phase at the same time (all of them LDS-bound, then all
   // VALU-bound): delay the k-th workgroup of a CU by k quarter-patches so their phases interleave.
-  {
+  if constexpr (PERSIST) {
     const int slot = (blockIdx.x / a.stagger_div) & 3;
     for (int i = 0; i < slot * a.stagger_units; ++i) __builtin_amdgcn_s_sleep(100);
   }
-  for (; p < a.total; p += gridDim.x) {
+  for (; p < a.total; p += PERSIST ? (int)gridDim.x : a.total) {
   // The lane / wave indices are laundered once per patch: otherwise LICM hoists every LDS address of the body out
   // of the persistent loop (+70 VGPRs), which costs a whole workgroup of occupancy per CU.
   int lane = lane0, wave = wave0;
@@ -362,6 +386,16 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   lane &= 63;             // give the value ranges back to the optimiser (they fold the skew and the
   wave &= P::WAVES - 1;   // Hermitian row cases at compile time)
   const int tid = wave * 64 + lane;
+#ifdef MOF_EXTRA_VALU  // diagnostic build: MOF_EXTRA_VALU independent FMAs per wave and patch (is K1 VALU-issue bound?)
+  {
+    float d0 = (float)lane, d1 = 1.f, d2 = 2.f, d3 = 3.f;
+#pragma unroll
+    for (int i = 0; i < MOF_EXTRA_VALU / 4; ++i)
+      asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3"
+                   : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+    if (d0 + d1 + d2 + d3 == 12345.678f) a.out[0] = d0;
+  }
+#endif
   // ---- the wave's own LPW rows: u8 -> f32 (exact), z = cur + i*prev  (convertTo, :1805-1806)
   {
     const int row = wave * LPW + lane / CPR, col = (lane % CPR) * 16;
@@ -372,8 +406,10 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
 #pragma unroll
           for (int b = 0; b < 4; ++b)
             z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cw[q] >> (8 * b)) & 0xffu), (float)((pw[q] >> (8 * b)) & 0xffu)};
-        const int pn = p + gridDim.x;
-        if (pn < a.total) fetch16(pn, cw, pw);
+        if constexpr (PERSIST) {
+          const int pn = p + gridDim.x;
+          if (pn < a.total) fetch16(pn, cw, pw);
+        }
       }
     } else if (ld_on) {
       // pixel (row, col+i) <- (s(4r+1,4c+1) + s(4r+1,4c+2) + s(4r+2,4c+1) + s(4r+2,4c+2) + 2) >> 2 of the full-res frame
@@ -525,33 +561,43 @@ static hipError_t launch_n(const PcArgs& a_in, int n_pairs, hipStream_t stream) 
     static const int units = [] { const char* e = getenv("MOF_PC_STAGGER"); return e ? atoi(e) : 0; }();
     a.stagger_units = units;
   }
-  // persistent grid: as many workgroups as are resident at once (LDS-limited), each loops over patches
-  const int per_cu = (int)((160u * 1024u) / (Tr::LDS_BYTES + extra_lds()));
-  int resident = (g_cu_count > 0 ? g_cu_count : 256) * (per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu));
-  // N = 128 (one 1024-thread workgroup per CU) gains from the persistent loop + prefetch (c4: +9 %); the small
-  // tiles run better as one workgroup per patch (c2: +6 %; the hardware dispatcher balances 4 workgroups per CU
-  // better than a static stride does). MOF_PC_PERSISTENT=0/1 overrides (diagnostics).
-  static const int force = [] { const char* e = getenv("MOF_PC_PERSISTENT"); return e ? atoi(e) : -1; }();
-  const bool persistent = force >= 0 ? force != 0 : (N >= 128);
-  if (!persistent) resident = a.total;
-  const unsigned blocks = (unsigned)(a.total < resident ? a.total : resident);
   if (a.downscale == 4 && a.channels == 3) return hipErrorInvalidValue;
-  const dim3 g(blocks), b(Tr::T);
+  const dim3 b(Tr::T);
   const size_t lds = Tr::LDS_BYTES + extra_lds();
-  if (a.peak_model == 1) {
-    if (a.downscale == 4) hipLaunchKernelGGL((pc_field_kernel<N, 4, 1, 1>), g, b, lds, stream, a);
-    else if (a.channels == 3) hipLaunchKernelGGL((pc_field_kernel<N, 1, 3, 1>), g, b, lds, stream, a);
-    else hipLaunchKernelGGL((pc_field_kernel<N, 1, 1, 1>), g, b, lds, stream, a);
+  auto launch = [&](const PcArgs& aa, dim3 g) {
+    if (aa.peak_model == 1) {
+      if (aa.downscale == 4) hipLaunchKernelGGL((pc_field_kernel<N, 4, 1, 1>), g, b, lds, stream, aa);
+      else if (aa.channels == 3) hipLaunchKernelGGL((pc_field_kernel<N, 1, 3, 1>), g, b, lds, stream, aa);
+      else hipLaunchKernelGGL((pc_field_kernel<N, 1, 1, 1>), g, b, lds, stream, aa);
+    } else {
+      if (aa.downscale == 4) hipLaunchKernelGGL((pc_field_kernel<N, 4, 1, 0>), g, b, lds, stream, aa);
+      else if (aa.channels == 3) hipLaunchKernelGGL((pc_field_kernel<N, 1, 3, 0>), g, b, lds, stream, aa);
+      else hipLaunchKernelGGL((pc_field_kernel<N, 1, 1, 0>), g, b, lds, stream, aa);
+    }
+  };
+  if constexpr (Tr::PERSIST) {
+    // as many workgroups as are resident at once (LDS-limited), each loops over patches (c4: +9 % over one per patch)
+    const int per_cu = (int)((160u * 1024u) / (Tr::LDS_BYTES + extra_lds()));
+    const int resident = (g_cu_count > 0 ? g_cu_count : 256) * (per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu));
+    launch(a, dim3((unsigned)(a.total < resident ? a.total : resident)));
   } else {
-    if (a.downscale == 4) hipLaunchKernelGGL((pc_field_kernel<N, 4, 1, 0>), g, b, lds, stream, a);
-    else if (a.channels == 3) hipLaunchKernelGGL((pc_field_kernel<N, 1, 3, 0>), g, b, lds, stream, a);
-    else hipLaunchKernelGGL((pc_field_kernel<N, 1, 1, 0>), g, b, lds, stream, a);
+    // one workgroup per patch; the pair index rides gridDim.z (at most 65535 per launch)
+    const int patches = a.grid_x * a.grid_y;
+    for (int k0 = 0; k0 < n_pairs; k0 += 65535) {
+      const int nk = n_pairs - k0 < 65535 ? n_pairs - k0 : 65535;
+      PcArgs c = a;
+      c.cur = a.cur + (size_t)k0 * a.cur_stride;
+      c.prev = a.prev + (size_t)k0 * a.prev_stride;
+      c.out = a.out + (size_t)k0 * patches * 2;
+      c.total = nk * patches;
+      launch(c, dim3((unsigned)a.grid_x, (unsigned)a.grid_y, (unsigned)nk));
+    }
   }
   return hipGetLastError();
 }
 
 // MOF_PC_QUAD=1 routes N = 64 to the quad-per-line formulation of pc_kernel_quad.hip (an evaluated alternative: a third
-// of the LDS traffic, 35 % more VALU instructions, 8 % slower on MI355X because K1 is VALU-bound -- DESIGN.md §4, K1).
+// of the LDS traffic, 35 % more VALU instructions, 8 % slower on MI355X -- DESIGN.md §4, K1).
 static bool classic64() {
   static const bool v = [] { const char* e = getenv("MOF_PC_QUAD"); return !(e && atoi(e) != 0); }();
   return v;

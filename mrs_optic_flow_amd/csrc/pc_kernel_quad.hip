@@ -19,9 +19,9 @@
 // (tools/design/quad_fft_emulator.py replays the lane maps, sign tricks and bank maths against numpy.fft).
 // Measured on MI355X (c2, 65,536 patches per launch): LDS instructions 210 -> 98 per wave, LDS busy 57 % -> 20 %, but
 // VALU instructions 1335 -> 1805 per wave (the cross-lane radix-4 costs six VALU slots per complex value, work the
-// Stockham form gets from the LDS for free) and 0.81 ms against 0.74 ms: K1 is bound by VALU issue
-// (SQ_ACTIVE_INST_VALU = 91 % of the SIMD cycles in pc_kernel.hip), not by the LDS. Kept because the formulation is
-// the right one for a part with more VALU per LDS byte, and as the worked example of v_fmac_f32 with DPP operands.
+// Stockham form gets from the LDS for free) and 0.81 ms against 0.74 ms: the LDS pipe is not what binds K1 (DESIGN.md
+// section 4: the latency of the per-patch phase chain at 4 workgroups per CU does), so its savings buy nothing and the
+// extra VALU work costs ~9 %. Kept as a tested alternative and as the worked example of v_fmac_f32 with DPP operands.
 //
 // Lane maps (q = lane & 3, K1 = {0, 2, 1, 3}):
 //   "blocked in"     lane q holds x[16 q + j]     -> exchange (xor 2, xor 1), twiddle, radix-16 -> X[K1[q] + 4 k]
