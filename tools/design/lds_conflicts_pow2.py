@@ -8,7 +8,7 @@ CFG = {32: dict(R1=8, R2=4, SK=3, PITCH=36, T=64), 64: dict(R1=8, R2=8, SK=3, PI
        128: dict(R1=16, R2=8, SK=4, PITCH=136, T=1024)}
 
 
-def evaluate(N, pitch=None, sk=None, T=None, za_fn=None):
+def evaluate(N, pitch=None, sk=None, T=None, za_fn=None, row_s2_perm=False, col_s2_blocked=False):
     c = CFG[N]
     R1, R2 = c["R1"], c["R2"]
     P = pitch or c["PITCH"]
@@ -41,6 +41,10 @@ def evaluate(N, pitch=None, sk=None, T=None, za_fn=None):
         for b in range(LINES * R1 // 64):
             q = lane + 64 * b
             line, x = line0 + q // R1, q % R1
+            if row_s2_perm:  # 8 consecutive x of 8 / (R1 / 8) lines per 32-lane group; x depends on the lane only
+                lpi = 8 // (R1 // 8)
+                line = line0 + ((lane >> 3) % lpi) + lpi * b
+                x = (lane & 7) + 8 * (lane // (8 * lpi))
             for k in range(R2):
                 add(tag + " s2 r", za(line, x + k * R1), allon, False)
                 add(tag + " s2 w", za(line, x + k * R1), allon, True)
@@ -62,6 +66,9 @@ def evaluate(N, pitch=None, sk=None, T=None, za_fn=None):
         CW = 64 // R1
         for b in range(LPW * R1 // 64):
             col, x = col0 + lane % CW + CW * b, lane // CW
+            if col_s2_blocked:  # 8 columns x 8 consecutive x per iteration: x = lane / 8 + 8 (b % (R1/8))
+                xb = R1 // 8
+                col, x = col0 + (lane & 7) + 8 * (b // xb), (lane >> 3) + 8 * (b % xb)
             for k in range(R2):
                 add("col s2 r", za(x + k * R1, col), allon, False)
                 add("col s2 w", za(x + k * R1, col), allon, True)
@@ -80,6 +87,9 @@ def evaluate(N, pitch=None, sk=None, T=None, za_fn=None):
             CW = 64 // R1
             for b in range(LI * R1 // 64):
                 col, x = col0 + lane % CW + CW * b, lane // CW
+                if col_s2_blocked:
+                    xb = R1 // 8
+                    col, x = col0 + (lane & 7) + 8 * (b // xb), (lane >> 3) + 8 * (b % xb)
                 for k in range(R2):
                     add("icol s2 r", za(x + k * R1, col), allon, False)
                     add("icol s2 w", za(x + k * R1, col), allon, True)
