@@ -400,3 +400,21 @@ def test_expected_variant(gpu):
     want = os.environ.get("MOF_EXPECT_VARIANT", "stockham")
     assert FftMethod(64, 64, 80.0).kernel_variant == want
     assert FftMethod(128, 128, 80.0).kernel_variant == "stockham"
+
+
+def test_more_pairs_than_one_grid_dimension_holds(gpu):
+    """64 x 64 patches run one workgroup per patch with the pair index on gridDim.z (at most 65535): a longer batch is
+    split into several launches inside the library. Circular shifts are exact, so every pair has a known answer."""
+    n, B = 64, 65535 + 9
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    base = torch.randint(0, 256, (n, n), dtype=torch.uint8, generator=gen)
+    shifts = [(3, -2), (-5, 7), (0, 1), (11, 0)]
+    protos = torch.stack([torch.roll(base, (dy, dx), dims=(0, 1)) for dx, dy in shifts]).to(gpu)
+    idx = torch.arange(B, device=gpu) % len(shifts)
+    cur = protos[idx]                                   # [B, 64, 64]
+    prev = base.to(gpu).expand(B, n, n)                 # stride-0 batch: every pair shares one previous frame
+    fm = FftMethod(n, n, 80.0)
+    got = fm.process_batch_device(cur, prev.contiguous()).cpu().numpy()[:, 0]
+    want = np.array(shifts, float)[idx.cpu().numpy()]
+    assert np.allclose(got, want, rtol=0, atol=3e-5)
+    assert np.allclose(got[65533:65540], want[65533:65540], rtol=0, atol=3e-5)  # across the launch boundary
