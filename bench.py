@@ -33,6 +33,20 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X vector fp32 peak (all-FMA; an add-dominated FFT can reach about half of it)
 
 
+def binding_note(name: str, wl) -> str:
+    """What actually bounds the dominant kernel of a workload (measured)."""
+    if wl["kind"] == "bm":
+        return "integer VALU: v_qsad_pk_u16_u8 at 1 byte-difference per lane per cycle, VALU 86 % active; not HBM"
+    if wl["kind"] == "fft+sr":
+        return ("scale/rotation pipeline K4-K8 (log-polar gather + whole-frame phase correlation through cache-resident "
+                "scratch) takes 90 % of the step; K1 as in c2; not HBM")
+    if wl["n"] >= 120:
+        return ("one persistent workgroup per CU (the tile fills the LDS): latency of the per-patch phase chain, "
+                "VALU 77-79 % active, LDS pipe 35-59 %; not HBM")
+    return ("latency of the per-patch phase chain at 4 workgroups/CU (LDS-capacity limit); VALU 91 % active, "
+            "LDS pipe 57-66 %; not HBM -- see DESIGN.md section 4 (K1)")
+
+
 def fft_flops_per_pair(n: int, patches: int) -> float:
     """fp32 work of one frame pair on the FFT path, BASELINE.md section 3 convention: per patch pair one complex 2-D
     forward transform (the two real images ride one complex transform) and half of one for the Hermitian inverse,
@@ -318,9 +332,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "binding": "integer VALU (v_qsad_pk_u16_u8), not HBM -- see DESIGN.md" if wl["kind"] == "bm"
-                         else "latency of the per-patch phase chain at 4 workgroups/CU (LDS-capacity limit); VALU 91 % active, "
-                              "LDS pipe 57-66 %; not HBM -- see DESIGN.md section 4 (K1)"},
+                         "binding": binding_note(args.workload, wl)},
         }
         if wl["kind"] == "fft":
             # the resource that actually binds K1: vector fp32. Informational, next to the HBM figure.
