@@ -142,7 +142,7 @@ __device__ __forceinline__ void lds_fft(cf* z, int nlines, const float* tw, int 
 #endif
 constexpr int ROWS_L = MOF_SR_ROWS;   // rows per workgroup in K5
 #ifndef MOF_SR_CW
-#define MOF_SR_CW 4
+#define MOF_SR_CW 8
 #endif
 constexpr int COLS_CW = MOF_SR_CW;  // columns (plus their mirrors) per workgroup in K6
 constexpr int INV_L = 8;    // row PAIRS per workgroup in K7
