@@ -34,6 +34,9 @@
 #include "mof_kernels.h"
 #include "pc_common.hpp"
 
+#ifndef MOF_FUSE_XPOW
+#define MOF_FUSE_XPOW 1  // 1: where it pays (PcTraits::FUSE_XPOW), the cross-power spectrum is formed inside the inverse row pass
+#endif
 #ifndef MOF_FUSED_TW
 #define MOF_FUSED_TW 1  // twiddles of the radix-8 second stage fused into its first layer (butterfly8_tw)
 #endif
@@ -80,6 +83,10 @@ struct PcTraits {
   static constexpr int WI = (N / 2) / LI;
   static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best);
   static constexpr bool PERSIST = N >= 128;  // see pc_field_kernel
+  // cross-power spectrum inside the inverse row pass (row_pass_xpow): one barrier and 1.5 tile passes fewer. Same-box
+  // A/B: +4.4 % at N = 64 (several workgroups per CU, latency-bound), -4.4 % at N = 128 (one workgroup per CU: the
+  // separate pass spreads the cross-power over all 16 waves, the fused one over the 8 that run the inverse)
+  static constexpr bool FUSE_XPOW = MOF_FUSE_XPOW && N <= 64;
   static_assert(R1 * R2 == N && T % 64 == 0 && 64 % R1 == 0 && 64 % R2 == 0, "bad plan");
 };
 
@@ -132,6 +139,71 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
 #else
         v[b][k] = (k == 0 || (R2 == 8 && MOF_FUSED_TW)) ? a : cmul(a, tw_row[k - 1]);
 #endif
+      }
+      if constexpr (R2 == 8 && MOF_FUSED_TW) butterfly8_tw(v[b], tw_row);
+      else butterfly<R2>(v[b]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < PER; ++b) {
+      const int q = lane + 64 * b;
+      const int line = line0 + q / R1, x = q % R1;
+#pragma unroll
+      for (int k = 0; k < R2; ++k) z[zaddr<N>(line, x + k * R1)] = v[b][k];
+    }
+    wave_sync();
+  }
+}
+
+// ---- inverse row pass with the cross-power spectrum formed on the fly (MOF_FUSE_XPOW) ------------------------------
+// Rows 0..H-1 of the half spectrum D = conj(C): stage 1 reads bin (v, u) AND its Hermitian partner (N-v, N-u) from the
+// forward spectrum, forms conj(C[v][u]) in registers and goes straight into the first butterfly. The separate
+// cross-power pass (a tile read and half a tile write, one workgroup barrier) disappears. Partner rows are N-1..H+1,
+// which nobody writes in this phase; row 0 (packed with row H by the owning wave beforehand) is taken as it is.
+template <int N, int PK>
+__device__ __forceinline__ void row_pass_xpow(cf* __restrict__ z, int line0, int lane, const cf* tw_row) {
+  using P = PcTraits<N>;
+  constexpr int R1 = P::R1, R2 = P::R2, LINES = P::LI;
+  {
+    constexpr int PER = LINES * R2 / 64;
+    static_assert(LINES * R2 % 64 == 0, "row stage 1 does not fill the wave");
+    cf v[PER][R1];
+#pragma unroll
+    for (int b = 0; b < PER; ++b) {
+      const int q = lane + 64 * b;
+      const int line = line0 + q / R2, x = q % R2;
+      const int pline = (N - line) % N;
+      const bool packed = line == 0;
+#pragma unroll
+      for (int k = 0; k < R1; ++k) {
+        const int u = x + k * R2, um = (N - u) % N;
+        const cf zk = lds_read(&z[zaddr<N>(line, u)]), zm = lds_read(&z[zaddr<N>(pline, um)]);
+        const cf C = cross_power<PK>(zk, zm, false);
+        v[b][k] = packed ? zk : cf{C.x, -C.y};
+      }
+      butterfly<R1>(v[b]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < PER; ++b) {
+      const int q = lane + 64 * b;
+      const int line = line0 + q / R2, x = q % R2;
+#pragma unroll
+      for (int k = 0; k < R1; ++k) z[zaddr<N>(line, x * R1 + k)] = v[b][k];
+    }
+    wave_sync();
+  }
+  {  // stage 2: as row_pass
+    constexpr int PER = LINES * R1 / 64;
+    cf v[PER][R2];
+#pragma unroll
+    for (int b = 0; b < PER; ++b) {
+      const int q = lane + 64 * b;
+      const int line = line0 + q / R1, x = q % R1;
+#pragma unroll
+      for (int k = 0; k < R2; ++k) {
+        cf a = lds_read(&z[zaddr<N>(line, x + k * R1)]);
+        v[b][k] = (k == 0 || (R2 == 8 && MOF_FUSED_TW)) ? a : cmul(a, tw_row[k - 1]);
       }
       if constexpr (R2 == 8 && MOF_FUSED_TW) butterfly8_tw(v[b], tw_row);
       else butterfly<R2>(v[b]);
@@ -445,6 +517,24 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   //      (mulSpectrums :1494, magSpectrums :70-168, divSpectrums :1086-1251, incl. the real-only-slot
   //      behaviour of :107-109 / :1127-1129). Only the half spectrum v < N/2 (+ row N/2 packed into the
   //      imaginary part of row 0) is kept, conjugated, for the Hermitian inverse.
+  if constexpr (P::FUSE_XPOW) {
+  // rows 0 and H share row 0: G'[u] = conj(C[0][u]) + i conj(C[H][u]) (partner of u is N-u in the same rows), packed
+  // by wave 0, which owns row 0 in the pass below; rows 1..H-1 get their cross-power inside row_pass_xpow
+  if (wave == 0) {
+    for (int u = lane; u <= H; u += 64) {
+      const int um = (N - u) % N;
+      const bool self = (u == um);
+      const cf C0 = cross_power<PK>(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
+      const cf Ch = cross_power<PK>(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
+      z[zaddr<N>(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
+      if (!self) z[zaddr<N>(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
+    }
+    wave_sync();
+  }
+  // ---- inverse (unscaled) of the Hermitian spectrum: forward transforms of conj(C); rows 0..H-1 only,
+  //      then column pairs  (idft :1497)
+  if (wave < P::WI) row_pass_xpow<N, PK>(z, wave * P::LI, lane, tw_row);
+  } else {
 #ifndef MOF_ABLATE_NOPW
   {
     // rows 1..H-1: every u; partner (N-v, N-u) lies in the untouched lower half. Fixed trip count, so every
@@ -487,6 +577,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
 #ifndef MOF_ABLATE_NOINV
   if (wave < P::WI) row_pass<N, P::LI>(z, wave * P::LI, lane, tw_row);
 #endif
+  }  // FUSE_XPOW
   __syncthreads();
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
 #ifndef MOF_ABLATE_NOINV
