@@ -82,7 +82,10 @@ struct PcTraits {
   static constexpr int LI = (LPW / 2 > 64 / BMIN) ? LPW / 2 : 64 / BMIN;
   static constexpr int WI = (N / 2) / LI;
   static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best);
-  static constexpr bool PERSIST = N >= 128;  // see pc_field_kernel
+#ifndef MOF_PERSIST_MIN_N
+#define MOF_PERSIST_MIN_N 128
+#endif
+  static constexpr bool PERSIST = N >= MOF_PERSIST_MIN_N;  // see pc_field_kernel
   // cross-power spectrum inside the inverse row pass (row_pass_xpow): one barrier and 1.5 tile passes fewer. Same-box
   // A/B: +4.4 % at N = 64 (several workgroups per CU, latency-bound), -4.4 % at N = 128 (one workgroup per CU: the
   // separate pass spreads the cross-power over all 16 waves, the fused one over the 8 that run the inverse)
@@ -608,7 +611,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       return x < H ? s.x : s.y;
     });
   }
-  __syncthreads();
+  __syncthreads();  // (needed by the persistent form only; dropping it for one-workgroup-per-patch sizes measured -1 %)
   if (wave == 0) centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p);
   }  // persistent loop
 }
