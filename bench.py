@@ -31,6 +31,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X vector fp32 peak (all-FMA; an add-dominated FFT can reach about half of it)
+# which pipe the FFT arithmetic of K1 runs on (the MFMA form of the forward row pass was built and measured)
+COMPUTE_PIPE_NOTE = "VALU fp32 (Stockham passes in LDS; MFMA row-DFT variant: see DESIGN.md section 4, K1/MFMA experiment)"
 
 
 def binding_note(name: str, wl) -> str:
@@ -155,6 +157,146 @@ def load_traffic(tag: str):
         return None
 
 
+def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
+    """Generates the HBM-resident batch of one workload and returns (launch, engine, out_buffer_setter).
+    `launch()` runs one step (one pass of the hot path over the batch) on torch's current stream."""
+    import torch
+
+    from mrs_optic_flow_amd import FastSpacedBMMethod, FftMethod, ScaleRotationEstimator, synth
+
+    B = wl["batch"]
+    # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
+    cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
+    state = {"out": None}
+    if wl["kind"] in ("fft", "fft+sr"):
+        eng = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"],
+                        origin=wl["origin"], stride=wl["stride"], device=local_rank)
+        state["out"] = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
+        if wl["kind"] == "fft+sr":
+            sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank)
+            x0, r = wl["sr_x0"], wl["sr_res"]
+            cur_c, prev_c = cur[:, :r, x0:x0 + r], prev[:, :r, x0:x0 + r]
+
+            def launch():
+                eng.process_batch_device(cur, prev, out=state["out"])
+                srout = sr.process_batch_device(cur_c, prev_c)
+                return torch.cat([state["out"].reshape(B, -1), srout], dim=1)
+        elif wl.get("bgr"):
+            # synthetic colour frames: three different affine maps of the gray texture (data stays u8)
+            def colour(g):
+                g16 = g.to(torch.int16)
+                return torch.stack([g, (255 - g16 // 2).to(torch.uint8), (g16 * 3 // 4 + 20).to(torch.uint8)], dim=-1).contiguous()
+            cur3, prev3 = colour(cur), colour(prev)
+
+            def launch():
+                return eng.process_batch_device_bgr(cur3, prev3)
+        else:
+            def launch():
+                eng.process_batch_device(cur, prev, out=state["out"])
+                return state["out"]
+    else:
+        if wl.get("block_method"):
+            from mrs_optic_flow_amd import BlockMethod
+            eng = BlockMethod(wl["h"], wl["block"], wl["radius"], device=local_rank)
+        else:
+            eng = FastSpacedBMMethod(wl["block"], wl["radius"], wl["step"], (wl["h"], wl["w"]), device=local_rank)
+
+        def launch():
+            return eng.process_batch_device(cur, prev)[2]
+
+    if graph:
+        eager_launch = launch
+        eager_launch()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                graph_result = eager_launch()
+
+        def launch():
+            g.replay()
+            return graph_result
+
+    return launch, eng, state
+
+
+def timed_steps(step, steps: int, world: int, dev):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks. Returns seconds."""
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    step(None, drain=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def roofline_block(tag: str, wl, B: int, kern_ms: float):
+    bytes_per_launch = wl["bytes_per_pair"] * B
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    traffic = load_traffic(tag)
+    blk = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+           # `traffic` is NOT measured by this run: PMC counters need their own rocprofv3 pass (tools/pmc.sh); the
+           # number is the committed result of that pass for this command (per launch of `batch` pairs)
+           "traffic_source": (f"profiles/traffic_{tag}.json (separate rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass of this "
+                              "command; not measured live)") if traffic is not None else None,
+           "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+           "binding": binding_note(tag, wl)}
+    if wl["kind"] == "fft":
+        # the resource that actually binds K1 (DESIGN.md section 4 (K1)): vector fp32. Informational, next to the HBM figure.
+        fl = fft_flops_per_pair(wl["n"], wl["grid"][0] * wl["grid"][1]) * B
+        blk["compute"] = {"unit": "TFLOP/s", "achieved": fl / (kern_ms * 1e-3) / 1e12, "peak": VALU_FP32_PEAK_TFLOPS,
+                          "frac": fl / (kern_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS, "flop_per_launch": fl,
+                          "pipe": COMPUTE_PIPE_NOTE}
+    return blk
+
+
+def measure_other(tag: str, dev, steps: int, warmup: int):
+    """Compact record of one more BASELINE workload (N=1): value, kernel time, HBM fraction."""
+    import torch
+
+    wl = dict(WORKLOADS[tag])
+    launch, eng, _ = build_workload(wl, dev, dev.index or 0, 0)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    for _ in range(warmup):
+        launch()
+
+    def step(i, drain=False):
+        if drain:
+            return
+        ev0[i].record()
+        launch()
+        ev1[i].record()
+
+    elapsed = timed_steps(step, steps, 1, dev)
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / steps
+    B = wl["batch"]
+    rec = {"workload": wl["name"], "value": B * steps / elapsed, "unit": "frame-pairs/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kern_ms,
+           "frac": wl["bytes_per_pair"] * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "algorithmic_bytes_per_launch": wl["bytes_per_pair"] * B, "traffic": load_traffic(tag)}
+    del launch, eng
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,9 +305,15 @@ def main() -> None:
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frame pairs per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the compact records of the other BASELINE workloads (c3, c4, c5, ref) after the headline")
+    ap.add_argument("--sustain-s", type=float, default=2.0,
+                    help="after the timed steps, run back-to-back steps for at least this long and report that rate too")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl == RCCL; gloo only to rehearse several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--blocking-gather", action="store_true",
+                    help="--gpus > 1: blocking all_gather_into_tensor per step instead of the double-buffered non-blocking one")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph and replay it (helps the multi-launch c5 pipeline)")
     args = ap.parse_args()
@@ -173,7 +321,7 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    from mrs_optic_flow_amd import FastSpacedBMMethod, FftMethod, ScaleRotationEstimator, sharding, synth
+    from mrs_optic_flow_amd import sharding
 
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -196,78 +344,35 @@ def main() -> None:
             dist.init_process_group("gloo")
 
     B = wl["batch"]
-    # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
-    cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
-    if wl["kind"] in ("fft", "fft+sr"):
-        eng = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"],
-                        origin=wl["origin"], stride=wl["stride"], device=local_rank)
-        out = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
-        if wl["kind"] == "fft+sr":
-            sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank)
-            x0, r = wl["sr_x0"], wl["sr_res"]
-            cur_c, prev_c = cur[:, :r, x0:x0 + r], prev[:, :r, x0:x0 + r]
-
-            def launch():
-                eng.process_batch_device(cur, prev, out=out)
-                srout = sr.process_batch_device(cur_c, prev_c)
-                return torch.cat([out.reshape(B, -1), srout], dim=1)
-        elif wl.get("bgr"):
-            # synthetic colour frames: three different affine maps of the gray texture (data stays u8)
-            def colour(g):
-                g16 = g.to(torch.int16)
-                return torch.stack([g, (255 - g16 // 2).to(torch.uint8), (g16 * 3 // 4 + 20).to(torch.uint8)], dim=-1).contiguous()
-            cur3, prev3 = colour(cur), colour(prev)
-
-            def launch():
-                return eng.process_batch_device_bgr(cur3, prev3)
-        else:
-            def launch():
-                eng.process_batch_device(cur, prev, out=out)
-                return out
-    else:
-        if wl.get("block_method"):
-            from mrs_optic_flow_amd import BlockMethod
-            eng = BlockMethod(wl["h"], wl["block"], wl["radius"], device=local_rank)
-        else:
-            eng = FastSpacedBMMethod(wl["block"], wl["radius"], wl["step"], (wl["h"], wl["w"]), device=local_rank)
-
-        def launch():
-            return eng.process_batch_device(cur, prev)[2]
-
-    if args.graph and world == 1:
-        eager_launch = launch
-        eager_launch()
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                graph_result = eager_launch()
-
-        def launch():
-            graph.replay()
-            return graph_result
+    launch, eng, state = build_workload(wl, dev, local_rank, rank, graph=bool(args.graph and world == 1))
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    # the one collective of the batched-frames mode: all-gather of the flow vectors. With RCCL it is issued
-    # non-blocking and double-buffered, so it overlaps the next batch's kernels (it is ~1 MB per rank).
+    # The one collective of the batched-frames mode: all-gather of the flow vectors. With RCCL it is issued
+    # non-blocking and double-buffered, so it overlaps the next batch's kernels (it is ~1 MB per rank). Which gather
+    # runs is decided HERE from the arguments, identically on every rank, and reported in the JSON line; a failure
+    # of the chosen path ends the run (no silent per-rank fallback: ranks that disagree would dead-lock).
     ag = None
-    if world > 1 and args.backend == "nccl" and wl["kind"] == "fft" and not wl.get("bgr"):
-        try:
+    gather = "none (1 rank)"
+    if world > 1:
+        if args.backend == "nccl" and wl["kind"] == "fft" and not wl.get("bgr") and not args.blocking_gather:
             ag = sharding.AsyncGather((B, eng.n_patches, 2), torch.float64, dev, B * world)
-        except Exception as exc:  # fall back to the blocking gather rather than lose the run
-            print(f"[bench] async gather unavailable ({exc}); using the blocking all-gather", file=sys.stderr)
-            ag = None
+            gather = "non-blocking double-buffered all_gather_into_tensor (RCCL)"
+        else:
+            gather = ("blocking all_gather_into_tensor (RCCL)" if args.backend == "nccl"
+                      else "blocking all_gather (gloo rehearsal, host staging)")
 
-    def step(i=None):
-        nonlocal out, ag
+    def step(i=None, drain=False):
+        if drain:
+            if ag is not None:
+                ag.drain()
+            return None
         if ag is not None:
-            out = ag.slot()
-        if i is not None:
+            state["out"] = ag.slot()
+        if i is not None and i < len(ev0):
             ev0[i].record()
         res = launch()
-        if i is not None:
+        if i is not None and i < len(ev1):
             ev1[i].record()
         if ag is not None:
             return ag.submit()
@@ -275,43 +380,26 @@ def main() -> None:
             res = sharding.gather_results(res, B * world)
         return res
 
-    try:
-        for _ in range(args.warmup):
-            step()
-        if ag is not None:
-            ag.drain()
-    except Exception as exc:  # the non-blocking gather failed at run time: redo the warm-up with the blocking one
-        if ag is None:
-            raise
-        print(f"[bench] async gather failed in warm-up ({exc}); using the blocking all-gather", file=sys.stderr)
-        ag = None
-        out = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
-        for _ in range(args.warmup):
-            step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    if ag is not None:
-        ag.drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    for _ in range(args.warmup):
+        step()
+    step(None, drain=True)
+    elapsed = timed_steps(step, args.steps, world, dev)
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps  # HIP events on the launch stream
+
+    # sustained rate: the 20-step burst above lasts ~15 ms at c2; repeat the same step back to back for >= sustain_s
+    sustained = None
+    if args.sustain_s > 0:
+        n_sus = max(args.steps, int(args.sustain_s / (elapsed / args.steps)) + 1)
+        if world > 1:  # every rank must run the same number of steps (collectives inside)
+            t = torch.tensor([n_sus], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n_sus = int(t.item())
+        sus_elapsed = timed_steps(lambda i, drain=False: step(None, drain=drain), n_sus, world, dev)
+        sustained = {"steps": n_sus, "seconds": sus_elapsed, "value": B * world * n_sus / sus_elapsed,
+                     "ms_per_step": sus_elapsed / n_sus * 1e3}
+
     if rank == 0:
         pairs = B * world * args.steps
-        bytes_per_launch = wl["bytes_per_pair"] * B
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fft+sr": "_fft_phase_corr_plus_scale_rotation",
                                              "bm": "_block_method" if wl.get("block_method") else "_fast_spaced_bm"}[wl["kind"]],
@@ -328,21 +416,19 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": wl["name"], "batch_per_gpu": B, "frame": f'{wl["w"]}x{wl["h"]} u8',
                        "parallelism": f"frame-pair shards x{world}, all-gather of flow vectors" if world > 1 else "1 GPU",
-                       "hip_graph": bool(args.graph and world == 1)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(args.workload),
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "binding": binding_note(args.workload, wl)},
+                       "gather": gather, "hip_graph": bool(args.graph and world == 1)},
+            "roofline": roofline_block(args.workload, wl, B, kern_ms),
         }
-        if wl["kind"] == "fft":
-            # the resource that actually binds K1: vector fp32. Informational, next to the HBM figure.
-            fl = fft_flops_per_pair(wl["n"], wl["grid"][0] * wl["grid"][1]) * B
-            line["roofline"]["compute"] = {"unit": "TFLOP/s", "achieved": fl / (kern_ms * 1e-3) / 1e12,
-                                           "peak": VALU_FP32_PEAK_TFLOPS,
-                                           "frac": fl / (kern_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
-                                           "flop_per_launch": fl, "pipe": "VALU fp32 (no MFMA form of this FFT)"}
+        if sustained is not None:
+            line["sustained"] = sustained
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)
+        if world == 1 and not args.no_others and args.workload == "c2" and not args.batch:
+            del launch, eng, state, step
+            torch.cuda.empty_cache()
+            # driver-visible records of the other BASELINE configurations (same protocol, fewer steps)
+            line["other_workloads"] = {tag: measure_other(tag, dev, st, 2)
+                                       for tag, st in (("c3", 10), ("c4", 5), ("c5", 5), ("ref", 10))}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

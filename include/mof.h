@@ -221,9 +221,24 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
 
 /* Batched mode on DEVICE pointers; each pair (prev, cur) is processed as the two-call sequence of a fresh estimator.
  * d_cur / d_prev point at the top-left pixel of the resolution^2 crop inside each frame (pitch bytes per row).
- * d_out receives n_pairs * 4 doubles: scale, rot, pt.x, pt.y. Asynchronous on `stream`. */
+ * d_out receives n_pairs * 4 doubles: scale, rot, pt.x, pt.y. Asynchronous on `stream`.
+ * The pipeline runs through scratch owned by the engine. Calls on the same stream are ordered by the stream; a call
+ * on a different stream than the previous one first makes its stream wait (hipStreamWaitEvent) for the previous
+ * call's last kernel, so back-to-back batches on different streams are safe but do not overlap. While `stream` is
+ * being captured into a HIP graph no cross-stream dependency is taken or left: replays of graphs that contain calls
+ * on one engine must be ordered by the caller. */
 int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                 size_t prev_stride, size_t pitch, int n_pairs, double* d_out, void* stream);
+
+/* The remap stage alone: cv::logPolar(src, dst, Point2f(res/2, res/2), M, interpolation) (scaleRotationEstimator.cpp:45
+ * INTER_CUBIC, :112 INTER_LANCZOS4) on n_images res x res CV_8UC1 crops (image i at d_src + i*src_stride, `pitch` bytes
+ * per row) into tightly packed res*res outputs at d_dst + i*res*res. As with cv::remap's BORDER_TRANSPARENT,
+ * destination pixels whose source falls outside the image KEEP their content, so the caller initialises d_dst (the
+ * estimator starts from cv::Mat::zeros, :27). Integer arithmetic; exposed so that the remap can be compared byte for
+ * byte. Asynchronous on `stream`; uses no engine scratch. */
+enum { MOF_INTER_CUBIC = 2, MOF_INTER_LANCZOS4 = 4 }; /* cv::INTER_CUBIC, cv::INTER_LANCZOS4 */
+int mof_sr_logpolar_batch_device(mof_sr_engine* e, const uint8_t* d_src, size_t src_stride, size_t pitch, int n_images,
+                                 int interpolation, uint8_t* d_dst, void* stream);
 
 #ifdef __cplusplus
 }

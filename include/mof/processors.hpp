@@ -76,7 +76,12 @@ class FftMethod {
   FftMethod& operator=(const FftMethod&) = delete;
 
   // OpticFlowCalc::setImPrev (OpticFlowCalc.h:14-16)
-  void setImPrev(ImageView imPrev_t) { detail::check(mof_fft_set_prev(engine_, imPrev_t.data, imPrev_t.step), "setImPrev"); }
+  // The C ABI sees a pointer and a pitch only: the frame size is checked here.
+  void setImPrev(ImageView imPrev_t) {
+    if (imPrev_t.rows != cfg_.frame_height || imPrev_t.cols != cfg_.frame_width)
+      throw std::runtime_error("setImPrev: frame size does not match the engine geometry");
+    detail::check(mof_fft_set_prev(engine_, imPrev_t.data, imPrev_t.step), "setImPrev");
+  }
 
   // FftMethod::processImage (FftMethod.cpp:1772-1903). midPoint_t, yaw_angle, rot_center and raw_output are
   // ignored exactly as the reference ignores them; fx, fy are stored only (:1781-1782).
@@ -130,7 +135,11 @@ class BlockMatcherBase {
   ~BlockMatcherBase() { mof_bm_destroy(engine_); }
   BlockMatcherBase(const BlockMatcherBase&) = delete;
   BlockMatcherBase& operator=(const BlockMatcherBase&) = delete;
-  void setImPrev(ImageView imPrev_t) { detail::check(mof_bm_set_prev(engine_, imPrev_t.data, imPrev_t.step), "setImPrev"); }
+  void setImPrev(ImageView imPrev_t) {
+    if (imPrev_t.rows != cfg_.frame_height || imPrev_t.cols != cfg_.frame_width)
+      throw std::runtime_error("setImPrev: frame size does not match the engine geometry");
+    detail::check(mof_bm_set_prev(engine_, imPrev_t.data, imPrev_t.step), "setImPrev");
+  }
   // per-block integer shifts of the last processImage call, index by*grid_x + bx
   const std::vector<int8_t>& flowX() const { return dx_; }
   const std::vector<int8_t>& flowY() const { return dy_; }

@@ -317,6 +317,10 @@ static int long_range_args(const mof_fft_engine* e, mof::PcArgs* a) {
   a->grid_x = c.grid_x / 4;
   a->grid_y = c.grid_y / 4;
   a->downscale = 4;
+  // the long-range gate is held in ints (`int max_px_speed_lr, max_px_speed_sq_lr`, FftMethod.h:393):
+  // max_px_speed_lr = 1 * max_px_speed_t truncates, max_px_speed_sq_lr = pow(max_px_speed_lr, 2) (FftMethod.cpp:1687-1688)
+  const int speed_lr = (int)c.max_px_speed;
+  a->max_px_speed_sq = (double)(int)std::pow((double)speed_lr, 2);
   return MOF_OK;
 }
 

@@ -158,7 +158,45 @@ struct mof_sr_engine {
   double* h_out = nullptr;
   bool first = true;             // :31
   std::atomic<bool> busy{false};
+  // Ordering of the engine-owned scratch (d_lp, d_Z, d_D, d_S, d_cand, d_out) across streams: every call that
+  // touches it records `scratch_ev` behind its last kernel; a later call on a DIFFERENT stream first makes its
+  // stream wait for that event (same-stream calls are ordered by the stream itself).
+  hipEvent_t scratch_ev = nullptr;
+  hipStream_t scratch_stream = nullptr;  // stream of the last user
+  bool scratch_used = false;
 };
+
+namespace {
+
+// Called with the busy flag held, before the first launch that reads or writes the scratch.
+hipError_t scratch_acquire(mof_sr_engine* e, hipStream_t s) {
+  if (e->scratch_used && e->scratch_stream != s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    hipError_t err = hipStreamIsCapturing(s, &cap);
+    if (err != hipSuccess) return err;
+    // a capturing stream must not take a dependency on work outside its graph: the caller orders graph replays
+    if (cap == hipStreamCaptureStatusNone) {
+      err = hipStreamWaitEvent(s, e->scratch_ev, 0);
+      if (err != hipSuccess) return err;
+    }
+  }
+  return hipSuccess;
+}
+
+// Called behind the last launch of the call.
+hipError_t scratch_release(mof_sr_engine* e, hipStream_t s) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  hipError_t err = hipStreamIsCapturing(s, &cap);
+  if (err != hipSuccess) return err;
+  if (cap != hipStreamCaptureStatusNone) return hipSuccess;  // events recorded while capturing belong to the graph
+  err = hipEventRecord(e->scratch_ev, s);
+  if (err != hipSuccess) return err;
+  e->scratch_stream = s;
+  e->scratch_used = true;
+  return hipSuccess;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -166,12 +204,14 @@ void mof_sr_destroy(mof_sr_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
   void* dev[] = {e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_twiddles, e->d_frame, e->d_temp_im, e->d_prev_lp,
                  e->d_lp,  e->d_Z,       e->d_D,         e->d_S,        e->d_cand,  e->d_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   if (e->h_out) (void)hipHostFree(e->h_out);
+  if (e->scratch_ev) (void)hipEventDestroy(e->scratch_ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -218,6 +258,7 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
     }                                                                                     \
   } while (0)
   CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreateWithFlags(&e->scratch_ev, hipEventDisableTiming));
   CREATE_TRY(hipMalloc(&e->d_map, map.size() * sizeof(mof::SrMapEntry)));
   CREATE_TRY(hipMemcpy(e->d_map, map.data(), map.size() * sizeof(mof::SrMapEntry), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_w_cubic, wc.size() * sizeof(int16_t)));
@@ -305,8 +346,10 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
   lp.weights = e->d_w_lanczos;
   SR_TRY(mof::launch_sr_logpolar(lp, 4, 1, e->stream));  // INTER_LANCZOS4, :112
   mof::SrPcArgs a = pc_args(e, e->d_temp_im, e->d_prev_lp, 0, e->d_out);
+  SR_TRY(scratch_acquire(e, e->stream));
   SR_TRY(mof::launch_sr_phase_correlate(a, res, 1, e->stream));  // :117
   SR_TRY(hipMemcpyAsync(e->h_out, e->d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  SR_TRY(scratch_release(e, e->stream));
   SR_TRY(hipStreamSynchronize(e->stream));
   out_scale_rot[0] = e->h_out[0];
   out_scale_rot[1] = e->h_out[1];
@@ -329,6 +372,7 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
   SR_TRY(hipSetDevice(e->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   const size_t nn = (size_t)res * res;
+  SR_TRY(scratch_acquire(e, s));
   for (int k0 = 0; k0 < n_pairs; k0 += kChunk) {
     const int n = (n_pairs - k0 < kChunk) ? n_pairs - k0 : kChunk;
     // every pair is the two-call sequence of a fresh estimator: prev -> INTER_CUBIC (:45), cur -> INTER_LANCZOS4
@@ -352,6 +396,32 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
     mof::SrPcArgs a = pc_args(e, e->d_lp, e->d_lp + nn, 2 * nn, d_out + 4 * (size_t)k0);
     SR_TRY(mof::launch_sr_phase_correlate(a, res, n, s));
   }
+  SR_TRY(scratch_release(e, s));
+  return MOF_OK;
+}
+
+
+int mof_sr_logpolar_batch_device(mof_sr_engine* e, const uint8_t* d_src, size_t src_stride, size_t pitch, int n_images,
+                                 int interpolation, uint8_t* d_dst, void* stream) {
+  if (!e) return mof::capi_fail(MOF_ERR_NOT_INIT, "null engine");
+  const int res = e->cfg.resolution;
+  if (n_images == 0) return MOF_OK;
+  if (!d_src || !d_dst || n_images < 0 || pitch < (size_t)res) return mof::capi_fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if (interpolation != MOF_INTER_CUBIC && interpolation != MOF_INTER_LANCZOS4)
+    return mof::capi_fail(MOF_ERR_BAD_ARG, "interpolation must be MOF_INTER_CUBIC (2) or MOF_INTER_LANCZOS4 (4)");
+  BusyGuard g(e->busy);
+  if (!g.owned) return mof::capi_fail(MOF_ERR_BUSY, "engine busy");
+  SR_TRY(hipSetDevice(e->cfg.device));
+  mof::SrLpArgs lp{};
+  lp.src = d_src;
+  lp.src_stride = src_stride;
+  lp.pitch = pitch;
+  lp.dst = d_dst;
+  lp.dst_stride = (size_t)res * res;
+  lp.map = e->d_map;
+  lp.res = res;
+  lp.weights = interpolation == MOF_INTER_CUBIC ? e->d_w_cubic : e->d_w_lanczos;
+  SR_TRY(mof::launch_sr_logpolar(lp, interpolation, n_images, (hipStream_t)stream));  // touches no engine scratch
   return MOF_OK;
 }
 

@@ -35,6 +35,36 @@ def _stream_ptr(stream):
 
 
 PEAK_OPENCV, PEAK_OCL = 0, 1  # include/mof.h
+INTER_CUBIC, INTER_LANCZOS4 = 2, 4  # include/mof.h (cv::INTER_CUBIC, cv::INTER_LANCZOS4)
+
+
+def _check_device_batch(cur, prev, frame_hw, device_index: int, channels: int = 1) -> None:
+    """The C ABI receives raw pointers, a pitch and a frame stride: everything it cannot see is checked here.
+    cur/prev: torch uint8 [n, H, W] (or [n, H, W, 3]) on the engine's device, innermost dimension(s) dense."""
+    import torch
+
+    want_dim = 3 if channels == 1 else 4
+    for name, t in (("cur", cur), ("prev", prev)):
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.uint8:
+            raise ValueError(f"{name} must be a torch uint8 tensor")
+        if not t.is_cuda:
+            raise ValueError(f"{name} must live on the GPU (there is no CPU path)")
+        if t.device.index != device_index:
+            raise ValueError(f"{name} is on cuda:{t.device.index}, the engine on cuda:{device_index}")
+        if t.dim() != want_dim:
+            raise ValueError(f"{name} must have {want_dim} dimensions, got {t.dim()}")
+        if tuple(t.shape[1:3]) != tuple(frame_hw):
+            raise ValueError(f"{name} frames are {tuple(t.shape[1:3])}, engine expects {tuple(frame_hw)}")
+        if channels == 3 and (t.shape[3] != 3 or t.stride(3) != 1 or t.stride(2) != 3):
+            raise ValueError(f"{name} must be interleaved BGR8 ([n, H, W, 3], pixel stride 3)")
+        if channels == 1 and t.stride(2) != 1:
+            raise ValueError(f"{name} rows must be dense (stride 1 along x)")
+        if t.stride(1) < t.shape[2] * channels or t.stride(0) < 0:
+            raise ValueError(f"{name} has overlapping rows or a negative frame stride")
+    if cur.shape != prev.shape:
+        raise ValueError(f"cur {tuple(cur.shape)} and prev {tuple(prev.shape)} differ")
+    if cur.stride(1) != prev.stride(1):
+        raise ValueError("cur and prev must share one row pitch")
 
 
 class FftMethod:
@@ -120,8 +150,7 @@ class FftMethod:
     def process_long_range_batch_device(self, cur, prev, stream=None):
         import torch
 
-        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and cur.shape == prev.shape
-        assert cur.stride(2) == 1 and prev.stride(2) == 1 and cur.stride(1) == prev.stride(1)
+        _check_device_batch(cur, prev, (self.cfg.frame_height, self.cfg.frame_width), self.cfg.device)
         n_lr = self._lib.mof_fft_long_range_patches(self._h)
         if n_lr < 0:
             check(n_lr)
@@ -137,7 +166,8 @@ class FftMethod:
     def process_batch_host(self, cur: np.ndarray, prev: np.ndarray) -> np.ndarray:
         cur = np.ascontiguousarray(cur, dtype=np.uint8)
         prev = np.ascontiguousarray(prev, dtype=np.uint8)
-        assert cur.shape == prev.shape and cur.ndim == 3
+        if cur.shape != prev.shape or cur.ndim != 3:
+            raise ValueError("cur and prev must be [n, H, W] arrays of one shape")
         self._check_shape(cur)
         n = cur.shape[0]
         out = np.empty((n, self.n_patches, 2), np.float64)
@@ -152,14 +182,13 @@ class FftMethod:
         float64 tensor [n, patches, 2]."""
         import torch
 
-        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and prev.is_cuda
-        assert cur.dim() == 3 and cur.shape == prev.shape and cur.stride(2) == 1 and prev.stride(2) == 1
-        assert cur.stride(1) == prev.stride(1)
-        self._check_shape(cur)
+        _check_device_batch(cur, prev, (self.cfg.frame_height, self.cfg.frame_width), self.cfg.device)
         n = cur.shape[0]
         if out is None:
             out = torch.empty((n, self.n_patches, 2), dtype=torch.float64, device=cur.device)
-        assert out.is_contiguous() and out.dtype == torch.float64 and out.numel() == n * self.n_patches * 2
+        if not (out.is_cuda and out.device == cur.device and out.is_contiguous() and out.dtype == torch.float64
+                and out.numel() == n * self.n_patches * 2):
+            raise ValueError("out must be a dense float64 tensor of n * patches * 2 elements on the engine's device")
         s = stream if stream is not None else torch.cuda.current_stream(cur.device)
         check(self._lib.mof_fft_process_batch_device(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
                                                      prev.stride(0), cur.stride(1), n, out.data_ptr(), _stream_ptr(s)))
@@ -170,10 +199,7 @@ class FftMethod:
         CV_RGB2GRAY (as the node applies it to BGR data) is fused into the kernel's load."""
         import torch
 
-        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and cur.shape == prev.shape
-        assert cur.dim() == 4 and cur.shape[3] == 3 and cur.stride(3) == 1 and cur.stride(2) == 3
-        assert prev.stride(3) == 1 and prev.stride(2) == 3 and cur.stride(1) == prev.stride(1)
-        self._check_shape(cur[0, :, :, 0])
+        _check_device_batch(cur, prev, (self.cfg.frame_height, self.cfg.frame_width), self.cfg.device, channels=3)
         n = cur.shape[0]
         out = torch.empty((n, self.n_patches, 2), dtype=torch.float64, device=cur.device)
         s = stream if stream is not None else torch.cuda.current_stream(cur.device)
@@ -211,8 +237,14 @@ class _BmBase:
     def n_blocks(self) -> int:
         return self.cfg.grid_x * self.cfg.grid_y
 
+    def _check_shape(self, f) -> None:
+        if tuple(f.shape[-2:]) != (self.cfg.frame_height, self.cfg.frame_width):
+            raise ValueError(f"frame is {tuple(f.shape[-2:])}, engine expects "
+                             f"{(self.cfg.frame_height, self.cfg.frame_width)}")
+
     def setImPrev(self, frame) -> None:
         f = _np_u8(frame)
+        self._check_shape(f)
         check(self._lib.mof_bm_set_prev(self._h, f.ctypes.data, f.strides[0]))
 
     def reset(self) -> None:
@@ -221,8 +253,7 @@ class _BmBase:
     def processBlocks(self, imCurr):
         """Integer stage: (dx[gy,gx], dy[gy,gx], (modeX, modeY))."""
         f = _np_u8(imCurr)
-        if f.shape != (self.cfg.frame_height, self.cfg.frame_width):
-            raise ValueError("frame shape does not match the engine")
+        self._check_shape(f)
         dx = np.empty(self.n_blocks, np.int8)
         dy = np.empty(self.n_blocks, np.int8)
         mode = np.zeros(2, np.int8)
@@ -248,6 +279,9 @@ class _BmBase:
     def process_batch_host(self, cur: np.ndarray, prev: np.ndarray):
         cur = np.ascontiguousarray(cur, dtype=np.uint8)
         prev = np.ascontiguousarray(prev, dtype=np.uint8)
+        if cur.shape != prev.shape or cur.ndim != 3:
+            raise ValueError("cur and prev must be [n, H, W] arrays of one shape")
+        self._check_shape(cur)
         n = cur.shape[0]
         dx = np.empty((n, self.cfg.grid_y, self.cfg.grid_x), np.int8)
         dy = np.empty_like(dx)
@@ -260,9 +294,7 @@ class _BmBase:
     def process_batch_device(self, cur, prev, stream=None):
         import torch
 
-        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and prev.is_cuda
-        assert cur.dim() == 3 and cur.shape == prev.shape and cur.stride(2) == 1 and prev.stride(2) == 1
-        assert cur.stride(1) == prev.stride(1)
+        _check_device_batch(cur, prev, (self.cfg.frame_height, self.cfg.frame_width), self.cfg.device)
         n = cur.shape[0]
         dx = torch.empty((n, self.cfg.grid_y, self.cfg.grid_x), dtype=torch.int8, device=cur.device)
         dy = torch.empty_like(dx)
@@ -333,15 +365,30 @@ class ScaleRotationEstimator:
         """cur, prev: torch uint8 [n, res, res] views (any pitch/stride) -> float64 [n, 4] = scale, rot, pt.x, pt.y."""
         import torch
 
-        assert cur.dtype == torch.uint8 and prev.dtype == torch.uint8 and cur.is_cuda and cur.shape == prev.shape
-        assert cur.shape[1] == cur.shape[2] == self.cfg.resolution
-        assert cur.stride(2) == 1 and prev.stride(2) == 1 and cur.stride(1) == prev.stride(1)
+        _check_device_batch(cur, prev, (self.cfg.resolution, self.cfg.resolution), self.cfg.device)
         n = cur.shape[0]
         out = torch.empty((n, 4), dtype=torch.float64, device=cur.device)
         s = stream if stream is not None else torch.cuda.current_stream(cur.device)
         check(self._lib.mof_sr_process_batch_device(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
                                                     prev.stride(0), cur.stride(1), n, out.data_ptr(), _stream_ptr(s)))
         return out
+
+    def logpolar_batch_device(self, src, interpolation: int = INTER_LANCZOS4, dst=None, stream=None):
+        """cv::logPolar of n res x res crops (torch uint8 [n, res, res], any pitch/stride) -> uint8 [n, res, res].
+        Destination pixels whose source lies outside the image keep the content of ``dst`` (zeros when omitted)."""
+        import torch
+
+        _check_device_batch(src, src, (self.cfg.resolution, self.cfg.resolution), self.cfg.device)
+        n, res = src.shape[0], self.cfg.resolution
+        if dst is None:
+            dst = torch.zeros((n, res, res), dtype=torch.uint8, device=src.device)
+        if not (dst.is_cuda and dst.device == src.device and dst.dtype == torch.uint8 and dst.is_contiguous()
+                and tuple(dst.shape) == (n, res, res)):
+            raise ValueError("dst must be a dense uint8 [n, res, res] tensor on the engine's device")
+        s = stream if stream is not None else torch.cuda.current_stream(src.device)
+        check(self._lib.mof_sr_logpolar_batch_device(self._h, src.data_ptr(), src.stride(0), src.stride(1), n,
+                                                     int(interpolation), dst.data_ptr(), _stream_ptr(s)))
+        return dst
 
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:

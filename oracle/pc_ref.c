@@ -177,6 +177,10 @@ int oracle_fft_process_long_range_u8(const uint8_t* cur, const uint8_t* prev, si
   lr.height = h;
   lr.grid_x = L->grid_x / 4; /* sqNum_lr = sqNum / LONG_RANGE_RATIO, ref :1720 */
   lr.grid_y = L->grid_y / 4;
+  /* ref include/FftMethod.h:393 `int max_px_speed_lr, max_px_speed_sq_lr`; src/FftMethod.cpp:1687-1688: the speed is
+   * truncated to int, its square is what the gate compares with (:1963). oracle_fft_process_u8 squares
+   * max_px_speed itself, and the square of the truncated integer is exact in double. */
+  lr.max_px_speed = (double)(int)L->max_px_speed;
   int rc = oracle_fft_process_u8(c, p, (size_t)w, &lr, precision, out_xy, n_invalid, NULL);
   free(c);
   free(p);
