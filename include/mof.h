@@ -202,7 +202,14 @@ typedef struct mof_sr_config {
   int resolution;   /* side of the square image (scaleRotationEstimator.cpp:5): 240, 256 or 480       */
   double magnitude; /* log-polar magnitude M (scale_rot_magnitude, config/default.yaml:13: 49.9)      */
   int device;
+  int logpolar_variant; /* MOF_LOGPOLAR_CV4 (0, default) or MOF_LOGPOLAR_CV3: see below              */
 } mof_sr_config;
+
+/* The reference calls cv::logPolar under ROS Noetic (OpenCV 4.2) and the C API cvLogPolar under ROS Melodic
+ * (OpenCV 3.2) (scaleRotationEstimator.cpp:41-46, :107-113). Their maps differ: 4.x goes through cv::warpPolar,
+ * radius exp(rho * Kmag) - 1; 3.2 uses radius exp(rho / M) without the "- 1". Both are available; everything after
+ * the map (remap's fixed point, the phase correlation) is the same. */
+enum { MOF_LOGPOLAR_CV4 = 0, MOF_LOGPOLAR_CV3 = 1 };
 
 typedef struct mof_sr_engine mof_sr_engine;
 
@@ -239,6 +246,88 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
 enum { MOF_INTER_CUBIC = 2, MOF_INTER_LANCZOS4 = 4 }; /* cv::INTER_CUBIC, cv::INTER_LANCZOS4 */
 int mof_sr_logpolar_batch_device(mof_sr_engine* e, const uint8_t* d_src, size_t src_stride, size_t pitch, int n_images,
                                  int interpolation, uint8_t* d_dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Geometry tail: per-patch shifts -> camera-frame velocity (OpticFlow::getRT / get2DT)       */
+/* ------------------------------------------------------------------------------------------ */
+/* The consumers of processImage / processImageLongRange in the node (optic_flow.cpp:1719 -> :515-774 getRT,
+ * :1780 -> :388-510 get2DT), SURVEY section 8(f) N1 / N3. getRT leans on OpenCV calib3d and tf2, which are restated
+ * from their published algorithms (csrc/geom_core.hpp lists what exactly): cv::undistortPoints (5 coefficients, 5
+ * iterations), cv::decomposeHomographyMat (Malis-Vargas, K = I), the tf2 quaternion members, and -- the one piece
+ * that CANNOT reproduce OpenCV's numbers, because cv::RNG's sequence is not restated -- cv::findHomography(RANSAC,
+ * 0.01) with the library's own documented counter-based sampler (same threshold, confidence 0.995, 2000 iterations,
+ * normalised-DLT + 10 LM steps on the consensus set). On data with a clear consensus set the mask and the refined
+ * homography do not depend on the sampler. No HIP device is needed for the host forms. */
+
+typedef struct mof_geom_camera { /* camMatrix_, distCoeffs_ (optic_flow.cpp:1511-1522) */
+  double fx, fy, cx, cy;
+  double k1, k2, p1, p2, k3;
+} mof_geom_camera;
+
+typedef struct mof_geom_layout { /* patch (i, j) centre = origin + (i, j) * stride + patch_size / 2 (:537-538) */
+  int grid_x, grid_y, origin_x, origin_y, stride_x, stride_y, patch_size;
+} mof_geom_layout;
+
+typedef struct mof_geom_rt_params { /* per frame pair */
+  double height;        /* uav_height_curr (:1719)                                                          */
+  double dt;            /* dur_.toSec()                                                                     */
+  double ul_corner_x;   /* ulCorner.x: camMatrixLocal(0,2) -= ulCorner.x (:521-522); ulCorner.y is unused    */
+  double ang_rate_q[4]; /* angular_rate_tf_ (x, y, z, w): Quaternion::setRPY of the gyro rates (:1314)        */
+  double c2b_q[4];      /* transformCam2Base_ rotation (x, y, z, w) (:600-601)                               */
+  double c2b_t[3];      /* its translation -- `tempTfC2B * axis` applies the WHOLE transform (:643)          */
+} mof_geom_rt_params;
+
+typedef struct mof_geom_2dt_params { /* per frame pair */
+  double height;        /* uav_height_curr / (cos(imu_pitch_) cos(imu_roll_)), formed by the caller (:1780)  */
+  double dt;
+  double roll_rate, pitch_rate; /* imu_roll_rate_, imu_pitch_rate_ (:481-482)                               */
+  double cam_yaw;       /* cam_yaw_ (:484)                                                                   */
+} mof_geom_2dt_params;
+
+/* `status` of getRT / get2DT: 0 <=> the reference returns true; the others name the early return taken. */
+enum {
+  MOF_GEOM_OK = 0,
+  MOF_GEOM_BAD_DURATION = 1,      /* !isfinite(1/dt)                       :516-519, :393-396 */
+  MOF_GEOM_TOO_FEW_POINTS = 2,    /* valid points < shifted_pts_thr        :544-547 (get2DT: none valid, :425-429) */
+  MOF_GEOM_TOO_FEW_INLIERS = 3,   /* after RANSAC                          :575-578 */
+  MOF_GEOM_ANGLE_TOO_LARGE = 4,   /* best solution > pi/4 from the IMU     :682-685 */
+  MOF_GEOM_SINGLE_NO_MATCH = 5,   /* :725-728 */
+  MOF_GEOM_SINGLE_NON_FINITE = 6, /* :744-751 */
+  MOF_GEOM_UNCLASSIFIED = 7,      /* :769-771 */
+  MOF_GEOM_NO_HOMOGRAPHY = 8,     /* < 4 points or no model: OpenCV would throw in decomposeHomographyMat */
+  MOF_GEOM_NO_POINTS = 9          /* get2DT on an empty vector, :389-392 */
+};
+
+/* The node's tiling: sqNum = frame_size / sample_point_size patches per side, origin 0, stride = patch (:525). */
+int mof_geom_layout_reference(mof_geom_layout* layout, int frame_size, int sample_point_size);
+
+/* Stages, exposed for parity tests. cv::undistortPoints(pts, out, camMatrixLocal, distCoeffs): pixels -> normalised. */
+int mof_geom_undistort_points(const mof_geom_camera* cam, double ul_corner_x, const double* pts_xy, int n, double* out_xy);
+/* cv::findHomography(a, b, cv::RANSAC, 0.01, mask): H9 row-major with H[8] = 1, mask[n] of 0/1, *found = 0 when no model. */
+int mof_geom_find_homography(const double* a_xy, const double* b_xy, int n, double* H9, uint8_t* mask, int* found);
+/* cv::decomposeHomographyMat(H, I, R, t, n): *n_solutions = 1 or 4 (0: degenerate); R[4][9] row-major, t[4][3], normals[4][3]. */
+int mof_geom_decompose_homography(const double* H9, double* R, double* t, double* normals, int* n_solutions);
+
+/* OpticFlow::getRT (:515-774). shifts_xy: the 2*grid_x*grid_y doubles processImage returned (NaN = invalid).
+ * out_rot_tran[7] = o_rot (x, y, z, w), o_tran (x, y, z); identity/zero unless *status == MOF_GEOM_OK.
+ * inlier_mask (optional, grid_x*grid_y bytes, 1 = RANSAC inlier) and homography (optional, 9) are diagnostics. */
+int mof_geom_get_rt(const double* shifts_xy, const mof_geom_layout* layout, const mof_geom_camera* cam,
+                    const mof_geom_rt_params* params, int shifted_pts_thr, double* out_rot_tran, int* status,
+                    uint8_t* inlier_mask, double* homography);
+/* OpticFlow::get2DT (:388-510, LONG_RANGE_RATIO 4). shifts_xy: what processImageLongRange returned (layout = the
+ * long-range grid, patch_size = sample_point_size_lr). out_tran_diff[6] = o_tran (3), o_tran_diff (3). Closed form. */
+int mof_geom_get_2dt(const double* shifts_xy, const mof_geom_layout* layout, const mof_geom_camera* cam,
+                     const mof_geom_2dt_params* params, double* out_tran_diff, int* status);
+
+/* Batched forms on DEVICE pointers, asynchronous on `stream`: d_shifts_xy is the [n_pairs][grid_y*grid_x][2] output of
+ * mof_fft_process_batch_device / ..._long_range_batch_device, d_params one struct per pair. d_out: [n_pairs][8] doubles
+ * = getRT: rot (4), tran (3), status; get2DT: tran (3), diff (3), status, 0. One wavefront per frame pair; the 64 lanes
+ * evaluate 64 RANSAC hypotheses at a time and replay the host's in-order acceptance, so the model chosen is the host's. */
+int mof_geom_get_rt_batch_device(const double* d_shifts_xy, const mof_geom_layout* layout, const mof_geom_camera* cam,
+                                 const mof_geom_rt_params* d_params, int n_pairs, int shifted_pts_thr, double* d_out,
+                                 void* stream);
+int mof_geom_get_2dt_batch_device(const double* d_shifts_xy, const mof_geom_layout* layout, const mof_geom_camera* cam,
+                                  const mof_geom_2dt_params* d_params, int n_pairs, double* d_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -228,8 +228,8 @@ class FastSpacedBMMethod : public BlockMatcherBase {
 class scaleRotationEstimator {
  public:
   scaleRotationEstimator(int res, double m, bool /*i_storeVideo*/ = false, std::string* /*videoPath*/ = nullptr,
-                         int /*videoFPS*/ = 0, int device = 0) {
-    mof_sr_config c{res, m, device};
+                         int /*videoFPS*/ = 0, int device = 0, int logpolar_variant = MOF_LOGPOLAR_CV4) {
+    mof_sr_config c{res, m, device, logpolar_variant};
     detail::check(mof_sr_create(&c, &engine_), "mof_sr_create");
     res_ = res;
   }
@@ -259,7 +259,9 @@ class scaleRotationEstimator {
 
 #include <opencv2/core.hpp>
 
-class MofFftMethod : public OpticFlowCalc {
+// `final`: OpticFlowCalc has no virtual destructor (OpticFlowCalc.h:6-22), so the object must be destroyed through its own type,
+// as the node does with its concrete `FftMethod* fftProcessor_` (optic_flow.cpp:251).
+class MofFftMethod final : public OpticFlowCalc {
  public:
   MofFftMethod(int i_frameSize, int i_samplePointSize, double max_px_speed_t, bool i_storeVideo, bool i_raw_enable,
                bool i_rot_corr_enable, bool i_tilt_corr_enable, std::string* videoPath, int videoFPS,

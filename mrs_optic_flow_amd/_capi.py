@@ -40,7 +40,7 @@ class FftConfig(C.Structure):
 
 
 class SrConfig(C.Structure):
-    _fields_ = [("resolution", C.c_int), ("magnitude", C.c_double), ("device", C.c_int)]
+    _fields_ = [("resolution", C.c_int), ("magnitude", C.c_double), ("device", C.c_int), ("logpolar_variant", C.c_int)]
 
 
 class BmConfig(C.Structure):
@@ -86,6 +86,14 @@ SYMBOLS = {
     "mof_sr_process": (_I, [_VP, _VP, _SZ, _VP]),
     "mof_sr_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_sr_logpolar_batch_device": (_I, [_VP, _VP, _SZ, _SZ, _I, _I, _VP, _VP]),
+    "mof_geom_layout_reference": (_I, [_VP, _I, _I]),
+    "mof_geom_undistort_points": (_I, [_VP, C.c_double, _VP, _I, _VP]),
+    "mof_geom_find_homography": (_I, [_VP, _VP, _I, _VP, _VP, C.POINTER(_I)]),
+    "mof_geom_decompose_homography": (_I, [_VP, _VP, _VP, _VP, C.POINTER(_I)]),
+    "mof_geom_get_rt": (_I, [_VP, _VP, _VP, _VP, _I, _VP, C.POINTER(_I), _VP, _VP]),
+    "mof_geom_get_2dt": (_I, [_VP, _VP, _VP, _VP, _VP, C.POINTER(_I)]),
+    "mof_geom_get_rt_batch_device": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "mof_geom_get_2dt_batch_device": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP]),
 }
 
 _lib = None

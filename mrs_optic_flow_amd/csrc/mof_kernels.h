@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace mof {
 
 // ---- K1: per-patch FFT phase correlation ----------------------------------------------------
@@ -90,6 +92,10 @@ struct SrPcArgs {
   double M;                // log-polar magnitude
   double* out;             // [pairs][4] = scale, rot, pt.x, pt.y
 };
+
+// host-side tables of cv::logPolar / cv::remap (mof_sr.hip); exposed so that the CPU suite can compare them with the oracle
+std::vector<SrMapEntry> sr_logpolar_map(int res, double M, int variant);
+std::vector<int16_t> sr_weight_table(int ksize /* 4 cubic, 8 Lanczos4 */);  // [32*32][ksize*ksize], each summing to 2^15
 
 bool sr_resolution_supported(int res);
 int sr_candidates(int res);

@@ -100,19 +100,38 @@ std::vector<int16_t> weight_table(int ksize) {
   return tab;
 }
 
-// cv::logPolar's maps in remap's fixed-point form: x = (exp(rho/M) - 1) cos(phi) + cx (float), rows = phi
-std::vector<mof::SrMapEntry> logpolar_map(int res, double M) {
-  std::vector<mof::SrMapEntry> map((size_t)res * res);
+// cv::logPolar's maps in remap's fixed-point form; rows = phi, columns = rho, centre (res/2, res/2)
+// (cv::Point2f(resolution / 2, resolution / 2), scaleRotationEstimator.cpp:25). The reference compiles against one of
+// two OpenCV generations (scaleRotationEstimator.cpp:41-46, :107-113) whose maps differ:
+//   MOF_LOGPOLAR_CV4 (ROS Noetic, OpenCV 4.2) cv::logPolar = cv::warpPolar(.., maxRadius = exp(width / M), WARP_POLAR_LOG):
+//     Kmag = log(maxRadius) / width, float table rhos[rho] = (float)(exp(rho * Kmag) - 1.0),
+//     x = rhos[rho] * cos((2 pi / height) * phi) + cx, in double, stored as float;
+//   MOF_LOGPOLAR_CV3 (ROS Melodic, OpenCV 3.2) cvLogPolar: double table exp(rho / M) -- no "- 1" --,
+//     x = exp_tab[rho] * cos(phi * 2 pi / height) + cx.
+// remap then rounds the float coordinates to 1/32 px: (anchor, fractional index) per destination pixel.
+}  // namespace
+
+namespace mof {
+
+std::vector<SrMapEntry> sr_logpolar_map(int res, double M, int variant) {
+  std::vector<SrMapEntry> map((size_t)res * res);
+  const float cx = (float)(res / 2), cy = (float)(res / 2);
+  const double PI = 3.14159265358979323846;
   std::vector<float> rhos((size_t)res);
-  for (int rho = 0; rho < res; ++rho) rhos[(size_t)rho] = (float)(std::exp((double)rho / M) - 1.0);
-  const float cx = (float)(res / 2), cy = (float)(res / 2);  // cv::Point2f(resolution / 2, resolution / 2)
-  const double kangle = 2.0 * 3.14159265358979323846 / (double)res;
+  std::vector<double> exp_tab((size_t)res);
+  const double Kmag = std::log(std::exp((double)res / M)) / (double)res, Kangle = 2.0 * PI / (double)res;
+  for (int rho = 0; rho < res; ++rho) {
+    rhos[(size_t)rho] = (float)(std::exp(rho * Kmag) - 1.0);
+    exp_tab[(size_t)rho] = std::exp(rho / M);
+  }
   for (int phi = 0; phi < res; ++phi) {
-    const double cp = std::cos(phi * kangle), sp = std::sin(phi * kangle);
+    const double ang = variant == MOF_LOGPOLAR_CV3 ? phi * 2 * PI / res : Kangle * phi;
+    const double cp = std::cos(ang), sp = std::sin(ang);
     for (int rho = 0; rho < res; ++rho) {
-      const double r = (double)rhos[(size_t)rho];
-      const float fx = (float)(r * cp + (double)cx) * (float)kTab, fy = (float)(r * sp + (double)cy) * (float)kTab;
-      mof::SrMapEntry e{0, 0, 0, 0};
+      const double r = variant == MOF_LOGPOLAR_CV3 ? exp_tab[(size_t)rho] : (double)rhos[(size_t)rho];
+      const float mx = (float)(r * cp + (double)cx), my = (float)(r * sp + (double)cy);
+      const float fx = mx * (float)kTab, fy = my * (float)kTab;
+      SrMapEntry e{0, 0, 0, 0};
       if (std::fabs(fx) < 1.0e9f && std::fabs(fy) < 1.0e9f) {
         const long ix = std::lrintf(fx), iy = std::lrintf(fy);
         long ax = ix >> 5, ay = iy >> 5;
@@ -128,6 +147,12 @@ std::vector<mof::SrMapEntry> logpolar_map(int res, double M) {
   }
   return map;
 }
+
+std::vector<int16_t> sr_weight_table(int ksize) { return weight_table(ksize); }
+
+}  // namespace mof
+
+namespace {
 
 struct BusyGuard {
   std::atomic<bool>& flag;
@@ -220,6 +245,8 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   if (!out) return mof::capi_fail(MOF_ERR_BAD_ARG, "null out");
   *out = nullptr;
   if (!cfg || !(cfg->magnitude > 0.0)) return mof::capi_fail(MOF_ERR_BAD_ARG, "bad scale/rotation config");
+  if (cfg->logpolar_variant != MOF_LOGPOLAR_CV4 && cfg->logpolar_variant != MOF_LOGPOLAR_CV3)
+    return mof::capi_fail(MOF_ERR_BAD_ARG, "logpolar_variant must be MOF_LOGPOLAR_CV4 (0) or MOF_LOGPOLAR_CV3 (1)");
   if (!mof::sr_resolution_supported(cfg->resolution))
     return mof::capi_fail(MOF_ERR_UNSUPPORTED, "resolution %d not supported by the HIP pipeline (240, 256, 480)", cfg->resolution);
   int ndev = 0;
@@ -231,7 +258,7 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   SR_TRY(hipSetDevice(cfg->device));
   const int res = cfg->resolution;
   const size_t nn = (size_t)res * res;
-  const std::vector<mof::SrMapEntry> map = logpolar_map(res, cfg->magnitude);
+  const std::vector<mof::SrMapEntry> map = mof::sr_logpolar_map(res, cfg->magnitude, cfg->logpolar_variant);
   const std::vector<int16_t> wc = weight_table(4), wl = weight_table(8);
   std::vector<float> tw(2 * (size_t)res);
   mof_sr_engine* e = new (std::nothrow) mof_sr_engine();

@@ -36,6 +36,7 @@ def _stream_ptr(stream):
 
 PEAK_OPENCV, PEAK_OCL = 0, 1  # include/mof.h
 INTER_CUBIC, INTER_LANCZOS4 = 2, 4  # include/mof.h (cv::INTER_CUBIC, cv::INTER_LANCZOS4)
+LOGPOLAR_CV4, LOGPOLAR_CV3 = 0, 1  # include/mof.h
 
 
 def _check_device_batch(cur, prev, frame_hw, device_index: int, channels: int = 1) -> None:
@@ -344,9 +345,11 @@ class ScaleRotationEstimator:
     returns (scale, rotation [rad]) like :34-148."""
 
     def __init__(self, resolution: int, m: float = 49.9, storeVideo: bool = False, videoPath=None, videoFPS: int = 30,
-                 device: int = 0):
+                 device: int = 0, logpolar_variant: int = 0):
+        """logpolar_variant: LOGPOLAR_CV4 (cv::logPolar of OpenCV 4.x, ROS Noetic) or LOGPOLAR_CV3 (cvLogPolar of OpenCV 3.2,
+        ROS Melodic) -- the two calls scaleRotationEstimator.cpp:41-46 compiles."""
         self._lib = _capi.load()
-        self.cfg = SrConfig(resolution, float(m), device)
+        self.cfg = SrConfig(resolution, float(m), device, int(logpolar_variant))
         self._h = C.c_void_p()
         check(self._lib.mof_sr_create(C.byref(self.cfg), C.byref(self._h)))
 

@@ -5,9 +5,17 @@
  * their previous content -- cv::logPolar calls remap with BORDER_TRANSPARENT).
  *
  * TEST INFRASTRUCTURE ONLY. PARITY UNPINNED, twice over: cv::logPolar / cv::remap live in OpenCV (absent here,
- * version unpinned), and the reference ships no fixtures. What is restated is OpenCV 3.x/4.x's published
- * algorithm as recalled: float maps x = (exp(rho/M) - 1) cos(phi) + cx, y = ... sin(phi) + cy, rows = phi over
- * 2 pi, cols = rho; remap's fixed-point path for 8-bit images: map coordinates rounded to 1/32 px
+ * version unpinned), and the reference ships no fixtures. What is restated is OpenCV's published algorithm as
+ * recalled, in the TWO forms the reference compiles against (scaleRotationEstimator.cpp:41-46, :107-113):
+ *   variant 0, ROS Noetic / OpenCV 4.2 `cv::logPolar`: a wrapper of cv::warpPolar(src, dst, src.size(), center,
+ *     maxRadius = exp(width / M), flags | WARP_POLAR_LOG): Kmag = log(maxRadius) / width, a FLOAT table
+ *     rhos[rho] = (float)(exp(rho * Kmag) - 1.0), Kangle = 2 pi / height, x = rhos[rho] * cos(Kangle * phi) + cx
+ *     evaluated in double and stored as float;
+ *   variant 1, ROS Melodic / OpenCV 3.2 `cvLogPolar` (C API): a DOUBLE table exp_tab[rho] = exp(rho / M) -- no "- 1" --
+ *     and x = exp_tab[rho] * cos(phi * 2 pi / height) + cx, stored as float.
+ * Both hand the maps to remap with BORDER_TRANSPARENT (neither call passes WARP_FILL_OUTLIERS). tools/opencv_ab/ dumps
+ * the real maps and images on a machine that has OpenCV so that these recollections can be pinned.
+ * Rows = phi over 2 pi, cols = rho; remap's fixed-point path for 8-bit images: map coordinates rounded to 1/32 px
  * (INTER_BITS = 5), separable kernel tables (cubic A = -0.75; Lanczos4) expanded to 2-D, scaled to 2^15
  * (INTER_REMAP_COEF_BITS) and corrected to sum exactly 2^15, pixel = (sum + 2^14) >> 15 saturated; footprints
  * crossing the border use BORDER_REFLECT_101 taps, anchors outside the image are skipped.
@@ -101,20 +109,59 @@ static int reflect101(int p, int len) {
   return p;
 }
 
+/* The float maps of cv::logPolar for a res x res image centred at (res/2, res/2); mapx/mapy: res*res floats, [phi][rho]. */
+int oracle_logpolar_maps(int res, double M, int variant, float* mapx, float* mapy) {
+  if (!mapx || !mapy || res < 8 || !(M > 0) || (variant != 0 && variant != 1)) return -1;
+  const float cx = (float)(res / 2), cy = (float)(res / 2); /* cv::Point2f(resolution / 2, resolution / 2), :25 */
+  const double PI = 3.14159265358979323846;
+  if (variant == 0) {
+    /* cv::logPolar -> cv::warpPolar (OpenCV >= 3.4.2, 4.x) */
+    float* rhos = (float*)malloc(sizeof(float) * (size_t)res);
+    if (!rhos) return -2;
+    const double maxRadius = exp((double)res / M);
+    const double Kmag = log(maxRadius) / (double)res;
+    const double Kangle = 2.0 * PI / (double)res;
+    for (int rho = 0; rho < res; ++rho) rhos[rho] = (float)(exp(rho * Kmag) - 1.0);
+    for (int phi = 0; phi < res; ++phi) {
+      const double KKy = Kangle * phi, cp = cos(KKy), sp = sin(KKy);
+      for (int rho = 0; rho < res; ++rho) {
+        mapx[(size_t)phi * res + rho] = (float)(rhos[rho] * cp + cx);
+        mapy[(size_t)phi * res + rho] = (float)(rhos[rho] * sp + cy);
+      }
+    }
+    free(rhos);
+  } else {
+    /* cvLogPolar (OpenCV 2.4 ... 3.2 C API) */
+    double* exp_tab = (double*)malloc(sizeof(double) * (size_t)res);
+    if (!exp_tab) return -2;
+    for (int rho = 0; rho < res; ++rho) exp_tab[rho] = exp(rho / M);
+    for (int phi = 0; phi < res; ++phi) {
+      const double cp = cos(phi * 2 * PI / res), sp = sin(phi * 2 * PI / res);
+      for (int rho = 0; rho < res; ++rho) {
+        const double r = exp_tab[rho];
+        mapx[(size_t)phi * res + rho] = (float)(r * cp + cx);
+        mapy[(size_t)phi * res + rho] = (float)(r * sp + cy);
+      }
+    }
+    free(exp_tab);
+  }
+  return 0;
+}
+
 int oracle_logpolar_u8(const uint8_t* src, size_t pitch, int res, double M, int interp, uint8_t* dst) {
-  if (!src || !dst || res < 8 || !(M > 0) || (interp != 2 && interp != 4)) return -1;
+  return oracle_logpolar_variant_u8(src, pitch, res, M, interp, 0, dst);
+}
+
+int oracle_logpolar_variant_u8(const uint8_t* src, size_t pitch, int res, double M, int interp, int variant, uint8_t* dst) {
+  if (!src || !dst || res < 8 || !(M > 0) || (interp != 2 && interp != 4) || (variant != 0 && variant != 1)) return -1;
   const int ksize = interp == 2 ? 4 : 8, half = ksize / 2 - 1; /* taps start at anchor - half */
   short* itab = build_table(ksize);
-  float* rhos = (float*)malloc(sizeof(float) * (size_t)res);
-  if (!itab || !rhos) { free(itab); free(rhos); return -2; }
-  const float cx = (float)(res / 2), cy = (float)(res / 2); /* cv::Point2f(resolution / 2, resolution / 2), :25 */
-  const double Kangle = 2.0 * 3.14159265358979323846 / (double)res;
-  for (int rho = 0; rho < res; ++rho) rhos[rho] = (float)(exp((double)rho / M) - 1.0);
+  float* mapx = (float*)malloc(sizeof(float) * (size_t)res * res);
+  float* mapy = (float*)malloc(sizeof(float) * (size_t)res * res);
+  if (!itab || !mapx || !mapy || oracle_logpolar_maps(res, M, variant, mapx, mapy)) { free(itab); free(mapx); free(mapy); return -2; }
   for (int phi = 0; phi < res; ++phi) {
-    const double cp = cos(phi * Kangle), sp = sin(phi * Kangle);
     for (int rho = 0; rho < res; ++rho) {
-      const double r = (double)rhos[rho];
-      const float mx = (float)(r * cp + (double)cx), my = (float)(r * sp + (double)cy);
+      const float mx = mapx[(size_t)phi * res + rho], my = mapy[(size_t)phi * res + rho];
       /* remap: fixed-point coordinates, 1/32 px. Far-away coordinates saturate like saturate_cast<short>. */
       const float fx = mx * (float)TAB, fy = my * (float)TAB;
       if (!(fabsf(fx) < 1.0e9f) || !(fabsf(fy) < 1.0e9f)) continue; /* certainly outside */
@@ -144,16 +191,22 @@ int oracle_logpolar_u8(const uint8_t* src, size_t pitch, int res, double M, int 
     }
   }
   free(itab);
-  free(rhos);
+  free(mapx);
+  free(mapy);
   return 0;
 }
 
 int oracle_scale_rotation_step(const uint8_t* frame, size_t pitch, int res, double M, int first, uint8_t* temp_im,
                                float* prev_lp, int precision, double* out, double* pt_xy) {
+  return oracle_scale_rotation_step_variant(frame, pitch, res, M, first, temp_im, prev_lp, precision, 0, out, pt_xy);
+}
+
+int oracle_scale_rotation_step_variant(const uint8_t* frame, size_t pitch, int res, double M, int first, uint8_t* temp_im,
+                                       float* prev_lp, int precision, int variant, double* out, double* pt_xy) {
   if (!frame || !temp_im || !prev_lp || !out || res < 8 || (res & 1)) return -1;
   const size_t nn = (size_t)res * res;
   if (first) {
-    int rc = oracle_logpolar_u8(frame, pitch, res, M, 2, temp_im); /* INTER_CUBIC, :45 */
+    int rc = oracle_logpolar_variant_u8(frame, pitch, res, M, 2, variant, temp_im); /* INTER_CUBIC, :45 (:44 on Melodic) */
     if (rc) return rc;
     for (size_t i = 0; i < nn; ++i) prev_lp[i] = (float)temp_im[i]; /* convertTo CV_32FC1, :48 */
     out[0] = 1.0;
@@ -161,7 +214,7 @@ int oracle_scale_rotation_step(const uint8_t* frame, size_t pitch, int res, doub
     if (pt_xy) pt_xy[0] = pt_xy[1] = 0.0;
     return 0;
   }
-  int rc = oracle_logpolar_u8(frame, pitch, res, M, 4, temp_im); /* INTER_LANCZOS4, :112 */
+  int rc = oracle_logpolar_variant_u8(frame, pitch, res, M, 4, variant, temp_im); /* INTER_LANCZOS4, :112 (:110 on Melodic) */
   if (rc) return rc;
   float* cur = (float*)malloc(sizeof(float) * nn);
   if (!cur) return -2;

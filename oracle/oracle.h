@@ -103,6 +103,12 @@ int oracle_rgb2gray_u8(const uint8_t* src, size_t pitch_bytes, int w, int h, uin
  * (pixels mapped outside the source keep their content: BORDER_TRANSPARENT). interp: 2 = INTER_CUBIC,
  * 4 = INTER_LANCZOS4. See lp_ref.c for the restated OpenCV semantics (unpinned). */
 int oracle_logpolar_u8(const uint8_t* src, size_t pitch, int res, double M, int interp, uint8_t* dst);
+/* Same with the OpenCV generation chosen explicitly: variant 0 = cv::logPolar of OpenCV 4.x (ROS Noetic; the warpPolar
+ * form, `exp(rho * Kmag) - 1` in a float table), variant 1 = cvLogPolar of OpenCV 3.2 (ROS Melodic; `exp(rho / M)`,
+ * no "- 1", double table). scaleRotationEstimator.cpp:41-46, :107-113 compile one or the other. */
+int oracle_logpolar_variant_u8(const uint8_t* src, size_t pitch, int res, double M, int interp, int variant, uint8_t* dst);
+/* The float maps either variant hands to cv::remap ([phi][rho], res*res each). */
+int oracle_logpolar_maps(int res, double M, int variant, float* mapx, float* mapy);
 
 /* scaleRotationEstimator::processImage (src/scaleRotationEstimator.cpp:34-148), one call:
  * first != 0: temp_im <- logPolar(frame, INTER_CUBIC), prev_lp <- float(temp_im), out = (1, 0)      (:36-74)
@@ -112,6 +118,10 @@ int oracle_logpolar_u8(const uint8_t* src, size_t pitch, int res, double M, int 
  * temp_im (res*res u8) and prev_lp (res*res float) are the estimator's state; pt_xy (optional) gets pt. */
 int oracle_scale_rotation_step(const uint8_t* frame, size_t pitch, int res, double M, int first, uint8_t* temp_im,
                                float* prev_lp, int precision, double* out_scale_rot, double* pt_xy);
+
+/* Same with the cv::logPolar generation chosen (see oracle_logpolar_variant_u8). */
+int oracle_scale_rotation_step_variant(const uint8_t* frame, size_t pitch, int res, double M, int first, uint8_t* temp_im,
+                                       float* prev_lp, int precision, int variant, double* out_scale_rot, double* pt_xy);
 
 /* Block geometry shared by both block-matching paths.
  * BlockMethod (src/BlockMethod.cpp:11, :45): step=0, threshold off,
@@ -159,6 +169,32 @@ int oracle_bm_refine_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, i
 /* Histogram_C1_D0 top-TestDepth output (src/FastSpacedBMMethod.cl:155-167):
  * sorted shift indices per axis (stable descending by count), first `depth`. */
 int oracle_bm_histogram_top(const int8_t* d, int count, int radius, int depth, int8_t* top);
+
+/* ---- geometry tail (geom_ref.c): OpticFlow::get2DT (src/optic_flow.cpp:388-510), OpticFlow::getRT (:515-774) ---- */
+typedef struct oracle_camera { double fx, fy, cx, cy, k1, k2, p1, p2, k3; } oracle_camera; /* :1511-1522 */
+typedef struct oracle_geom_layout { int grid_x, grid_y, origin_x, origin_y, stride_x, stride_y, patch; } oracle_geom_layout;
+typedef struct oracle_rt_params {
+  double height, dt, ul_corner_x;
+  double ang_rate_q[4]; /* angular_rate_tf_ (x, y, z, w) */
+  double c2b_q[4];      /* transformCam2Base_ rotation   */
+  double c2b_t[3];      /* and translation               */
+} oracle_rt_params;
+typedef struct oracle_2dt_params { double height, dt, roll_rate, pitch_rate, cam_yaw; } oracle_2dt_params;
+
+/* cv::undistortPoints on one pixel (camMatrixLocal = camMatrix with cx - ul_corner_x, 5 distortion coefficients). */
+void oracle_undistort_point(const oracle_camera* c, double ul_corner_x, double u, double v, double* ox, double* oy);
+/* cv::findHomography(a, b, RANSAC, 0.01, mask) with the project's documented sampler (see geom_ref.c). 1 = found. */
+int oracle_find_homography(const double* a_xy, const double* b_xy, int n, double* H9, uint8_t* mask);
+/* cv::decomposeHomographyMat(H, I, ...): returns the number of solutions (1, 4; 0 degenerate). R[4][9], t[4][3], n[4][3]. */
+int oracle_decompose_homography(const double* H9, double* R, double* t, double* normals);
+/* tf2::Quaternion::setRPY -> (x, y, z, w) */
+void oracle_quat_from_rpy(double roll, double pitch, double yaw, double* q_xyzw);
+/* getRT: returns the status (0 = true; codes as MOF_GEOM_* in include/mof.h). out[7] = rot (x,y,z,w), tran (x,y,z). */
+int oracle_get_rt(const double* shifts_xy, const oracle_geom_layout* L, const oracle_camera* cam, const oracle_rt_params* p,
+                  int shifted_pts_thr, double* out_rot_tran, uint8_t* mask_out /*optional*/, double* H_out /*optional*/);
+/* get2DT: returns the status. out[6] = o_tran (3), o_tran_diff (3). */
+int oracle_get_2dt(const double* shifts_xy, const oracle_geom_layout* L, const oracle_camera* cam,
+                   const oracle_2dt_params* p, double* out_tran_diff);
 
 const char* oracle_version(void);
 

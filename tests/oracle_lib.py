@@ -30,6 +30,24 @@ class PcDiag(C.Structure):
                 ("second_value", C.c_double), ("response", C.c_double)]
 
 
+class GeomCamera(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+
+class GeomLayout(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("grid_x", "grid_y", "origin_x", "origin_y", "stride_x", "stride_y", "patch")]
+
+
+class GeomRtParams(C.Structure):
+    _fields_ = [("height", C.c_double), ("dt", C.c_double), ("ul_corner_x", C.c_double),
+                ("ang_rate_q", C.c_double * 4), ("c2b_q", C.c_double * 4), ("c2b_t", C.c_double * 3)]
+
+
+class Geom2dtParams(C.Structure):
+    _fields_ = [("height", C.c_double), ("dt", C.c_double), ("roll_rate", C.c_double), ("pitch_rate", C.c_double),
+                ("cam_yaw", C.c_double)]
+
+
 class BmConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("block", C.c_int), ("step", C.c_int),
                 ("radius", C.c_int), ("grid_x", C.c_int), ("grid_y", C.c_int),
@@ -90,6 +108,28 @@ def lib():
                                           C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_bm_histogram_top.restype = C.c_int
         L.oracle_bm_histogram_top.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_logpolar_variant_u8.restype = C.c_int
+        L.oracle_logpolar_variant_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_logpolar_maps.restype = C.c_int
+        L.oracle_logpolar_maps.argtypes = [C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_scale_rotation_step_variant.restype = C.c_int
+        L.oracle_scale_rotation_step_variant.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                                         C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_undistort_point.restype = None
+        L.oracle_undistort_point.argtypes = [C.POINTER(GeomCamera), C.c_double, C.c_double, C.c_double,
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.oracle_find_homography.restype = C.c_int
+        L.oracle_find_homography.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_decompose_homography.restype = C.c_int
+        L.oracle_decompose_homography.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_quat_from_rpy.restype = None
+        L.oracle_quat_from_rpy.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.oracle_get_rt.restype = C.c_int
+        L.oracle_get_rt.argtypes = [C.c_void_p, C.POINTER(GeomLayout), C.POINTER(GeomCamera), C.POINTER(GeomRtParams), C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_get_2dt.restype = C.c_int
+        L.oracle_get_2dt.argtypes = [C.c_void_p, C.POINTER(GeomLayout), C.POINTER(GeomCamera), C.POINTER(Geom2dtParams),
+                                     C.c_void_p]
         L.oracle_version.restype = C.c_char_p
         _lib = L
     return _lib
@@ -222,25 +262,35 @@ def rgb2gray(img: np.ndarray) -> np.ndarray:
     return out
 
 
-def logpolar(src: np.ndarray, M: float, interp: int, dst: np.ndarray | None = None) -> np.ndarray:
-    """cv::logPolar(src, dst, (res/2, res/2), M, interp) on a square uint8 image; dst is updated in place."""
+def logpolar(src: np.ndarray, M: float, interp: int, dst: np.ndarray | None = None, variant: int = 0) -> np.ndarray:
+    """cv::logPolar(src, dst, (res/2, res/2), M, interp) on a square uint8 image; dst is updated in place.
+    variant 0 = OpenCV 4.x cv::logPolar (warpPolar form), 1 = OpenCV 3.2 cvLogPolar."""
     src = np.ascontiguousarray(src, dtype=np.uint8)
     res = src.shape[0]
     assert src.shape == (res, res)
     if dst is None:
         dst = np.zeros((res, res), np.uint8)
     assert dst.flags.c_contiguous and dst.dtype == np.uint8 and dst.shape == (res, res)
-    rc = lib().oracle_logpolar_u8(_ptr(src), res, res, float(M), int(interp), _ptr(dst))
+    rc = lib().oracle_logpolar_variant_u8(_ptr(src), res, res, float(M), int(interp), int(variant), _ptr(dst))
     if rc:
-        raise ValueError(f"oracle_logpolar_u8 rc={rc}")
+        raise ValueError(f"oracle_logpolar_variant_u8 rc={rc}")
     return dst
+
+
+def logpolar_maps(res: int, M: float, variant: int = 0):
+    """The float maps cv::logPolar hands to cv::remap: (mapx, mapy), each [res, res] float32, rows = phi."""
+    mx, my = np.zeros((res, res), np.float32), np.zeros((res, res), np.float32)
+    rc = lib().oracle_logpolar_maps(res, float(M), int(variant), _ptr(mx), _ptr(my))
+    if rc:
+        raise ValueError(f"oracle_logpolar_maps rc={rc}")
+    return mx, my
 
 
 class ScaleRotationEstimator:
     """scaleRotationEstimator restated (state: tempIm, prevIm_F32, first)."""
 
-    def __init__(self, res: int, M: float, precision: int = 32):
-        self.res, self.M, self.precision = res, float(M), precision
+    def __init__(self, res: int, M: float, precision: int = 32, variant: int = 0):
+        self.res, self.M, self.precision, self.variant = res, float(M), precision, int(variant)
         self.temp_im = np.zeros((res, res), np.uint8)
         self.prev_lp = np.zeros((res, res), np.float32)
         self.first = True
@@ -251,8 +301,9 @@ class ScaleRotationEstimator:
         assert frame.shape == (self.res, self.res)
         out = np.zeros(2)
         pt = np.zeros(2)
-        rc = lib().oracle_scale_rotation_step(_ptr(frame), self.res, self.res, self.M, int(self.first), _ptr(self.temp_im),
-                                              _ptr(self.prev_lp), self.precision, _ptr(out), _ptr(pt))
+        rc = lib().oracle_scale_rotation_step_variant(_ptr(frame), self.res, self.res, self.M, int(self.first),
+                                                      _ptr(self.temp_im), _ptr(self.prev_lp), self.precision, self.variant,
+                                                      _ptr(out), _ptr(pt))
         if rc:
             raise ValueError(f"oracle_scale_rotation_step rc={rc}")
         self.first = False
@@ -322,3 +373,52 @@ def bm_refine(cur: np.ndarray, prev: np.ndarray, fullpix, passes: int = 2, faith
     if rc:
         raise ValueError(f"oracle_bm_refine_u8 rc={rc}")
     return ((float(out[0]), float(out[1])), sads) if want_sads else (float(out[0]), float(out[1]))
+
+
+# ---- geometry tail (oracle/geom_ref.c) ---------------------------------------------------------------------------
+
+def geom_undistort(cam: GeomCamera, ul_corner_x: float, pts) -> np.ndarray:
+    pts = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    x, y = C.c_double(), C.c_double()
+    for i, (u, v) in enumerate(pts):
+        lib().oracle_undistort_point(C.byref(cam), float(ul_corner_x), float(u), float(v), C.byref(x), C.byref(y))
+        out[i] = (x.value, y.value)
+    return out
+
+
+def geom_find_homography(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 2)
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, 2)
+    H = np.zeros(9)
+    mask = np.zeros(max(a.shape[0], 1), np.uint8)
+    found = lib().oracle_find_homography(_ptr(a), _ptr(b), a.shape[0], _ptr(H), _ptr(mask))
+    return (H.reshape(3, 3) if found else None), mask[:a.shape[0]]
+
+
+def geom_decompose(H):
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+    R, t, n = np.zeros(36), np.zeros(12), np.zeros(12)
+    k = lib().oracle_decompose_homography(_ptr(H), _ptr(R), _ptr(t), _ptr(n))
+    return R.reshape(4, 3, 3)[:k], t.reshape(4, 3)[:k], n.reshape(4, 3)[:k]
+
+
+def geom_quat_from_rpy(roll, pitch, yaw) -> np.ndarray:
+    q = np.zeros(4)
+    lib().oracle_quat_from_rpy(float(roll), float(pitch), float(yaw), _ptr(q))
+    return q
+
+
+def geom_get_rt(shifts, layout: GeomLayout, cam: GeomCamera, params: GeomRtParams, thr: int = 8):
+    s = np.ascontiguousarray(shifts, dtype=np.float64)
+    out, H = np.zeros(7), np.zeros(9)
+    mask = np.zeros(layout.grid_x * layout.grid_y, np.uint8)
+    status = lib().oracle_get_rt(_ptr(s), C.byref(layout), C.byref(cam), C.byref(params), int(thr), _ptr(out), _ptr(mask), _ptr(H))
+    return status, out[:4].copy(), out[4:].copy(), mask, H.reshape(3, 3)
+
+
+def geom_get_2dt(shifts, layout: GeomLayout, cam: GeomCamera, params: Geom2dtParams):
+    s = np.ascontiguousarray(shifts, dtype=np.float64)
+    out = np.zeros(6)
+    status = lib().oracle_get_2dt(_ptr(s), C.byref(layout), C.byref(cam), C.byref(params), _ptr(out))
+    return status, out[:3].copy(), out[3:].copy()

@@ -76,3 +76,33 @@ def test_fast_spaced_bm_sequence(gpu, tmp_path):
         got = np.array([int(v) for v in tok[6:]]).reshape(-1, 2)
         assert (got[:, 0] == dx.ravel()).all() and (got[:, 1] == dy.ravel()).all()
         prev = frames[t]
+
+
+def test_drop_in_adapter_against_the_reference_interface_header(gpu, tmp_path):
+    """tests/cpp/test_adapter.cpp: `MofFftMethod : OpticFlowCalc` compiled against /root/reference/include/OpticFlowCalc.h
+    (with type-check stand-ins for the OpenCV headers, tests/stubs/) and driven exactly like the node drives its
+    FftMethod (optic_flow.cpp:1001-1002, :1016-1018, :1685-1690): setImPrev(zeros), processImage through the abstract
+    interface, processImageLongRange on the concrete type. The binary is built where the reference exists (the build
+    container) and travels with the snapshot."""
+    binary = os.path.join(os.path.dirname(__file__), "cpp", "test_adapter")
+    assert os.path.exists(binary), "tests/cpp/test_adapter missing: run __graft_entry__.build() where /root/reference exists"
+    fs, sps, n = 256, 64, 5   # sqNum 4 -> long-range grid 1 x 1
+    frames = np.stack([synth.pair_np(37, fs, fs, 4 * t, -2 * t)[0] for t in range(n)])
+    path = tmp_path / "frames.raw"
+    frames.tofile(path)
+    out = subprocess.run([binary, str(fs), str(sps), "80", str(n), str(path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    lines = [line.split() for line in out.stdout.strip().splitlines()]
+    assert lines[-1] == ["wrong-size", "refused"]
+    lay = O.fft_layout(fs, fs, sps, 4, 4)
+    for t, tok in enumerate(lines[:-1]):
+        assert tok[0] == "frame" and int(tok[1]) == t
+        prev = frames[t] if t == 0 else frames[t - 1]  # `first` (FftMethod.cpp:1791-1793); setImPrev(zeros) does not clear it
+        if tok[2] == "lr":
+            assert t % 2 == 1 and int(tok[4]) == 1
+            want, _ = O.fft_process_long_range(frames[t], prev, lay, 64)
+        else:
+            assert int(tok[4]) == 16
+            want, _ = O.fft_process(frames[t], prev, lay, 64)
+        got = np.array([float(v) for v in tok[5:]]).reshape(-1, 2)
+        assert np.allclose(got, want, rtol=0, atol=1e-4, equal_nan=True), (t, tok[2])

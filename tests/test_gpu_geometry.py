@@ -1,0 +1,118 @@
+"""GPU tests of the batched geometry tail (mof_geom_get_rt_batch_device / ..._get_2dt_batch_device): one wavefront per
+frame pair, 64 RANSAC hypotheses at a time. The device must pick the SAME model as the host form (same sampler, same
+in-order acceptance), so status and inlier-derived results agree; values to 1e-9 (device libm differs from glibc in the
+last bits of acos / sin / cos / log, nothing else does -- the file is built with -ffp-contract=off).
+Also: frames -> FFT shifts -> velocity entirely on the device, compared with the oracle chain."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import geom_scenes as S
+import oracle_lib as O
+from mrs_optic_flow_amd import FftMethod, geometry as G, synth
+from test_geometry import CAM, _rt_scene, layouts
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(structs, width):
+    return np.stack([np.frombuffer(bytes(s), dtype=np.float64, count=width) for s in structs])
+
+
+@pytest.mark.parametrize("geometry", [
+    (4, 4, (0, 0), (120, 120), 120, 136.0, CAM),
+    (8, 8, (1, 1), (98, 59), 64, 0.0, (520.0, 518.0, 376.0, 240.0, -0.12, 0.03, 0.0004, -0.0003, -0.002)),
+    (16, 16, (0, 0), (119, 63), 128, 0.0, (1300.0, 1295.0, 960.0, 540.0, -0.12, 0.03, 0.0004, -0.0003, -0.002))])
+def test_get_rt_batch_equals_host_and_oracle(gpu, geometry):
+    gx, gy, origin, stride, patch, ulx, cam = geometry
+    rng = np.random.default_rng(gx + 7)
+    gcam, ocam = G.Camera(*cam), O.GeomCamera(*cam)
+    gl, ol = layouts(gx, gy, origin, stride, patch)
+    total, B = gx * gy, 96
+    shifts, params, oparams = [], [], []
+    for k in range(B):
+        sh, R, t, rate, bad, nan_idx = _rt_scene(rng, gx, gy, origin, stride, patch, outliers=(k % 5) * total // 16,
+                                                 nans=(k % 3) * total // 12, ulx=ulx, cam=cam)
+        dt = 0.0 if k == 17 else 0.02                       # one pair with a bad duration
+        if k == 23:
+            sh[:] = np.nan                                  # nothing valid
+        if k == 29:
+            sh = rng.uniform(-60, 60, sh.shape)             # no consensus
+        q = O.geom_quat_from_rpy(*(-rate)) if k != 31 else O.geom_quat_from_rpy(0, 0, 3.0)   # IMU disagrees
+        a4, c4, c3 = (C.c_double * 4)(*q), (C.c_double * 4)(0, 0, 0, 1), (C.c_double * 3)(0, 0, 0)
+        shifts.append(sh)
+        params.append(G.RtParams(2.5, dt, ulx, a4, c4, c3))
+        oparams.append(O.GeomRtParams(2.5, dt, ulx, a4, c4, c3))
+    d_sh = torch.from_numpy(np.stack(shifts)).to(gpu)
+    d_par = torch.from_numpy(_rows(params, G.RT_PARAMS_DOUBLES)).to(gpu)
+    got = G.get_rt_batch_device(d_sh, gl, gcam, d_par, 8)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    statuses = set()
+    for k in range(B):
+        st, rot, tran, mask, H = G.get_rt(shifts[k], gl, gcam, params[k], 8)
+        wst, wrot, wtran, _, _ = O.geom_get_rt(shifts[k], ol, ocam, oparams[k], 8)
+        statuses.add(st)
+        assert int(got[k, 7]) == st == wst, (k, got[k, 7], st, wst)
+        assert np.allclose(got[k, :4], rot, rtol=0, atol=1e-9) and np.allclose(got[k, 4:7], tran, rtol=0, atol=1e-9), (k, got[k], rot, tran)
+        assert np.allclose(got[k, :4], wrot, rtol=0, atol=1e-9) and np.allclose(got[k, 4:7], wtran, rtol=0, atol=1e-9)
+    assert {0, 1, 2, 3, 4} <= statuses
+    assert G.get_rt_batch_device(d_sh[:0], gl, gcam, d_par[:0], 8).shape == (0, 8)
+    with pytest.raises(ValueError):
+        G.get_rt_batch_device(d_sh, gl, gcam, d_par[:, :5], 8)
+
+
+def test_get_2dt_batch_equals_host(gpu):
+    rng = np.random.default_rng(3)
+    gcam, ocam = G.Camera(*CAM), O.GeomCamera(*CAM)
+    gl, ol = layouts(2, 2, (0, 0), (120, 120), 120)
+    B = 300
+    shifts = rng.normal(0, 6, (B, 4, 2))
+    shifts[::5, 0] = np.nan
+    shifts[7] = np.nan
+    vals = np.stack([rng.uniform(0.5, 9, B), rng.uniform(0.002, 0.1, B), rng.normal(0, 0.4, B), rng.normal(0, 0.4, B),
+                     rng.uniform(-3.2, 3.2, B)], axis=1)
+    vals[11, 1] = 0.0
+    got = G.get_2dt_batch_device(torch.from_numpy(shifts).to(gpu), gl, gcam, torch.from_numpy(vals).to(gpu))
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    for k in range(B):
+        st, tran, diff = G.get_2dt(shifts[k], gl, gcam, G.T2dParams(*vals[k]))
+        wst, wtran, wdiff = O.geom_get_2dt(shifts[k], ol, ocam, O.Geom2dtParams(*vals[k]))
+        assert int(got[k, 6]) == st == wst
+        assert np.allclose(got[k, :3], wtran, rtol=1e-12, atol=1e-12) and np.allclose(got[k, 3:6], wdiff, rtol=1e-9, atol=1e-11)
+    assert int(got[7, 6]) == 2 and int(got[11, 6]) == 1
+
+
+def test_frames_to_velocity_stays_on_the_device(gpu):
+    """The batched chain the tail exists for: u8 frame pairs -> K1 shifts -> getRT, no host round trip in between.
+    Planted pure translations of a textured plane seen through an undistorted camera: the recovered translation must
+    equal -shift * height / f / dt per axis (pinhole geometry) and agree with the oracle chain run on the same bytes."""
+    fs, n, B = 480, 120, 12
+    cam = (400.0, 400.0, 240.0, 240.0, 0, 0, 0, 0, 0)
+    gcam, ocam = G.Camera(*cam), O.GeomCamera(*cam)
+    gl, ol = layouts(4, 4, (0, 0), (120, 120), 120)
+    cur, prev, shifts, kinds = synth.batch_torch(B, fs, fs, 9, gpu, k0=40, classes=False)
+    fm = FftMethod(fs, n, 80.0)
+    flow = fm.process_batch_device(cur, prev)
+    dt, height = 0.02, 3.0
+    q = (C.c_double * 4)(0, 0, 0, 1)
+    par = G.RtParams(height, dt, 0.0, q, (C.c_double * 4)(0, 0, 0, 1), (C.c_double * 3)(0, 0, 0))
+    d_par = torch.from_numpy(np.repeat(_rows([par], G.RT_PARAMS_DOUBLES), B, axis=0)).to(gpu)
+    vel = G.get_rt_batch_device(flow, gl, gcam, d_par, 8)
+    torch.cuda.synchronize()
+    vel, flow_h = vel.cpu().numpy(), flow.cpu().numpy()
+    lay = O.fft_layout(fs, fs, n, 4, 4)
+    sh = shifts.numpy()
+    for k in range(B):
+        want_flow, _ = O.fft_process(cur[k].cpu().numpy(), prev[k].cpu().numpy(), lay, 64)
+        wst, wrot, wtran, _, _ = O.geom_get_rt(want_flow, ol, ocam, O.GeomRtParams(height, dt, 0.0, q, q, (C.c_double * 3)(0, 0, 0)), 8)
+        assert int(vel[k, 7]) == wst
+        assert np.allclose(vel[k, :7], np.concatenate([wrot, wtran]), rtol=0, atol=1e-6), (k, vel[k], wrot, wtran)
+        if wst == 0 and (sh[k] != 0).any():
+            # a pure image translation by s px is the plane-induced homography of a camera translation t = -s * d / f
+            # (x2 = x1 + t_xy / d in normalised coordinates); getRT reports t * height / dt up to its sign convention
+            speed = np.abs(sh[k]) / 400.0 * height / dt
+            assert np.allclose(np.abs(vel[k, 4:6]), speed, rtol=0.02, atol=0.02), (k, vel[k], speed)

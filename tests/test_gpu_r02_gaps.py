@@ -81,14 +81,15 @@ def test_full_size_c4_batch_properties(gpu):
 
 @pytest.mark.parametrize("res,M", [(240, 40.0), (256, 45.0), (480, 49.9)])
 @pytest.mark.parametrize("interp", [INTER_CUBIC, INTER_LANCZOS4])
-def test_logpolar_remap_is_byte_exact(gpu, res, M, interp):
+@pytest.mark.parametrize("variant", [0, 1])   # cv::logPolar of OpenCV 4.x (Noetic) / cvLogPolar of OpenCV 3.2 (Melodic)
+def test_logpolar_remap_is_byte_exact(gpu, res, M, interp, variant):
     """K4 against oracle_logpolar_u8, every byte, for both interpolations and both kernel variants (n < 4 images
     take the global-table kernel, n >= 4 the LDS-resident-table kernel); BORDER_TRANSPARENT pixels keep dst."""
     base = sr_scenes.canvas(5 + res + interp, res)
     frames = np.stack([sr_scenes.view(base, res, s, r) for s, r in [(1.0, 0.0), (1.05, 7.0), (0.93, -11.0),
                                                                    (1.0, 90.0), (1.2, 33.0)]])
     frames[4, :7, :] = 255  # saturating content next to the border (reflect-101 taps, clamping)
-    est = ScaleRotationEstimator(res, M)
+    est = ScaleRotationEstimator(res, M, logpolar_variant=variant)
     big = torch.zeros((5, res + 2, res + 24), dtype=torch.uint8, device=gpu)
     big[:, 1:1 + res, 8:8 + res] = torch.from_numpy(frames).to(gpu)
     view = big[:, 1:1 + res, 8:8 + res]  # pitch > res, crop origin passed as the pointer
@@ -98,12 +99,12 @@ def test_logpolar_remap_is_byte_exact(gpu, res, M, interp):
         got = est.logpolar_batch_device(view[:n_img], interp, dst=dst).cpu().numpy()
         untouched = 0
         for k in range(n_img):
-            want = O.logpolar(frames[k], M, interp, dst=np.full((res, res), fill, np.uint8))
+            want = O.logpolar(frames[k], M, interp, dst=np.full((res, res), fill, np.uint8), variant=variant)
             assert np.array_equal(got[k], want), (res, interp, n_img, k, int((got[k] != want).sum()))
             untouched += int((want == fill).sum())
         assert untouched > 0  # the outermost rings map outside the source: transparent pixels were exercised
     zero = est.logpolar_batch_device(view[:1], interp).cpu().numpy()[0]  # default dst = zeros (tempIm, :27)
-    assert np.array_equal(zero, O.logpolar(frames[0], M, interp))
+    assert np.array_equal(zero, O.logpolar(frames[0], M, interp, variant=variant))
 
 
 def test_c5_batch_crossing_the_pipeline_chunk(gpu):

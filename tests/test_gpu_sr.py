@@ -52,3 +52,29 @@ def test_stateful_sequence_and_gate(gpu):
     ws, wr = ref2.processImage(seq[3])
     s, r = est.processImage(wide[:, 8:8 + res])
     assert abs(s - ws) < 1e-5 and abs(r - wr) < 1e-5
+
+
+def test_opencv3_logpolar_generation(gpu):
+    """logpolar_variant = LOGPOLAR_CV3: the estimator as it runs under ROS Melodic (cvLogPolar, scaleRotationEstimator.cpp:41-46)."""
+    from mrs_optic_flow_amd.engine import LOGPOLAR_CV3
+    res, M = 240, 40.0
+    base = sr_scenes.canvas(23, res)
+    seq = [sr_scenes.view(base, res, 1.0 + 0.015 * t, -1.2 * t) for t in range(4)]
+    est, ref = ScaleRotationEstimator(res, M, logpolar_variant=LOGPOLAR_CV3), O.ScaleRotationEstimator(res, M, 64, variant=1)
+    other = O.ScaleRotationEstimator(res, M, 64, variant=0)
+    differs = False
+    for f in seq:
+        s, r = est.processImage(f)
+        ws, wr = ref.processImage(f)
+        os_, or_ = other.processImage(f)
+        assert abs(s - ws) < 1e-5 and abs(r - wr) < 1e-5
+        differs = differs or abs(s - os_) > 1e-7 or abs(r - or_) > 1e-7
+    assert differs   # the two generations are different estimators
+    cur = torch.from_numpy(np.stack(seq[1:])).to(gpu)
+    prev = torch.from_numpy(np.stack(seq[:-1])).to(gpu)
+    got = est.process_batch_device(cur, prev).cpu().numpy()
+    for k in range(3):
+        fresh = O.ScaleRotationEstimator(res, M, 64, variant=1)
+        fresh.processImage(seq[k])
+        fresh.processImage(seq[k + 1])
+        assert np.allclose(got[k, 2:], fresh.pt, rtol=0, atol=1e-4)
