@@ -39,7 +39,7 @@ def test_get_rt_batch_equals_host_and_oracle(gpu, geometry):
         if k == 23:
             sh[:] = np.nan                                  # nothing valid
         if k == 29:
-            sh = rng.uniform(-60, 60, sh.shape)             # no consensus
+            sh = rng.uniform(-cam[0], cam[0], sh.shape)     # no consensus (+-1 in normalised units against a 0.01 threshold)
         q = O.geom_quat_from_rpy(*(-rate)) if k != 31 else O.geom_quat_from_rpy(0, 0, 3.0)   # IMU disagrees
         a4, c4, c3 = (C.c_double * 4)(*q), (C.c_double * 4)(0, 0, 0, 1), (C.c_double * 3)(0, 0, 0)
         shifts.append(sh)
