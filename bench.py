@@ -89,6 +89,11 @@ WORKLOADS = {
     "c1": dict(kind="bm", block_method=True, h=272, w=272, block=32, step=0, radius=8, batch=1024, s=6,
                name="c1: BlockMethod 272x272 crop, 8x8 grid of 32x32 blocks, scanRadius=8, batch=1024 per GPU",
                bytes_per_pair=65536 + 73984 + 130),
+    # the reference's own block-matching defaults (config/default.yaml:29-32): scan_radius 21, step_size 24,
+    # sample_point_size 120 on the 752x480 camera frame -> 4 x 3 blocks of 120 x 120, 43 x 43 candidate shifts each
+    "bmref": dict(kind="bm", h=480, w=752, block=120, step=24, radius=21, batch=256, s=12,
+                  name="bmref: FastSpacedBMMethod 752x480, samplePointSize=120, stepSize=24, scanRadius=21 (reference default.yaml), batch=256 per GPU",
+                  bytes_per_pair=12 * 120 * 120 + (4 * 144 - 24 + 42) * (3 * 144 - 24 + 42) + 2 * 12 + 2),
     "c3": dict(kind="bm", h=480, w=752, block=16, step=8, radius=16, batch=1024, s=12,
                name="c3: FastSpacedBMMethod 752x480, samplePointSize=16, stepSize=8, scanRadius=16, batch=1024 per GPU",
                # blocks*sps^2 + window area + 2*blocks + 2

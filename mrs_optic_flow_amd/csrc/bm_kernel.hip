@@ -1,12 +1,15 @@
 // bm_kernel.hip -- K2 (SAD block scan) and K3 (per-axis histogram mode) for gfx950 (CDNA4).
 //
-// K2: one workgroup per block. The (sps+2r)^2 search window of the previous frame and the
-// sps^2 current block are staged once in LDS; each lane then owns one y-shift and FOUR
-// consecutive x-shifts and walks the block with v_qsad_pk_u16_u8, which produces the four
-// byte-SADs of one 4-pixel group against the 8-byte sliding window in a single VALU
-// instruction (16 absolute differences per lane-op, exact integer arithmetic). Packed u16
-// partial sums are widened to u32 every <=256 pixels so no block size can overflow.
-// The arg-min (first occurrence in row-major order) is a wave-shuffle + LDS reduction.
+// K2 comes in two forms:
+//  * bm_scan16_kernel<R> (c3's geometry class: 16 x 16 blocks, scan radius 8 or 16): one WAVE per workgroup, the
+//    block's pixels and all live y-shift accumulators in registers, one sweep over an LDS strip of the previous frame;
+//  * bm_scan_kernel (every other geometry, up to the reference's default 120 x 120 blocks / radius 21): a workgroup
+//    stages the (sps+2r)^2 windows and sps^2 blocks of 1..8 neighbouring blocks in LDS; each lane owns one block, one
+//    y-shift and FOUR consecutive x-shifts and walks the block with v_qsad_pk_u16_u8, which produces the four
+//    byte-SADs of one 4-pixel group against the 8-byte sliding window in a single VALU instruction (16 absolute
+//    differences per lane-op, exact integer arithmetic). Packed u16 partial sums are widened to u32 every <=256
+//    pixels so no block size can overflow. The arg-min (first occurrence in row-major order) is a 64-bit LDS
+//    atomic min over (sad, index) keys.
 //
 // Replaces
 //   BlockMethod::processImage's scan          /root/reference/src/BlockMethod.cpp:43-66
@@ -52,9 +55,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 }  // namespace
 
-// LDS layout (dwords): window rows [WH][WPD], current block [sps][sps/4], SAD table [D][4*XG],
-// reduction scratch.
-__global__ void __launch_bounds__(BM_THREADS) bm_scan_kernel(BmArgs a) {
+// LDS layout per block slot (dwords): window rows [WW][WPD], current block [sps][sps/4], SAD table [D][4*XG];
+// then one 64-bit arg-min key per slot. A workgroup holds `bpw` neighbouring blocks of one block row so that small
+// scans (c1: 17 x 5 = 85 items) still fill its 256 lanes; big blocks (the reference default 120 / r 21: 473 items) run
+// one per workgroup.
+__global__ void __launch_bounds__(BM_THREADS) bm_scan_kernel(BmArgs a, int bpw, int groups_per_row) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int tid = threadIdx.x;
   const int r = a.radius, sps = a.block, S = a.block + a.step, D = 2 * r + 1;
@@ -62,35 +67,42 @@ __global__ void __launch_bounds__(BM_THREADS) bm_scan_kernel(BmArgs a) {
   const int WW = sps + 2 * r;           // window width == height in pixels
   const int WPD = XG + sps / 4 + 1;     // window row pitch in dwords (covers the 8-byte over-read)
   const int CPD = sps / 4;              // current-block row pitch in dwords
-  uint32_t* win = lds;
-  uint32_t* blk = win + WW * WPD;
-  uint32_t* sad = blk + sps * CPD;
-  Cand* red = reinterpret_cast<Cand*>(sad + D * 4 * XG);
+  const int slot_dwords = WW * WPD + sps * CPD + D * 4 * XG;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds + (size_t)bpw * slot_dwords + ((bpw * slot_dwords) & 1));
 
   const int blocks = a.grid_x * a.grid_y;
-  const int pair = blockIdx.x / blocks;
-  const int b = blockIdx.x % blocks;
-  const int bx = b % a.grid_x, by = b / a.grid_x;
-  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + r) * a.pitch + (bx * S + r);
-  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + bx * S;
+  const int grp = blockIdx.x % groups_per_row;
+  const int by = (blockIdx.x / groups_per_row) % a.grid_y;
+  const int pair = blockIdx.x / (groups_per_row * a.grid_y);
+  const int bx0 = grp * bpw;
+  const int nb = (a.grid_x - bx0 < bpw) ? a.grid_x - bx0 : bpw;  // blocks of this workgroup (>= 1)
 
-  // ---- stage window + block in LDS (bytes beyond the window width are zero, never loaded)
-  {
+  // ---- stage windows + blocks in LDS (bytes beyond the window width are zero, never loaded)
+  for (int s = 0; s < nb; ++s) {
+    const int bx = bx0 + s;
+    const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + r) * a.pitch + (bx * S + r);
+    const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + bx * S;
+    uint32_t* win = lds + (size_t)s * slot_dwords;
     uint8_t* wb = reinterpret_cast<uint8_t*>(win);
     for (int i = tid; i < WW * WPD * 4; i += BM_THREADS) {
       const int y = i / (WPD * 4), x = i % (WPD * 4);
       wb[i] = (x < WW) ? prev[(size_t)y * a.pitch + x] : (uint8_t)0;
     }
-    uint8_t* cb = reinterpret_cast<uint8_t*>(blk);
+    uint8_t* cb = reinterpret_cast<uint8_t*>(win + WW * WPD);
     for (int i = tid; i < sps * sps; i += BM_THREADS) cb[i] = cur[(size_t)(i / sps) * a.pitch + (i % sps)];
   }
+  if (tid < nb) keys[tid] = ~0ull;
   __syncthreads();
 
-  // ---- SAD scan: item = (ys, xg) -> shifts (4xg..4xg+3, ys)
-  const int rows_per_flush = (256 / sps) > 0 ? (256 / sps) : 1;  // rows*sps <= 256 px -> u16 safe
-  Cand best = {0xffffffffu, 0xffffffffu};
-  for (int item = tid; item < D * XG; item += BM_THREADS) {
-    const int ys = item / XG, xg = item % XG;
+  // ---- SAD scan: item = (slot, ys, xg) -> shifts (4xg..4xg+3, ys) of block bx0 + slot
+  const int rows_per_flush = (256 / sps) > 0 ? (256 / sps) : 1;  // rows*sps <= 256 px -> packed u16 sums cannot overflow
+  const int per_block = D * XG;
+  for (int item = tid; item < nb * per_block; item += BM_THREADS) {
+    const int s = item / per_block, rem = item % per_block;
+    const int ys = rem / XG, xg = rem % XG;
+    const uint32_t* win = lds + (size_t)s * slot_dwords;
+    const uint32_t* blk = win + WW * WPD;
+    uint32_t* sad = lds + (size_t)s * slot_dwords + WW * WPD + sps * CPD;
     uint32_t acc[4] = {0u, 0u, 0u, 0u};
     for (int j0 = 0; j0 < sps; j0 += rows_per_flush) {
       uint64_t pk = 0;
@@ -110,34 +122,36 @@ __global__ void __launch_bounds__(BM_THREADS) bm_scan_kernel(BmArgs a) {
       acc[2] += (uint32_t)((pk >> 32) & 0xffffu);
       acc[3] += (uint32_t)(pk >> 48);
     }
+    // arg-min, first occurrence in row-major order (BlockMethod.cpp:63; .cl:50-56, :66-73): min over (sad, index) keys
+    unsigned long long best = ~0ull;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int xs = 4 * xg + q;
       sad[ys * 4 * XG + xs] = acc[q];
-      if (xs < D) best = first_min(best, Cand{acc[q], (uint32_t)(ys * D + xs)});
+      if (xs < D) {
+        const unsigned long long k = ((unsigned long long)acc[q] << 32) | (uint32_t)(ys * D + xs);
+        best = k < best ? k : best;
+      }
     }
+    atomicMin(&keys[s], best);
   }
-  // ---- arg-min, first occurrence in row-major order (BlockMethod.cpp:63; .cl:50-56, :66-73)
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    Cand o = {(uint32_t)__shfl_xor((int)best.sad, off, 64), (uint32_t)__shfl_xor((int)best.idx, off, 64)};
-    best = first_min(best, o);
-  }
-  if ((tid & 63) == 0) red[tid >> 6] = best;
   __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < BM_THREADS / 64; ++w) best = first_min(best, red[w]);
-    int mx = (int)(best.idx % (uint32_t)D), my = (int)(best.idx / (uint32_t)D);
+  if (tid < nb) {
+    const unsigned long long k = keys[tid];
+    const uint32_t idx = (uint32_t)k, best_sad = (uint32_t)(k >> 32);
+    int mx = (int)(idx % (uint32_t)D), my = (int)(idx / (uint32_t)D);
     // low-contrast rule (FastSpacedBMMethod.cl:2, :77-82): int difference vs double threshold
     if (a.low_contrast_rule) {
-      const int diff = (int)sad[r * 4 * XG + r] - (int)best.sad;
+      const uint32_t* sad = lds + (size_t)tid * slot_dwords + WW * WPD + sps * CPD;
+      const int diff = (int)sad[r * 4 * XG + r] - (int)best_sad;
       if ((double)diff <= (double)(r * r) * 0.2) {
         mx = r;
         my = r;
       }
     }
-    a.dx[(size_t)pair * blocks + b] = (int8_t)(mx - r);
-    a.dy[(size_t)pair * blocks + b] = (int8_t)(my - r);
+    const size_t o = (size_t)pair * blocks + (size_t)by * a.grid_x + bx0 + tid;
+    a.dx[o] = (int8_t)(mx - r);
+    a.dy[o] = (int8_t)(my - r);
   }
 }
 
@@ -430,24 +444,44 @@ hipError_t launch_bm_refine_sad(const uint8_t* A, const uint8_t* B, int W2, int 
   return hipGetLastError();
 }
 
-bool bm_config_supported(int block, int radius) {
-  return block >= 4 && block <= 64 && (block % 4) == 0 && radius >= 1 && radius <= 48;
+constexpr size_t BM_LDS_MAX = 160 * 1024;  // LDS of one CU on gfx950
+
+static size_t bm_slot_dwords(int block, int radius) {
+  const int D = 2 * radius + 1, XG = (D + 3) / 4, WW = block + 2 * radius;
+  const int WPD = XG + block / 4 + 1;
+  return (size_t)WW * WPD + (size_t)block * (block / 4) + (size_t)D * 4 * XG;
 }
 
-static size_t bm_lds_bytes(const BmArgs& a) {
-  const int D = 2 * a.radius + 1, XG = (D + 3) / 4, WW = a.block + 2 * a.radius;
-  const int WPD = XG + a.block / 4 + 1;
-  return sizeof(uint32_t) * ((size_t)WW * WPD + (size_t)a.block * (a.block / 4) + (size_t)D * 4 * XG) + 8 * 8;
+static size_t bm_lds_bytes(int block, int radius, int bpw) {
+  return sizeof(uint32_t) * (bpw * bm_slot_dwords(block, radius) + 1) + 8 * (size_t)bpw;
+}
+
+// Block sizes up to 128 (the reference's default sample_point_size is 120, config/default.yaml:32) and radii up to 48
+// (its own limit is 2r + 1 <= 50, FastSpacedBMMethod.cl:1), as long as one block's window fits the LDS.
+bool bm_config_supported(int block, int radius) {
+  return block >= 4 && block <= 128 && (block % 4) == 0 && radius >= 1 && radius <= 48 &&
+         bm_lds_bytes(block, radius, 1) <= BM_LDS_MAX;
 }
 
 hipError_t launch_bm_scan(const BmArgs& a, int n_pairs, hipStream_t stream) {
   if (fast16_ok(a) && !getenv("MOF_BM_GENERIC")) {
     return a.radius == 16 ? launch_scan16<16>(a, n_pairs, stream) : launch_scan16<8>(a, n_pairs, stream);
   }
-  const size_t lds = bm_lds_bytes(a);
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
-  const unsigned blocks = (unsigned)n_pairs * (unsigned)(a.grid_x * a.grid_y);
-  hipLaunchKernelGGL(bm_scan_kernel, dim3(blocks), dim3(BM_THREADS), lds, stream, a);
+  // blocks per workgroup: enough (slot, y-shift, x-group) items to fill the 256 lanes, within 64 KB of LDS
+  const int D = 2 * a.radius + 1, per_block = D * ((D + 3) / 4);
+  int bpw = BM_THREADS / per_block;
+  bpw = bpw < 1 ? 1 : (bpw > 8 ? 8 : bpw);
+  bpw = bpw > a.grid_x ? a.grid_x : bpw;
+  while (bpw > 1 && bm_lds_bytes(a.block, a.radius, bpw) > 64 * 1024) --bpw;
+  const size_t lds = bm_lds_bytes(a.block, a.radius, bpw);
+  if (lds > BM_LDS_MAX) return hipErrorInvalidValue;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bm_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int groups_per_row = (a.grid_x + bpw - 1) / bpw;
+  const unsigned wgs = (unsigned)n_pairs * (unsigned)(groups_per_row * a.grid_y);
+  hipLaunchKernelGGL(bm_scan_kernel, dim3(wgs), dim3(BM_THREADS), lds, stream, a, bpw, groups_per_row);
   return hipGetLastError();
 }
 

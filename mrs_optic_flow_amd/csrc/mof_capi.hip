@@ -495,7 +495,7 @@ static int validate_bm(const mof_bm_config* c) {
     return fail(MOF_ERR_BAD_ARG, "bad block-matching geometry");
   if (!mof::bm_config_supported(c->block_size, c->scan_radius))
     return fail(MOF_ERR_UNSUPPORTED, "block_size %d / scan_radius %d not supported by the HIP kernel "
-                "(block multiple of 4 in 4..64, radius 1..48)", c->block_size, c->scan_radius);
+                "(block multiple of 4 in 4..128, radius 1..48, window within the LDS)", c->block_size, c->scan_radius);
   const long S = c->block_size + c->step_size;
   if ((c->grid_x - 1) * S + c->block_size + 2 * c->scan_radius > c->frame_width ||
       (c->grid_y - 1) * S + c->block_size + 2 * c->scan_radius > c->frame_height)

@@ -69,6 +69,12 @@ struct SrMapEntry {
   uint16_t valid;   // anchor inside the source (BORDER_TRANSPARENT otherwise)
 };
 
+// Bounding box (source pixels) of the K x K footprints of the valid pixels of one 8 x 8 destination tile, taps that
+// leave the image reflected back in (BORDER_REFLECT_101); w = h = 0 when the tile has no valid pixel.
+struct SrTileBox {
+  int16_t x0, y0, w, h;
+};
+
 struct SrLpArgs {
   const uint8_t* src;   // image i at src + i*src_stride, `pitch` bytes per row, res x res pixels
   size_t src_stride, pitch;
@@ -77,6 +83,10 @@ struct SrLpArgs {
   const SrMapEntry* map;   // res*res
   const int16_t* weights;  // [1024][K*K]
   int res;
+  int zero_invalid;        // 1: pixels mapped outside the source are written as 0 (destination known to start as zeros)
+  const SrTileBox* boxes;  // [tiles*tiles] for THIS interpolation's footprint size
+  int lds_per_wave;        // bytes of LDS one wave needs for the largest box (multiple of 16)
+  int box_dwords_max;      // dwords of the largest box
 };
 
 struct SrPcArgs {
@@ -84,9 +94,8 @@ struct SrPcArgs {
   const uint8_t* lp_prev;
   size_t lp_stride;
   const float* twiddles;   // res (cos, -sin) pairs
-  float* Z;                // scratch [pairs][res][res] complex
-  float* D;                // scratch [pairs][res][res/2+1] complex
-  float* S;                // scratch [pairs][res][res] real surface (un-shifted)
+  float* Zt;               // scratch [pairs][res u][res v] complex: row transforms, stored transposed
+  float* Dt;               // scratch [pairs][res/2+1 u][res y] complex: half spectrum after the column passes
   float2* cand;            // scratch [pairs][n_cand] (value, shifted index)
   int n_cand;
   double M;                // log-polar magnitude
@@ -96,6 +105,8 @@ struct SrPcArgs {
 // host-side tables of cv::logPolar / cv::remap (mof_sr.hip); exposed so that the CPU suite can compare them with the oracle
 std::vector<SrMapEntry> sr_logpolar_map(int res, double M, int variant);
 std::vector<int16_t> sr_weight_table(int ksize /* 4 cubic, 8 Lanczos4 */);  // [32*32][ksize*ksize], each summing to 2^15
+// per-tile footprint boxes for a ksize x ksize kernel; *lds_per_wave receives the LDS bytes of the largest one
+std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave);
 
 bool sr_resolution_supported(int res);
 int sr_candidates(int res);

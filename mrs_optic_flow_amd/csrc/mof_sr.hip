@@ -150,6 +150,43 @@ std::vector<SrMapEntry> sr_logpolar_map(int res, double M, int variant) {
 
 std::vector<int16_t> sr_weight_table(int ksize) { return weight_table(ksize); }
 
+std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave) {
+  const int tiles = (res + 7) / 8, half = ksize / 2 - 1;
+  std::vector<SrTileBox> boxes((size_t)tiles * tiles, SrTileBox{0, 0, 0, 0});
+  int worst = 16;
+  for (int ty = 0; ty < tiles; ++ty)
+    for (int tx = 0; tx < tiles; ++tx) {
+      int x0 = 1 << 20, y0 = 1 << 20, x1 = -1, y1 = -1;
+      for (int l = 0; l < 64; ++l) {
+        const int rho = tx * 8 + (l & 7), phi = ty * 8 + (l >> 3);
+        if (rho >= res || phi >= res) continue;
+        const SrMapEntry& m = map[(size_t)phi * res + rho];
+        const int sx = m.ax - half, sy = m.ay - half;
+        if (!m.valid) continue;
+        // rows: every tap row, rows beyond the border reflected back in (BORDER_REFLECT_101; a valid anchor lies inside
+        // the image and the kernel reaches at most ksize pixels from it, so one reflection is enough); columns: the
+        // ksize-wide window the kernel reads, clamped into the image -- it contains every reflected tap column
+        const int wx = sx < 0 ? 0 : (sx > res - ksize ? res - ksize : sx);
+        x0 = wx < x0 ? wx : x0;
+        x1 = wx + ksize > x1 ? wx + ksize : x1;
+        for (int k = 0; k < ksize; ++k) {
+          int yy = sy + k;
+          yy = yy < 0 ? -yy : yy;
+          yy = yy >= res ? 2 * res - 2 - yy : yy;
+          y0 = yy < y0 ? yy : y0;
+          y1 = yy + 1 > y1 ? yy + 1 : y1;
+        }
+      }
+      if (x1 < 0) continue;
+      boxes[(size_t)ty * tiles + tx] = SrTileBox{(int16_t)x0, (int16_t)y0, (int16_t)(x1 - x0), (int16_t)(y1 - y0)};
+      const int lpd = ((x1 - x0) + 3 + 3) / 4 + 1;  // LDS row pitch in dwords, as the kernel computes it
+      const int bytes = (y1 - y0) * lpd * 4;
+      worst = bytes > worst ? bytes : worst;
+    }
+  *lds_per_wave = (worst + 15) & ~15;
+  return boxes;
+}
+
 }  // namespace mof
 
 namespace {
@@ -169,6 +206,8 @@ struct mof_sr_engine {
   mof_sr_config cfg{};
   hipStream_t stream = nullptr;
   mof::SrMapEntry* d_map = nullptr;
+  mof::SrTileBox* d_boxes[2] = {nullptr, nullptr};  // cubic, Lanczos4
+  int lds_per_wave[2] = {0, 0};
   int16_t* d_w_cubic = nullptr;
   int16_t* d_w_lanczos = nullptr;
   float* d_twiddles = nullptr;
@@ -176,14 +215,14 @@ struct mof_sr_engine {
   uint8_t* d_temp_im = nullptr;  // tempIm, :27
   uint8_t* d_prev_lp = nullptr;  // prevIm_F32 (kept as the u8 image it was converted from)
   uint8_t* d_lp = nullptr;       // batch: [kChunk][2][res*res] log-polar images (cur, prev)
-  float *d_Z = nullptr, *d_D = nullptr, *d_S = nullptr;
+  float *d_Zt = nullptr, *d_Dt = nullptr;
   float2* d_cand = nullptr;
   double* d_out = nullptr;       // [kChunk][4]
   uint8_t* h_stage = nullptr;
   double* h_out = nullptr;
   bool first = true;             // :31
   std::atomic<bool> busy{false};
-  // Ordering of the engine-owned scratch (d_lp, d_Z, d_D, d_S, d_cand, d_out) across streams: every call that
+  // Ordering of the engine-owned scratch (d_lp, d_Zt, d_Dt, d_cand, d_out) across streams: every call that
   // touches it records `scratch_ev` behind its last kernel; a later call on a DIFFERENT stream first makes its
   // stream wait for that event (same-stream calls are ordered by the stream itself).
   hipEvent_t scratch_ev = nullptr;
@@ -230,8 +269,8 @@ void mof_sr_destroy(mof_sr_engine* e) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
-  void* dev[] = {e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_twiddles, e->d_frame, e->d_temp_im, e->d_prev_lp,
-                 e->d_lp,  e->d_Z,       e->d_D,         e->d_S,        e->d_cand,  e->d_out};
+  void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_twiddles, e->d_frame, e->d_temp_im, e->d_prev_lp,
+                 e->d_lp,  e->d_Zt,      e->d_Dt,        e->d_cand,     e->d_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -260,6 +299,8 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   const size_t nn = (size_t)res * res;
   const std::vector<mof::SrMapEntry> map = mof::sr_logpolar_map(res, cfg->magnitude, cfg->logpolar_variant);
   const std::vector<int16_t> wc = weight_table(4), wl = weight_table(8);
+  int lds_c = 0, lds_l = 0;
+  const std::vector<mof::SrTileBox> bc = mof::sr_tile_boxes(map, res, 4, &lds_c), bl = mof::sr_tile_boxes(map, res, 8, &lds_l);
   std::vector<float> tw(2 * (size_t)res);
   mof_sr_engine* e = new (std::nothrow) mof_sr_engine();
   if (!e) return mof::capi_fail(MOF_ERR_NO_MEMORY, "out of host memory");
@@ -288,6 +329,12 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   CREATE_TRY(hipEventCreateWithFlags(&e->scratch_ev, hipEventDisableTiming));
   CREATE_TRY(hipMalloc(&e->d_map, map.size() * sizeof(mof::SrMapEntry)));
   CREATE_TRY(hipMemcpy(e->d_map, map.data(), map.size() * sizeof(mof::SrMapEntry), hipMemcpyHostToDevice));
+  e->lds_per_wave[0] = lds_c;
+  e->lds_per_wave[1] = lds_l;
+  CREATE_TRY(hipMalloc(&e->d_boxes[0], bc.size() * sizeof(mof::SrTileBox)));
+  CREATE_TRY(hipMemcpy(e->d_boxes[0], bc.data(), bc.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
+  CREATE_TRY(hipMalloc(&e->d_boxes[1], bl.size() * sizeof(mof::SrTileBox)));
+  CREATE_TRY(hipMemcpy(e->d_boxes[1], bl.data(), bl.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_w_cubic, wc.size() * sizeof(int16_t)));
   CREATE_TRY(hipMemcpy(e->d_w_cubic, wc.data(), wc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_w_lanczos, wl.size() * sizeof(int16_t)));
@@ -300,9 +347,8 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   CREATE_TRY(hipMemset(e->d_temp_im, 0, nn));  // tempIm = cv::Mat::zeros, :27
   CREATE_TRY(hipMemset(e->d_prev_lp, 0, nn));
   CREATE_TRY(hipMalloc(&e->d_lp, (size_t)kChunk * 2 * nn));
-  CREATE_TRY(hipMalloc(&e->d_Z, (size_t)kChunk * nn * 2 * sizeof(float)));
-  CREATE_TRY(hipMalloc(&e->d_D, (size_t)kChunk * res * (res / 2 + 1) * 2 * sizeof(float)));
-  CREATE_TRY(hipMalloc(&e->d_S, (size_t)kChunk * nn * sizeof(float)));
+  CREATE_TRY(hipMalloc(&e->d_Zt, (size_t)kChunk * nn * 2 * sizeof(float)));
+  CREATE_TRY(hipMalloc(&e->d_Dt, (size_t)kChunk * res * (res / 2 + 1) * 2 * sizeof(float)));
   CREATE_TRY(hipMalloc(&e->d_cand, (size_t)kChunk * mof::sr_candidates(res) * sizeof(float2)));
   CREATE_TRY(hipMalloc(&e->d_out, (size_t)kChunk * 4 * sizeof(double)));
   CREATE_TRY(hipHostMalloc(&e->h_stage, nn, hipHostMallocDefault));
@@ -325,6 +371,14 @@ int mof_sr_reset(mof_sr_engine* e) {
   return MOF_OK;
 }
 
+static void lp_tables(const mof_sr_engine* e, int interp, mof::SrLpArgs* lp) {
+  const int k = interp == 2 ? 0 : 1;
+  lp->weights = k == 0 ? e->d_w_cubic : e->d_w_lanczos;
+  lp->boxes = e->d_boxes[k];
+  lp->lds_per_wave = e->lds_per_wave[k];
+  lp->box_dwords_max = e->lds_per_wave[k] / 4;
+}
+
 static mof::SrPcArgs pc_args(const mof_sr_engine* e, const uint8_t* lp_cur, const uint8_t* lp_prev, size_t lp_stride,
                              double* out) {
   mof::SrPcArgs a{};
@@ -332,9 +386,8 @@ static mof::SrPcArgs pc_args(const mof_sr_engine* e, const uint8_t* lp_cur, cons
   a.lp_prev = lp_prev;
   a.lp_stride = lp_stride;
   a.twiddles = e->d_twiddles;
-  a.Z = e->d_Z;
-  a.D = e->d_D;
-  a.S = e->d_S;
+  a.Zt = e->d_Zt;
+  a.Dt = e->d_Dt;
   a.cand = e->d_cand;
   a.n_cand = mof::sr_candidates(e->cfg.resolution);
   a.M = e->cfg.magnitude;
@@ -361,7 +414,7 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
   lp.map = e->d_map;
   lp.res = res;
   if (e->first) {
-    lp.weights = e->d_w_cubic;
+    lp_tables(e, 2, &lp);
     SR_TRY(mof::launch_sr_logpolar(lp, 2, 1, e->stream));  // INTER_CUBIC, :45
     SR_TRY(hipMemcpyAsync(e->d_prev_lp, e->d_temp_im, nn, hipMemcpyDeviceToDevice, e->stream));  // :48
     SR_TRY(hipStreamSynchronize(e->stream));
@@ -370,7 +423,7 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
     out_scale_rot[1] = 0.0;  // :74
     return MOF_OK;
   }
-  lp.weights = e->d_w_lanczos;
+  lp_tables(e, 4, &lp);
   SR_TRY(mof::launch_sr_logpolar(lp, 4, 1, e->stream));  // INTER_LANCZOS4, :112
   mof::SrPcArgs a = pc_args(e, e->d_temp_im, e->d_prev_lp, 0, e->d_out);
   SR_TRY(scratch_acquire(e, e->stream));
@@ -403,9 +456,10 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
   for (int k0 = 0; k0 < n_pairs; k0 += kChunk) {
     const int n = (n_pairs - k0 < kChunk) ? n_pairs - k0 : kChunk;
     // every pair is the two-call sequence of a fresh estimator: prev -> INTER_CUBIC (:45), cur -> INTER_LANCZOS4
-    // (:112) onto the same zero-initialised tempIm (the transparent pixels are the same for both maps)
-    SR_TRY(hipMemsetAsync(e->d_lp, 0, (size_t)n * 2 * nn, s));
+    // (:112) onto the same zero-initialised tempIm; the transparent pixels are the same for both maps, so both
+    // remaps simply write zeros there (zero_invalid) and the scratch needs no clearing pass
     mof::SrLpArgs lp{};
+    lp.zero_invalid = 1;
     lp.pitch = pitch;
     lp.map = e->d_map;
     lp.res = res;
@@ -413,12 +467,12 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
     lp.src = d_prev + (size_t)k0 * prev_stride;
     lp.src_stride = prev_stride;
     lp.dst = e->d_lp + nn;
-    lp.weights = e->d_w_cubic;
+    lp_tables(e, 2, &lp);
     SR_TRY(mof::launch_sr_logpolar(lp, 2, n, s));
     lp.src = d_cur + (size_t)k0 * cur_stride;
     lp.src_stride = cur_stride;
     lp.dst = e->d_lp;
-    lp.weights = e->d_w_lanczos;
+    lp_tables(e, 4, &lp);
     SR_TRY(mof::launch_sr_logpolar(lp, 4, n, s));
     mof::SrPcArgs a = pc_args(e, e->d_lp, e->d_lp + nn, 2 * nn, d_out + 4 * (size_t)k0);
     SR_TRY(mof::launch_sr_phase_correlate(a, res, n, s));
@@ -447,7 +501,7 @@ int mof_sr_logpolar_batch_device(mof_sr_engine* e, const uint8_t* d_src, size_t 
   lp.dst_stride = (size_t)res * res;
   lp.map = e->d_map;
   lp.res = res;
-  lp.weights = interpolation == MOF_INTER_CUBIC ? e->d_w_cubic : e->d_w_lanczos;
+  lp_tables(e, interpolation, &lp);
   SR_TRY(mof::launch_sr_logpolar(lp, interpolation, n_images, (hipStream_t)stream));  // touches no engine scratch
   return MOF_OK;
 }

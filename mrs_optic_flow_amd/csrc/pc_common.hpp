@@ -1,5 +1,5 @@
 // pc_common.hpp -- device helpers shared by the phase-correlation kernels (pc_kernel.hip: power-of-two patch
-// sizes; pc_kernel_mixed.hip: 120 = 15 x 8): complex arithmetic, radix butterflies, wave-local LDS ordering, the
+// sizes; pc_kernel_mixed.hip: 120 = 15 x 8; sr_kernel.hip: whole frames of 240 / 256 / 480): complex arithmetic, radix butterflies, wave-local LDS ordering, the
 // normalised cross-power spectrum of one bin and the centroid / gate tail. Reference citations as in pc_kernel.hip.
 #pragma once
 
@@ -122,6 +122,86 @@ __device__ __forceinline__ void butterfly<16>(cf* v) {
     butterfly<4>(a);
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = a[k2];
+  }
+}
+
+__device__ __forceinline__ void butterfly3(cf* a) {
+  const float s3 = 0.86602540378443864676f;  // sin(2 pi / 3)
+  const cf s = cadd(a[1], a[2]), d = csub(a[1], a[2]);
+  const cf m = {a[0].x - 0.5f * s.x, a[0].y - 0.5f * s.y};
+  a[0] = cadd(a[0], s);
+  a[1] = {m.x + s3 * d.y, m.y - s3 * d.x};
+  a[2] = {m.x - s3 * d.y, m.y + s3 * d.x};
+}
+
+__device__ __forceinline__ void butterfly5(cf* a) {
+  const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;  // cos(2pi/5), cos(4pi/5)
+  const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;   // sin(2pi/5), sin(4pi/5)
+  const cf s14 = cadd(a[1], a[4]), d14 = csub(a[1], a[4]), s23 = cadd(a[2], a[3]), d23 = csub(a[2], a[3]);
+  const cf p1 = {a[0].x + c1 * s14.x + c2 * s23.x, a[0].y + c1 * s14.y + c2 * s23.y};
+  const cf p2 = {a[0].x + c2 * s14.x + c1 * s23.x, a[0].y + c2 * s14.y + c1 * s23.y};
+  const cf q1 = {s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y};
+  const cf q2 = {s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y};
+  a[0] = {a[0].x + s14.x + s23.x, a[0].y + s14.y + s23.y};
+  a[1] = {p1.x + q1.y, p1.y - q1.x};  // p1 - i q1
+  a[4] = {p1.x - q1.y, p1.y + q1.x};  // p1 + i q1
+  a[2] = {p2.x + q2.y, p2.y - q2.x};
+  a[3] = {p2.x - q2.y, p2.y + q2.x};
+}
+
+// 15-point DFT: n = 5 n1 + n2, k = k1 + 3 k2 (radix 3, twiddle W15^{n2 k1}, radix 5)
+__device__ __forceinline__ void butterfly15(cf* v) {
+  // W15^m = (cos(2 pi m / 15), -sin(2 pi m / 15)), m = 0..8
+  const cf w15[9] = {{1.f, 0.f},
+                     {0.91354545764260089550f, -0.40673664307580020775f},
+                     {0.66913060635885821383f, -0.74314482547739423501f},
+                     {0.30901699437494742410f, -0.95105651629515357212f},
+                     {-0.10452846326765347140f, -0.99452189536827333692f},
+                     {-0.5f, -0.86602540378443864676f},
+                     {-0.80901699437494742410f, -0.58778525229247312917f},
+                     {-0.97814760073380563793f, -0.20791169081775933710f},
+                     {-0.97814760073380563793f, 0.20791169081775933710f}};
+  cf t[5][3];
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    cf a[3] = {v[n2], v[5 + n2], v[10 + n2]};
+    butterfly3(a);
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) t[n2][k1] = (n2 * k1 == 0) ? a[k1] : cmul(a[k1], w15[n2 * k1]);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    cf b[5] = {t[0][k1], t[1][k1], t[2][k1], t[3][k1], t[4][k1]};
+    butterfly5(b);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) v[k1 + 3 * k2] = b[k2];
+  }
+}
+
+// 32-point DFT: n = 8 n1 + n2, k = k1 + 4 k2 (eight radix-4 over n1, twiddle W32^{n2 k1}, four radix-8 over n2)
+__device__ __forceinline__ void butterfly32(cf* v) {
+  // W32^m = (cos(pi m / 16), -sin(pi m / 16)), m = 0..21
+  const float c1 = 0.98078528040323044913f, s1 = 0.19509032201612826785f;  // pi/16
+  const float c2 = 0.92387953251128675613f, s2 = 0.38268343236508977173f;  // pi/8
+  const float c3 = 0.83146961230254523708f, s3 = 0.55557023301960222474f;  // 3 pi/16
+  const float h = 0.70710678118654752440f;
+  const cf w[22] = {{1.f, 0.f}, {c1, -s1}, {c2, -s2}, {c3, -s3}, {h, -h}, {s3, -c3}, {s2, -c2}, {s1, -c1}, {0.f, -1.f},
+                    {-s1, -c1}, {-s2, -c2}, {-s3, -c3}, {-h, -h}, {-c3, -s3}, {-c2, -s2}, {-c1, -s1}, {-1.f, 0.f},
+                    {-c1, s1}, {-c2, s2}, {-c3, s3}, {-h, h}, {-s3, c3}};
+  cf t[8][4];
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2) {
+    cf a[4] = {v[n2], v[8 + n2], v[16 + n2], v[24 + n2]};
+    butterfly<4>(a);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) t[n2][k1] = (n2 * k1 == 0) ? a[k1] : cmul(a[k1], w[n2 * k1]);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    cf b[8] = {t[0][k1], t[1][k1], t[2][k1], t[3][k1], t[4][k1], t[5][k1], t[6][k1], t[7][k1]};
+    butterfly<8>(b);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) v[k1 + 4 * k2] = b[k2];
   }
 }
 

@@ -9,8 +9,10 @@
 //   * 15 waves (960 threads), wave w owns lines [8w, 8w+8); the radix-8 stage has 15 butterflies per line,
 //     which does not divide the wave, so lanes are predicated and the inter-stage twiddles W_120^{kx} are
 //     fetched from the (L1-resident, host-computed-in-double) table instead of living in registers;
-//   * tile pitch 121 complex, no skew: the stride-15 accesses are already conflict-free (30 dwords mod 32).
-// One workgroup per CU (113 KB of LDS).
+//   * tile pitch 136 complex (= 8 mod 32) with the lane maps of row_pass / col_pass: every ds_read_b64 / ds_write_b64
+//     group of the transform passes hits distinct banks (tools/design/lds_conflicts_120.py; r01: 0.85 -> 0.95 M pairs/s);
+//   * persistent: one resident workgroup per CU (the tile is 130 KB of LDS) that prefetches the next patch's pixels.
+// The radix-3/5/15 butterflies live in pc_common.hpp (shared with sr_kernel.hip).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,59 +35,6 @@ constexpr int PITCH = MOF_PITCH120;
 constexpr size_t LDS_BYTES_120 = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best);
 
 __device__ __forceinline__ int za(int r, int c) { return r * PITCH + c; }
-
-__device__ __forceinline__ void butterfly3(cf* a) {
-  const float s3 = 0.86602540378443864676f;  // sin(2 pi / 3)
-  const cf s = cadd(a[1], a[2]), d = csub(a[1], a[2]);
-  const cf m = {a[0].x - 0.5f * s.x, a[0].y - 0.5f * s.y};
-  a[0] = cadd(a[0], s);
-  a[1] = {m.x + s3 * d.y, m.y - s3 * d.x};
-  a[2] = {m.x - s3 * d.y, m.y + s3 * d.x};
-}
-
-__device__ __forceinline__ void butterfly5(cf* a) {
-  const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;  // cos(2pi/5), cos(4pi/5)
-  const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;   // sin(2pi/5), sin(4pi/5)
-  const cf s14 = cadd(a[1], a[4]), d14 = csub(a[1], a[4]), s23 = cadd(a[2], a[3]), d23 = csub(a[2], a[3]);
-  const cf p1 = {a[0].x + c1 * s14.x + c2 * s23.x, a[0].y + c1 * s14.y + c2 * s23.y};
-  const cf p2 = {a[0].x + c2 * s14.x + c1 * s23.x, a[0].y + c2 * s14.y + c1 * s23.y};
-  const cf q1 = {s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y};
-  const cf q2 = {s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y};
-  a[0] = {a[0].x + s14.x + s23.x, a[0].y + s14.y + s23.y};
-  a[1] = {p1.x + q1.y, p1.y - q1.x};  // p1 - i q1
-  a[4] = {p1.x - q1.y, p1.y + q1.x};  // p1 + i q1
-  a[2] = {p2.x + q2.y, p2.y - q2.x};
-  a[3] = {p2.x - q2.y, p2.y + q2.x};
-}
-
-// 15-point DFT: n = 5 n1 + n2, k = k1 + 3 k2
-__device__ __forceinline__ void butterfly15(cf* v) {
-  // W15^m = (cos(2 pi m / 15), -sin(2 pi m / 15)), m = 1..8
-  const cf w15[9] = {{1.f, 0.f},
-                     {0.91354545764260089550f, -0.40673664307580020775f},
-                     {0.66913060635885821383f, -0.74314482547739423501f},
-                     {0.30901699437494742410f, -0.95105651629515357212f},
-                     {-0.10452846326765347140f, -0.99452189536827333692f},
-                     {-0.5f, -0.86602540378443864676f},
-                     {-0.80901699437494742410f, -0.58778525229247312917f},
-                     {-0.97814760073380563793f, -0.20791169081775933710f},
-                     {-0.97814760073380563793f, 0.20791169081775933710f}};
-  cf t[5][3];
-#pragma unroll
-  for (int n2 = 0; n2 < 5; ++n2) {
-    cf a[3] = {v[n2], v[5 + n2], v[10 + n2]};
-    butterfly3(a);
-#pragma unroll
-    for (int k1 = 0; k1 < 3; ++k1) t[n2][k1] = (n2 * k1 == 0) ? a[k1] : cmul(a[k1], w15[n2 * k1]);
-  }
-#pragma unroll
-  for (int k1 = 0; k1 < 3; ++k1) {
-    cf b[5] = {t[0][k1], t[1][k1], t[2][k1], t[3][k1], t[4][k1]};
-    butterfly5(b);
-#pragma unroll
-    for (int k2 = 0; k2 < 5; ++k2) v[k1 + 3 * k2] = b[k2];
-  }
-}
 
 __device__ __forceinline__ cf twiddle(const float* __restrict__ table, int idx) {  // W_120^idx, idx < 120
   const float2 t = *reinterpret_cast<const float2*>(table + 2 * idx);

@@ -3,15 +3,20 @@
 // Replaces scaleRotationEstimator::processImage (/root/reference/src/scaleRotationEstimator.cpp:34-148):
 //   cv::logPolar(imCurr, tempIm, center, M, INTER_CUBIC | INTER_LANCZOS4)     :45, :112     -> K4 sr_logpolar_kernel
 //   cv::phaseCorrelate(tempIm_F32, prevIm_F32) on the whole res x res image   :117          -> K5..K8
-// The res x res complex tile (480^2 x 8 B = 1.8 MB) does not fit in LDS, so unlike K1 the whole-frame
-// correlation is a short pipeline through L2/Infinity-Cache-resident scratch (a few MB per frame pair):
-//   K5 sr_rows_fwd   : u8 log-polar rows of cur/prev packed as cur + i*prev, row FFTs in LDS  -> Z
+// The res x res complex tile (480^2 x 8 B = 1.8 MB) fits neither the LDS nor the registers of a CU, so unlike K1 the
+// whole-frame correlation has to cross CUs twice (after the row pass and after the column pass); everything between
+// those two hand-overs stays on chip:
+//   K5 sr_rows_fwd   : u8 log-polar rows of cur/prev packed as cur + i*prev, row FFTs in LDS, written TRANSPOSED
+//                      (Zt[u][v], 64-byte segments) so that the column pass reads whole lines                  -> Zt
 //   K6 sr_cols       : column FFTs of a column group AND its mirror, untangle + normalised cross-power
 //                      spectrum (same rules as K1, incl. the real-only slots), inverse column FFTs of the
-//                      half spectrum                                                          -> D (N x (N/2+1))
-//   K7 sr_rows_inv   : Hermitian rows, two per complex transform -> real surface + per-workgroup arg-max
-//   K8 sr_final      : first-maximum reduction, 5x5 fp64 centroid, pt -> (scale, rot) with the reference's gate
-// 1-D transforms are Stockham stages in LDS over mixed radices (480 = 15 x 8 x 4, 240 = 15 x 16, 256 = 16 x 16).
+//                      half spectrum, written line by line                                                    -> Dt (N/2+1 lines of N)
+//   K7 sr_rows_inv   : Hermitian rows, two per complex transform; the real surface is NEVER written: the arg-max is
+//                      taken from the registers of the last stage                                             -> candidates
+//   K8 sr_final      : first-maximum reduction; the 5x5 window around the peak is re-evaluated from Dt (25 dot products
+//                      of 240 terms in fp64), centroid, pt -> (scale, rot) with the reference's gate
+// A 1-D transform is two in-register stages N = R1 x R2 (480 = 15 x 32, 240 = 15 x 16, 256 = 16 x 16) with ONE LDS
+// round trip between them, done by a single wave on the lines it owns (no workgroup barrier inside a transform).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,130 +29,115 @@ namespace mof {
 
 namespace {
 
-constexpr int SR_T = 256;  // threads per workgroup in K5..K7
-
-__device__ __forceinline__ void butterfly3(cf* a) {
-  const float s3 = 0.86602540378443864676f;
-  const cf s = cadd(a[1], a[2]), d = csub(a[1], a[2]);
-  const cf m = {a[0].x - 0.5f * s.x, a[0].y - 0.5f * s.y};
-  a[0] = cadd(a[0], s);
-  a[1] = {m.x + s3 * d.y, m.y - s3 * d.x};
-  a[2] = {m.x - s3 * d.y, m.y + s3 * d.x};
-}
-
-__device__ __forceinline__ void butterfly5(cf* a) {
-  const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
-  const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-  const cf s14 = cadd(a[1], a[4]), d14 = csub(a[1], a[4]), s23 = cadd(a[2], a[3]), d23 = csub(a[2], a[3]);
-  const cf p1 = {a[0].x + c1 * s14.x + c2 * s23.x, a[0].y + c1 * s14.y + c2 * s23.y};
-  const cf p2 = {a[0].x + c2 * s14.x + c1 * s23.x, a[0].y + c2 * s14.y + c1 * s23.y};
-  const cf q1 = {s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y};
-  const cf q2 = {s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y};
-  a[0] = {a[0].x + s14.x + s23.x, a[0].y + s14.y + s23.y};
-  a[1] = {p1.x + q1.y, p1.y - q1.x};
-  a[4] = {p1.x - q1.y, p1.y + q1.x};
-  a[2] = {p2.x + q2.y, p2.y - q2.x};
-  a[3] = {p2.x - q2.y, p2.y + q2.x};
-}
+template <int N>
+struct SrPlan;
+// LINE = complex elements per line buffer: >= R1 * Y2 (the padded stage-1 output), odd so that the 8 lines of a
+// workgroup start on different banks; Y2 = row pitch of the stage-1 output (R2 + 1: stride-Y2 reads hit distinct banks)
+template <>
+struct SrPlan<480> {
+  static constexpr int R1 = 15, R2 = 32, Y2 = 33, LINE = 497;
+};
+template <>
+struct SrPlan<240> {
+  static constexpr int R1 = 15, R2 = 16, Y2 = 17, LINE = 257;
+};
+template <>
+struct SrPlan<256> {
+  static constexpr int R1 = 16, R2 = 16, Y2 = 17, LINE = 273;
+};
 
 template <int R>
 __device__ __forceinline__ void bfly(cf* v) {
-  if constexpr (R == 15) {
-    const cf w15[9] = {{1.f, 0.f},
-                       {0.91354545764260089550f, -0.40673664307580020775f},
-                       {0.66913060635885821383f, -0.74314482547739423501f},
-                       {0.30901699437494742410f, -0.95105651629515357212f},
-                       {-0.10452846326765347140f, -0.99452189536827333692f},
-                       {-0.5f, -0.86602540378443864676f},
-                       {-0.80901699437494742410f, -0.58778525229247312917f},
-                       {-0.97814760073380563793f, -0.20791169081775933710f},
-                       {-0.97814760073380563793f, 0.20791169081775933710f}};
-    cf t[5][3];
-#pragma unroll
-    for (int n2 = 0; n2 < 5; ++n2) {
-      cf a[3] = {v[n2], v[5 + n2], v[10 + n2]};
-      butterfly3(a);
-#pragma unroll
-      for (int k1 = 0; k1 < 3; ++k1) t[n2][k1] = (n2 * k1 == 0) ? a[k1] : cmul(a[k1], w15[n2 * k1]);
-    }
-#pragma unroll
-    for (int k1 = 0; k1 < 3; ++k1) {
-      cf b[5] = {t[0][k1], t[1][k1], t[2][k1], t[3][k1], t[4][k1]};
-      butterfly5(b);
-#pragma unroll
-      for (int k2 = 0; k2 < 5; ++k2) v[k1 + 3 * k2] = b[k2];
-    }
-  } else {
-    butterfly<R>(v);
-  }
+  if constexpr (R == 15) butterfly15(v);
+  else if constexpr (R == 32) butterfly32(v);
+  else butterfly<R>(v);
 }
 
-// One in-place Stockham stage (radix R, P = product of the radices already applied) over `nlines` lines of
-// length N stored line-major in LDS. Every thread of the workgroup must call it (two barriers inside).
-template <int N, int R, int LINES>
-__device__ __forceinline__ void lds_stage(cf* __restrict__ z, int nlines, int P, const float* __restrict__ tw, int tid) {
-  constexpr int BPL = N / R, PER = (LINES * BPL + SR_T - 1) / SR_T;
-  const int total = nlines * BPL;
-  cf v[PER][R];
-  int dst[PER];
+constexpr int SR_LINES = 8;      // lines per workgroup in K5 / K7 (8 rows, 8 row pairs) and in K6 (4 columns + 4 mirrors)
+constexpr int SR_T = 128;        // two waves, four lines each
+constexpr int COLS_CW = SR_LINES / 2;
+
+// Inter-stage twiddles of the lane's stage-1 slot: W_N^{n2 k1}, k1 = 1..R1-1, n2 = lane % R2 (the same for every line
+// the lane ever transforms, so they are fetched once per kernel).
+template <int N>
+struct SrTw {
+  cf w[SrPlan<N>::R1 - 1];
+  __device__ __forceinline__ void load(const float* __restrict__ table, int lane) {
+    const int n2 = lane % SrPlan<N>::R2;
 #pragma unroll
-  for (int b = 0; b < PER; ++b) {
-    const int g = tid + b * SR_T;
-    dst[b] = -1;
-    if (g < total) {
-      const int line = g / BPL, x = g % BPL, j = x % P;
-      const cf* src = z + line * N + x;
-      const int tstep = N / (P * R);
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        cf a = src[k * BPL];
-        if (k > 0 && P > 1) {
-          const float2 w = *reinterpret_cast<const float2*>(tw + 2 * ((k * j) * tstep));
-          a = cmul(a, cf{w.x, w.y});
-        }
-        v[b][k] = a;
-      }
-      bfly<R>(v[b]);
-      dst[b] = line * N + (x - j) * R + j;
+    for (int k1 = 1; k1 < SrPlan<N>::R1; ++k1) {
+      const float2 t = *reinterpret_cast<const float2*>(table + 2 * (n2 * k1));  // n2 * k1 < N
+      w[k1 - 1] = {t.x, t.y};
     }
   }
-  __syncthreads();
+};
+
+// Forward DFT of `nl` (2 or 4) lines of length N owned by ONE wave, in place, natural order in and out.
+//   stage 1: lane = (line, n2): radix R1 over x[R2 n1 + n2], twiddle W_N^{n2 k1}, stored at y[Y2 k1 + n2]
+//   stage 2: lane = (line, k1): radix R2 over y[Y2 k1 + n2], X[k1 + R1 k2] stored in natural order (or handed to
+//            `sink(line, k1, v)` instead when the caller consumes the result from registers).
+// A wave's LDS instructions execute in order and every lane reads all its inputs before it writes, so in place is safe.
+template <int N, class Sink>
+__device__ __forceinline__ void wave_fft(cf* __restrict__ z, int nl, int lane, const SrTw<N>& tw, Sink sink) {
+  using P = SrPlan<N>;
+  constexpr int LP1 = 64 / P::R2;  // lines per stage-1 pass
+  for (int l0 = 0; l0 < nl; l0 += LP1) {
+    const int l = l0 + lane / P::R2, n2 = lane % P::R2;
+    if (l < nl) {  // (R2 = 16 packs four lines into a pass; a two-line call leaves half the wave idle)
+      cf* line = z + l * P::LINE;
+      cf v[P::R1];
 #pragma unroll
-  for (int b = 0; b < PER; ++b)
-    if (dst[b] >= 0) {
+      for (int n1 = 0; n1 < P::R1; ++n1) v[n1] = lds_read(&line[P::R2 * n1 + n2]);
+      bfly<P::R1>(v);
+      line[n2] = v[0];
 #pragma unroll
-      for (int k = 0; k < R; ++k) z[dst[b] + k * P] = v[b][k];
+      for (int k1 = 1; k1 < P::R1; ++k1) line[P::Y2 * k1 + n2] = cmul(v[k1], tw.w[k1 - 1]);
     }
-  __syncthreads();
-}
-
-template <int N, int LINES>
-__device__ __forceinline__ void lds_fft(cf* z, int nlines, const float* tw, int tid) {
-  if constexpr (N == 480) {
-    lds_stage<N, 15, LINES>(z, nlines, 1, tw, tid);
-    lds_stage<N, 8, LINES>(z, nlines, 15, tw, tid);
-    lds_stage<N, 4, LINES>(z, nlines, 120, tw, tid);
-  } else if constexpr (N == 240) {
-    lds_stage<N, 15, LINES>(z, nlines, 1, tw, tid);
-    lds_stage<N, 16, LINES>(z, nlines, 15, tw, tid);
-  } else {
-    static_assert(N == 256, "scale/rotation resolutions: 240, 256, 480");
-    lds_stage<N, 16, LINES>(z, nlines, 1, tw, tid);
-    lds_stage<N, 16, LINES>(z, nlines, 16, tw, tid);
   }
+  wave_sync();
+  {
+    // 16 lanes per line (15 of them active when R1 = 15); nl = 2 leaves the upper half of the wave idle
+    const int l = lane >> 4, k1 = lane & 15;
+    const bool on = l < nl && k1 < P::R1;
+    cf* line = z + l * P::LINE;
+    cf v[P::R2];
+    if (on) {
+#pragma unroll
+      for (int n2 = 0; n2 < P::R2; ++n2) v[n2] = lds_read(&line[P::Y2 * k1 + n2]);
+      bfly<P::R2>(v);
+      sink(line, l, k1, v);
+    }
+  }
+  wave_sync();
 }
 
-#ifndef MOF_SR_ROWS
-#define MOF_SR_ROWS 4
-#endif
-constexpr int ROWS_L = MOF_SR_ROWS;   // rows per workgroup in K5
-#ifndef MOF_SR_CW
-#define MOF_SR_CW 8
-#endif
-constexpr int COLS_CW = MOF_SR_CW;  // columns (plus their mirrors) per workgroup in K6
-constexpr int INV_L = 8;    // row PAIRS per workgroup in K7
+// default sink: natural-order store
+template <int N>
+struct StoreNatural {
+  __device__ __forceinline__ void operator()(cf* line, int, int k1, const cf* v) const {
+#pragma unroll
+    for (int k2 = 0; k2 < SrPlan<N>::R2; ++k2) line[k1 + SrPlan<N>::R1 * k2] = v[k2];
+  }
+};
 
 }  // namespace
+
+// Eight (four) taps of one footprint row: the u8 pixels are spread to u16 pairs with v_perm_b32 and meet the int16
+// weight pairs -- stored exactly like that in the table -- in v_dot2c_i32_i16: one instruction per tap instead of the
+// three (two bit-field extracts + multiply-add) of the scalar form; exact integer arithmetic either way. (Measured r02:
+// no change in kernel time -- the remap is bound by the L1's line look-ups, one per lane and tap row, not by the VALU.)
+template <int K>
+__device__ __forceinline__ int dot_row(const uint32_t* px, const uint32_t* wq, int sum) {
+  typedef short short2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int d = 0; d < K / 4; ++d) {
+    const uint32_t p01 = __builtin_amdgcn_perm(0u, px[d], 0x0c010c00u);  // (p0, p1) as two u16
+    const uint32_t p23 = __builtin_amdgcn_perm(0u, px[d], 0x0c030c02u);  // (p2, p3)
+    sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, p01), __builtin_bit_cast(short2_t, wq[2 * d]), sum, false);
+    sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, p23), __builtin_bit_cast(short2_t, wq[2 * d + 1]), sum, false);
+  }
+  return sum;
+}
 
 // ---- K4: cv::logPolar as one gather per destination pixel -----------------------------------------------
 // map[pixel] = {anchor x, anchor y, table index, valid}; valid = anchor inside the source (BORDER_TRANSPARENT:
@@ -166,7 +156,10 @@ __global__ void __launch_bounds__(256) sr_logpolar_kernel(SrLpArgs a) {
   const int pix = phi * res + rho;
   const int img = blockIdx.y;
   const SrMapEntry m = a.map[pix];
-  if (!m.valid) return;
+  if (!m.valid) {
+    if (a.zero_invalid) a.dst[(size_t)img * a.dst_stride + pix] = 0;
+    return;
+  }
   const uint8_t* src = a.src + (size_t)img * a.src_stride;
 #ifdef MOF_SR_ABL_W  // diagnostic build: every lane reads weight row 0 (results wrong by design)
   const int16_t* w = a.weights;
@@ -183,12 +176,7 @@ __global__ void __launch_bounds__(256) sr_logpolar_kernel(SrLpArgs a) {
       uint32_t px[K / 4], wq[K / 2];
       __builtin_memcpy(px, src + (size_t)(sy + k1) * a.pitch + sx, K);
       __builtin_memcpy(wq, __builtin_assume_aligned(w + k1 * K, 2 * K), 2 * K);
-#pragma unroll
-      for (int k2 = 0; k2 < K; ++k2) {
-        const int pv = (int)((px[k2 >> 2] >> (8 * (k2 & 3))) & 0xffu);
-        const int wv = (int)(int16_t)(wq[k2 >> 1] >> (16 * (k2 & 1)));
-        sum += pv * wv;
-      }
+      sum = dot_row<K>(px, wq, sum);
     }
   } else {
     for (int k1 = 0; k1 < K; ++k1) {
@@ -237,7 +225,12 @@ __global__ void __launch_bounds__(1024) sr_logpolar_lds_kernel(SrLpArgs a, int n
     if (rho >= res || phi >= res) continue;
     const int pix = phi * res + rho;
     const SrMapEntry m = a.map[pix];
-    if (!m.valid) continue;
+    if (!m.valid) {
+      // BORDER_TRANSPARENT keeps the destination; a batch whose destination is the estimator's zero-initialised
+      // tempIm (scaleRotationEstimator.cpp:27) gets that zero written here instead of a separate memset pass
+      if (a.zero_invalid) a.dst[(size_t)img * a.dst_stride + pix] = 0;
+      continue;
+    }
     const uint8_t* src = a.src + (size_t)img * a.src_stride;
     const unsigned char* w = wl + (int)m.widx * ROW_B;
     const int sx = m.ax - HALF, sy = m.ay - HALF;
@@ -248,12 +241,7 @@ __global__ void __launch_bounds__(1024) sr_logpolar_lds_kernel(SrLpArgs a, int n
         uint32_t px[K / 4], wq[K / 2];
         __builtin_memcpy(px, src + (size_t)(sy + k1) * a.pitch + sx, K);
         __builtin_memcpy(wq, __builtin_assume_aligned(w + k1 * 2 * K, 8), 2 * K);
-#pragma unroll
-        for (int k2 = 0; k2 < K; ++k2) {
-          const int pv = (int)((px[k2 >> 2] >> (8 * (k2 & 3))) & 0xffu);
-          const int wv = (int)(int16_t)(wq[k2 >> 1] >> (16 * (k2 & 1)));
-          sum += pv * wv;
-        }
+        sum = dot_row<K>(px, wq, sum);
       }
     } else {
       const int16_t* ws = reinterpret_cast<const int16_t*>(w);
@@ -273,89 +261,274 @@ __global__ void __launch_bounds__(1024) sr_logpolar_lds_kernel(SrLpArgs a, int n
   }
 }
 
-// ---- K5: forward row transforms of z = cur_lp + i prev_lp ------------------------------------------------
+// ---- K4, batched fast path: tile-stationary, source boxes staged in LDS ------------------------------------
+// The map and the weights depend on the destination pixel only, never on the image. A WAVE owns one 8 (phi) x 8 (rho)
+// destination tile, reads its map entries and its K x K weights ONCE into registers and then walks `img_per_wave`
+// images. Gathering the taps straight from global memory costs one L1 line look-up per (lane, tap row) -- at the outer
+// radii neighbouring destination pixels are 5-7 source pixels apart, so every look-up is a different line, and the L1's
+// one line per cycle sets the time (measured r01/r02: 125 us per 64 Lanczos4 images whether the arithmetic is 192 or
+// 64 instructions per pixel, twice the cubic kernel's time). Here the wave instead copies the bounding box of its
+// tile's footprints (SrTileBox, precomputed on the host from the map, reflected border taps included; a few KB) into LDS with aligned dword loads
+// -- a few dozen line look-ups per image -- and gathers from there. The box of image i+1 is fetched into registers
+// BEFORE the taps of image i are gathered (U images form a group whose boxes travel together), so the memory latency
+// hides behind the arithmetic.
+// Needs pitch % 4 == 0 and src_stride % 4 == 0 (then a row's misalignment is the same for every row and image).
+template <int K, int NR, int U>
+__global__ void __launch_bounds__(256) sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lp_lds[];
+  const int res = a.res, tiles = (res + 7) / 8, n_tiles = tiles * tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wid = blockIdx.x * 4 + wave;
+  const int tile = wid % n_tiles, img0 = (wid / n_tiles) * img_per_wave;
+  if (img0 >= n_images) return;
+  const int img1 = img0 + img_per_wave < n_images ? img0 + img_per_wave : n_images;
+  const int rho = (tile % tiles) * 8 + (lane & 7), phi = (tile / tiles) * 8 + (lane >> 3);
+  const bool inside = rho < res && phi < res;
+  const int pix = phi * res + rho;
+  SrMapEntry m{0, 0, 0, 0};
+  if (inside) m = a.map[pix];
+  const bool valid = inside && m.valid;
+  constexpr int HALF = K / 2 - 1;
+  const int sx = m.ax - HALF, sy = m.ay - HALF;
+  uint8_t* dst = a.dst + (size_t)img0 * a.dst_stride + pix;
+  if (__ballot(valid) == 0ull) {  // the whole tile maps outside the source (rho beyond the corners)
+    if (a.zero_invalid && inside)
+      for (int img = img0; img < img1; ++img, dst += a.dst_stride) *dst = 0;
+    return;
+  }
+  uint32_t wq[K * K / 2];  // this pixel's K x K int16 weights, two per dword
+#pragma unroll
+  for (int i = 0; i < K * K / 2; ++i) wq[i] = 0;
+  if (valid) __builtin_memcpy(wq, __builtin_assume_aligned(a.weights + (size_t)m.widx * (K * K), 2 * K), 2 * K * K);
+  // the box: bw x bh source pixels at (bx, by); LDS rows of lpd dwords; every row starts `mis` bytes into its first dword
+  const SrTileBox box = a.boxes[tile];
+  const int bx = box.x0, by = box.y0, bw = box.w, bh = box.h;
+  const int lpd = (bw + 3 + 3) / 4 + 1, cnt = bh * lpd;
+  const uint8_t* src = a.src + (size_t)img0 * a.src_stride;
+  const uint32_t mis = (uint32_t)(uintptr_t)(src + (size_t)by * a.pitch + bx) & 3u;
+  const uint8_t* b0 = src + (size_t)by * a.pitch + bx - mis;  // dword-aligned; the same offset in every image
+  // Box dword i = lane + 64 t comes from byte offset goff[t]. Slots past the box, or past the last needed byte of a
+  // row (they may lie outside the buffer), re-read the box's first dword and park it in a dump slot behind the box, so
+  // that the T = ceil(cnt / 64) loads and LDS writes of a box are unconditional for the whole wave.
+  const int T = __builtin_amdgcn_readfirstlane((cnt + 63) / 64);
+  uint32_t goff[NR];
+  uint32_t okmask = 0;
+#pragma unroll
+  for (int t = 0; t < NR; ++t) {
+    const int i = lane + 64 * t, r = i / lpd, j = i % lpd;
+    const bool ok = i < cnt && 4 * j < (int)mis + bw;
+    goff[t] = ok ? (uint32_t)r * (uint32_t)a.pitch + 4u * (uint32_t)j : 0u;
+    okmask |= ok ? (1u << t) : 0u;
+  }
+  const int box_dwords = a.lds_per_wave / 4 + 64;  // + the dump slots
+  uint32_t* L = lp_lds + (size_t)wave * U * box_dwords;  // U boxes: the images of one group
+  // Footprints that cross the border take BORDER_REFLECT_101 taps. They go through the SAME code as interior ones:
+  // tap row k1 is source row reflect(sy + k1); the K taps of a row are read as the K-byte window starting at
+  // wx = clamp(sx, 0, res - K) -- it holds every reflected column -- and put in tap order by one byte permute
+  // whose selector depends on the pixel only (identity for interior pixels).
+  const int wx = sx < 0 ? 0 : (sx > res - K ? res - K : sx);
+  uint32_t sel[K / 4];
+#pragma unroll
+  for (int d = 0; d < K / 4; ++d) {
+    sel[d] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int xx = sx + 4 * d + q;
+      xx = xx < 0 ? -xx : xx;
+      xx = xx >= res ? 2 * res - 2 - xx : xx;
+      sel[d] |= (uint32_t)(xx - wx) << (8 * q);
+    }
+  }
+  int rowoff[K];
+#pragma unroll
+  for (int k1 = 0; k1 < K; ++k1) {
+    int yy = sy + k1;
+    yy = yy < 0 ? -yy : yy;
+    yy = yy >= res ? 2 * res - 2 - yy : yy;
+    rowoff[k1] = valid ? (yy - by) * lpd : 0;
+  }
+  const uint32_t o = valid ? (uint32_t)(wx - bx) + mis : 0u;
+  const int lcol = (int)(o >> 2);
+  const uint32_t sh = o & 3u;
+  uint32_t stage[U][NR];
+  auto fetch = [&](const uint8_t* base, int n) {  // the boxes of the next n images into registers
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < n) {
+#pragma unroll
+        for (int t = 0; t < NR; ++t)
+          if (t < T) stage[u][t] = *reinterpret_cast<const uint32_t*>(base + (size_t)u * a.src_stride + goff[t]);
+      }
+  };
+  auto commit = [&](int n) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < n) {
+#pragma unroll
+        for (int t = 0; t < NR; ++t)
+          if (t < T) L[u * box_dwords + (((okmask >> t) & 1u) ? lane + 64 * t : box_dwords - 64 + lane)] = stage[u][t];
+      }
+  };
+  int n_cur = img1 - img0 < U ? img1 - img0 : U;
+  fetch(b0, n_cur);
+  commit(n_cur);
+  wave_sync();
+  for (int img = img0; img < img1; img += U) {
+    const int left = img1 - (img + U);
+    const int n_next = left <= 0 ? 0 : (left < U ? left : U);
+    if (n_next > 0) fetch(b0 + (size_t)U * a.src_stride, n_next);  // in flight while this group is gathered
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < n_cur) {
+        int v = 0;
+        if (valid) {
+          int sum = 0;
+#pragma unroll
+          for (int k1 = 0; k1 < K; ++k1) {
+            const uint32_t* p = L + u * box_dwords + rowoff[k1] + lcol;
+            uint32_t px[K / 4];
+            if constexpr (K == 8) {
+              const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+              const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+              px[0] = __builtin_amdgcn_perm(a1, a0, sel[0]);
+              px[1] = __builtin_amdgcn_perm(a1, a0, sel[1]);
+            } else {
+              const uint32_t d0 = p[0], d1 = p[1];
+              px[0] = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(d1, d0, sh), sel[0]);
+            }
+            sum = dot_row<K>(px, wq + k1 * (K / 2), sum);
+          }
+          v = (sum + (1 << 14)) >> 15;
+          v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        if (valid || (a.zero_invalid && inside)) dst[(size_t)u * a.dst_stride] = (uint8_t)v;
+      }
+    wave_sync();  // every lane has read this group's boxes ...
+    commit(n_next);
+    wave_sync();  // ... and sees the next group's
+    n_cur = n_next;
+    b0 += (size_t)U * a.src_stride;
+    dst += (size_t)U * a.dst_stride;
+  }
+}
+
+// ---- K5: forward row transforms of z = cur_lp + i prev_lp, written transposed -----------------------------
 template <int N>
 __global__ void __launch_bounds__(SR_T) sr_rows_fwd_kernel(SrPcArgs a) {
-  __shared__ cf z[ROWS_L * N];
-  const int tid = threadIdx.x, pair = blockIdx.y, row0 = blockIdx.x * ROWS_L;
-  const uint8_t* cur = a.lp_cur + (size_t)pair * a.lp_stride + (size_t)row0 * N;
-  const uint8_t* prev = a.lp_prev + (size_t)pair * a.lp_stride + (size_t)row0 * N;
-  for (int i = tid; i < ROWS_L * N; i += SR_T) z[i] = {(float)cur[i], (float)prev[i]};  // convertTo CV_32FC1, :115
+  using P = SrPlan<N>;
+  __shared__ cf z[SR_LINES * P::LINE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = blockIdx.y, row0 = blockIdx.x * SR_LINES;
+  SrTw<N> tw;
+  tw.load(a.twiddles, lane);
+  // wave w owns rows row0 + 4w .. +3: it loads them (4 px of cur and prev per lane and step), transforms them ...
+  const uint8_t* cur = a.lp_cur + (size_t)pair * a.lp_stride + (size_t)(row0 + 4 * wave) * N;
+  const uint8_t* prev = a.lp_prev + (size_t)pair * a.lp_stride + (size_t)(row0 + 4 * wave) * N;
+  cf* mine = z + 4 * wave * P::LINE;
+  for (int i = lane; i < 4 * N / 4; i += 64) {
+    const uint32_t c = *reinterpret_cast<const uint32_t*>(cur + 4 * i), p = *reinterpret_cast<const uint32_t*>(prev + 4 * i);
+    const int l = (4 * i) / N, x = (4 * i) % N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)  // convertTo CV_32FC1, :115
+      mine[l * P::LINE + x + q] = {(float)((c >> (8 * q)) & 0xffu), (float)((p >> (8 * q)) & 0xffu)};
+  }
+  wave_sync();
+  wave_fft<N>(mine, 4, lane, tw, StoreNatural<N>{});
   __syncthreads();
-  lds_fft<N, ROWS_L>(z, ROWS_L, a.twiddles, tid);
-  cf* Z = reinterpret_cast<cf*>(a.Z) + (size_t)pair * N * N + (size_t)row0 * N;
-  for (int i = tid; i < ROWS_L * N; i += SR_T) Z[i] = z[i];
+  // ... and the workgroup stores its 8 rows transposed: Zt[u][row0 .. row0+7] is one 64-byte segment per u
+  cf* Zt = reinterpret_cast<cf*>(a.Zt) + (size_t)pair * N * N + row0;
+  for (int i = tid; i < SR_LINES * N; i += SR_T) {
+    const int u = i / SR_LINES, dv = i % SR_LINES;
+    Zt[(size_t)u * N + dv] = z[dv * P::LINE + u];
+  }
 }
 
 // ---- K6: column transforms, cross-power spectrum, inverse column transforms of the half spectrum -----------
 template <int N>
 __global__ void __launch_bounds__(SR_T) sr_cols_kernel(SrPcArgs a) {
+  using P = SrPlan<N>;
   constexpr int H = N / 2, CW = COLS_CW;
-  __shared__ cf z[2 * CW * N];  // slots 0..CW-1: columns u0+s ; slots CW..2CW-1: their mirrors (N - u) % N
-  const int tid = threadIdx.x, pair = blockIdx.y, u0 = blockIdx.x * CW;
-  const cf* Z = reinterpret_cast<const cf*>(a.Z) + (size_t)pair * N * N;
-  for (int i = tid; i < 2 * CW * N; i += SR_T) {
-    const int v = i / (2 * CW), s = i % (2 * CW);
-    int u = u0 + (s % CW);
-    if (u > H) u = H;  // tail group: clamp (results of clamped slots are never stored)
-    const int col = s < CW ? u : (N - u) % N;
-    z[s * N + v] = Z[(size_t)v * N + col];
+  __shared__ cf z[2 * CW * P::LINE];  // lines 0..CW-1: columns u0+s ; lines CW..2CW-1: their mirrors (N - u) % N
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = blockIdx.y, u0 = blockIdx.x * CW;
+  SrTw<N> tw;
+  tw.load(a.twiddles, lane);
+  const cf* Zt = reinterpret_cast<const cf*>(a.Zt) + (size_t)pair * N * N;
+  // wave 0 loads and transforms the columns, wave 1 their mirrors: whole lines of N complex, 16 bytes per lane
+  {
+    cf* mine = z + wave * CW * P::LINE;
+    for (int i = lane; i < CW * N / 2; i += 64) {
+      const int s = (2 * i) / N, v = (2 * i) % N;
+      int u = u0 + s;
+      if (u > H) u = H;  // tail group: clamp (results of clamped lines are never stored)
+      const int col = wave == 0 ? u : (N - u) % N;
+      const float4 t = *reinterpret_cast<const float4*>(Zt + (size_t)col * N + v);
+      mine[s * P::LINE + v] = {t.x, t.y};
+      mine[s * P::LINE + v + 1] = {t.z, t.w};
+    }
+    wave_sync();
+    wave_fft<N>(mine, CW, lane, tw, StoreNatural<N>{});
   }
   __syncthreads();
-  lds_fft<N, 2 * CW>(z, 2 * CW, a.twiddles, tid);
   // normalised cross-power spectrum of bins (v, u), conjugated in place (see K1 for the rules)
   for (int i = tid; i < CW * N; i += SR_T) {
     const int s = i / N, v = i % N;
     int u = u0 + s;
     if (u > H) u = H;
-    const cf zk = z[s * N + v], zm = z[(CW + s) * N + (N - v) % N];
+    const cf zk = z[s * P::LINE + v], zm = z[(CW + s) * P::LINE + (N - v) % N];
     const bool real_only = (v == 0 || v == H) && (u == 0 || u == H);
     const cf C = cross_power(zk, zm, real_only);
-    z[s * N + v] = {C.x, -C.y};
+    z[s * P::LINE + v] = {C.x, -C.y};
   }
   __syncthreads();
-  lds_fft<N, 2 * CW>(z, CW, a.twiddles, tid);  // only the CW lines of the half spectrum
-  cf* D = reinterpret_cast<cf*>(a.D) + (size_t)pair * N * (H + 1);
-  for (int i = tid; i < CW * N; i += SR_T) {
-    const int y = i / CW, s = i % CW, u = u0 + s;
-    if (u <= H) D[(size_t)y * (H + 1) + u] = z[s * N + y];
+  // the CW lines of the half spectrum: two per wave
+  wave_fft<N>(z + 2 * wave * P::LINE, 2, lane, tw, StoreNatural<N>{});
+  __syncthreads();
+  cf* Dt = reinterpret_cast<cf*>(a.Dt) + (size_t)pair * (H + 1) * N;
+  for (int i = tid; i < CW * N / 2; i += SR_T) {
+    const int s = (2 * i) / N, y = (2 * i) % N, u = u0 + s;
+    if (u <= H) {
+      const cf a0 = z[s * P::LINE + y], a1 = z[s * P::LINE + y + 1];
+      *reinterpret_cast<float4*>(Dt + (size_t)u * N + y) = make_float4(a0.x, a0.y, a1.x, a1.y);
+    }
   }
 }
 
-// ---- K7: Hermitian rows back to the real surface, two rows per complex transform ---------------------------
+// ---- K7: Hermitian rows back to the real surface, two rows per complex transform; arg-max from registers -----
 template <int N>
 __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
+  using P = SrPlan<N>;
   constexpr int H = N / 2;
-  __shared__ cf z[INV_L * N];
+  __shared__ cf z[SR_LINES * P::LINE];
   __shared__ Best red[SR_T / 64];
-  const int tid = threadIdx.x, pair = blockIdx.y, p0 = blockIdx.x * INV_L;  // row pairs p0 .. p0+INV_L-1
-  const cf* D = reinterpret_cast<const cf*>(a.D) + (size_t)pair * N * (H + 1);
-  for (int i = tid; i < INV_L * N; i += SR_T) {
-    const int l = i / N, u = i % N, y1 = 2 * (p0 + l), y2 = y1 + 1;
-    const int uu = u <= H ? u : N - u;
-    const cf f1 = D[(size_t)y1 * (H + 1) + uu], f2 = D[(size_t)y2 * (H + 1) + uu];
-    // E[u] = F1[y1][u] + i F1[y2][u], F1[y][N-u] = conj F1[y][u]
-    z[i] = u <= H ? cf{f1.x - f2.y, f1.y + f2.x} : cf{f1.x + f2.y, f2.x - f1.y};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = blockIdx.y, p0 = blockIdx.x * SR_LINES;
+  SrTw<N> tw;
+  tw.load(a.twiddles, lane);
+  const cf* Dt = reinterpret_cast<const cf*>(a.Dt) + (size_t)pair * (H + 1) * N;
+  // line l carries rows y1 = 2 (p0 + l), y2 = y1 + 1: E[u] = F[y1][u] + i F[y2][u], F[y][N-u] = conj F[y][u].
+  // Dt[u][y1], Dt[u][y2] are neighbours: one 16-byte load; 8 lanes fetch the 16 rows of the workgroup (128 bytes).
+  for (int i = tid; i < SR_LINES * (H + 1); i += SR_T) {
+    const int u = i / SR_LINES, l = i % SR_LINES;
+    const float4 t = *reinterpret_cast<const float4*>(Dt + (size_t)u * N + 2 * (p0 + l));
+    z[l * P::LINE + u] = {t.x - t.w, t.y + t.z};
+    if (u > 0 && u < H) z[l * P::LINE + N - u] = {t.x + t.w, t.z - t.y};
   }
   __syncthreads();
-  lds_fft<N, INV_L>(z, INV_L, a.twiddles, tid);
-  float* S = a.S + (size_t)pair * N * N;
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
-  for (int i = tid; i < INV_L * N; i += SR_T) {
-    const int l = i / N, x = i % N, y1 = 2 * (p0 + l), y2 = y1 + 1;
-    const cf e = z[i];
-    S[(size_t)y1 * N + x] = e.x;
-    S[(size_t)y2 * N + x] = e.y;
-    const int xs = (x + H) % N;
-    best = better(best, Best{e.x, ((y1 + H) % N) * N + xs});  // fftShift + first maximum (minMaxLoc)
-    best = better(best, Best{e.y, ((y2 + H) % N) * N + xs});
-  }
+  wave_fft<N>(z + 4 * wave * P::LINE, 4, lane, tw, [&](cf*, int l, int k1, const cf* v) {
+    const int y1 = 2 * (p0 + 4 * wave + l), y2 = y1 + 1;
+    const int r1 = ((y1 + H) % N) * N, r2 = ((y2 + H) % N) * N;  // fftShift + first maximum (minMaxLoc)
+#pragma unroll
+    for (int k2 = 0; k2 < P::R2; ++k2) {
+      const int xs = (k1 + P::R1 * k2 + H) % N;
+      best = better(best, Best{v[k2].x, r1 + xs});
+      best = better(best, Best{v[k2].y, r2 + xs});
+    }
+  });
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     Best o = {__shfl_xor(best.v, off, 64), __shfl_xor(best.idx, off, 64)};
     best = better(best, o);
   }
-  if ((tid & 63) == 0) red[tid >> 6] = best;
+  if (lane == 0) red[wave] = best;
   __syncthreads();
   if (tid == 0) {
     for (int w = 1; w < SR_T / 64; ++w) best = better(best, red[w]);
@@ -366,9 +539,13 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
 // ---- K8: peak, centroid, (scale, rot) ----------------------------------------------------------------------
 // out[pair] = {scale, rot, pt.x, pt.y}; pt = cv::phaseCorrelate(cur_lp, prev_lp) = center - t (NOT negated, :117);
 // |pt.x| > res/2 -> (1, 0) (:119-121); scale = exp(pt.x / M), rot = (pt.y / Ky) pi/180, Ky = res/360 (:123-124).
+// The 25 surface values of the window are re-evaluated from the half spectrum of their rows (Dt), in double:
+//   S[y][x] = Re F[y][0] + (-1)^x Re F[y][N/2] + 2 sum_{u=1}^{N/2-1} (Re F[y][u] cos(2 pi u x / N) + Im F[y][u] sin(..))
+// which is what K7's transform computes for that point (K7 keeps no surface).
 template <int N>
 __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
   constexpr int H = N / 2;
+  __shared__ double part[25][65];
   const int lane = threadIdx.x, pair = blockIdx.x;
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
   for (int i = lane; i < a.n_cand; i += 64) {
@@ -380,12 +557,43 @@ __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
     Best o = {__shfl_xor(best.v, off, 64), __shfl_xor(best.idx, off, 64)};
     best = better(best, o);
   }
-  const float* S = a.S + (size_t)pair * N * N;
-  const int px = best.idx % N, py = best.idx / N;
+  const cf* Dt = reinterpret_cast<const cf*>(a.Dt) + (size_t)pair * (H + 1) * N;
+  const bool have = best.idx != 0x7fffffff;
+  const int px = have ? best.idx % N : 0, py = have ? best.idx / N : 0;
+  // window rows / columns in un-shifted coordinates (entries outside the clamped window are skipped at the end)
+  int wy[5], wx[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    wy[k] = (((py - 2 + k) % N + N) + H) % N;
+    wx[k] = (((px - 2 + k) % N + N) + H) % N;
+  }
+  // the 240-term sums are split over the lanes by u (lane, lane + 64, ..), 25 partial sums each, ...
+  double acc[25];
+#pragma unroll
+  for (int k = 0; k < 25; ++k) acc[k] = 0.0;
+  for (int u = 1 + lane; u < H; u += 64) {
+    cf f[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) f[r] = Dt[(size_t)u * N + wy[r]];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float2 w = *reinterpret_cast<const float2*>(a.twiddles + 2 * (int)(((long)u * wx[c]) % N));  // (cos, -sin)
+#pragma unroll
+      for (int r = 0; r < 5; ++r) acc[r * 5 + c] += (double)f[r].x * (double)w.x - (double)f[r].y * (double)w.y;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 25; ++k) part[k][lane] = acc[k];
+  __syncthreads();
+  // ... and lane k < 25 adds the 64 partial sums of its window point in a fixed order
   const int ys = py - 2 + lane / 5, xs = px - 2 + lane % 5;
   double cx = 0.0, cy = 0.0, sum = 0.0;
-  if (lane < 25 && ys >= 0 && ys <= N - 1 && xs >= 0 && xs <= N - 1) {
-    const double val = (double)S[(size_t)((ys + H) % N) * N + (xs + H) % N];
+  if (have && lane < 25 && ys >= 0 && ys <= N - 1 && xs >= 0 && xs <= N - 1) {
+    const int y = wy[lane / 5], x = wx[lane % 5];
+    double s2 = 0.0;
+    for (int l = 0; l < 64; ++l) s2 += part[lane][l];
+    const double s0 = (double)Dt[y].x + ((x & 1) ? -1.0 : 1.0) * (double)Dt[(size_t)H * N + y].x;
+    const double val = (double)(float)(s0 + 2.0 * s2);  // the surface is CV_32F
     cx = (double)xs * val;
     cy = (double)ys * val;
     sum = val;
@@ -436,6 +644,24 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
   // MOF_SR_LP_GLOBAL=1: the first formulation (weights fetched from L2 per pixel), kept for A/B measurements; it also
   // serves single images, where staging the table would cost more than it saves
   static const bool global_w = [] { const char* e = getenv("MOF_SR_LP_GLOBAL"); return e && atoi(e) != 0; }();
+  // batches whose rows and frames keep one dword alignment: tile-stationary kernel with LDS-staged source boxes
+  // (MOF_SR_LP_STAGED=0 falls back to the table-in-LDS formulation, kept for A/B runs and unaligned layouts)
+  static const bool staged_on = [] { const char* e = getenv("MOF_SR_LP_STAGED"); return !e || atoi(e) != 0; }();
+  constexpr int NR = 16;
+  if (staged_on && !global_w && n_images >= 4 && a.pitch % 4 == 0 && a.src_stride % 4 == 0 && a.boxes &&
+      a.box_dwords_max <= 64 * NR && 8 * (size_t)(a.lds_per_wave + 256) <= 64 * 1024) {
+    const int tiles = (a.res + 7) / 8, n_tiles = tiles * tiles;
+    const int ipw = n_images >= 64 ? 16 : (n_images >= 16 ? 8 : 4);
+    const int groups = (n_images + ipw - 1) / ipw;
+    const unsigned blocks = (unsigned)(((long)n_tiles * groups + 3) / 4);
+    constexpr int U = 2;  // images per group: their boxes are in flight together (two boxes of a few KB per wave)
+    const size_t lds = (size_t)4 * U * (a.lds_per_wave + 256);
+    if (interp == 2)
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, U>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw);
+    else
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, U>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw);
+    return hipGetLastError();
+  }
   if (!global_w && n_images >= 4) return interp == 2 ? launch_lp_lds<4>(a, n_images, stream) : launch_lp_lds<8>(a, n_images, stream);
   const dim3 grid((unsigned)(((a.res + 31) / 32) * ((a.res + 7) / 8)), (unsigned)n_images);
   if (interp == 2)
@@ -448,14 +674,15 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
 template <int N>
 static hipError_t launch_sr_pc_n(const SrPcArgs& a, int n_pairs, hipStream_t stream) {
   constexpr int H = N / 2;
-  hipLaunchKernelGGL(sr_rows_fwd_kernel<N>, dim3(N / ROWS_L, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
+  static_assert(N % SR_LINES == 0 && H % SR_LINES == 0, "rows and row pairs are dealt out eight per workgroup");
+  hipLaunchKernelGGL(sr_rows_fwd_kernel<N>, dim3(N / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
   hipLaunchKernelGGL(sr_cols_kernel<N>, dim3((H + 1 + COLS_CW - 1) / COLS_CW, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
-  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(H / INV_L, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
+  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(H / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
   hipLaunchKernelGGL(sr_final_kernel<N>, dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
-int sr_candidates(int res) { return (res / 2) / INV_L; }
+int sr_candidates(int res) { return (res / 2) / SR_LINES; }
 
 hipError_t launch_sr_phase_correlate(const SrPcArgs& a, int res, int n_pairs, hipStream_t stream) {
   switch (res) {

@@ -31,6 +31,14 @@ def test_golden_vectors(gpu, name):
     (True, (100, 140), 8, 4, 5),
     (False, (120, 120), 16, 0, 21),   # default.yaml scan_radius 21
     (True, (150, 150), 64, 0, 3),     # >256 px per block: u16 partial sums are flushed
+    # the reference's OWN default geometry (config/default.yaml:29-32: scan_radius 21, step_size 24, sample_point_size
+    # 120) on the 752x480 camera frame and on the 480^2 crop the node hands its processors
+    (True, (480, 752), 120, 24, 21),
+    (True, (480, 480), 120, 24, 21),
+    (False, (480, 480), 120, 0, 21),  # BlockMethod(frame_size 480, sample_point_size 120, scan_radius 21): 3 x 3 blocks
+    (True, (400, 300), 128, 0, 24),   # the largest block size, at the reference's radius limit (2r + 1 <= 50, .cl:1)
+    (True, (230, 420), 100, 4, 48),   # > 64 KB of LDS per workgroup: opt-in dynamic LDS
+    (True, (60, 200), 8, 0, 2),       # tiny scans: eight blocks share a workgroup
 ])
 def test_seeded_batches_bit_exact(gpu, fast, shape, block, step, radius):
     h, w = shape
@@ -116,8 +124,8 @@ def test_full_size_c3_batch_properties(gpu):
 def test_random_geometries_bit_exact(gpu):
     """Seeded sweep over block sizes / steps / radii / frame sizes (fast 16x16 path and the generic kernel)."""
     rng = np.random.default_rng(20261003)
-    for trial in range(14):
-        block = int(rng.choice([4, 8, 12, 16, 16, 16, 20, 32]))
+    for trial in range(24):
+        block = int(rng.choice([4, 8, 12, 16, 16, 16, 20, 32, 72, 120]))
         radius = int(rng.choice([2, 5, 8, 8, 16, 16, 21])) if block != 16 else int(rng.choice([8, 16, 16, 5]))
         step = int(rng.choice([0, 4, 8, 3])) if block != 16 else int(rng.choice([0, 4, 8, 12]))
         gx, gy = int(rng.integers(1, 9)), int(rng.integers(1, 5))
