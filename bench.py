@@ -259,8 +259,10 @@ def roofline_block(tag: str, wl, B: int, kern_ms: float):
            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
            # `traffic` is NOT measured by this run: PMC counters need their own rocprofv3 pass (tools/pmc.sh); the
            # number is the committed result of that pass for this command (per launch of `batch` pairs)
-           "traffic_source": (f"profiles/traffic_{tag}.json (separate rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass of this "
-                              "command; not measured live)") if traffic is not None else None,
+           "traffic_source": (f"profiles/traffic_{tag}.json: fabric bytes of ALL the library's kernels in one step, from "
+                              "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_all.sh, "
+                              "tools/summarize_round.py; FETCH_SIZE doubled for the kernels a known byte count shows it halves); "
+                              "not measured live") if traffic is not None else None,
            "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
            "binding": binding_note(tag, wl)}
     if wl["kind"] == "fft":

@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmof_hip.so")
+# MOF_LIB_PATH: diagnostic override used by the same-box A/B scripts (tools/ab_variants.sh, tools/ab_commit.sh) to load a
+# variant built under /tmp without touching the product library
+LIB_PATH = os.environ.get("MOF_LIB_PATH") or os.path.join(_HERE, "libmof_hip.so")
 
 MOF_OK = 0
 MOF_ERR_BAD_ARG = -1

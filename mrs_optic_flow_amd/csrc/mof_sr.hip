@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -30,9 +31,20 @@ namespace {
 constexpr int kTab = 32;            // INTER_TAB_SIZE
 constexpr int kCoefScale = 1 << 15; // INTER_REMAP_COEF_SCALE
 #ifndef MOF_SR_CHUNK
-#define MOF_SR_CHUNK 64
+#define MOF_SR_CHUNK 256
 #endif
-constexpr int kChunk = MOF_SR_CHUNK;  // frame pairs per pipeline pass (64 pairs = ~240 MB of scratch; 16/32/64/128 measured 89/99/106/109 k pairs/s at c5)
+// frame pairs per pipeline pass: 256 pairs of 480^2 = 0.83 GB of scratch (log-polar images, Zt, Dt); same-box sweep r02
+// (tools/sweep_c5.sh): 64 / 128 / 256 pairs -> 201 / 209 / 214 k pairs/s at c5
+constexpr int kChunkDefault = MOF_SR_CHUNK;
+// frame pairs per pipeline pass of an engine; MOF_SR_CHUNK in the environment overrides the default at create() (diagnostic)
+int chunk_pairs() {
+  static const int v = [] {
+    const char* e = getenv("MOF_SR_CHUNK");
+    const int n = e ? atoi(e) : 0;
+    return n >= 1 && n <= 4096 ? n : kChunkDefault;
+  }();
+  return v;
+}
 
 #define SR_TRY(expr)                                                                                  \
   do {                                                                                                \
@@ -220,6 +232,7 @@ struct mof_sr_engine {
   double* d_out = nullptr;       // [kChunk][4]
   uint8_t* h_stage = nullptr;
   double* h_out = nullptr;
+  int chunk = 0;                 // frame pairs per pipeline pass (sizes the scratch)
   bool first = true;             // :31
   std::atomic<bool> busy{false};
   // Ordering of the engine-owned scratch (d_lp, d_Zt, d_Dt, d_cand, d_out) across streams: every call that
@@ -305,6 +318,8 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   mof_sr_engine* e = new (std::nothrow) mof_sr_engine();
   if (!e) return mof::capi_fail(MOF_ERR_NO_MEMORY, "out of host memory");
   e->cfg = *cfg;
+  e->chunk = chunk_pairs();
+  const int kChunk = e->chunk;
   for (int k = 0; k < res; ++k) {
     double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)res;
     double c = std::cos(ang), s = std::sin(ang);
@@ -453,6 +468,7 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
   hipStream_t s = (hipStream_t)stream;
   const size_t nn = (size_t)res * res;
   SR_TRY(scratch_acquire(e, s));
+  const int kChunk = e->chunk;
   for (int k0 = 0; k0 < n_pairs; k0 += kChunk) {
     const int n = (n_pairs - k0 < kChunk) ? n_pairs - k0 : kChunk;
     // every pair is the two-call sequence of a fresh estimator: prev -> INTER_CUBIC (:45), cur -> INTER_LANCZOS4

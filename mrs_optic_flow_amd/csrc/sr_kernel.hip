@@ -274,12 +274,25 @@ __global__ void __launch_bounds__(1024) sr_logpolar_lds_kernel(SrLpArgs a, int n
 // hides behind the arithmetic.
 // Needs pitch % 4 == 0 and src_stride % 4 == 0 (then a row's misalignment is the same for every row and image).
 template <int K, int NR, int U>
-__global__ void __launch_bounds__(256) sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave) {
+__global__ void __launch_bounds__(256) sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave, int xcd_groups) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lp_lds[];
   const int res = a.res, tiles = (res + 7) / 8, n_tiles = tiles * tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wid = blockIdx.x * 4 + wave;
-  const int tile = wid % n_tiles, img0 = (wid / n_tiles) * img_per_wave;
+  int tile, img0;
+  if (xcd_groups > 0) {
+    // XCD-aware order (speed only): workgroups b, b + 8, b + 16, .. share an XCD and its L2, so image group g goes to
+    // the workgroups with b % 8 == g % 8 -- every image is then fetched into ONE L2 instead of up to eight
+    // (r02: 3.3x the image bytes in FETCH_SIZE with the plain order)
+    const int nq = (n_tiles + 3) / 4, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int g = xcd + 8 * (j / nq);
+    tile = 4 * (j % nq) + wave;
+    img0 = g * img_per_wave;
+    if (g >= xcd_groups || tile >= n_tiles) return;
+  } else {
+    const int wid = blockIdx.x * 4 + wave;
+    tile = wid % n_tiles;
+    img0 = (wid / n_tiles) * img_per_wave;
+  }
   if (img0 >= n_images) return;
   const int img1 = img0 + img_per_wave < n_images ? img0 + img_per_wave : n_images;
   const int rho = (tile % tiles) * 8 + (lane & 7), phi = (tile / tiles) * 8 + (lane >> 3);
@@ -313,12 +326,22 @@ __global__ void __launch_bounds__(256) sr_logpolar_staged_kernel(SrLpArgs a, int
   const int T = __builtin_amdgcn_readfirstlane((cnt + 63) / 64);
   uint32_t goff[NR];
   uint32_t okmask = 0;
+  {
+    // (row, dword) of slot lane + 64 t, advanced by 64 slots per step: two integer divisions per wave instead of 2 NR
+    int r = lane / lpd, j = lane % lpd;
+    const int dr = 64 / lpd, dj = 64 % lpd;
 #pragma unroll
-  for (int t = 0; t < NR; ++t) {
-    const int i = lane + 64 * t, r = i / lpd, j = i % lpd;
-    const bool ok = i < cnt && 4 * j < (int)mis + bw;
-    goff[t] = ok ? (uint32_t)r * (uint32_t)a.pitch + 4u * (uint32_t)j : 0u;
-    okmask |= ok ? (1u << t) : 0u;
+    for (int t = 0; t < NR; ++t) {
+      const bool ok = lane + 64 * t < cnt && 4 * j < (int)mis + bw;
+      goff[t] = ok ? (uint32_t)r * (uint32_t)a.pitch + 4u * (uint32_t)j : 0u;
+      okmask |= ok ? (1u << t) : 0u;
+      j += dj;
+      r += dr;
+      if (j >= lpd) {
+        j -= lpd;
+        ++r;
+      }
+    }
   }
   const int box_dwords = a.lds_per_wave / 4 + 64;  // + the dump slots
   uint32_t* L = lp_lds + (size_t)wave * U * box_dwords;  // U boxes: the images of one group
@@ -413,11 +436,18 @@ __global__ void __launch_bounds__(256) sr_logpolar_staged_kernel(SrLpArgs a, int
 }
 
 // ---- K5: forward row transforms of z = cur_lp + i prev_lp, written transposed -----------------------------
+#ifndef MOF_SR_FWD_ROWS
+#define MOF_SR_FWD_ROWS 16
+#endif
+constexpr int FWD_ROWS = MOF_SR_FWD_ROWS;  // rows per workgroup: the transposed store writes FWD_ROWS * 8 bytes per segment
+constexpr int FWD_T = FWD_ROWS * 16;       // four rows per wave
+
 template <int N>
-__global__ void __launch_bounds__(SR_T) sr_rows_fwd_kernel(SrPcArgs a) {
+__global__ void __launch_bounds__(FWD_T) sr_rows_fwd_kernel(SrPcArgs a) {
   using P = SrPlan<N>;
-  __shared__ cf z[SR_LINES * P::LINE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = blockIdx.y, row0 = blockIdx.x * SR_LINES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fwd_lds[];
+  cf* z = reinterpret_cast<cf*>(fwd_lds);  // [FWD_ROWS][LINE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = blockIdx.y, row0 = blockIdx.x * FWD_ROWS;
   SrTw<N> tw;
   tw.load(a.twiddles, lane);
   // wave w owns rows row0 + 4w .. +3: it loads them (4 px of cur and prev per lane and step), transforms them ...
@@ -434,10 +464,10 @@ __global__ void __launch_bounds__(SR_T) sr_rows_fwd_kernel(SrPcArgs a) {
   wave_sync();
   wave_fft<N>(mine, 4, lane, tw, StoreNatural<N>{});
   __syncthreads();
-  // ... and the workgroup stores its 8 rows transposed: Zt[u][row0 .. row0+7] is one 64-byte segment per u
+  // ... and the workgroup stores its rows transposed: Zt[u][row0 .. row0 + FWD_ROWS) is one contiguous segment per u
   cf* Zt = reinterpret_cast<cf*>(a.Zt) + (size_t)pair * N * N + row0;
-  for (int i = tid; i < SR_LINES * N; i += SR_T) {
-    const int u = i / SR_LINES, dv = i % SR_LINES;
+  for (int i = tid; i < FWD_ROWS * N; i += FWD_T) {
+    const int u = i / FWD_ROWS, dv = i % FWD_ROWS;
     Zt[(size_t)u * N + dv] = z[dv * P::LINE + u];
   }
 }
@@ -651,15 +681,21 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
   if (staged_on && !global_w && n_images >= 4 && a.pitch % 4 == 0 && a.src_stride % 4 == 0 && a.boxes &&
       a.box_dwords_max <= 64 * NR && 8 * (size_t)(a.lds_per_wave + 256) <= 64 * 1024) {
     const int tiles = (a.res + 7) / 8, n_tiles = tiles * tiles;
-    const int ipw = n_images >= 64 ? 16 : (n_images >= 16 ? 8 : 4);
+    // images per wave: long runs amortise the per-tile set-up; short ones keep the images that the resident waves
+    // share within the L2 (MOF_SR_LP_IPW: diagnostic override)
+    static const int forced_ipw = [] { const char* e = getenv("MOF_SR_LP_IPW"); return e ? atoi(e) : 0; }();
+    const int ipw = forced_ipw > 0 ? forced_ipw : (n_images >= 128 ? 32 : (n_images >= 64 ? 16 : (n_images >= 16 ? 8 : 4)));
     const int groups = (n_images + ipw - 1) / ipw;
-    const unsigned blocks = (unsigned)(((long)n_tiles * groups + 3) / 4);
+    static const bool xcd_off = [] { const char* e = getenv("MOF_SR_LP_XCD"); return e && atoi(e) == 0; }();
+    const int nq = (n_tiles + 3) / 4;
+    const int xcd_groups = (groups >= 8 && !xcd_off) ? groups : 0;  // fewer than 8 groups would leave XCDs idle
+    const unsigned blocks = xcd_groups ? (unsigned)(8 * ((groups + 7) / 8) * nq) : (unsigned)(((long)n_tiles * groups + 3) / 4);
     constexpr int U = 2;  // images per group: their boxes are in flight together (two boxes of a few KB per wave)
     const size_t lds = (size_t)4 * U * (a.lds_per_wave + 256);
     if (interp == 2)
-      hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, U>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw);
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, U>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
     else
-      hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, U>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw);
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, U>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
     return hipGetLastError();
   }
   if (!global_w && n_images >= 4) return interp == 2 ? launch_lp_lds<4>(a, n_images, stream) : launch_lp_lds<8>(a, n_images, stream);
@@ -674,8 +710,13 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
 template <int N>
 static hipError_t launch_sr_pc_n(const SrPcArgs& a, int n_pairs, hipStream_t stream) {
   constexpr int H = N / 2;
-  static_assert(N % SR_LINES == 0 && H % SR_LINES == 0, "rows and row pairs are dealt out eight per workgroup");
-  hipLaunchKernelGGL(sr_rows_fwd_kernel<N>, dim3(N / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
+  static_assert(N % FWD_ROWS == 0 && H % SR_LINES == 0, "rows and row pairs divide evenly over the workgroups");
+  constexpr size_t fwd_lds = sizeof(cf) * FWD_ROWS * SrPlan<N>::LINE;
+  if (fwd_lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_rows_fwd_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(sr_rows_fwd_kernel<N>, dim3(N / FWD_ROWS, (unsigned)n_pairs), dim3(FWD_T), fwd_lds, stream, a);
   hipLaunchKernelGGL(sr_cols_kernel<N>, dim3((H + 1 + COLS_CW - 1) / COLS_CW, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
   hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(H / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
   hipLaunchKernelGGL(sr_final_kernel<N>, dim3((unsigned)n_pairs), dim3(64), 0, stream, a);

@@ -108,9 +108,9 @@ def test_logpolar_remap_is_byte_exact(gpu, res, M, interp, variant):
 
 
 def test_c5_batch_crossing_the_pipeline_chunk(gpu):
-    """More pairs than one pass of the scale/rotation pipeline holds (the chunk size is an internal constant <= 64):
-    every pair, on both sides of each chunk boundary, equals the same pair processed alone, and samples match the oracle."""
-    res, M, B = 240, 40.0, 150
+    """More pairs than one pass of the scale/rotation pipeline holds (the chunk size is an internal constant, 256 pairs):
+    every pair, on both sides of the chunk boundary, equals the same pair processed alone, and samples match the oracle."""
+    res, M, B = 240, 40.0, 300
     base = sr_scenes.canvas(91, res)
     protos = [(1.0, 0.0), (1.03, 2.0), (0.96, -3.0), (1.0, 5.0), (1.08, -1.0), (0.9, 8.0), (1.01, 0.5)]
     views = np.stack([sr_scenes.view(base, res, s, r) for s, r in protos])
@@ -121,13 +121,13 @@ def test_c5_batch_crossing_the_pipeline_chunk(gpu):
     got = est.process_batch_device(cur, prev)
     torch.cuda.synchronize()
     got = got.cpu().numpy()
-    for k in (0, 15, 16, 31, 32, 63, 64, 65, 127, 128, 149):
+    for k in (0, 15, 16, 31, 32, 63, 64, 65, 127, 128, 149, 254, 255, 256, 257, 299):
         alone = est.process_batch_device(cur[k:k + 1], prev[k:k + 1]).cpu().numpy()[0]
         assert np.array_equal(alone, got[k]), k
     # the (cur, prev) prototypes of pair k depend on k mod 7 only: identical bits wherever a pair sits in the batch
     for k in range(len(protos), B):
         assert np.array_equal(got[k], got[k % len(protos)]), k
-    for k in (3, 64, 100, 149):
+    for k in (3, 64, 255, 256, 299):
         ref = O.ScaleRotationEstimator(res, M, 64)
         ref.processImage(views[(idx[k] * 3 + 1) % len(protos)])
         s, r = ref.processImage(views[idx[k]])

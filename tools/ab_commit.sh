@@ -16,11 +16,10 @@ BASE="-O3 -std=c++17 -fPIC -fno-slp-vectorize -Wno-unused-parameter -Wno-unused-
 OBJS=""
 for f in *.hip; do hipcc --offload-arch=gfx950 $BASE -I../include -I. -c -o /tmp/old_${f%.hip}.o $f; OBJS="$OBJS /tmp/old_${f%.hip}.o"; done
 hipcc --offload-arch=gfx950 -shared -o /tmp/lib_old.so $OBJS
-cp $R/mrs_optic_flow_amd/libmof_hip.so /tmp/lib_new.so
+# the old library is selected through MOF_LIB_PATH: the product library is never overwritten
 for rep in 1 2 3; do
   for v in old new; do
-    cp /tmp/lib_$v.so $R/mrs_optic_flow_amd/libmof_hip.so
-    echo "$v $(python3 $R/bench.py --no-cpu-baseline --steps 30 "$@" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"]), d["roofline"]["kernel_ms"])')"
+    LIB=$R/mrs_optic_flow_amd/libmof_hip.so; [ $v == old ] && LIB=/tmp/lib_old.so
+    echo "$v $(MOF_LIB_PATH=$LIB python3 $R/bench.py --no-cpu-baseline --no-others --sustain-s 0 --steps 30 "$@" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d["value"]), d["roofline"]["kernel_ms"])')"
   done
 done
-cp /tmp/lib_new.so $R/mrs_optic_flow_amd/libmof_hip.so

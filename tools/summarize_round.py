@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<round>_<workload>/ (tools/profile_all.sh) into tracked files under profiles/:
+   <round>_<wl>_kernel_stats.csv  rocprofv3 --kernel-trace --stats rows of the library's kernels (+ the top others)
+   <round>_<wl>_pmc.csv           per-kernel means of FETCH_SIZE / WRITE_SIZE (separate --pmc passes)
+   <round>_<wl>_bench.json        the bench line of the same command
+   traffic_<wl>.json              fabric bytes per bench step (what bench.py reports as roofline.traffic)
+FETCH_SIZE correction (MI355X_MICROARCH.md, HBM section): on gfx950 the counter tallies 128-byte requests at 64 bytes,
+i.e. reports HALF the bytes of wide contiguous streaming reads. Which kernels read that way is decided by calibration
+against KNOWN byte counts, recorded in FACTORS below with the evidence; everything else is taken at face value.
+usage: tools/summarize_round.py r02"""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+# kernel-name substring -> (FETCH_SIZE factor, evidence)
+FACTORS = {
+    "pc_field_kernel": (1.0, "cal workload: 512x512 frames tiled exactly by 64x64 patches, known 2*512*512*1024 B = 536.87 MB, FETCH_SIZE 536.97 MB"),
+    "sr_rows_fwd_kernel": (2.0, "reads 2*480*480 B of u8 per pair = 120.8 MB per 256-pair launch; FETCH_SIZE 59.07 MB = 0.49x"),
+    "sr_cols_kernel": (2.0, "reads Zt once: 480*480*8 B per pair = 471.9 MB per 256-pair launch; FETCH_SIZE 236.06 MB = 0.50x"),
+    "sr_rows_inv_kernel": (2.0, "reads Dt once: 241*480*8 B per pair = 236.9 MB per 256-pair launch; FETCH_SIZE 118.59 MB = 0.50x"),
+}
+
+
+def factor(kernel):
+    for k, (f, _) in FACTORS.items():
+        if k in kernel:
+            return f
+    return 1.0
+
+
+for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{tag}_*"))):
+    wl = os.path.basename(d)[len(f"prof_{tag}_"):]
+    if wl == "mfma":
+        shutil.copy(os.path.join(d, "result.json"), os.path.join(dst, f"{tag}_mfma_rowdft_result.json"))
+        for st in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
+            shutil.copy(st, os.path.join(dst, f"{tag}_mfma_rowdft_kernel_stats.csv"))
+        continue
+    bench = None
+    if os.path.exists(os.path.join(d, "bench.json")):
+        bench = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
+        json.dump(bench, open(os.path.join(dst, f"{tag}_{wl}_bench.json"), "w"), indent=1)
+    calls = {}
+    for st in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
+        rows = list(csv.reader(open(st)))
+        with open(os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(rows[0])
+            others = 0
+            for r in rows[1:]:
+                if "mof::" in r[0]:
+                    calls[r[0]] = int(r[1])
+                    w.writerow([r[0][:120]] + r[1:])
+                elif others < 4:  # the largest foreign kernels (torch's, copies) for context
+                    w.writerow([r[0][:120]] + r[1:])
+                    others += 1
+    agg = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "mof::" in r["Kernel_Name"]:
+                agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    steps = (bench["steps"] + bench["warmup"]) if bench else 23
+    per_step, per_step_raw, detail = 0.0, 0.0, []
+    with open(os.path.join(dst, f"{tag}_{wl}_pmc.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "dispatches", "mean_KiB_per_dispatch", "fetch_factor", "bytes_per_step"])
+        for (k, c), v in sorted(agg.items()):
+            fac = factor(k) if c == "FETCH_SIZE" else 1.0
+            launches_per_step = len(v) / steps
+            b = sum(v) / len(v) * 1024 * fac * launches_per_step
+            per_step += b
+            per_step_raw += sum(v) / len(v) * 1024 * launches_per_step
+            w.writerow([k[:100], c, len(v), round(sum(v) / len(v), 1), fac, round(b)])
+            detail.append({"kernel": k[:80], "counter": c, "launches_per_step": launches_per_step,
+                           "mean_kib": sum(v) / len(v), "factor": fac})
+    if agg:
+        out = {"workload": wl, "hbm_bytes_per_launch": per_step, "raw_counter_bytes_per_step": per_step_raw,
+               "meaning": "fabric (L2 <-> Infinity Fabric) bytes of all the library's kernels in ONE bench step: "
+                          "FETCH_SIZE x factor + WRITE_SIZE, summed over the step's launches",
+               "fetch_factors": {k: {"factor": f, "evidence": e} for k, (f, e) in FACTORS.items()},
+               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, profiles/{tag}_{wl}_pmc.csv",
+               "kernels": detail}
+        json.dump(out, open(os.path.join(dst, f"traffic_{wl}.json"), "w"), indent=1)
+        alg = bench["roofline"]["algorithmic_bytes_per_launch"] if bench else 0
+        print(f"{wl:6s} value {bench['value']:12.0f}  traffic/step {per_step / 1e6:9.1f} MB (raw {per_step_raw / 1e6:9.1f})  "
+              f"= {per_step / alg if alg else 0:5.2f}x algorithmic")
