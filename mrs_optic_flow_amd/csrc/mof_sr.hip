@@ -241,6 +241,13 @@ struct mof_sr_engine {
   hipEvent_t scratch_ev = nullptr;
   hipStream_t scratch_stream = nullptr;  // stream of the last user
   bool scratch_used = false;
+  // Two-lane batch pipeline: the log-polar remaps of chunk k+1 (bound by LDS / L1 latency, little HBM traffic) run on
+  // `remap_stream` while the transforms of chunk k (bound by HBM) run on the caller's stream; the log-polar images are
+  // double-buffered and handed over with events.
+  hipStream_t remap_stream = nullptr;
+  hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_lp[2] = {nullptr, nullptr};   // remaps of the chunk using buffer b are done
+  hipEvent_t ev_fft[2] = {nullptr, nullptr};  // transforms reading buffer b are done (it may be overwritten)
 };
 
 namespace {
@@ -289,6 +296,10 @@ void mof_sr_destroy(mof_sr_engine* e) {
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->scratch_ev) (void)hipEventDestroy(e->scratch_ev);
+  if (e->remap_stream) (void)hipStreamSynchronize(e->remap_stream);
+  for (hipEvent_t ev : {e->ev_fork, e->ev_lp[0], e->ev_lp[1], e->ev_fft[0], e->ev_fft[1]})
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->remap_stream) (void)hipStreamDestroy(e->remap_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -342,6 +353,12 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   } while (0)
   CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CREATE_TRY(hipEventCreateWithFlags(&e->scratch_ev, hipEventDisableTiming));
+  CREATE_TRY(hipStreamCreateWithFlags(&e->remap_stream, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  for (int b = 0; b < 2; ++b) {
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_lp[b], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_fft[b], hipEventDisableTiming));
+  }
   CREATE_TRY(hipMalloc(&e->d_map, map.size() * sizeof(mof::SrMapEntry)));
   CREATE_TRY(hipMemcpy(e->d_map, map.data(), map.size() * sizeof(mof::SrMapEntry), hipMemcpyHostToDevice));
   e->lds_per_wave[0] = lds_c;
@@ -361,7 +378,7 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   CREATE_TRY(hipMalloc(&e->d_prev_lp, nn));
   CREATE_TRY(hipMemset(e->d_temp_im, 0, nn));  // tempIm = cv::Mat::zeros, :27
   CREATE_TRY(hipMemset(e->d_prev_lp, 0, nn));
-  CREATE_TRY(hipMalloc(&e->d_lp, (size_t)kChunk * 2 * nn));
+  CREATE_TRY(hipMalloc(&e->d_lp, (size_t)2 * kChunk * 2 * nn));  // two chunks: remap of chunk k+1 beside the transforms of chunk k
   CREATE_TRY(hipMalloc(&e->d_Zt, (size_t)kChunk * nn * 2 * sizeof(float)));
   CREATE_TRY(hipMalloc(&e->d_Dt, (size_t)kChunk * res * (res / 2 + 1) * 2 * sizeof(float)));
   CREATE_TRY(hipMalloc(&e->d_cand, (size_t)kChunk * mof::sr_candidates(res) * sizeof(float2)));
@@ -469,11 +486,23 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
   const size_t nn = (size_t)res * res;
   SR_TRY(scratch_acquire(e, s));
   const int kChunk = e->chunk;
-  for (int k0 = 0; k0 < n_pairs; k0 += kChunk) {
+  // MOF_SR_OVERLAP=0: everything on the caller's stream (diagnostic A/B)
+  static const bool overlap_on = [] { const char* v = getenv("MOF_SR_OVERLAP"); return !v || atoi(v) != 0; }();
+  const bool two_lanes = overlap_on && n_pairs > kChunk;
+  hipStream_t sr = two_lanes ? e->remap_stream : s;
+  if (two_lanes) {  // fork: the remap lane starts behind whatever the caller's stream holds (works under graph capture too)
+    SR_TRY(hipEventRecord(e->ev_fork, s));
+    SR_TRY(hipStreamWaitEvent(sr, e->ev_fork, 0));
+  }
+  int chunk_no = 0;
+  for (int k0 = 0; k0 < n_pairs; k0 += kChunk, ++chunk_no) {
     const int n = (n_pairs - k0 < kChunk) ? n_pairs - k0 : kChunk;
+    const int b = two_lanes ? (chunk_no & 1) : 0;
+    uint8_t* lp_buf = e->d_lp + (size_t)b * kChunk * 2 * nn;
     // every pair is the two-call sequence of a fresh estimator: prev -> INTER_CUBIC (:45), cur -> INTER_LANCZOS4
     // (:112) onto the same zero-initialised tempIm; the transparent pixels are the same for both maps, so both
     // remaps simply write zeros there (zero_invalid) and the scratch needs no clearing pass
+    if (two_lanes && chunk_no >= 2) SR_TRY(hipStreamWaitEvent(sr, e->ev_fft[b], 0));  // buffer b is free again
     mof::SrLpArgs lp{};
     lp.zero_invalid = 1;
     lp.pitch = pitch;
@@ -482,16 +511,21 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
     lp.dst_stride = 2 * nn;
     lp.src = d_prev + (size_t)k0 * prev_stride;
     lp.src_stride = prev_stride;
-    lp.dst = e->d_lp + nn;
+    lp.dst = lp_buf + nn;
     lp_tables(e, 2, &lp);
-    SR_TRY(mof::launch_sr_logpolar(lp, 2, n, s));
+    SR_TRY(mof::launch_sr_logpolar(lp, 2, n, sr));
     lp.src = d_cur + (size_t)k0 * cur_stride;
     lp.src_stride = cur_stride;
-    lp.dst = e->d_lp;
+    lp.dst = lp_buf;
     lp_tables(e, 4, &lp);
-    SR_TRY(mof::launch_sr_logpolar(lp, 4, n, s));
-    mof::SrPcArgs a = pc_args(e, e->d_lp, e->d_lp + nn, 2 * nn, d_out + 4 * (size_t)k0);
+    SR_TRY(mof::launch_sr_logpolar(lp, 4, n, sr));
+    if (two_lanes) {
+      SR_TRY(hipEventRecord(e->ev_lp[b], sr));
+      SR_TRY(hipStreamWaitEvent(s, e->ev_lp[b], 0));  // also the join: every remap precedes a wait on the caller's stream
+    }
+    mof::SrPcArgs a = pc_args(e, lp_buf, lp_buf + nn, 2 * nn, d_out + 4 * (size_t)k0);
     SR_TRY(mof::launch_sr_phase_correlate(a, res, n, s));
+    if (two_lanes) SR_TRY(hipEventRecord(e->ev_fft[b], s));
   }
   SR_TRY(scratch_release(e, s));
   return MOF_OK;

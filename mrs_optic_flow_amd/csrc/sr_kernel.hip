@@ -454,12 +454,28 @@ __global__ void __launch_bounds__(FWD_T) sr_rows_fwd_kernel(SrPcArgs a) {
   const uint8_t* cur = a.lp_cur + (size_t)pair * a.lp_stride + (size_t)(row0 + 4 * wave) * N;
   const uint8_t* prev = a.lp_prev + (size_t)pair * a.lp_stride + (size_t)(row0 + 4 * wave) * N;
   cf* mine = z + 4 * wave * P::LINE;
-  for (int i = lane; i < 4 * N / 4; i += 64) {
-    const uint32_t c = *reinterpret_cast<const uint32_t*>(cur + 4 * i), p = *reinterpret_cast<const uint32_t*>(prev + 4 * i);
-    const int l = (4 * i) / N, x = (4 * i) % N;
+  {
+    // all loads first (a load-use loop would pay the memory latency once per trip), then the conversion
+    constexpr int NL = (N + 63) / 64;  // dwords per lane: four rows of N bytes
+    uint32_t c[NL], p[NL];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)  // convertTo CV_32FC1, :115
-      mine[l * P::LINE + x + q] = {(float)((c >> (8 * q)) & 0xffu), (float)((p >> (8 * q)) & 0xffu)};
+    for (int k = 0; k < NL; ++k) {
+      const int i = lane + 64 * k;
+      if (i < N) {
+        c[k] = *reinterpret_cast<const uint32_t*>(cur + 4 * i);
+        p[k] = *reinterpret_cast<const uint32_t*>(prev + 4 * i);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = lane + 64 * k;
+      if (i < N) {
+        const int l = (4 * i) / N, x = (4 * i) % N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)  // convertTo CV_32FC1, :115
+          mine[l * P::LINE + x + q] = {(float)((c[k] >> (8 * q)) & 0xffu), (float)((p[k] >> (8 * q)) & 0xffu)};
+      }
+    }
   }
   wave_sync();
   wave_fft<N>(mine, 4, lane, tw, StoreNatural<N>{});
@@ -485,14 +501,27 @@ __global__ void __launch_bounds__(SR_T) sr_cols_kernel(SrPcArgs a) {
   // wave 0 loads and transforms the columns, wave 1 their mirrors: whole lines of N complex, 16 bytes per lane
   {
     cf* mine = z + wave * CW * P::LINE;
-    for (int i = lane; i < CW * N / 2; i += 64) {
-      const int s = (2 * i) / N, v = (2 * i) % N;
-      int u = u0 + s;
-      if (u > H) u = H;  // tail group: clamp (results of clamped lines are never stored)
-      const int col = wave == 0 ? u : (N - u) % N;
-      const float4 t = *reinterpret_cast<const float4*>(Zt + (size_t)col * N + v);
-      mine[s * P::LINE + v] = {t.x, t.y};
-      mine[s * P::LINE + v + 1] = {t.z, t.w};
+    constexpr int NL = (CW * N / 2 + 63) / 64;  // 16-byte loads per lane, all in flight before the first LDS write
+    float4 t[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = lane + 64 * k;
+      if (i < CW * N / 2) {
+        const int s = (2 * i) / N, v = (2 * i) % N;
+        int u = u0 + s;
+        if (u > H) u = H;  // tail group: clamp (results of clamped lines are never stored)
+        const int col = wave == 0 ? u : (N - u) % N;
+        t[k] = *reinterpret_cast<const float4*>(Zt + (size_t)col * N + v);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = lane + 64 * k;
+      if (i < CW * N / 2) {
+        const int s = (2 * i) / N, v = (2 * i) % N;
+        mine[s * P::LINE + v] = {t[k].x, t[k].y};
+        mine[s * P::LINE + v + 1] = {t[k].z, t[k].w};
+      }
     }
     wave_sync();
     wave_fft<N>(mine, CW, lane, tw, StoreNatural<N>{});
@@ -535,11 +564,23 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
   const cf* Dt = reinterpret_cast<const cf*>(a.Dt) + (size_t)pair * (H + 1) * N;
   // line l carries rows y1 = 2 (p0 + l), y2 = y1 + 1: E[u] = F[y1][u] + i F[y2][u], F[y][N-u] = conj F[y][u].
   // Dt[u][y1], Dt[u][y2] are neighbours: one 16-byte load; 8 lanes fetch the 16 rows of the workgroup (128 bytes).
-  for (int i = tid; i < SR_LINES * (H + 1); i += SR_T) {
-    const int u = i / SR_LINES, l = i % SR_LINES;
-    const float4 t = *reinterpret_cast<const float4*>(Dt + (size_t)u * N + 2 * (p0 + l));
-    z[l * P::LINE + u] = {t.x - t.w, t.y + t.z};
-    if (u > 0 && u < H) z[l * P::LINE + N - u] = {t.x + t.w, t.z - t.y};
+  {
+    constexpr int NL = (SR_LINES * (H + 1) + SR_T - 1) / SR_T;  // all loads in flight before the first LDS write
+    float4 t[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + SR_T * k;
+      if (i < SR_LINES * (H + 1)) t[k] = *reinterpret_cast<const float4*>(Dt + (size_t)(i / SR_LINES) * N + 2 * (p0 + i % SR_LINES));
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + SR_T * k;
+      if (i < SR_LINES * (H + 1)) {
+        const int u = i / SR_LINES, l = i % SR_LINES;
+        z[l * P::LINE + u] = {t[k].x - t[k].w, t[k].y + t[k].z};
+        if (u > 0 && u < H) z[l * P::LINE + N - u] = {t[k].x + t[k].w, t[k].z - t[k].y};
+      }
+    }
   }
   __syncthreads();
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
