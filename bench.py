@@ -219,7 +219,7 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
             with torch.cuda.graph(g, stream=side):
                 graph_result = eager_launch()
 
-        def launch():
+        def launch(keep=(eager_launch, side)):  # the captured graph uses the engines' scratch: keep every engine alive
             g.replay()
             return graph_result
 

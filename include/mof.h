@@ -233,7 +233,11 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
  * on a different stream than the previous one first makes its stream wait (hipStreamWaitEvent) for the previous
  * call's last kernel, so back-to-back batches on different streams are safe but do not overlap. While `stream` is
  * being captured into a HIP graph no cross-stream dependency is taken or left: replays of graphs that contain calls
- * on one engine must be ordered by the caller. */
+ * on one engine must be ordered by the caller.
+ * Batches longer than one pipeline pass (256 pairs) run as two lanes -- the log-polar remaps of pass k+1 on a stream of
+ * the engine's own, beside the transforms of pass k on `stream`, handed over with events; everything is complete when
+ * `stream` is. Under graph capture the engine's stream joins the capture (fork / join by events) and the graph replays
+ * with the same two lanes. A captured graph uses the engine's scratch: the engine must outlive it. */
 int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                 size_t prev_stride, size_t pitch, int n_pairs, double* d_out, void* stream);
 

@@ -488,9 +488,11 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
   const int kChunk = e->chunk;
   // MOF_SR_OVERLAP=0: everything on the caller's stream (diagnostic A/B)
   static const bool overlap_on = [] { const char* v = getenv("MOF_SR_OVERLAP"); return !v || atoi(v) != 0; }();
+  // Under graph capture the fork / join below pulls the engine's stream into the caller's capture (event record on the
+  // capturing stream, wait on the other), so a captured batch replays with the same two lanes.
   const bool two_lanes = overlap_on && n_pairs > kChunk;
   hipStream_t sr = two_lanes ? e->remap_stream : s;
-  if (two_lanes) {  // fork: the remap lane starts behind whatever the caller's stream holds (works under graph capture too)
+  if (two_lanes) {  // fork: the remap lane starts behind whatever the caller's stream holds (also under graph capture)
     SR_TRY(hipEventRecord(e->ev_fork, s));
     SR_TRY(hipStreamWaitEvent(sr, e->ev_fork, 0));
   }

@@ -295,3 +295,15 @@ def test_long_range_gate_is_held_in_ints(gpu):
         tq = torch.from_numpy(np.stack([cur, prev])).to(gpu)
         batch = fm.process_long_range_batch_device(tq[:1], tq[1:]).cpu().numpy()[0]
         assert np.array_equal(batch, got, equal_nan=True)
+
+
+def test_multi_pass_batch_is_graph_capturable(gpu):
+    """A scale/rotation batch longer than one pipeline pass runs as two lanes (remaps on the engine's own stream beside
+    the transforms). Under HIP-graph capture the engine's stream joins the caller's capture by an event fork / join and
+    the graph must replay to the bits of the eager run. Run in a child process with MOF_SR_CHUNK=2 (seven pairs = four
+    passes) at 240 and 480."""
+    script = os.path.join(ROOT, "tools", "check_graph_capture.py")
+    for res in ("240", "480"):
+        r = subprocess.run([sys.executable, script, res], env=dict(os.environ, MOF_SR_CHUNK="2"), capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0 and f"graph ok {res}" in r.stdout, (r.stdout + r.stderr)[-2000:]
