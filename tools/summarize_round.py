@@ -18,7 +18,7 @@ os.makedirs(dst, exist_ok=True)
 # kernel-name substring -> (FETCH_SIZE factor, evidence)
 FACTORS = {
     "pc_field_kernel": (1.0, "cal workload: 512x512 frames tiled exactly by 64x64 patches, known 2*512*512*1024 B = 536.87 MB, FETCH_SIZE 536.97 MB"),
-    "sr_rows_fwd_kernel": (2.0, "reads 2*480*480 B of u8 per pair = 120.8 MB per 256-pair launch; FETCH_SIZE 59.07 MB = 0.49x"),
+    "sr_rows_fwd_kernel": (2.0, "reads 2*480*480 B of u8 per pair = 118.0 MB per 256-pair launch; FETCH_SIZE 59.1 MB = 0.50x"),
     "sr_cols_kernel": (2.0, "reads Zt once: 480*480*8 B per pair = 471.9 MB per 256-pair launch; FETCH_SIZE 236.06 MB = 0.50x"),
     "sr_rows_inv_kernel": (2.0, "reads Dt once: 241*480*8 B per pair = 236.9 MB per 256-pair launch; FETCH_SIZE 118.59 MB = 0.50x"),
 }
