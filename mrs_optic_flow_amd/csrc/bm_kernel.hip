@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -32,7 +33,7 @@ namespace mof {
 
 namespace {
 
-constexpr int BM_THREADS = 256;
+constexpr int BM_THREADS_MAX = 1024;  // generic scan: one lane per item, whole waves
 
 struct Cand {
   uint32_t sad;
@@ -55,20 +56,31 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 }  // namespace
 
-// LDS layout per block slot (dwords): window rows [WW][WPD], current block [sps][sps/4], SAD table [D][4*XG];
-// then one 64-bit arg-min key per slot. A workgroup holds `bpw` neighbouring blocks of one block row so that small
-// scans (c1: 17 x 5 = 85 items) still fill its 256 lanes; big blocks (the reference default 120 / r 21: 473 items) run
-// one per workgroup.
-__global__ void __launch_bounds__(BM_THREADS) bm_scan_kernel(BmArgs a, int bpw, int groups_per_row) {
+// LDS layout per block slot (dwords): window rows [WW][WPD], current block [sps][sps/4]; then per slot one 64-bit
+// arg-min key and the centre SAD (for the low-contrast rule). A workgroup holds `bpw` neighbouring blocks of one block
+// row and has one lane per (block, y-shift, lane group) item, rounded up to whole waves (launch_bm_scan picks XB, bpw
+// and the padded window pitch WPD from a small cost model).
+// A lane owns one (block, y-shift) and XB consecutive groups of four x-shifts. The XB chains share a sliding register
+// window over the previous-frame row -- chain k at step g needs window dwords (g + k, g + k + 1) -- so one step costs
+// ONE new window dword and ONE block dword from LDS for XB v_qsad_pk_u16_u8. The row loop runs in chunks of G
+// steps with every LDS offset an immediate and the window rotation resolved by the unrolling: the round-1 form spent
+// five address / move VALU instructions per v_qsad (24 of every 40 issue cycles) and sat at 38-41 % of the ceiling.
+// Exact i / d for i * d < 2^32 with m = ceil(2^32 / d), m = 0 standing for d = 1 (the staging loops index at most
+// 40 K dwords).
+__device__ __forceinline__ uint32_t fast_div(uint32_t i, uint32_t m) { return m ? __umulhi(i, m) : i; }
+__device__ __forceinline__ uint32_t div_magic(uint32_t d) { return d == 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
+
+template <int XB, int G>
+__global__ void __launch_bounds__(BM_THREADS_MAX) bm_scan_kernel(BmArgs a, int bpw, int groups_per_row, int WPD, int slot_dwords) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
   const int r = a.radius, sps = a.block, S = a.block + a.step, D = 2 * r + 1;
   const int XG = div_up(D, 4);          // x-shift groups of 4
+  const int XGL = div_up(XG, XB);       // lanes per (block, y-shift)
   const int WW = sps + 2 * r;           // window width == height in pixels
-  const int WPD = XG + sps / 4 + 1;     // window row pitch in dwords (covers the 8-byte over-read)
   const int CPD = sps / 4;              // current-block row pitch in dwords
-  const int slot_dwords = WW * WPD + sps * CPD + D * 4 * XG;
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds + (size_t)bpw * slot_dwords + ((bpw * slot_dwords) & 1));
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds + (size_t)bpw * slot_dwords);  // slot_dwords is even
+  uint32_t* centre = reinterpret_cast<uint32_t*>(keys + bpw);
 
   const int blocks = a.grid_x * a.grid_y;
   const int grp = blockIdx.x % groups_per_row;
@@ -77,62 +89,125 @@ __global__ void __launch_bounds__(BM_THREADS) bm_scan_kernel(BmArgs a, int bpw, 
   const int bx0 = grp * bpw;
   const int nb = (a.grid_x - bx0 < bpw) ? a.grid_x - bx0 : bpw;  // blocks of this workgroup (>= 1)
 
-  // ---- stage windows + blocks in LDS (bytes beyond the window width are zero, never loaded)
-  for (int s = 0; s < nb; ++s) {
-    const int bx = bx0 + s;
-    const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + r) * a.pitch + (bx * S + r);
-    const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + bx * S;
-    uint32_t* win = lds + (size_t)s * slot_dwords;
-    uint8_t* wb = reinterpret_cast<uint8_t*>(win);
-    for (int i = tid; i < WW * WPD * 4; i += BM_THREADS) {
-      const int y = i / (WPD * 4), x = i % (WPD * 4);
-      wb[i] = (x < WW) ? prev[(size_t)y * a.pitch + x] : (uint8_t)0;
+  // ---- stage windows + blocks in LDS: one flat loop over every slot's dwords (independent loads, several in flight
+  // per lane). A dword that straddles the window's right edge is loaded ending AT the edge and shifted down, so bytes
+  // beyond the window width are zero and nothing outside the window is touched.
+  {
+    const uint8_t* prev0 = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + bx0 * S;
+    const uint8_t* cur0 = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + r) * a.pitch + (bx0 * S + r);
+    const uint32_t win_dwords = (uint32_t)(WW * WPD), blk_dwords = (uint32_t)(sps * CPD);
+    const uint32_t m_win = div_magic(win_dwords), m_wpd = div_magic((uint32_t)WPD);
+    const uint32_t m_blk = div_magic(blk_dwords), m_cpd = div_magic((uint32_t)CPD);
+#pragma unroll 4
+    for (uint32_t i = tid; i < (uint32_t)nb * win_dwords; i += nthreads) {
+      const uint32_t s = fast_div(i, m_win), rem = i - s * win_dwords;
+      const uint32_t y = fast_div(rem, m_wpd), x = 4 * (rem - y * (uint32_t)WPD);
+      uint32_t v = 0;
+      if ((int)x < WW) {
+        const uint32_t off = (int)x + 4 <= WW ? x : (uint32_t)(WW - 4);
+        __builtin_memcpy(&v, prev0 + (size_t)y * a.pitch + s * (uint32_t)S + off, 4);  // any alignment
+        v >>= 8 * (x - off);
+      }
+      lds[s * (uint32_t)slot_dwords + rem] = v;
     }
-    uint8_t* cb = reinterpret_cast<uint8_t*>(win + WW * WPD);
-    for (int i = tid; i < sps * sps; i += BM_THREADS) cb[i] = cur[(size_t)(i / sps) * a.pitch + (i % sps)];
+#pragma unroll 4
+    for (uint32_t i = tid; i < (uint32_t)nb * blk_dwords; i += nthreads) {
+      const uint32_t s = fast_div(i, m_blk), rem = i - s * blk_dwords;
+      const uint32_t y = fast_div(rem, m_cpd), x = 4 * (rem - y * (uint32_t)CPD);
+      uint32_t v;
+      __builtin_memcpy(&v, cur0 + (size_t)y * a.pitch + s * (uint32_t)S + x, 4);
+      lds[s * (uint32_t)slot_dwords + win_dwords + rem] = v;
+    }
   }
   if (tid < nb) keys[tid] = ~0ull;
   __syncthreads();
 
-  // ---- SAD scan: item = (slot, ys, xg) -> shifts (4xg..4xg+3, ys) of block bx0 + slot
+  // ---- SAD scan: item = (slot, ys, lane group) -> x-shifts 4 (xl XB) .. 4 (xl XB + XB) - 1 of block bx0 + slot at ys
   const int rows_per_flush = (256 / sps) > 0 ? (256 / sps) : 1;  // rows*sps <= 256 px -> packed u16 sums cannot overflow
-  const int per_block = D * XG;
-  for (int item = tid; item < nb * per_block; item += BM_THREADS) {
+  const int per_block = D * XGL;
+  const bool c64 = (CPD & 1) == 0 && ((WW * WPD) & 1) == 0;  // block rows 8-byte aligned in LDS
+  for (int item = tid; item < nb * per_block; item += nthreads) {
     const int s = item / per_block, rem = item % per_block;
-    const int ys = rem / XG, xg = rem % XG;
+    const int ys = rem / XGL, xg0 = (rem % XGL) * XB;
     const uint32_t* win = lds + (size_t)s * slot_dwords;
-    const uint32_t* blk = win + WW * WPD;
-    uint32_t* sad = lds + (size_t)s * slot_dwords + WW * WPD + sps * CPD;
-    uint32_t acc[4] = {0u, 0u, 0u, 0u};
+    const uint32_t* wrow = win + ys * WPD + xg0;
+    const uint32_t* crow = win + WW * WPD;
+    uint32_t acc[XB][4];
+#pragma unroll
+    for (int k = 0; k < XB; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[k][q] = 0u;
     for (int j0 = 0; j0 < sps; j0 += rows_per_flush) {
-      uint64_t pk = 0;
+      uint64_t pk[XB];
+#pragma unroll
+      for (int k = 0; k < XB; ++k) pk[k] = 0;
       const int j1 = (j0 + rows_per_flush < sps) ? j0 + rows_per_flush : sps;
-      for (int j = j0; j < j1; ++j) {
-        const uint32_t* wrow = win + (ys + j) * WPD + xg;
-        const uint32_t* crow = blk + j * CPD;
-        uint32_t lo = wrow[0];
-        for (int g = 0; g < CPD; ++g) {
-          const uint32_t hi = wrow[g + 1];
-          pk = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)hi << 32) | lo, crow[g], pk);
-          lo = hi;
+      for (int j = j0; j < j1; ++j, wrow += WPD, crow += CPD) {
+        uint32_t w[G + XB];
+#pragma unroll
+        for (int k = 0; k < XB; ++k) w[k] = wrow[k];
+        int g0 = 0;
+        for (; g0 + G <= CPD; g0 += G) {
+          uint32_t c[G];
+          if constexpr ((G & 1) == 0) {
+            if (c64) {  // block row as 8-byte LDS reads (256 B/clk against ds_read_b32's 128)
+#pragma unroll
+              for (int i = 0; i < G; i += 2) {
+                const uint2 t = *reinterpret_cast<const uint2*>(crow + g0 + i);
+                c[i] = t.x, c[i + 1] = t.y;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < G; ++i) c[i] = crow[g0 + i];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < G; ++i) c[i] = crow[g0 + i];
+          }
+#pragma unroll
+          for (int i = 0; i < G; ++i) w[XB + i] = wrow[g0 + XB + i];
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int k = 0; k < XB; ++k)
+              pk[k] = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w[i + k + 1] << 32) | w[i + k], c[i], pk[k]);
+#pragma unroll
+          for (int k = 0; k < XB; ++k) w[k] = w[G + k];
+        }
+        if (g0 < CPD) {  // ragged tail of the row (CPD % G steps; launch_bm_scan prefers a G that divides CPD)
+#pragma unroll
+          for (int i = 0; i < G - 1; ++i) {
+            if (g0 + i < CPD) {
+              const uint32_t c = crow[g0 + i];
+              w[XB + i] = wrow[g0 + XB + i];
+#pragma unroll
+              for (int k = 0; k < XB; ++k)
+                pk[k] = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w[i + k + 1] << 32) | w[i + k], c, pk[k]);
+            }
+          }
         }
       }
-      acc[0] += (uint32_t)(pk & 0xffffu);
-      acc[1] += (uint32_t)((pk >> 16) & 0xffffu);
-      acc[2] += (uint32_t)((pk >> 32) & 0xffffu);
-      acc[3] += (uint32_t)(pk >> 48);
+#pragma unroll
+      for (int k = 0; k < XB; ++k) {
+        acc[k][0] += (uint32_t)(pk[k] & 0xffffu);
+        acc[k][1] += (uint32_t)((pk[k] >> 16) & 0xffffu);
+        acc[k][2] += (uint32_t)((pk[k] >> 32) & 0xffffu);
+        acc[k][3] += (uint32_t)(pk[k] >> 48);
+      }
     }
     // arg-min, first occurrence in row-major order (BlockMethod.cpp:63; .cl:50-56, :66-73): min over (sad, index) keys
     unsigned long long best = ~0ull;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int xs = 4 * xg + q;
-      sad[ys * 4 * XG + xs] = acc[q];
-      if (xs < D) {
-        const unsigned long long k = ((unsigned long long)acc[q] << 32) | (uint32_t)(ys * D + xs);
-        best = k < best ? k : best;
+    for (int k = 0; k < XB; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int xs = 4 * (xg0 + k) + q;
+        if (xs < D) {
+          const unsigned long long key = ((unsigned long long)acc[k][q] << 32) | (uint32_t)(ys * D + xs);
+          best = key < best ? key : best;
+          if (ys == r && xs == r) centre[s] = acc[k][q];  // SAD(0, 0), FastSpacedBMMethod.cl:77
+        }
       }
-    }
     atomicMin(&keys[s], best);
   }
   __syncthreads();
@@ -142,8 +217,7 @@ __global__ void __launch_bounds__(BM_THREADS) bm_scan_kernel(BmArgs a, int bpw, 
     int mx = (int)(idx % (uint32_t)D), my = (int)(idx / (uint32_t)D);
     // low-contrast rule (FastSpacedBMMethod.cl:2, :77-82): int difference vs double threshold
     if (a.low_contrast_rule) {
-      const uint32_t* sad = lds + (size_t)tid * slot_dwords + WW * WPD + sps * CPD;
-      const int diff = (int)sad[r * 4 * XG + r] - (int)best_sad;
+      const int diff = (int)centre[tid] - (int)best_sad;
       if ((double)diff <= (double)(r * r) * 0.2) {
         mx = r;
         my = r;
@@ -445,44 +519,128 @@ hipError_t launch_bm_refine_sad(const uint8_t* A, const uint8_t* B, int W2, int 
 }
 
 constexpr size_t BM_LDS_MAX = 160 * 1024;  // LDS of one CU on gfx950
+constexpr int BM_XB_MAX = 3;
 
-static size_t bm_slot_dwords(int block, int radius) {
-  const int D = 2 * radius + 1, XG = (D + 3) / 4, WW = block + 2 * radius;
-  const int WPD = XG + block / 4 + 1;
-  return (size_t)WW * WPD + (size_t)block * (block / 4) + (size_t)D * 4 * XG;
+// Launch shape of the generic scan for one geometry.
+struct BmPlan {
+  int xb = 0, g = 8, bpw = 0, wpd = 0, slot_dwords = 0, threads = 0;
+  size_t lds = 0;
+  double cost = 1e30;  // modelled issue cycles per useful v_qsad (16 = the instruction's own rate)
+};
+
+static int bm_env_int(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
 }
 
-static size_t bm_lds_bytes(int block, int radius, int bpw) {
-  return sizeof(uint32_t) * (bpw * bm_slot_dwords(block, radius) + 1) + 8 * (size_t)bpw;
+// LDS cycles of one window ds_read_b32 of a wave (two 32-lane groups, 32 banks; (ds_read_b32: 2 cycles conflict-free)
+static double bm_window_read_cycles(int D, int XGL, int xb, int wpd, int slot, int items) {
+  int total = 0, groups = 0;
+  for (int g0 = 0; g0 < items && g0 < 1024; g0 += 32, ++groups) {
+    int cnt[32] = {0}, worst = 0;
+    for (int l = 0; l < 32 && g0 + l < items; ++l) {
+      const int rem = (g0 + l) % (D * XGL);
+      const int bank = (((g0 + l) / (D * XGL)) * slot + (rem / XGL) * wpd + (rem % XGL) * xb) & 31;
+      worst = ++cnt[bank] > worst ? cnt[bank] : worst;
+    }
+    total += worst;
+  }
+  return groups ? 2.0 * total / groups : 2.0;
+}
+
+static BmPlan bm_plan(int block, int radius, int grid_x) {
+  const int D = 2 * radius + 1, XG = (D + 3) / 4, WW = block + 2 * radius, CPD = block / 4;
+  const int forced_xb = bm_env_int("MOF_BM_XB"), forced_bpw = bm_env_int("MOF_BM_BPW");
+  BmPlan best;
+  for (int xb = 1; xb <= BM_XB_MAX; ++xb) {
+    if (forced_xb && xb != forced_xb) continue;
+    const int XGL = (XG + xb - 1) / xb, per_block = D * XGL;
+    for (int pad = 0; pad < 8; ++pad) {
+      const int wpd = XGL * xb + CPD + 1 + pad;
+      const int slot = (WW * wpd + block * CPD + 1) & ~1;  // even: 8-byte LDS reads of the block rows, 64-bit keys behind
+      for (int bpw = 1; bpw <= 16 && bpw <= (grid_x > 0 ? grid_x : 1); ++bpw) {
+        if (forced_bpw && grid_x > 0 && bpw != forced_bpw && !(forced_bpw > grid_x && bpw == grid_x)) continue;
+        const int items = bpw * per_block;
+        const int threads = ((items + 63) / 64) * 64;
+        if (threads > BM_THREADS_MAX) break;
+        const size_t lds = sizeof(uint32_t) * (size_t)bpw * slot + 12 * (size_t)bpw;
+        if (lds > BM_LDS_MAX) break;
+        const int waves = threads / 64;
+        const int wgs_per_cu = (int)(BM_LDS_MAX / lds) < (32 / waves > 0 ? 32 / waves : 1) ? (int)(BM_LDS_MAX / lds) : (32 / waves > 0 ? 32 / waves : 1);
+        const int waves_per_cu = waves * (wgs_per_cu < 1 ? 1 : wgs_per_cu);
+        // per row step and wave: xb v_qsad (16 cycles each on its SIMD); one window + one block dword from the CU's LDS
+        const double valu = 16.0 * xb;
+        const double ldsc = 4.0 * (bm_window_read_cycles(D, XGL, xb, wpd, slot, items) + 2.0);  // four SIMDs share the LDS
+        double c = (valu > ldsc ? valu : ldsc) / xb;
+        c *= (double)(XGL * xb) / XG;                       // padded x-shift groups
+        c *= (double)(4 * XG) / D;                          // padded x-shifts of the last group
+        c *= (double)threads / items;                       // idle lanes of the last wave
+        const int groups = grid_x > 0 ? (grid_x + bpw - 1) / bpw : 1;
+        if (grid_x > 0) c *= (double)(groups * bpw) / grid_x;  // ragged last workgroup of a block row
+        if (waves_per_cu < 8) c *= 1.0 + 0.08 * (8 - waves_per_cu);  // little left to hide the staging phase behind
+        if (wgs_per_cu <= 1) c *= 1.3;                               // ... and nothing at all with one workgroup per CU
+        else if (wgs_per_cu == 2) c *= 1.08;
+        c *= 1.0 + 0.002 * pad;
+        if (c < best.cost) {
+          best.cost = c;
+          best.xb = xb, best.bpw = bpw, best.wpd = wpd, best.slot_dwords = slot, best.threads = threads, best.lds = lds;
+        }
+      }
+    }
+  }
+  return best;
 }
 
 // Block sizes up to 128 (the reference's default sample_point_size is 120, config/default.yaml:32) and radii up to 48
 // (its own limit is 2r + 1 <= 50, FastSpacedBMMethod.cl:1), as long as one block's window fits the LDS.
 bool bm_config_supported(int block, int radius) {
-  return block >= 4 && block <= 128 && (block % 4) == 0 && radius >= 1 && radius <= 48 &&
-         bm_lds_bytes(block, radius, 1) <= BM_LDS_MAX;
+  return block >= 4 && block <= 128 && (block % 4) == 0 && radius >= 1 && radius <= 48 && bm_plan(block, radius, 0).xb > 0;
+}
+
+template <int XB, int G>
+static hipError_t launch_bm_generic(const BmArgs& a, int n_pairs, const BmPlan& p, hipStream_t stream) {
+  if (p.lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bm_scan_kernel<XB, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+    if (e != hipSuccess) return e;
+  }
+  const int groups_per_row = (a.grid_x + p.bpw - 1) / p.bpw;
+  const unsigned wgs = (unsigned)n_pairs * (unsigned)(groups_per_row * a.grid_y);
+  hipLaunchKernelGGL((bm_scan_kernel<XB, G>), dim3(wgs), dim3(p.threads), p.lds, stream, a, p.bpw, groups_per_row, p.wpd, p.slot_dwords);
+  return hipGetLastError();
+}
+
+template <int XB>
+static hipError_t launch_bm_generic_g(const BmArgs& a, int n_pairs, const BmPlan& p, hipStream_t stream) {
+  switch (p.g) {
+    case 6: return launch_bm_generic<XB, 6>(a, n_pairs, p, stream);
+    case 7: return launch_bm_generic<XB, 7>(a, n_pairs, p, stream);
+    case 10: return launch_bm_generic<XB, 10>(a, n_pairs, p, stream);
+    default: return launch_bm_generic<XB, 8>(a, n_pairs, p, stream);
+  }
 }
 
 hipError_t launch_bm_scan(const BmArgs& a, int n_pairs, hipStream_t stream) {
   if (fast16_ok(a) && !getenv("MOF_BM_GENERIC")) {
     return a.radius == 16 ? launch_scan16<16>(a, n_pairs, stream) : launch_scan16<8>(a, n_pairs, stream);
   }
-  // blocks per workgroup: enough (slot, y-shift, x-group) items to fill the 256 lanes, within 64 KB of LDS
-  const int D = 2 * a.radius + 1, per_block = D * ((D + 3) / 4);
-  int bpw = BM_THREADS / per_block;
-  bpw = bpw < 1 ? 1 : (bpw > 8 ? 8 : bpw);
-  bpw = bpw > a.grid_x ? a.grid_x : bpw;
-  while (bpw > 1 && bm_lds_bytes(a.block, a.radius, bpw) > 64 * 1024) --bpw;
-  const size_t lds = bm_lds_bytes(a.block, a.radius, bpw);
-  if (lds > BM_LDS_MAX) return hipErrorInvalidValue;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bm_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+  BmPlan p = bm_plan(a.block, a.radius, a.grid_x);
+  if (p.xb == 0) return hipErrorInvalidValue;
+  // row chunk: the length in {10, 8, 6, 7} that leaves the shortest ragged tail, longer on ties
+  const int CPD = a.block / 4, cand[4] = {10, 8, 6, 7};
+  int best_tail = 1 << 30;
+  for (int g : cand) {
+    if (g > CPD && CPD >= 6) continue;
+    const int tail = CPD % g;
+    if (tail < best_tail) best_tail = tail, p.g = g;
   }
-  const int groups_per_row = (a.grid_x + bpw - 1) / bpw;
-  const unsigned wgs = (unsigned)n_pairs * (unsigned)(groups_per_row * a.grid_y);
-  hipLaunchKernelGGL(bm_scan_kernel, dim3(wgs), dim3(BM_THREADS), lds, stream, a, bpw, groups_per_row);
-  return hipGetLastError();
+  if (const int fg = bm_env_int("MOF_BM_G")) p.g = fg;
+  if (getenv("MOF_BM_VERBOSE"))
+    fprintf(stderr, "mof: block scan plan xb %d g %d bpw %d wpd %d threads %d lds %zu cost %.1f\n", p.xb, p.g, p.bpw, p.wpd, p.threads, p.lds, p.cost);
+  switch (p.xb) {
+    case 1: return launch_bm_generic_g<1>(a, n_pairs, p, stream);
+    case 2: return launch_bm_generic_g<2>(a, n_pairs, p, stream);
+    default: return launch_bm_generic_g<3>(a, n_pairs, p, stream);
+  }
 }
 
 hipError_t launch_bm_mode(const BmArgs& a, int n_pairs, hipStream_t stream) {
