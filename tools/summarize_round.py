@@ -43,7 +43,8 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{tag}_*"))):
         bench = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
         json.dump(bench, open(os.path.join(dst, f"{tag}_{wl}_bench.json"), "w"), indent=1)
     calls = {}
-    for st in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
+    # gpurun MERGES result files: a re-profiled workload leaves the older run's files beside the new ones -- newest only
+    for st in sorted(glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
         rows = list(csv.reader(open(st)))
         with open(os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.writer(f)
@@ -57,7 +58,9 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{tag}_*"))):
                     w.writerow([r[0][:120]] + r[1:])
                     others += 1
     agg = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv")):
+    newest = [sorted(glob.glob(os.path.join(pd, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]
+              for pd in glob.glob(os.path.join(d, "pmc_*")) if os.path.isdir(pd)]
+    for f in [x for fs in newest for x in fs]:
         for r in csv.DictReader(open(f)):
             if "mof::" in r["Kernel_Name"]:
                 agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -82,7 +85,10 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{tag}_*"))):
                "fetch_factors": {k: {"factor": f, "evidence": e} for k, (f, e) in FACTORS.items()},
                "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, profiles/{tag}_{wl}_pmc.csv",
                "kernels": detail}
-        json.dump(out, open(os.path.join(dst, f"traffic_{wl}.json"), "w"), indent=1)
         alg = bench["roofline"]["algorithmic_bytes_per_launch"] if bench else 0
+        if alg and per_step < 0.98 * alg:
+            out["note"] = ("below the bytes the kernels must fetch at least once: FETCH_SIZE under-reports this access pattern by an "
+                           "uncalibrated factor between 1 and 2 (see fetch_factors for the calibrated kernels) -- a lower bound only")
+        json.dump(out, open(os.path.join(dst, f"traffic_{wl}.json"), "w"), indent=1)
         print(f"{wl:6s} value {bench['value']:12.0f}  traffic/step {per_step / 1e6:9.1f} MB (raw {per_step_raw / 1e6:9.1f})  "
               f"= {per_step / alg if alg else 0:5.2f}x algorithmic")
