@@ -313,23 +313,36 @@ __global__ void __launch_bounds__(64) bm_scan16_kernel(BmArgs a, int strip_dword
   }
 
   // ---- stage the strip: 16-byte loads at any byte alignment (global_load_dwordx4 -> ds_write_b128);
-  //      strip_dwords is a multiple of 4; bytes beyond the strip are zero and never loaded
+  //      strip_dwords is a multiple of 4; bytes beyond the strip are zero and never loaded: the one chunk per row that
+  //      straddles the strip's right edge is loaded ENDING at the edge and shifted down by whole bytes (strip_w >= 48).
+  //      (The first form walked that chunk byte by byte -- every wave iteration holds a few such lanes, so all of them
+  //      paid 16 predicated byte loads: 1300 of the wave's 3800 VALU instructions.)
   {
     const int chunks = strip_dwords / 4;
+    const uint32_t m_chunks = div_magic((uint32_t)chunks);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll 2
     for (int i = lane; i < WW * chunks; i += 64) {
-      const int y = i / chunks, x = 16 * (i % chunks);
+      const int y = (int)fast_div((uint32_t)i, m_chunks), cx = i - y * chunks, x = 16 * cx;
       u32x4 v = {0u, 0u, 0u, 0u};
-      const uint8_t* src = prev + (size_t)y * a.pitch + x;
-      if (x + 16 <= strip_w) {
-        __builtin_memcpy(&v, src, 16);
-      } else {
-        uint32_t t[4] = {0u, 0u, 0u, 0u};
-        for (int q = 0; q < 16; ++q)
-          if (x + q < strip_w) t[q >> 2] |= (uint32_t)src[q] << (8 * (q & 3));
-        v = u32x4{t[0], t[1], t[2], t[3]};
+      if (x < strip_w) {
+        const int off = x + 16 <= strip_w ? x : strip_w - 16;
+        __builtin_memcpy(&v, prev + (size_t)y * a.pitch + off, 16);
+        const int d = x - off;  // 0, or 1..15 bytes for the edge chunk
+        if (d) {
+          const int q = d >> 2;
+          const uint32_t b = 8u * (uint32_t)(d & 3);
+          uint32_t t[8] = {v.x, v.y, v.z, v.w, 0u, 0u, 0u, 0u};
+          uint32_t u[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) u[k] = q == 0 ? t[k] : q == 1 ? t[k + 1] : q == 2 ? t[k + 2] : t[k + 3];
+          v.x = (uint32_t)((((uint64_t)u[1] << 32) | u[0]) >> b);
+          v.y = (uint32_t)((((uint64_t)u[2] << 32) | u[1]) >> b);
+          v.z = (uint32_t)((((uint64_t)u[3] << 32) | u[2]) >> b);
+          v.w = (uint32_t)((((uint64_t)u[4] << 32) | u[3]) >> b);
+        }
       }
-      *reinterpret_cast<u32x4*>(strip + (size_t)y * strip_dwords + 4 * (i % chunks)) = v;
+      *reinterpret_cast<u32x4*>(strip + (size_t)y * strip_dwords + 4 * cx) = v;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
