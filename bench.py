@@ -307,8 +307,9 @@ def measure_other(tag: str, dev, steps: int, warmup: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps (default 200: a 20-step burst ends before the GPU's clocks have settled and reads 13 %% low)")
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frame pairs per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -434,8 +435,8 @@ def main() -> None:
             del launch, eng, state, step
             torch.cuda.empty_cache()
             # driver-visible records of the other BASELINE configurations (same protocol, fewer steps)
-            line["other_workloads"] = {tag: measure_other(tag, dev, st, 2)
-                                       for tag, st in (("c3", 10), ("c4", 5), ("c5", 5), ("ref", 10))}
+            line["other_workloads"] = {tag: measure_other(tag, dev, st, 5)
+                                       for tag, st in (("c3", 50), ("c4", 10), ("c5", 20), ("ref", 50), ("bmref", 50))}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
