@@ -203,6 +203,12 @@ typedef struct mof_sr_config {
   double magnitude; /* log-polar magnitude M (scale_rot_magnitude, config/default.yaml:13: 49.9)      */
   int device;
   int logpolar_variant; /* MOF_LOGPOLAR_CV4 (0, default) or MOF_LOGPOLAR_CV3: see below              */
+  /* Batched mode only (no reference counterpart; zero-initialise for the defaults):                 */
+  int batch_chunk;      /* frame pairs per pipeline pass, 0 = default (512; 1..4096). The engine owns     */
+                        /* batch_chunk * (4 res^2 + 8 res^2 + 8 res (res/2+1)) bytes of scratch: 1.9 GB   */
+                        /* at 480^2 and 512 pairs                                                         */
+  int pipeline_lanes;   /* 0 = default (1), 1 = every pass on the caller's stream, 2 = the remap of pass  */
+                        /* k+1 runs beside the transforms of pass k on a second stream of the engine      */
 } mof_sr_config;
 
 /* The reference calls cv::logPolar under ROS Noetic (OpenCV 4.2) and the C API cvLogPolar under ROS Melodic

@@ -42,7 +42,8 @@ class FftConfig(C.Structure):
 
 
 class SrConfig(C.Structure):
-    _fields_ = [("resolution", C.c_int), ("magnitude", C.c_double), ("device", C.c_int), ("logpolar_variant", C.c_int)]
+    _fields_ = [("resolution", C.c_int), ("magnitude", C.c_double), ("device", C.c_int), ("logpolar_variant", C.c_int),
+                ("batch_chunk", C.c_int), ("pipeline_lanes", C.c_int)]
 
 
 class BmConfig(C.Structure):

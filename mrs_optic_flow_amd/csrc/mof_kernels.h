@@ -82,6 +82,7 @@ struct SrLpArgs {
   size_t dst_stride;
   const SrMapEntry* map;   // res*res
   const int16_t* weights;  // [1024][K*K]
+  const uint32_t* wplanes; // [1024][K*K/2 + 2]: signed-byte planes of the same weights (sr_weight_planes), staged kernel
   int res;
   int zero_invalid;        // 1: pixels mapped outside the source are written as 0 (destination known to start as zeros)
   const SrTileBox* boxes;  // [tiles*tiles] for THIS interpolation's footprint size
@@ -105,6 +106,10 @@ struct SrPcArgs {
 // host-side tables of cv::logPolar / cv::remap (mof_sr.hip); exposed so that the CPU suite can compare them with the oracle
 std::vector<SrMapEntry> sr_logpolar_map(int res, double M, int variant);
 std::vector<int16_t> sr_weight_table(int ksize /* 4 cubic, 8 Lanczos4 */);  // [32*32][ksize*ksize], each summing to 2^15
+// The same weights as two planes of signed bytes, w = 256 hi + lo, four taps per dword, for v_dot4c_i32_i8 against
+// (pixel - 128): per table row K*K/4 dwords hi, K*K/4 dwords lo, then 128 * sum(w) and the index of the one tap whose
+// hi would be 128 (kept at 127; -1 if none): sum w p = 256 sum hi p' + sum lo p' + 128 sum w [+ 256 p'(tap)].
+std::vector<uint32_t> sr_weight_planes(const std::vector<int16_t>& weights, int ksize);
 // per-tile footprint boxes for a ksize x ksize kernel; *lds_per_wave receives the LDS bytes of the largest one
 std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave);
 

@@ -31,19 +31,23 @@ namespace {
 constexpr int kTab = 32;            // INTER_TAB_SIZE
 constexpr int kCoefScale = 1 << 15; // INTER_REMAP_COEF_SCALE
 #ifndef MOF_SR_CHUNK
-#define MOF_SR_CHUNK 256
+#define MOF_SR_CHUNK 512
 #endif
-// frame pairs per pipeline pass: 256 pairs of 480^2 = 0.83 GB of scratch (log-polar images, Zt, Dt); same-box sweep r02
-// (tools/sweep_c5.sh): 64 / 128 / 256 pairs -> 201 / 209 / 214 k pairs/s at c5
+// frame pairs per pipeline pass: 512 pairs of 480^2 = 1.9 GB of scratch (log-polar images, Zt, Dt). Same-box sweeps at c5
+// (tools/sweep_c5.sh, profiles/r02_c5_sweep.txt): 64 / 128 / 256 pairs -> 240 / 277 / 308 k pairs/s on one lane, 512 ->
+// 326 k, 1024 -> 324 k; with the second lane 254 / 283 / 312 / 318 / 313 k -- once a pass is long enough to fill the
+// chip the two-lane overlap has nothing left to hide, so one lane is the default.
 constexpr int kChunkDefault = MOF_SR_CHUNK;
-// frame pairs per pipeline pass of an engine; MOF_SR_CHUNK in the environment overrides the default at create() (diagnostic)
-int chunk_pairs() {
-  static const int v = [] {
-    const char* e = getenv("MOF_SR_CHUNK");
-    const int n = e ? atoi(e) : 0;
-    return n >= 1 && n <= 4096 ? n : kChunkDefault;
-  }();
-  return v;
+// mof_sr_config.batch_chunk / .pipeline_lanes; MOF_SR_CHUNK / MOF_SR_OVERLAP in the environment override both at
+// create() (sweeps)
+int chunk_pairs(int cfg_chunk) {
+  const char* e = getenv("MOF_SR_CHUNK");
+  const int n = e ? atoi(e) : cfg_chunk;
+  return n >= 1 && n <= 4096 ? n : kChunkDefault;
+}
+bool two_lane_default(int cfg_lanes) {
+  const char* v = getenv("MOF_SR_OVERLAP");
+  return v ? atoi(v) != 0 : cfg_lanes == 2;
 }
 
 #define SR_TRY(expr)                                                                                  \
@@ -162,6 +166,31 @@ std::vector<SrMapEntry> sr_logpolar_map(int res, double M, int variant) {
 
 std::vector<int16_t> sr_weight_table(int ksize) { return weight_table(ksize); }
 
+std::vector<uint32_t> sr_weight_planes(const std::vector<int16_t>& weights, int ksize) {
+  const int kk = ksize * ksize, stride = kk / 2 + 2;
+  const size_t rows = weights.size() / kk;
+  std::vector<uint32_t> out(rows * stride, 0u);
+  for (size_t r = 0; r < rows; ++r) {
+    uint32_t* o = out.data() + r * stride;
+    int sum = 0, rem = -1;
+    for (int t = 0; t < kk; ++t) {
+      const int w = weights[r * kk + t];
+      const int lo = (int)(int8_t)(w & 0xff);
+      int hi = (w - lo) >> 8;
+      if (hi > 127) {
+        hi = 127;  // w >= 32640: at most one tap of a footprint (the weights sum to 2^15)
+        rem = t;
+      }
+      sum += w;
+      o[t / 4] |= (uint32_t)(hi & 0xff) << (8 * (t % 4));
+      o[kk / 4 + t / 4] |= (uint32_t)(lo & 0xff) << (8 * (t % 4));
+    }
+    o[kk / 2] = (uint32_t)(128 * sum);
+    o[kk / 2 + 1] = (uint32_t)rem;
+  }
+  return out;
+}
+
 std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave) {
   const int tiles = (res + 7) / 8, half = ksize / 2 - 1;
   std::vector<SrTileBox> boxes((size_t)tiles * tiles, SrTileBox{0, 0, 0, 0});
@@ -222,6 +251,7 @@ struct mof_sr_engine {
   int lds_per_wave[2] = {0, 0};
   int16_t* d_w_cubic = nullptr;
   int16_t* d_w_lanczos = nullptr;
+  uint32_t* d_wp[2] = {nullptr, nullptr};  // byte planes of the two tables (cubic, Lanczos4)
   float* d_twiddles = nullptr;
   uint8_t* d_frame = nullptr;    // staging for the stateful path (res*res)
   uint8_t* d_temp_im = nullptr;  // tempIm, :27
@@ -233,6 +263,7 @@ struct mof_sr_engine {
   uint8_t* h_stage = nullptr;
   double* h_out = nullptr;
   int chunk = 0;                 // frame pairs per pipeline pass (sizes the scratch)
+  bool two_lanes = false;        // remap of pass k+1 beside the transforms of pass k (mof_sr_config.pipeline_lanes == 2)
   bool first = true;             // :31
   std::atomic<bool> busy{false};
   // Ordering of the engine-owned scratch (d_lp, d_Zt, d_Dt, d_cand, d_out) across streams: every call that
@@ -289,7 +320,7 @@ void mof_sr_destroy(mof_sr_engine* e) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
-  void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_twiddles, e->d_frame, e->d_temp_im, e->d_prev_lp,
+  void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_wp[0], e->d_wp[1], e->d_twiddles, e->d_frame, e->d_temp_im, e->d_prev_lp,
                  e->d_lp,  e->d_Zt,      e->d_Dt,        e->d_cand,     e->d_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -310,6 +341,8 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   if (!cfg || !(cfg->magnitude > 0.0)) return mof::capi_fail(MOF_ERR_BAD_ARG, "bad scale/rotation config");
   if (cfg->logpolar_variant != MOF_LOGPOLAR_CV4 && cfg->logpolar_variant != MOF_LOGPOLAR_CV3)
     return mof::capi_fail(MOF_ERR_BAD_ARG, "logpolar_variant must be MOF_LOGPOLAR_CV4 (0) or MOF_LOGPOLAR_CV3 (1)");
+  if (cfg->batch_chunk < 0 || cfg->batch_chunk > 4096 || cfg->pipeline_lanes < 0 || cfg->pipeline_lanes > 2)
+    return mof::capi_fail(MOF_ERR_BAD_ARG, "batch_chunk must be 0..4096 and pipeline_lanes 0..2");
   if (!mof::sr_resolution_supported(cfg->resolution))
     return mof::capi_fail(MOF_ERR_UNSUPPORTED, "resolution %d not supported by the HIP pipeline (240, 256, 480)", cfg->resolution);
   int ndev = 0;
@@ -329,7 +362,8 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   mof_sr_engine* e = new (std::nothrow) mof_sr_engine();
   if (!e) return mof::capi_fail(MOF_ERR_NO_MEMORY, "out of host memory");
   e->cfg = *cfg;
-  e->chunk = chunk_pairs();
+  e->chunk = chunk_pairs(cfg->batch_chunk);
+  e->two_lanes = two_lane_default(cfg->pipeline_lanes);
   const int kChunk = e->chunk;
   for (int k = 0; k < res; ++k) {
     double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)res;
@@ -371,6 +405,13 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   CREATE_TRY(hipMemcpy(e->d_w_cubic, wc.data(), wc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_w_lanczos, wl.size() * sizeof(int16_t)));
   CREATE_TRY(hipMemcpy(e->d_w_lanczos, wl.data(), wl.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  {
+    const std::vector<uint32_t> pc = mof::sr_weight_planes(wc, 4), pl = mof::sr_weight_planes(wl, 8);
+    CREATE_TRY(hipMalloc(&e->d_wp[0], pc.size() * sizeof(uint32_t)));
+    CREATE_TRY(hipMemcpy(e->d_wp[0], pc.data(), pc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&e->d_wp[1], pl.size() * sizeof(uint32_t)));
+    CREATE_TRY(hipMemcpy(e->d_wp[1], pl.data(), pl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   CREATE_TRY(hipMalloc(&e->d_twiddles, tw.size() * sizeof(float)));
   CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_frame, nn));
@@ -406,6 +447,7 @@ int mof_sr_reset(mof_sr_engine* e) {
 static void lp_tables(const mof_sr_engine* e, int interp, mof::SrLpArgs* lp) {
   const int k = interp == 2 ? 0 : 1;
   lp->weights = k == 0 ? e->d_w_cubic : e->d_w_lanczos;
+  lp->wplanes = e->d_wp[k];
   lp->boxes = e->d_boxes[k];
   lp->lds_per_wave = e->lds_per_wave[k];
   lp->box_dwords_max = e->lds_per_wave[k] / 4;
@@ -486,11 +528,9 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
   const size_t nn = (size_t)res * res;
   SR_TRY(scratch_acquire(e, s));
   const int kChunk = e->chunk;
-  // MOF_SR_OVERLAP=0: everything on the caller's stream (diagnostic A/B)
-  static const bool overlap_on = [] { const char* v = getenv("MOF_SR_OVERLAP"); return !v || atoi(v) != 0; }();
   // Under graph capture the fork / join below pulls the engine's stream into the caller's capture (event record on the
   // capturing stream, wait on the other), so a captured batch replays with the same two lanes.
-  const bool two_lanes = overlap_on && n_pairs > kChunk;
+  const bool two_lanes = e->two_lanes && n_pairs > kChunk;
   hipStream_t sr = two_lanes ? e->remap_stream : s;
   if (two_lanes) {  // fork: the remap lane starts behind whatever the caller's stream holds (also under graph capture)
     SR_TRY(hipEventRecord(e->ev_fork, s));

@@ -273,8 +273,16 @@ __global__ void __launch_bounds__(1024) sr_logpolar_lds_kernel(SrLpArgs a, int n
 // BEFORE the taps of image i are gathered (U images form a group whose boxes travel together), so the memory latency
 // hides behind the arithmetic.
 // Needs pitch % 4 == 0 and src_stride % 4 == 0 (then a row's misalignment is the same for every row and image).
+#ifdef MOF_LP_WPE
+#define MOF_LP_ATTR __attribute__((amdgpu_waves_per_eu(MOF_LP_WPE, MOF_LP_WPE)))
+#else
+#define MOF_LP_ATTR
+#endif
+#ifndef MOF_LP_U
+#define MOF_LP_U 1
+#endif
 template <int K, int NR, int U>
-__global__ void __launch_bounds__(256) sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave, int xcd_groups) {
+__global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave, int xcd_groups) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lp_lds[];
   const int res = a.res, tiles = (res + 7) / 8, n_tiles = tiles * tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -309,10 +317,25 @@ __global__ void __launch_bounds__(256) sr_logpolar_staged_kernel(SrLpArgs a, int
       for (int img = img0; img < img1; ++img, dst += a.dst_stride) *dst = 0;
     return;
   }
-  uint32_t wq[K * K / 2];  // this pixel's K x K int16 weights, two per dword
+  // This pixel's K x K int16 weights as two planes of SIGNED bytes, w = 256 wh + wl, four taps per dword: the staged
+  // pixels are kept as signed bytes too (p - 128, one xor when a box is committed), so a tap row is K/4 pairs of
+  // v_dot4c_i32_i8 on the raw window bytes -- the u8 -> u16 spreading of the 16-bit form (two v_perm per dword) is gone:
+  //   sum w p = 256 sum wh (p - 128) + sum wl (p - 128) + 128 sum w.
+  // wh would be 128 for a weight >= 32640 (the one tap of a footprint that sits on a source pixel: 32767); it is kept
+  // at 127 and the missing 256 (p - 128) of that tap is added after the rows (`rem_*`, at most one tap per pixel).
+  // The planes are built on the host (sr_weight_planes): splitting 64 int16 in the kernel cost 70 VGPRs of set-up.
+  uint32_t wh[K * K / 4], wl[K * K / 4];
+  int wconst = 0, rem_k = -1;
+  {
+    uint32_t t[K * K / 2 + 2];
 #pragma unroll
-  for (int i = 0; i < K * K / 2; ++i) wq[i] = 0;
-  if (valid) __builtin_memcpy(wq, __builtin_assume_aligned(a.weights + (size_t)m.widx * (K * K), 2 * K), 2 * K * K);
+    for (int i = 0; i < K * K / 2 + 2; ++i) t[i] = 0;
+    if (valid) __builtin_memcpy(t, __builtin_assume_aligned(a.wplanes + (size_t)m.widx * (K * K / 2 + 2), 8), sizeof(t));
+#pragma unroll
+    for (int i = 0; i < K * K / 4; ++i) wh[i] = t[i], wl[i] = t[K * K / 4 + i];
+    wconst = (int)t[K * K / 2];
+    rem_k = valid ? (int)t[K * K / 2 + 1] : -1;
+  }
   // the box: bw x bh source pixels at (bx, by); LDS rows of lpd dwords; every row starts `mis` bytes into its first dword
   const SrTileBox box = a.boxes[tile];
   const int bx = box.x0, by = box.y0, bw = box.w, bh = box.h;
@@ -389,9 +412,57 @@ __global__ void __launch_bounds__(256) sr_logpolar_staged_kernel(SrLpArgs a, int
       if (u < n) {
 #pragma unroll
         for (int t = 0; t < NR; ++t)
-          if (t < T) L[u * box_dwords + (((okmask >> t) & 1u) ? lane + 64 * t : box_dwords - 64 + lane)] = stage[u][t];
+          if (t < T) L[u * box_dwords + (((okmask >> t) & 1u) ? lane + 64 * t : box_dwords - 64 + lane)] = stage[u][t] ^ 0x80808080u;
       }
   };
+  // the tap that carries `rem`: LDS dword (relative to the box row start of its tap row) and byte within it
+  int rem_off = 0;
+  uint32_t rem_sh = 0;
+  if (rem_k >= 0) {
+    const int k1 = rem_k / K, k2 = rem_k % K;
+#pragma unroll
+    for (int i = 0; i < K; ++i) rem_off = i == k1 ? rowoff[i] : rem_off;
+    const uint32_t byte = sh + ((sel[k2 >> 2] >> (8 * (k2 & 3))) & 0xffu);  // position of tap k2 in the row's window
+    rem_off += lcol + (int)(byte >> 2);
+    rem_sh = 8u * (byte & 3u);
+  }
+  const bool wave_rem = __ballot(valid && rem_k >= 0) != 0ull;
+  // columns reflected at the border need the byte permute; interior waves (nearly all) skip it
+  const bool wave_border = __ballot(valid && (sx < 0 || sx + K > res)) != 0ull;
+
+  auto gather = [&](auto border_c, const uint32_t* Lu) -> int {
+    constexpr bool BORDER = decltype(border_c)::value;
+    int s_hi = 0, s_lo = 0;
+#pragma unroll
+    for (int k1 = 0; k1 < K; ++k1) {
+      const uint32_t* p = Lu + rowoff[k1] + lcol;
+      uint32_t px[K / 4];
+      if constexpr (K == 8) {
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        px[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        px[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        if constexpr (BORDER) {
+          const uint32_t a0 = px[0], a1 = px[1];
+          px[0] = __builtin_amdgcn_perm(a1, a0, sel[0]);
+          px[1] = __builtin_amdgcn_perm(a1, a0, sel[1]);
+        }
+      } else {
+        const uint32_t d0 = p[0], d1 = p[1];
+        px[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        if constexpr (BORDER) px[0] = __builtin_amdgcn_perm(0u, px[0], sel[0]);
+      }
+#pragma unroll
+      for (int d = 0; d < K / 4; ++d) {
+        s_hi = __builtin_amdgcn_sdot4((int)px[d], (int)wh[k1 * (K / 4) + d], s_hi, false);
+        s_lo = __builtin_amdgcn_sdot4((int)px[d], (int)wl[k1 * (K / 4) + d], s_lo, false);
+      }
+    }
+    int sum = 256 * s_hi + s_lo + wconst;
+    if (wave_rem && rem_k >= 0) sum += 256 * (int)(int8_t)(Lu[rem_off] >> rem_sh);
+    int v = (sum + (1 << 14)) >> 15;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+  };
+
   int n_cur = img1 - img0 < U ? img1 - img0 : U;
   fetch(b0, n_cur);
   commit(n_cur);
@@ -405,24 +476,8 @@ __global__ void __launch_bounds__(256) sr_logpolar_staged_kernel(SrLpArgs a, int
       if (u < n_cur) {
         int v = 0;
         if (valid) {
-          int sum = 0;
-#pragma unroll
-          for (int k1 = 0; k1 < K; ++k1) {
-            const uint32_t* p = L + u * box_dwords + rowoff[k1] + lcol;
-            uint32_t px[K / 4];
-            if constexpr (K == 8) {
-              const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-              const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-              px[0] = __builtin_amdgcn_perm(a1, a0, sel[0]);
-              px[1] = __builtin_amdgcn_perm(a1, a0, sel[1]);
-            } else {
-              const uint32_t d0 = p[0], d1 = p[1];
-              px[0] = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(d1, d0, sh), sel[0]);
-            }
-            sum = dot_row<K>(px, wq + k1 * (K / 2), sum);
-          }
-          v = (sum + (1 << 14)) >> 15;
-          v = v < 0 ? 0 : (v > 255 ? 255 : v);
+          const uint32_t* Lu = L + u * box_dwords;
+          v = wave_border ? gather(std::true_type{}, Lu) : gather(std::false_type{}, Lu);
         }
         if (valid || (a.zero_invalid && inside)) dst[(size_t)u * a.dst_stride] = (uint8_t)v;
       }
@@ -719,7 +774,7 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
   // (MOF_SR_LP_STAGED=0 falls back to the table-in-LDS formulation, kept for A/B runs and unaligned layouts)
   static const bool staged_on = [] { const char* e = getenv("MOF_SR_LP_STAGED"); return !e || atoi(e) != 0; }();
   constexpr int NR = 16;
-  if (staged_on && !global_w && n_images >= 4 && a.pitch % 4 == 0 && a.src_stride % 4 == 0 && a.boxes &&
+  if (staged_on && !global_w && n_images >= 4 && a.pitch % 4 == 0 && a.src_stride % 4 == 0 && a.boxes && a.wplanes &&
       a.box_dwords_max <= 64 * NR && 8 * (size_t)(a.lds_per_wave + 256) <= 64 * 1024) {
     const int tiles = (a.res + 7) / 8, n_tiles = tiles * tiles;
     // images per wave: long runs amortise the per-tile set-up; short ones keep the images that the resident waves
@@ -731,7 +786,7 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
     const int nq = (n_tiles + 3) / 4;
     const int xcd_groups = (groups >= 8 && !xcd_off) ? groups : 0;  // fewer than 8 groups would leave XCDs idle
     const unsigned blocks = xcd_groups ? (unsigned)(8 * ((groups + 7) / 8) * nq) : (unsigned)(((long)n_tiles * groups + 3) / 4);
-    constexpr int U = 2;  // images per group: their boxes are in flight together (two boxes of a few KB per wave)
+    constexpr int U = MOF_LP_U;  // images per group (1: 127 VGPRs = four waves per SIMD; 2 needs 209 and measured 5 % slower)
     const size_t lds = (size_t)4 * U * (a.lds_per_wave + 256);
     if (interp == 2)
       hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, U>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);

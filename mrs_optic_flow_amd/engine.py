@@ -345,11 +345,12 @@ class ScaleRotationEstimator:
     returns (scale, rotation [rad]) like :34-148."""
 
     def __init__(self, resolution: int, m: float = 49.9, storeVideo: bool = False, videoPath=None, videoFPS: int = 30,
-                 device: int = 0, logpolar_variant: int = 0):
+                 device: int = 0, logpolar_variant: int = 0, batch_chunk: int = 0, pipeline_lanes: int = 0):
         """logpolar_variant: LOGPOLAR_CV4 (cv::logPolar of OpenCV 4.x, ROS Noetic) or LOGPOLAR_CV3 (cvLogPolar of OpenCV 3.2,
-        ROS Melodic) -- the two calls scaleRotationEstimator.cpp:41-46 compiles."""
+        ROS Melodic) -- the two calls scaleRotationEstimator.cpp:41-46 compiles. batch_chunk / pipeline_lanes: batched mode
+        only (frame pairs per pipeline pass, one or two stream lanes; 0 = the library's defaults, see mof.h)."""
         self._lib = _capi.load()
-        self.cfg = SrConfig(resolution, float(m), device, int(logpolar_variant))
+        self.cfg = SrConfig(resolution, float(m), device, int(logpolar_variant), int(batch_chunk), int(pipeline_lanes))
         self._h = C.c_void_p()
         check(self._lib.mof_sr_create(C.byref(self.cfg), C.byref(self._h)))
 

@@ -107,9 +107,11 @@ def test_logpolar_remap_is_byte_exact(gpu, res, M, interp, variant):
     assert np.array_equal(zero, O.logpolar(frames[0], M, interp, variant=variant))
 
 
-def test_c5_batch_crossing_the_pipeline_chunk(gpu):
-    """More pairs than one pass of the scale/rotation pipeline holds (the chunk size is an internal constant, 256 pairs):
-    every pair, on both sides of the chunk boundary, equals the same pair processed alone, and samples match the oracle."""
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_c5_batch_crossing_the_pipeline_chunk(gpu, lanes):
+    """More pairs than one pass of the scale/rotation pipeline holds (mof_sr_config.batch_chunk, here 128 pairs; one
+    stream lane and the two-lane remap / transform overlap): every pair, on both sides of the pass boundaries, equals
+    the same pair processed alone, and samples match the oracle."""
     res, M, B = 240, 40.0, 300
     base = sr_scenes.canvas(91, res)
     protos = [(1.0, 0.0), (1.03, 2.0), (0.96, -3.0), (1.0, 5.0), (1.08, -1.0), (0.9, 8.0), (1.01, 0.5)]
@@ -117,11 +119,11 @@ def test_c5_batch_crossing_the_pipeline_chunk(gpu):
     idx = np.arange(B) % len(protos)
     cur = torch.from_numpy(views[idx]).to(gpu)
     prev = torch.from_numpy(views[(idx * 3 + 1) % len(protos)]).to(gpu)
-    est = ScaleRotationEstimator(res, M)
+    est = ScaleRotationEstimator(res, M, batch_chunk=128, pipeline_lanes=lanes)
     got = est.process_batch_device(cur, prev)
     torch.cuda.synchronize()
     got = got.cpu().numpy()
-    for k in (0, 15, 16, 31, 32, 63, 64, 65, 127, 128, 149, 254, 255, 256, 257, 299):
+    for k in (0, 15, 16, 31, 32, 63, 64, 65, 127, 128, 129, 149, 254, 255, 256, 257, 299):
         alone = est.process_batch_device(cur[k:k + 1], prev[k:k + 1]).cpu().numpy()[0]
         assert np.array_equal(alone, got[k]), k
     # the (cur, prev) prototypes of pair k depend on k mod 7 only: identical bits wherever a pair sits in the batch
@@ -298,12 +300,11 @@ def test_long_range_gate_is_held_in_ints(gpu):
 
 
 def test_multi_pass_batch_is_graph_capturable(gpu):
-    """A scale/rotation batch longer than one pipeline pass runs as two lanes (remaps on the engine's own stream beside
-    the transforms). Under HIP-graph capture the engine's stream joins the caller's capture by an event fork / join and
-    the graph must replay to the bits of the eager run. Run in a child process with MOF_SR_CHUNK=2 (seven pairs = four
-    passes) at 240 and 480."""
+    """A scale/rotation batch longer than one pipeline pass, on one lane and as two lanes (pipeline_lanes = 2: remaps on
+    the engine's own stream beside the transforms). Under HIP-graph capture the engine's stream joins the caller's capture
+    by an event fork / join and the graph must replay to the bits of the eager run. Run in a child process (batch_chunk =
+    2: seven pairs = four passes) at 240 and 480."""
     script = os.path.join(ROOT, "tools", "check_graph_capture.py")
     for res in ("240", "480"):
-        r = subprocess.run([sys.executable, script, res], env=dict(os.environ, MOF_SR_CHUNK="2"), capture_output=True,
-                           text=True, timeout=300)
+        r = subprocess.run([sys.executable, script, res], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and f"graph ok {res}" in r.stdout, (r.stdout + r.stderr)[-2000:]

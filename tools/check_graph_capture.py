@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Small-scale check that a multi-pass scale/rotation batch can be captured into a HIP graph and replayed
-(run with MOF_SR_CHUNK=2 so that 7 pairs take four pipeline passes). Prints 'graph ok' or raises."""
+(batch_chunk = 2 so that 7 pairs take four pipeline passes; both lane settings, the two-lane form forks the
+engine's second stream into the capture). Prints 'graph ok' or raises."""
 import os
 import sys
 
-os.environ.setdefault("MOF_SR_CHUNK", "2")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
@@ -20,17 +20,19 @@ views = np.stack([sr_scenes.view(base, res, 1.0 + 0.01 * k, 1.5 * k) for k in ra
 idx = np.arange(n_pairs) % 7
 cur = torch.from_numpy(views[1:][idx]).cuda()
 prev = torch.from_numpy(views[:-1][idx]).cuda()
-est = ScaleRotationEstimator(res, 45.0)
-want = est.process_batch_device(cur, prev).clone()   # eager: two lanes
-torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-side = torch.cuda.Stream()
-with torch.cuda.stream(side):
-    with torch.cuda.graph(g, stream=side):
-        out = est.process_batch_device(cur, prev)    # captured: one lane
-out.zero_()
-for _ in range(3):
-    g.replay()
-torch.cuda.synchronize()
-assert torch.equal(out, want), (out, want)
+for lanes in (1, 2):
+    est = ScaleRotationEstimator(res, 45.0, batch_chunk=2, pipeline_lanes=lanes)
+    want = est.process_batch_device(cur, prev).clone()   # eager
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            out = est.process_batch_device(cur, prev)    # captured
+    out.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want), (lanes, out, want)
+    del g, est
 print("graph ok", res, n_pairs)
