@@ -120,6 +120,15 @@ struct StoreNatural {
   }
 };
 
+// compile-time loop: the body sees its index as an integral_constant
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 }  // namespace
 
 // Eight (four) taps of one footprint row: the u8 pixels are spread to u16 pairs with v_perm_b32 and meet the int16
@@ -273,15 +282,19 @@ __global__ void __launch_bounds__(1024) sr_logpolar_lds_kernel(SrLpArgs a, int n
 // BEFORE the taps of image i are gathered (U images form a group whose boxes travel together), so the memory latency
 // hides behind the arithmetic.
 // Needs pitch % 4 == 0 and src_stride % 4 == 0 (then a row's misalignment is the same for every row and image).
+// LDS dwords of a wave's box: whole 64-lane slot rows of the ring class (4, 8 or 16 dwords per lane) that holds the
+// largest box of the map
+__host__ __device__ inline int lp_box_capacity(int box_dwords_max) {
+  const int t = (box_dwords_max + 63) / 64;
+  return 64 * (t <= 4 ? 4 : (t <= 8 ? 8 : 16));
+}
+
 #ifdef MOF_LP_WPE
 #define MOF_LP_ATTR __attribute__((amdgpu_waves_per_eu(MOF_LP_WPE, MOF_LP_WPE)))
 #else
 #define MOF_LP_ATTR
 #endif
-#ifndef MOF_LP_U
-#define MOF_LP_U 1
-#endif
-template <int K, int NR, int U>
+template <int K, int NR>
 __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave, int xcd_groups) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lp_lds[];
   const int res = a.res, tiles = (res + 7) / 8, n_tiles = tiles * tiles;
@@ -348,7 +361,6 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
   // that the T = ceil(cnt / 64) loads and LDS writes of a box are unconditional for the whole wave.
   const int T = __builtin_amdgcn_readfirstlane((cnt + 63) / 64);
   uint32_t goff[NR];
-  uint32_t okmask = 0;
   {
     // (row, dword) of slot lane + 64 t, advanced by 64 slots per step: two integer divisions per wave instead of 2 NR
     int r = lane / lpd, j = lane % lpd;
@@ -357,7 +369,6 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
     for (int t = 0; t < NR; ++t) {
       const bool ok = lane + 64 * t < cnt && 4 * j < (int)mis + bw;
       goff[t] = ok ? (uint32_t)r * (uint32_t)a.pitch + 4u * (uint32_t)j : 0u;
-      okmask |= ok ? (1u << t) : 0u;
       j += dj;
       r += dr;
       if (j >= lpd) {
@@ -366,8 +377,8 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
       }
     }
   }
-  const int box_dwords = a.lds_per_wave / 4 + 64;  // + the dump slots
-  uint32_t* L = lp_lds + (size_t)wave * U * box_dwords;  // U boxes: the images of one group
+  const int box_dwords = lp_box_capacity(a.box_dwords_max);
+  uint32_t* L = lp_lds + (size_t)wave * box_dwords;  // the wave's box: one image at a time
   // Footprints that cross the border take BORDER_REFLECT_101 taps. They go through the SAME code as interior ones:
   // tap row k1 is source row reflect(sy + k1); the K taps of a row are read as the K-byte window starting at
   // wx = clamp(sx, 0, res - K) -- it holds every reflected column -- and put in tap order by one byte permute
@@ -396,25 +407,6 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
   const uint32_t o = valid ? (uint32_t)(wx - bx) + mis : 0u;
   const int lcol = (int)(o >> 2);
   const uint32_t sh = o & 3u;
-  uint32_t stage[U][NR];
-  auto fetch = [&](const uint8_t* base, int n) {  // the boxes of the next n images into registers
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (u < n) {
-#pragma unroll
-        for (int t = 0; t < NR; ++t)
-          if (t < T) stage[u][t] = *reinterpret_cast<const uint32_t*>(base + (size_t)u * a.src_stride + goff[t]);
-      }
-  };
-  auto commit = [&](int n) {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (u < n) {
-#pragma unroll
-        for (int t = 0; t < NR; ++t)
-          if (t < T) L[u * box_dwords + (((okmask >> t) & 1u) ? lane + 64 * t : box_dwords - 64 + lane)] = stage[u][t] ^ 0x80808080u;
-      }
-  };
   // the tap that carries `rem`: LDS dword (relative to the box row start of its tap row) and byte within it
   int rem_off = 0;
   uint32_t rem_sh = 0;
@@ -463,31 +455,71 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
     return v < 0 ? 0 : (v > 255 ? 255 : v);
   };
 
-  int n_cur = img1 - img0 < U ? img1 - img0 : U;
-  fetch(b0, n_cur);
-  commit(n_cur);
-  wave_sync();
-  for (int img = img0; img < img1; img += U) {
-    const int left = img1 - (img + U);
-    const int n_next = left <= 0 ? 0 : (left < U ? left : U);
-    if (n_next > 0) fetch(b0 + (size_t)U * a.src_stride, n_next);  // in flight while this group is gathered
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (u < n_cur) {
-        int v = 0;
-        if (valid) {
-          const uint32_t* Lu = L + u * box_dwords;
-          v = wave_border ? gather(std::true_type{}, Lu) : gather(std::false_type{}, Lu);
-        }
-        if (valid || (a.zero_invalid && inside)) dst[(size_t)u * a.dst_stride] = (uint8_t)v;
-      }
-    wave_sync();  // every lane has read this group's boxes ...
-    commit(n_next);
-    wave_sync();  // ... and sees the next group's
-    n_cur = n_next;
-    b0 += (size_t)U * a.src_stride;
-    dst += (size_t)U * a.dst_stride;
+  // ---- the image loop. NR staging registers per lane form a ring of D = min(4, NR / TC) boxes of up to TC dwords per
+  // lane (TC = the smallest of 1, 2, 3, 4, 6, 8, 12, 16 that holds this tile's T): the boxes of the next D images are in flight while one
+  // image is gathered from the wave's single LDS box. One image's gather is ~60 VALU instructions, a fraction of a
+  // memory round trip, so a depth of one (r02 first form: 52 % VALU-busy at 14 waves per CU) left the waves waiting.
+  // Loads, LDS writes and the ring are unconditional (slots past the box re-read its first dword and land in LDS
+  // dwords nobody reads) so that the compiler's counted s_waitcnt vmcnt keeps the younger boxes in flight; images past
+  // the wave's last one re-fetch that last image and are not gathered.
+  // wave-uniform base in SGPRs + 32-bit lane offsets: global_load_dword v, v_off, s[base] -- no per-load address
+  // arithmetic (the explicit global address space keeps the rebuilt pointer from degrading to flat loads, whose
+  // waits cannot be counted per box)
+  typedef const __attribute__((address_space(1))) uint8_t* gbytes_t;
+  typedef const __attribute__((address_space(1))) uint32_t* gwords_t;
+  gbytes_t base_u;
+  {
+    const uint64_t b = (uint64_t)(uintptr_t)b0;
+    base_u = (gbytes_t)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b));
   }
+  const size_t img_stride = a.src_stride;
+  const int n_img = __builtin_amdgcn_readfirstlane(img1 - img0);  // wave-uniform (the analysis cannot see it: img0 depends on the wave index)
+  uint32_t ring[NR];
+  auto pipeline = [&](auto tc_c) {
+    constexpr int TC = decltype(tc_c)::value, D = NR / TC < 4 ? NR / TC : 4;
+    auto fetch = [&](auto slot_c, int i) {  // image i (clamped to the wave's last) into ring slot `slot`
+      constexpr int slot = decltype(slot_c)::value;
+      gbytes_t src_i = base_u + (size_t)(i < n_img ? i : n_img - 1) * img_stride;
+#pragma unroll
+      for (int t = 0; t < TC; ++t) ring[slot * TC + t] = *(gwords_t)(src_i + goff[t]);
+    };
+    // the scheduler must not reorder the boxes' loads: the counted waits below rest on slot order == issue order, on
+    // the entry path as on the loop's back edge
+    static_for<0, D>([&](auto q) {
+      fetch(q, (int)decltype(q)::value);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    for (int i = 0; i < n_img; i += D) {
+      static_for<0, D>([&](auto q) {
+        constexpr int slot = decltype(q)::value;
+        const int cur = i + slot;
+        wave_sync();  // every lane is done with the previous image's box
+#pragma unroll
+        for (int t = 0; t < TC; ++t) L[lane + 64 * t] = ring[slot * TC + t] ^ 0x80808080u;
+        wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(q, cur + D);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cur < n_img) {
+          int v = 0;
+          if (valid) v = wave_border ? gather(std::true_type{}, L) : gather(std::false_type{}, L);
+          if (valid || (a.zero_invalid && inside)) dst[(size_t)cur * a.dst_stride] = (uint8_t)v;
+        }
+      });
+    }
+  };
+  // ring classes: 60 % of the 480^2 map's tiles have a box of at most 64 dwords (T = 1), the mean is 2.2 -- rounding T
+  // up to {4, 8, 16} issued 2.2x the loads and made the texture addresser the limit (TA_BUSY 85 %)
+  static_assert(NR == 16, "ring classes are written for 16 staging registers");
+  if (T <= 1) pipeline(std::integral_constant<int, 1>{});
+  else if (T <= 2) pipeline(std::integral_constant<int, 2>{});
+  else if (T <= 3) pipeline(std::integral_constant<int, 3>{});
+  else if (T <= 4) pipeline(std::integral_constant<int, 4>{});
+  else if (T <= 6) pipeline(std::integral_constant<int, 6>{});
+  else if (T <= 8) pipeline(std::integral_constant<int, 8>{});
+  else if (T <= 12) pipeline(std::integral_constant<int, 12>{});
+  else pipeline(std::integral_constant<int, 16>{});
 }
 
 // ---- K5: forward row transforms of z = cur_lp + i prev_lp, written transposed -----------------------------
@@ -775,7 +807,7 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
   static const bool staged_on = [] { const char* e = getenv("MOF_SR_LP_STAGED"); return !e || atoi(e) != 0; }();
   constexpr int NR = 16;
   if (staged_on && !global_w && n_images >= 4 && a.pitch % 4 == 0 && a.src_stride % 4 == 0 && a.boxes && a.wplanes &&
-      a.box_dwords_max <= 64 * NR && 8 * (size_t)(a.lds_per_wave + 256) <= 64 * 1024) {
+      a.box_dwords_max <= 64 * NR) {
     const int tiles = (a.res + 7) / 8, n_tiles = tiles * tiles;
     // images per wave: long runs amortise the per-tile set-up; short ones keep the images that the resident waves
     // share within the L2 (MOF_SR_LP_IPW: diagnostic override)
@@ -786,12 +818,11 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
     const int nq = (n_tiles + 3) / 4;
     const int xcd_groups = (groups >= 8 && !xcd_off) ? groups : 0;  // fewer than 8 groups would leave XCDs idle
     const unsigned blocks = xcd_groups ? (unsigned)(8 * ((groups + 7) / 8) * nq) : (unsigned)(((long)n_tiles * groups + 3) / 4);
-    constexpr int U = MOF_LP_U;  // images per group (1: 127 VGPRs = four waves per SIMD; 2 needs 209 and measured 5 % slower)
-    const size_t lds = (size_t)4 * U * (a.lds_per_wave + 256);
+    const size_t lds = (size_t)4 * sizeof(uint32_t) * lp_box_capacity(a.box_dwords_max);
     if (interp == 2)
-      hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, U>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
     else
-      hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, U>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
     return hipGetLastError();
   }
   if (!global_w && n_images >= 4) return interp == 2 ? launch_lp_lds<4>(a, n_images, stream) : launch_lp_lds<8>(a, n_images, stream);
