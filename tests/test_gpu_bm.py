@@ -39,6 +39,14 @@ def test_golden_vectors(gpu, name):
     (True, (400, 300), 128, 0, 24),   # the largest block size, at the reference's radius limit (2r + 1 <= 50, .cl:1)
     (True, (230, 420), 100, 4, 48),   # > 64 KB of LDS per workgroup: opt-in dynamic LDS
     (True, (60, 200), 8, 0, 2),       # tiny scans: eight blocks share a workgroup
+    # row lengths that no chunk length of the generic scan divides (ragged row tails of 1, 3, 5 and 1 dwords) and odd radii
+    (True, (200, 330), 36, 4, 7),
+    (True, (180, 300), 44, 0, 9),
+    (False, (250, 250), 52, 0, 11),
+    (True, (330, 420), 100, 8, 13),
+    (True, (300, 300), 124, 0, 5),
+    (True, (90, 200), 12, 4, 3),
+    (True, (90, 230), 20, 0, 6),
 ])
 def test_seeded_batches_bit_exact(gpu, fast, shape, block, step, radius):
     h, w = shape

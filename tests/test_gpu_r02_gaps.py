@@ -79,22 +79,27 @@ def test_full_size_c4_batch_properties(gpu):
     assert checked > 0.6 * total
 
 
-@pytest.mark.parametrize("res,M", [(240, 40.0), (256, 45.0), (480, 49.9)])
+# M = 30 at 480^2: source boxes beyond the staged kernel's 4 KB -> the table-in-LDS kernel serves the batch; M = 80: every
+# ring class of the staged kernel down to one-dword boxes
+@pytest.mark.parametrize("res,M", [(240, 40.0), (256, 45.0), (480, 49.9), (480, 30.0), (480, 80.0)])
 @pytest.mark.parametrize("interp", [INTER_CUBIC, INTER_LANCZOS4])
 @pytest.mark.parametrize("variant", [0, 1])   # cv::logPolar of OpenCV 4.x (Noetic) / cvLogPolar of OpenCV 3.2 (Melodic)
 def test_logpolar_remap_is_byte_exact(gpu, res, M, interp, variant):
-    """K4 against oracle_logpolar_u8, every byte, for both interpolations and both kernel variants (n < 4 images
-    take the global-table kernel, n >= 4 the LDS-resident-table kernel); BORDER_TRANSPARENT pixels keep dst."""
+    """K4 against oracle_logpolar_u8, every byte, for both interpolations and both map variants (n < 4 images take the
+    global-table kernel, n >= 4 the tile-stationary staged kernel: 5 images = one full and one ragged group of its
+    register ring, 37 = four groups of eight and a ragged fifth); BORDER_TRANSPARENT pixels keep dst."""
     base = sr_scenes.canvas(5 + res + interp, res)
     frames = np.stack([sr_scenes.view(base, res, s, r) for s, r in [(1.0, 0.0), (1.05, 7.0), (0.93, -11.0),
                                                                    (1.0, 90.0), (1.2, 33.0)]])
     frames[4, :7, :] = 255  # saturating content next to the border (reflect-101 taps, clamping)
     est = ScaleRotationEstimator(res, M, logpolar_variant=variant)
-    big = torch.zeros((5, res + 2, res + 24), dtype=torch.uint8, device=gpu)
+    frames = frames[np.arange(37) % 5]
+    frames[5:] = np.roll(frames[5:], 3, axis=2)  # not mere repeats
+    big = torch.zeros((37, res + 2, res + 24), dtype=torch.uint8, device=gpu)
     big[:, 1:1 + res, 8:8 + res] = torch.from_numpy(frames).to(gpu)
     view = big[:, 1:1 + res, 8:8 + res]  # pitch > res, crop origin passed as the pointer
     fill = 37
-    for n_img in (1, 5):
+    for n_img in (1, 5, 37):
         dst = torch.full((n_img, res, res), fill, dtype=torch.uint8, device=gpu)
         got = est.logpolar_batch_device(view[:n_img], interp, dst=dst).cpu().numpy()
         untouched = 0
