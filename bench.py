@@ -39,6 +39,8 @@ def binding_note(name: str, wl) -> str:
     """What actually bounds the dominant kernel of a workload (measured)."""
     if wl["kind"] == "bm":
         return "integer VALU: v_qsad_pk_u16_u8 at 1 byte-difference per lane per cycle, VALU 86 % active; not HBM"
+    if wl["kind"] == "fft+rt":
+        return "K1 as in ref + the getRT tail (one wavefront per pair, fp64 recurrences: 0.35 ms per 1024 pairs); not HBM"
     if wl["kind"] == "fft+sr":
         return ("scale/rotation pipeline K4-K8 (log-polar gather + whole-frame phase correlation through cache-resident "
                 "scratch) takes 90 % of the step; K1 as in c2; not HBM")
@@ -70,6 +72,11 @@ WORKLOADS = {
     "ref": dict(kind="fft", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
                 name="ref: FftMethod 480x480, 4x4 grid of 120x120 patches (reference default.yaml), batch=1024 per GPU",
                 bytes_per_pair=2 * 480 * 480 + 16 * 8),
+    # the node's whole per-frame chain on the device: u8 frame pairs -> K1 shifts -> getRT (undistort,
+    # RANSAC homography, decomposition, IMU-consistent pick) -> rotation + velocity; nothing but 64 B per pair leaves the GPU
+    "refrt": dict(kind="fft+rt", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
+                  name="refrt: ref + the getRT geometry tail on the device (frames -> rotation, velocity), batch=1024 per GPU",
+                  bytes_per_pair=2 * 480 * 480 + 64),
     # c2 with the node's front end fused in: interleaved BGR8 frames, CV_RGB2GRAY inside the load
     "c2bgr": dict(kind="fft", bgr=True, h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=512, s=8,
                   name="c2bgr: c2 on interleaved BGR8 frames, CV_RGB2GRAY fused into the load, batch=512 per GPU",
@@ -119,6 +126,18 @@ def cpu_baseline(wl, budget_s: float = 12.0):
             est.processImage(prev[k % n_gen][:r, x0:x0 + r])
             est.processImage(cur[k % n_gen][:r, x0:x0 + r])
         what = "f32 oracle (oracle/pc_ref.c + lp_ref.c)"
+    elif wl["kind"] == "fft+rt":
+        import ctypes as C
+        lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
+        ocam = O.GeomCamera(400.0, 400.0, 240.0, 240.0, -0.01, 0.002, 0.0, 0.0, 0.0)
+        ol = O.GeomLayout(wl["grid"][0], wl["grid"][1], wl["origin"][0], wl["origin"][1], wl["stride"][0], wl["stride"][1], wl["n"])
+        ident = (C.c_double * 4)(0, 0, 0, 1)
+        opar = O.GeomRtParams(3.0, 0.02, 0.0, ident, ident, (C.c_double * 3)(0, 0, 0))
+
+        def run(k):
+            flow, _ = O.fft_process(cur[k % n_gen], prev[k % n_gen], lay, 32)
+            O.geom_get_rt(flow, ol, ocam, opar, 8)
+        what = "f32 oracle (oracle/pc_ref.c) + fp64 getRT (oracle/geom_ref.c)"
     elif wl["kind"] == "fft":
         lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
         run = lambda k: O.fft_process(cur[k % n_gen], prev[k % n_gen], lay, 32)
@@ -173,7 +192,7 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
     # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
     cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
     state = {"out": None}
-    if wl["kind"] in ("fft", "fft+sr"):
+    if wl["kind"] in ("fft", "fft+sr", "fft+rt"):
         eng = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"],
                         origin=wl["origin"], stride=wl["stride"], device=local_rank)
         state["out"] = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
@@ -186,6 +205,23 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
                 eng.process_batch_device(cur, prev, out=state["out"])
                 srout = sr.process_batch_device(cur_c, prev_c)
                 return torch.cat([state["out"].reshape(B, -1), srout], dim=1)
+        elif wl["kind"] == "fft+rt":
+            import ctypes as C
+
+            import numpy as np
+
+            from mrs_optic_flow_amd import geometry as G
+            gcam = G.Camera(400.0, 400.0, 240.0, 240.0, -0.01, 0.002, 0.0, 0.0, 0.0)
+            gl = G.Layout(wl["grid"][0], wl["grid"][1], wl["origin"][0], wl["origin"][1], wl["stride"][0], wl["stride"][1], wl["n"])
+            ident = (C.c_double * 4)(0, 0, 0, 1)
+            par = G.RtParams(3.0, 0.02, 0.0, ident, ident, (C.c_double * 3)(0, 0, 0))
+            row = np.frombuffer(bytes(par), dtype=np.float64).copy()
+            d_par = torch.from_numpy(np.repeat(row[None, :], B, axis=0)).to(dev)
+
+            def launch():  # (running the tail on a second stream under the next batch's K1 gains nothing: measured r02,
+                # its single-lane fp64 stretches still take whole VALU issue slots and K1 slows by the tail's duration)
+                eng.process_batch_device(cur, prev, out=state["out"])
+                return G.get_rt_batch_device(state["out"], gl, gcam, d_par, 8)
         elif wl.get("bgr"):
             # synthetic colour frames: three different affine maps of the gray texture (data stays u8)
             def colour(g):
@@ -410,6 +446,7 @@ def main() -> None:
         pairs = B * world * args.steps
         line = {
             "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fft+sr": "_fft_phase_corr_plus_scale_rotation",
+                                             "fft+rt": "_fft_phase_corr_plus_get_rt",
                                              "bm": "_block_method" if wl.get("block_method") else "_fast_spaced_bm"}[wl["kind"]],
             "value": pairs / elapsed,
             "unit": "frame-pairs/s",
@@ -436,7 +473,7 @@ def main() -> None:
             torch.cuda.empty_cache()
             # driver-visible records of the other BASELINE configurations (same protocol, fewer steps)
             line["other_workloads"] = {tag: measure_other(tag, dev, st, 5)
-                                       for tag, st in (("c3", 50), ("c4", 10), ("c5", 20), ("ref", 50), ("bmref", 50))}
+                                       for tag, st in (("c3", 50), ("c4", 10), ("c5", 20), ("ref", 50), ("bmref", 50), ("refrt", 50))}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

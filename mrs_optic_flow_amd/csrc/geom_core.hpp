@@ -117,6 +117,52 @@ MOF_HD bool solve_linear(double* a, double* x) {
   return true;
 }
 
+// solve_linear with every index a compile-time constant (loops fully unrolled, the pivot row brought up by conditional
+// element swaps): the same pivots, the same operations in the same order -- bit-identical results -- but the matrix
+// stays in registers. On the device the indexed form lives in scratch memory (one round of 64 RANSAC hypotheses: 200 k
+// cycles, nearly all of them scratch round trips).
+template <int N>
+MOF_HD bool solve_linear_unrolled(double* a, double* x) {
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    int piv = c;
+    double best = fabs(a[c * (N + 1) + c]);
+#pragma unroll
+    for (int r = c + 1; r < N; ++r) {
+      const double v = fabs(a[r * (N + 1) + c]);
+      if (v > best) best = v, piv = r;
+    }
+    if (!(best > 1e-300)) return false;
+#pragma unroll
+    for (int r = c + 1; r < N; ++r) {
+      const bool sw = piv == r;
+#pragma unroll
+      for (int k = c; k <= N; ++k) {
+        const double u = a[c * (N + 1) + k], w = a[r * (N + 1) + k];
+        a[c * (N + 1) + k] = sw ? w : u;
+        a[r * (N + 1) + k] = sw ? u : w;
+      }
+    }
+    const double inv = 1.0 / a[c * (N + 1) + c];
+#pragma unroll
+    for (int r = c + 1; r < N; ++r) {
+      const double f = a[r * (N + 1) + c] * inv;
+      if (f != 0.0) {
+#pragma unroll
+        for (int k = c; k <= N; ++k) a[r * (N + 1) + k] -= f * a[c * (N + 1) + k];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = N - 1; r >= 0; --r) {
+    double s = a[r * (N + 1) + N];
+#pragma unroll
+    for (int k = r + 1; k < N; ++k) s -= a[r * (N + 1) + k] * x[k];
+    x[r] = s / a[r * (N + 1) + r];
+  }
+  return true;
+}
+
 // Cyclic Jacobi eigen-decomposition of a symmetric N x N matrix (a is destroyed; its diagonal ends as the
 // eigenvalues, v holds the eigenvectors as COLUMNS). Fixed sweep order: deterministic on host and device.
 template <int N>
@@ -310,7 +356,11 @@ MOF_HD bool homography_4pt(const double* a, const double* b, const int* idx, dou
     r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -v * x; r1[7] = -v * y; r1[8] = v;
   }
   double h[8];
+#ifdef __HIP_DEVICE_COMPILE__
+  if (!solve_linear_unrolled<8>(m, h)) return false;
+#else
   if (!solve_linear<8>(m, h)) return false;
+#endif
   for (int k = 0; k < 8; ++k) {
     if (!finite_d(h[k])) return false;
     H[k] = h[k];

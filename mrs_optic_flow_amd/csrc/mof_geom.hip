@@ -119,8 +119,248 @@ int get_rt_host(const double* shifts, const Layout& L, const Camera& cam, const 
 
 // ---- device: one wavefront per frame pair --------------------------------------------------------------------
 
+__device__ __forceinline__ void geom_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// homography_fit (geom_core.hpp) executed by a whole wavefront. The one-lane form kept its 9 x 9 / 8 x 9 work arrays in
+// scratch memory (dynamic indices) and took 2.5 M of the kernel's 2.7 M cycles per pair; here the matrices live in LDS
+// and the lanes share the independent pieces: per-point rows (lane = point), normal-matrix entries (lane = entry, the sum
+// over the points in point order), the three element loops of a Jacobi rotation and the row operations of the
+// elimination (lane = element). Everything that is a sequential recurrence in the host form (rotation angles, pivots,
+// back substitution, the ordered error sums) is evaluated redundantly by every lane from the same LDS values. Each
+// accumulator therefore sees exactly the host form's operations in the host form's order: the results are bit-identical
+// (-ffp-contract=off on both sides). All lanes return the same H.
+// ws: tab[n][18], A[81], V[81], M[72], g[8] doubles in LDS.
+constexpr int kFitTab = 18;
+constexpr int kWaveFitPoints = 256;  // 36 KB of per-point rows: every BASELINE grid (c4: 16 x 16)
+__device__ bool homography_fit_wave(const double* a, const double* b, const unsigned char* mask, int n, double* H, double* ws,
+                                    int lane) {
+  double* tab = ws;
+  double* A = ws + (size_t)n * kFitTab;
+  double* V = A + 81;
+  double* M = V + 81;
+  double* g = M + 72;
+  int cnt = 0;
+  double cMx = 0, cMy = 0, cmx = 0, cmy = 0;
+  for (int i = 0; i < n; ++i)
+    if (mask[i]) {
+      cMx += a[2 * i]; cMy += a[2 * i + 1]; cmx += b[2 * i]; cmy += b[2 * i + 1];
+      ++cnt;
+    }
+  if (cnt < 4) return false;
+  cMx /= cnt; cMy /= cnt; cmx /= cnt; cmy /= cnt;
+  double sMx = 0, sMy = 0, smx = 0, smy = 0;
+  for (int i = 0; i < n; ++i)
+    if (mask[i]) {
+      sMx += fabs(a[2 * i] - cMx); sMy += fabs(a[2 * i + 1] - cMy);
+      smx += fabs(b[2 * i] - cmx); smy += fabs(b[2 * i + 1] - cmy);
+    }
+  if (fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON || fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON) return false;
+  sMx = cnt / sMx; sMy = cnt / sMy; smx = cnt / smx; smy = cnt / smy;
+  // ---- normalised DLT: rows of L per point, then LtL entry (j, k), j <= k, per lane
+  for (int i = lane; i < n; i += 64)
+    if (mask[i]) {
+      const double x = (b[2 * i] - cmx) * smx, y = (b[2 * i + 1] - cmy) * smy;
+      const double X = (a[2 * i] - cMx) * sMx, Y = (a[2 * i + 1] - cMy) * sMy;
+      double* t = tab + (size_t)i * kFitTab;
+      t[0] = X, t[1] = Y, t[2] = 1, t[3] = 0, t[4] = 0, t[5] = 0, t[6] = -x * X, t[7] = -x * Y, t[8] = -x;
+      t[9] = 0, t[10] = 0, t[11] = 0, t[12] = X, t[13] = Y, t[14] = 1, t[15] = -y * X, t[16] = -y * Y, t[17] = -y;
+    }
+  geom_wave_sync();
+  if (lane < 45) {
+    int j = 0, k = lane;
+    while (k >= 9 - j) k -= 9 - j, ++j;  // lane -> (j, k = j + offset): row-major upper triangle
+    k += j;
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i)
+      if (mask[i]) {
+        const double* t = tab + (size_t)i * kFitTab;
+        acc += t[j] * t[k] + t[9 + j] * t[9 + k];
+      }
+    A[j * 9 + k] = acc;
+    A[k * 9 + j] = acc;
+  }
+  for (int e = lane; e < 81; e += 64) V[e] = (e / 9 == e % 9) ? 1.0 : 0.0;
+  geom_wave_sync();
+  // ---- jacobi_eigen<9>: same sweep order, same arithmetic per element
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < 9; ++i) {
+      diag += A[i * 9 + i] * A[i * 9 + i];
+      for (int j = i + 1; j < 9; ++j) off += A[i * 9 + j] * A[i * 9 + j];
+    }
+    if (!(off > 1e-30 * diag) || off == 0.0) break;
+    for (int p = 0; p < 8; ++p)
+      for (int q = p + 1; q < 9; ++q) {
+        const double apq = A[p * 9 + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        // columns p, q of A (lanes 0..8) beside columns p, q of V (lanes 16..24)
+        if (lane < 9 || (lane >= 16 && lane < 25)) {
+          double* m = lane < 9 ? A : V;
+          const int k = lane < 9 ? lane : lane - 16;
+          const double mkp = m[k * 9 + p], mkq = m[k * 9 + q];
+          m[k * 9 + p] = c * mkp - sn * mkq;
+          m[k * 9 + q] = sn * mkp + c * mkq;
+        }
+        geom_wave_sync();
+        if (lane < 9) {  // rows p, q of A
+          const double apk = A[p * 9 + lane], aqk = A[q * 9 + lane];
+          A[p * 9 + lane] = c * apk - sn * aqk;
+          A[q * 9 + lane] = sn * apk + c * aqk;
+        }
+        geom_wave_sync();
+      }
+  }
+  int lo = 0;
+  for (int k = 1; k < 9; ++k)
+    if (A[k * 9 + k] < A[lo * 9 + lo]) lo = k;
+  double H0[9];
+  for (int k = 0; k < 9; ++k) H0[k] = V[k * 9 + lo];
+  const double invHnorm[9] = {1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1};
+  const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+  double T[9];
+  mat3_mul(invHnorm, H0, T);
+  mat3_mul(T, Hnorm2, H0);
+  if (!(fabs(H0[8]) > DBL_EPSILON)) return false;
+  const double sc = 1.0 / H0[8];
+  double h[8];
+  for (int k = 0; k < 8; ++k) h[k] = H0[k] * sc;
+  geom_wave_sync();  // every lane has read A / V before the table is rewritten
+
+  // ---- Levenberg-Marquardt on (h0..h7), h8 = 1
+  auto error_sum = [&](const double* hh) {  // the host form's `S += ex * ex + ey * ey` over the points in order
+    for (int i = lane; i < n; i += 64)
+      if (mask[i]) {
+        const double X = a[2 * i], Y = a[2 * i + 1];
+        const double ww = 1.0 / (hh[6] * X + hh[7] * Y + 1.0);
+        const double ex = (hh[0] * X + hh[1] * Y + hh[2]) * ww - b[2 * i], ey = (hh[3] * X + hh[4] * Y + hh[5]) * ww - b[2 * i + 1];
+        tab[(size_t)i * kFitTab + 16] = ex * ex + ey * ey;
+      }
+    geom_wave_sync();
+    double S = 0.0;
+    for (int i = 0; i < n; ++i)
+      if (mask[i]) S += tab[(size_t)i * kFitTab + 16];
+    geom_wave_sync();  // the slot may be rewritten
+    return S;
+  };
+  double lambda = 1e-3;
+  double S = error_sum(h);
+  for (int it = 0; it < 10; ++it) {
+    for (int i = lane; i < n; i += 64)
+      if (mask[i]) {
+        const double X = a[2 * i], Y = a[2 * i + 1];
+        const double ww = 1.0 / (h[6] * X + h[7] * Y + 1.0);
+        const double xi = (h[0] * X + h[1] * Y + h[2]) * ww, yi = (h[3] * X + h[4] * Y + h[5]) * ww;
+        double* t = tab + (size_t)i * kFitTab;
+        t[0] = X * ww, t[1] = Y * ww, t[2] = ww, t[3] = 0, t[4] = 0, t[5] = 0, t[6] = -X * ww * xi, t[7] = -Y * ww * xi;
+        t[8] = 0, t[9] = 0, t[10] = 0, t[11] = X * ww, t[12] = Y * ww, t[13] = ww, t[14] = -X * ww * yi, t[15] = -Y * ww * yi;
+        t[16] = xi - b[2 * i];
+        t[17] = yi - b[2 * i + 1];
+      }
+    geom_wave_sync();
+    if (lane < 36) {  // A8 entry (j, k), j <= k
+      int j = 0, k = lane;
+      while (k >= 8 - j) k -= 8 - j, ++j;
+      k += j;
+      double acc = 0.0;
+      for (int i = 0; i < n; ++i)
+        if (mask[i]) {
+          const double* t = tab + (size_t)i * kFitTab;
+          acc += t[j] * t[k] + t[8 + j] * t[8 + k];
+        }
+      A[j * 8 + k] = acc;
+      A[k * 8 + j] = acc;
+    } else if (lane < 44) {
+      const int j = lane - 36;
+      double acc = 0.0;
+      for (int i = 0; i < n; ++i)
+        if (mask[i]) {
+          const double* t = tab + (size_t)i * kFitTab;
+          acc += t[j] * t[16] + t[8 + j] * t[17];
+        }
+      g[j] = acc;
+    }
+    geom_wave_sync();
+    bool accepted = false;
+    for (int tries = 0; tries < 6 && !accepted; ++tries) {
+      for (int e = lane; e < 72; e += 64) {
+        const int j = e / 9, k = e % 9;
+        double v = k < 8 ? A[j * 8 + k] : -g[j];
+        if (k == j) v += lambda * A[j * 8 + j];
+        M[e] = v;
+      }
+      geom_wave_sync();
+      // solve_linear<8> on M (8 x 9)
+      bool ok = true;
+      for (int c = 0; c < 8 && ok; ++c) {
+        int piv = c;
+        double best = fabs(M[c * 9 + c]);
+        for (int r = c + 1; r < 8; ++r) {
+          const double v = fabs(M[r * 9 + c]);
+          if (v > best) best = v, piv = r;
+        }
+        if (!(best > 1e-300)) {
+          ok = false;
+          break;
+        }
+        if (piv != c) {
+          if (lane >= c && lane <= 8) {
+            const double t = M[c * 9 + lane];
+            M[c * 9 + lane] = M[piv * 9 + lane];
+            M[piv * 9 + lane] = t;
+          }
+          geom_wave_sync();
+        }
+        const double inv = 1.0 / M[c * 9 + c];
+        {
+          const int r = c + 1 + lane / 9, k = lane % 9;
+          if (r < 8 && k >= c) {
+            const double f = M[r * 9 + c] * inv;
+            const double mck = M[c * 9 + k], mrk = M[r * 9 + k];
+            if (f != 0.0) M[r * 9 + k] = mrk - f * mck;
+          }
+        }
+        geom_wave_sync();
+      }
+      double d[8];
+      if (ok) {
+        for (int r = 7; r >= 0; --r) {
+          double sacc = M[r * 9 + 8];
+          for (int k = r + 1; k < 8; ++k) sacc -= M[r * 9 + k] * d[k];
+          d[r] = sacc / M[r * 9 + r];
+        }
+      }
+      geom_wave_sync();  // M is rebuilt by the next try
+      if (ok) {
+        double hn[8];
+        for (int k = 0; k < 8; ++k) hn[k] = h[k] + d[k];
+        const double Sn = error_sum(hn);
+        if (Sn < S) {
+          for (int k = 0; k < 8; ++k) h[k] = hn[k];
+          S = Sn;
+          lambda *= 0.1;
+          accepted = true;
+          break;
+        }
+      }
+      lambda *= 10.0;
+    }
+    if (!accepted) break;
+  }
+  for (int k = 0; k < 8; ++k) H[k] = h[k];
+  H[8] = 1.0;
+  return true;
+}
+
+
 __global__ void __launch_bounds__(64) geom_get_rt_kernel(const double* __restrict__ shifts, Layout L, Camera cam,
-                                                         const RtParams* __restrict__ params, int thr,
+                                                         const RtParams* __restrict__ params, int thr, int wave_fit,
                                                          double* __restrict__ out) {
   extern __shared__ double lds[];
   const int total = L.grid_x * L.grid_y;
@@ -163,6 +403,9 @@ __global__ void __launch_bounds__(64) geom_get_rt_kernel(const double* __restric
     if (lane == 0) o[7] = (double)kTooFewPoints;
     return;
   }
+#ifdef MOF_GEOM_PROF  // diagnostic build (tools/geom_stage_cycles.py): stage cycle counts instead of results
+  const unsigned long long t_a = __builtin_readcyclecounter();
+#endif
   const double thr2 = kRansacThreshold * kRansacThreshold;
   double best[9];
   bool found = false;
@@ -196,20 +439,37 @@ __global__ void __launch_bounds__(64) geom_get_rt_kernel(const double* __restric
     for (int i = lane; i < n; i += 64) mask[i] = 0;
   }
   __syncthreads();
-  if (lane == 0) {  // the sequential rest: a few hundred flops, not worth spreading over lanes
-    int remaining = 0;
-    for (int i = 0; i < n; ++i) remaining += mask[i];
-    int status;
-    if (remaining < thr) status = kTooFewInliers;
-    else if (!found) status = kNoHomography;
-    else {
-      double H[9], res[7] = {0, 0, 0, 1, 0, 0, 0};
-      if (!homography_fit(a, b, mask, n, H))
-        for (int k = 0; k < 9; ++k) H[k] = best[k];
-      status = pick_motion(H, p, res);
-      if (status == kOk)
-        for (int k = 0; k < 7; ++k) o[k] = res[k];
-    }
+  int remaining = 0;
+  for (int i = 0; i < n; ++i) remaining += mask[i];
+  if (remaining < thr || !found) {
+    if (lane == 0) o[7] = (double)(remaining < thr ? kTooFewInliers : kNoHomography);
+    return;
+  }
+#ifdef MOF_GEOM_PROF
+  const unsigned long long t_b = __builtin_readcyclecounter();
+#endif
+  // refit on the inliers: by the whole wave when its LDS work space was granted (up to kWaveFitPoints patches), else by
+  // lane 0 through the host form
+  double H[9];
+  bool fitted;
+  if (wave_fit) {
+    fitted = homography_fit_wave(a, b, mask, n, H, reinterpret_cast<double*>(mask + ((total + 7) & ~7)), lane);
+  } else {
+    fitted = lane == 0 && homography_fit(a, b, mask, n, H);
+  }
+#ifdef MOF_GEOM_PROF
+  const unsigned long long t_c = __builtin_readcyclecounter();
+#endif
+  if (lane == 0) {  // decomposition + IMU-consistent pick: sequential
+    double res[7] = {0, 0, 0, 1, 0, 0, 0};
+    if (!fitted)
+      for (int k = 0; k < 9; ++k) H[k] = best[k];
+    const int status = pick_motion(H, p, res);
+#ifdef MOF_GEOM_PROF
+    res[0] = (double)(t_b - t_a), res[1] = (double)(t_c - t_b), res[2] = (double)(__builtin_readcyclecounter() - t_c);
+#endif
+    if (status == kOk)
+      for (int k = 0; k < 7; ++k) o[k] = res[k];
     o[7] = (double)status;
   }
 }
@@ -323,9 +583,11 @@ int mof_geom_get_rt_batch_device(const double* d_shifts_xy, const mof_geom_layou
   std::memcpy(&L, layout, sizeof(L));
   std::memcpy(&c, cam, sizeof(c));
   const int total = L.grid_x * L.grid_y;
-  const size_t lds = (size_t)(4 * total + (total + 7) / 8) * sizeof(double);  // a, b (2 doubles per point each) + mask bytes
+  size_t lds = (size_t)(4 * total + (total + 7) / 8) * sizeof(double);  // a, b (2 doubles per point each) + mask bytes
+  const int wave_fit = total <= kWaveFitPoints;
+  if (wave_fit) lds += ((size_t)total * kFitTab + 81 + 81 + 72 + 8) * sizeof(double);  // homography_fit_wave's work space
   hipLaunchKernelGGL(geom_get_rt_kernel, dim3((unsigned)n_pairs), dim3(64), lds, (hipStream_t)stream, d_shifts_xy, L, c,
-                     reinterpret_cast<const RtParams*>(d_params), shifted_pts_thr, d_out);
+                     reinterpret_cast<const RtParams*>(d_params), shifted_pts_thr, wave_fit, d_out);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mof::capi_fail(MOF_ERR_HIP, "geom_get_rt_kernel: %s", hipGetErrorString(e));
   return MOF_OK;
