@@ -204,9 +204,9 @@ typedef struct mof_sr_config {
   int device;
   int logpolar_variant; /* MOF_LOGPOLAR_CV4 (0, default) or MOF_LOGPOLAR_CV3: see below              */
   /* Batched mode only (no reference counterpart; zero-initialise for the defaults):                 */
-  int batch_chunk;      /* frame pairs per pipeline pass, 0 = default (512; 1..4096). The engine owns     */
-                        /* batch_chunk * (4 res^2 + 8 res^2 + 8 res (res/2+1)) bytes of scratch: 1.9 GB   */
-                        /* at 480^2 and 512 pairs                                                         */
+  int batch_chunk;      /* frame pairs per pipeline pass, 0 = default (512; 1..4096). From its first      */
+                        /* batch on the engine owns batch_chunk * (4 res^2 + 8 res^2 + 8 res (res/2+1))   */
+                        /* bytes of scratch (1.9 GB at 480^2 and 512 pairs); until then one pair's worth  */
   int pipeline_lanes;   /* 0 = default (1), 1 = every pass on the caller's stream, 2 = the remap of pass  */
                         /* k+1 runs beside the transforms of pass k on a second stream of the engine      */
 } mof_sr_config;
@@ -224,6 +224,10 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out);
 void mof_sr_destroy(mof_sr_engine* e);
 /* Re-arms `first` and clears tempIm (scaleRotationEstimator.cpp:27, :31). */
 int mof_sr_reset(mof_sr_engine* e);
+/* Batched mode: grow the engine's scratch to min(n_pairs, batch_chunk) pairs per pass now instead of inside the first
+ * batch. Needed before a batch is CAPTURED into a HIP graph on an engine that has not run a batch yet (allocation is
+ * not capturable: the batch call then fails with MOF_ERR_BAD_ARG). No reference counterpart. */
+int mof_sr_reserve(mof_sr_engine* e, int n_pairs);
 
 /* scaleRotationEstimator::processImage (scaleRotationEstimator.cpp:34-148), synchronous. frame: resolution^2
  * CV_8UC1. out_scale_rot[2] = (scale, rotation in rad): first call -> log-polar (INTER_CUBIC) kept as the previous

@@ -86,6 +86,7 @@ SYMBOLS = {
     "mof_sr_create": (_I, [C.POINTER(SrConfig), C.POINTER(_VP)]),
     "mof_sr_destroy": (None, [_VP]),
     "mof_sr_reset": (_I, [_VP]),
+    "mof_sr_reserve": (_I, [_VP, _I]),
     "mof_sr_process": (_I, [_VP, _VP, _SZ, _VP]),
     "mof_sr_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_sr_logpolar_batch_device": (_I, [_VP, _VP, _SZ, _SZ, _I, _I, _VP, _VP]),

@@ -262,7 +262,8 @@ struct mof_sr_engine {
   double* d_out = nullptr;       // [kChunk][4]
   uint8_t* h_stage = nullptr;
   double* h_out = nullptr;
-  int chunk = 0;                 // frame pairs per pipeline pass (sizes the scratch)
+  int chunk = 0;                 // frame pairs per pipeline pass
+  int scratch_pairs = 0;         // pairs per pass the scratch holds now (1 after create, `chunk` after the first batch)
   bool two_lanes = false;        // remap of pass k+1 beside the transforms of pass k (mof_sr_config.pipeline_lanes == 2)
   bool first = true;             // :31
   std::atomic<bool> busy{false};
@@ -311,9 +312,59 @@ hipError_t scratch_release(mof_sr_engine* e, hipStream_t s) {
   return hipSuccess;
 }
 
+// The pipeline scratch (log-polar images of two passes, Zt, Dt, peak candidates, results) for `pairs` pairs per pass.
+hipError_t scratch_alloc(mof_sr_engine* e, int pairs) {
+  const int res = e->cfg.resolution;
+  const size_t nn = (size_t)res * res;
+  void** bufs[] = {(void**)&e->d_lp, (void**)&e->d_Zt, (void**)&e->d_Dt, (void**)&e->d_cand, (void**)&e->d_out};
+  for (void** b : bufs) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  e->scratch_pairs = 0;
+  hipError_t err;
+  if ((err = hipMalloc(&e->d_lp, (size_t)2 * pairs * 2 * nn)) != hipSuccess) return err;  // two passes: remap of pass k+1 beside the transforms of pass k
+  if ((err = hipMalloc(&e->d_Zt, (size_t)pairs * nn * 2 * sizeof(float))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_Dt, (size_t)pairs * res * (res / 2 + 1) * 2 * sizeof(float))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_cand, (size_t)pairs * mof::sr_candidates(res) * sizeof(float2))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_out, (size_t)pairs * 4 * sizeof(double))) != hipSuccess) return err;
+  e->scratch_pairs = pairs;
+  return hipSuccess;
+}
+
+// Makes sure the scratch holds a pass of `pairs` pairs. Growing frees and re-allocates: not possible while `s` is
+// being captured into a graph (run one batch, or mof_sr_reserve, before the capture), and only after every earlier
+// user of the scratch has finished. Returns a MOF status.
+int scratch_reserve(mof_sr_engine* e, int pairs, hipStream_t s) {
+  if (pairs <= e->scratch_pairs) return MOF_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+    return mof::capi_fail(MOF_ERR_BAD_ARG, "the estimator's scratch must grow to %d pairs per pass, which cannot happen inside a graph capture: "
+                                            "call mof_sr_reserve (or run one batch) before capturing", pairs);
+  if (e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);
+  (void)hipStreamSynchronize(e->stream);
+  (void)hipStreamSynchronize(e->remap_stream);
+  const hipError_t err = scratch_alloc(e, pairs);
+  if (err != hipSuccess) {
+    (void)scratch_alloc(e, 1);  // keep the stateful entry usable
+    return mof::capi_fail(err == hipErrorOutOfMemory ? MOF_ERR_NO_MEMORY : MOF_ERR_HIP, "scale/rotation scratch for %d pairs: %s", pairs,
+                          hipGetErrorString(err));
+  }
+  return MOF_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mof_sr_reserve(mof_sr_engine* e, int n_pairs) {
+  if (!e) return mof::capi_fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_pairs < 0) return mof::capi_fail(MOF_ERR_BAD_ARG, "n_pairs must be >= 0");
+  BusyGuard g(e->busy);
+  if (!g.owned) return mof::capi_fail(MOF_ERR_BUSY, "engine busy");
+  if (hipSetDevice(e->cfg.device) != hipSuccess) return mof::capi_fail(MOF_ERR_HIP, "hipSetDevice failed");
+  return scratch_reserve(e, n_pairs < e->chunk ? (n_pairs < 1 ? 1 : n_pairs) : e->chunk, e->stream);
+}
 
 void mof_sr_destroy(mof_sr_engine* e) {
   if (!e) return;
@@ -364,7 +415,6 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   e->cfg = *cfg;
   e->chunk = chunk_pairs(cfg->batch_chunk);
   e->two_lanes = two_lane_default(cfg->pipeline_lanes);
-  const int kChunk = e->chunk;
   for (int k = 0; k < res; ++k) {
     double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)res;
     double c = std::cos(ang), s = std::sin(ang);
@@ -419,11 +469,7 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   CREATE_TRY(hipMalloc(&e->d_prev_lp, nn));
   CREATE_TRY(hipMemset(e->d_temp_im, 0, nn));  // tempIm = cv::Mat::zeros, :27
   CREATE_TRY(hipMemset(e->d_prev_lp, 0, nn));
-  CREATE_TRY(hipMalloc(&e->d_lp, (size_t)2 * kChunk * 2 * nn));  // two chunks: remap of chunk k+1 beside the transforms of chunk k
-  CREATE_TRY(hipMalloc(&e->d_Zt, (size_t)kChunk * nn * 2 * sizeof(float)));
-  CREATE_TRY(hipMalloc(&e->d_Dt, (size_t)kChunk * res * (res / 2 + 1) * 2 * sizeof(float)));
-  CREATE_TRY(hipMalloc(&e->d_cand, (size_t)kChunk * mof::sr_candidates(res) * sizeof(float2)));
-  CREATE_TRY(hipMalloc(&e->d_out, (size_t)kChunk * 4 * sizeof(double)));
+  CREATE_TRY(scratch_alloc(e, 1));  // the stateful call needs one pair; a batch grows it to a whole pass (scratch_reserve)
   CREATE_TRY(hipHostMalloc(&e->h_stage, nn, hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_out, 4 * sizeof(double), hipHostMallocDefault));
 #undef CREATE_TRY
@@ -526,6 +572,11 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
   SR_TRY(hipSetDevice(e->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   const size_t nn = (size_t)res * res;
+  {
+    // a whole pass at once (a batch that grows the scratch pair by pair would re-allocate on every call)
+    const int rc = scratch_reserve(e, n_pairs > 1 ? e->chunk : 1, s);
+    if (rc != MOF_OK) return rc;
+  }
   SR_TRY(scratch_acquire(e, s));
   const int kChunk = e->chunk;
   // Under graph capture the fork / join below pulls the engine's stream into the caller's capture (event record on the

@@ -357,6 +357,10 @@ class ScaleRotationEstimator:
     def reset(self) -> None:
         check(self._lib.mof_sr_reset(self._h))
 
+    def reserve(self, n_pairs: int) -> None:
+        """Grow the batch scratch now (needed before the first batch of a fresh engine is captured into a HIP graph)."""
+        check(self._lib.mof_sr_reserve(self._h, int(n_pairs)))
+
     def processImage(self, imCurr, gui=False, debug=False):
         f = _np_u8(imCurr)
         if f.shape != (self.cfg.resolution, self.cfg.resolution):

@@ -20,6 +20,36 @@ views = np.stack([sr_scenes.view(base, res, 1.0 + 0.01 * k, 1.5 * k) for k in ra
 idx = np.arange(n_pairs) % 7
 cur = torch.from_numpy(views[1:][idx]).cuda()
 prev = torch.from_numpy(views[:-1][idx]).cuda()
+# a fresh engine holds one pair's worth of scratch: capturing its first batch must fail loudly (allocation is not
+# capturable), and work after reserve()
+from mrs_optic_flow_amd import MofError
+fresh = ScaleRotationEstimator(res, 45.0, batch_chunk=4)
+g0 = torch.cuda.CUDAGraph()
+s0 = torch.cuda.Stream()
+refused = False
+with torch.cuda.stream(s0):
+    try:
+        with torch.cuda.graph(g0, stream=s0):
+            fresh.process_batch_device(cur, prev)
+    except (MofError, RuntimeError) as exc:
+        refused = "reserve" in str(exc) or "capture" in str(exc)
+assert refused, "capturing the first batch of a fresh engine must be refused"
+torch.cuda.synchronize()
+del g0, fresh
+fresh = ScaleRotationEstimator(res, 45.0, batch_chunk=4)
+fresh.reserve(n_pairs)
+g1 = torch.cuda.CUDAGraph()
+s1 = torch.cuda.Stream()
+with torch.cuda.stream(s1):
+    with torch.cuda.graph(g1, stream=s1):
+        out1 = fresh.process_batch_device(cur, prev)
+g1.replay()
+torch.cuda.synchronize()
+want1 = ScaleRotationEstimator(res, 45.0).process_batch_device(cur, prev)
+torch.cuda.synchronize()
+assert torch.equal(out1, want1)
+del g1, fresh
+
 for lanes in (1, 2):
     est = ScaleRotationEstimator(res, 45.0, batch_chunk=2, pipeline_lanes=lanes)
     want = est.process_batch_device(cur, prev).clone()   # eager
