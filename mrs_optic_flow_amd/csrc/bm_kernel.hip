@@ -561,7 +561,7 @@ static double bm_window_read_cycles(int D, int XGL, int xb, int wpd, int slot, i
   return groups ? 2.0 * total / groups : 2.0;
 }
 
-static BmPlan bm_plan(int block, int radius, int grid_x) {
+static BmPlan bm_plan_search(int block, int radius, int grid_x) {
   const int D = 2 * radius + 1, XG = (D + 3) / 4, WW = block + 2 * radius, CPD = block / 4;
   const int forced_xb = bm_env_int("MOF_BM_XB"), forced_bpw = bm_env_int("MOF_BM_BPW");
   BmPlan best;
@@ -602,6 +602,21 @@ static BmPlan bm_plan(int block, int radius, int grid_x) {
     }
   }
   return best;
+}
+
+// The search walks a few hundred candidates with a bank simulation each (~0.1-1 ms of host time): the last plan of each
+// thread is kept, an engine asks for the same geometry on every launch.
+static BmPlan bm_plan(int block, int radius, int grid_x) {
+  struct Key {
+    int block, radius, grid_x;
+  };
+  static thread_local Key key{-1, -1, -1};
+  static thread_local BmPlan plan;
+  if (key.block != block || key.radius != radius || key.grid_x != grid_x) {
+    plan = bm_plan_search(block, radius, grid_x);
+    key = Key{block, radius, grid_x};
+  }
+  return plan;
 }
 
 // Block sizes up to 128 (the reference's default sample_point_size is 120, config/default.yaml:32) and radii up to 48
