@@ -24,7 +24,9 @@ def _rows(structs, width):
 @pytest.mark.parametrize("geometry", [
     (4, 4, (0, 0), (120, 120), 120, 136.0, CAM),
     (8, 8, (1, 1), (98, 59), 64, 0.0, (520.0, 518.0, 376.0, 240.0, -0.12, 0.03, 0.0004, -0.0003, -0.002)),
-    (16, 16, (0, 0), (119, 63), 128, 0.0, (1300.0, 1295.0, 960.0, 540.0, -0.12, 0.03, 0.0004, -0.0003, -0.002))])
+    (16, 16, (0, 0), (119, 63), 128, 0.0, (1300.0, 1295.0, 960.0, 540.0, -0.12, 0.03, 0.0004, -0.0003, -0.002)),
+    # 400 patches: beyond the wave-parallel consensus fit's LDS work space (256) -> the one-lane host form on the device
+    (20, 20, (0, 0), (94, 52), 64, 0.0, (1300.0, 1295.0, 960.0, 540.0, -0.12, 0.03, 0.0004, -0.0003, -0.002))])
 def test_get_rt_batch_equals_host_and_oracle(gpu, geometry):
     gx, gy, origin, stride, patch, ulx, cam = geometry
     rng = np.random.default_rng(gx + 7)
