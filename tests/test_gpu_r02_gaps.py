@@ -108,6 +108,12 @@ def test_logpolar_remap_is_byte_exact(gpu, res, M, interp, variant):
             assert np.array_equal(got[k], want), (res, interp, n_img, k, int((got[k] != want).sum()))
             untouched += int((want == fill).sum())
         assert untouched > 0  # the outermost rings map outside the source: transparent pixels were exercised
+    # a layout the staged kernel does not take (pitch and frame stride not multiples of 4): the table-in-LDS kernel
+    odd = torch.zeros((6, res + 1, res + 7), dtype=torch.uint8, device=gpu)
+    odd[:, 1:1 + res, 3:3 + res] = torch.from_numpy(frames[:6]).to(gpu)
+    got = est.logpolar_batch_device(odd[:, 1:1 + res, 3:3 + res], interp).cpu().numpy()
+    for k in range(6):
+        assert np.array_equal(got[k], O.logpolar(frames[k], M, interp, variant=variant)), (res, interp, "odd pitch", k)
     zero = est.logpolar_batch_device(view[:1], interp).cpu().numpy()[0]  # default dst = zeros (tempIm, :27)
     assert np.array_equal(zero, O.logpolar(frames[0], M, interp, variant=variant))
 
