@@ -229,7 +229,11 @@ class scaleRotationEstimator {
  public:
   scaleRotationEstimator(int res, double m, bool /*i_storeVideo*/ = false, std::string* /*videoPath*/ = nullptr,
                          int /*videoFPS*/ = 0, int device = 0, int logpolar_variant = MOF_LOGPOLAR_CV4) {
-    mof_sr_config c{res, m, device, logpolar_variant};
+    mof_sr_config c{};  // batched-mode fields (batch_chunk, pipeline_lanes) at their defaults
+    c.resolution = res;
+    c.magnitude = m;
+    c.device = device;
+    c.logpolar_variant = logpolar_variant;
     detail::check(mof_sr_create(&c, &engine_), "mof_sr_create");
     res_ = res;
   }

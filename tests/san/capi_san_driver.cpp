@@ -79,7 +79,7 @@ int main() {
   mof_bm_destroy(nullptr);
   // ---- scale/rotation estimator: argument paths and the host-built tables against the oracle ----
   mof_sr_engine* se = nullptr;
-  mof_sr_config sc{480, 49.9, 0, MOF_LOGPOLAR_CV4};
+  mof_sr_config sc{480, 49.9, 0, MOF_LOGPOLAR_CV4, 0, 0};
   mof_sr_config sbad = sc;
   sbad.resolution = 100;
   CHECK(mof_sr_create(&sbad, &se) == MOF_ERR_UNSUPPORTED);
