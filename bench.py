@@ -101,6 +101,10 @@ WORKLOADS = {
     "bmref": dict(kind="bm", h=480, w=752, block=120, step=24, radius=21, batch=256, s=12,
                   name="bmref: FastSpacedBMMethod 752x480, samplePointSize=120, stepSize=24, scanRadius=21 (reference default.yaml), batch=256 per GPU",
                   bytes_per_pair=12 * 120 * 120 + (4 * 144 - 24 + 42) * (3 * 144 - 24 + 42) + 2 * 12 + 2),
+    # c3 with the node's front end fused in: interleaved BGR8 frames, CV_RGB2GRAY inside the staging loads
+    "c3bgr": dict(kind="bm", bgr=True, h=480, w=752, block=16, step=8, radius=16, batch=512, s=12,
+                  name="c3bgr: c3 on interleaved BGR8 frames, CV_RGB2GRAY fused into the staging loads, batch=512 per GPU",
+                  bytes_per_pair=3 * (540 * 256 + 744 * 456) + 2 * 540 + 2),
     "c3": dict(kind="bm", h=480, w=752, block=16, step=8, radius=16, batch=1024, s=12,
                name="c3: FastSpacedBMMethod 752x480, samplePointSize=16, stepSize=8, scanRadius=16, batch=1024 per GPU",
                # blocks*sps^2 + window area + 2*blocks + 2
@@ -242,8 +246,17 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
         else:
             eng = FastSpacedBMMethod(wl["block"], wl["radius"], wl["step"], (wl["h"], wl["w"]), device=local_rank)
 
-        def launch():
-            return eng.process_batch_device(cur, prev)[2]
+        if wl.get("bgr"):
+            def colour(g):
+                g16 = g.to(torch.int16)
+                return torch.stack([g, (255 - g16 // 2).to(torch.uint8), (g16 * 3 // 4 + 20).to(torch.uint8)], dim=-1).contiguous()
+            cur3, prev3 = colour(cur), colour(prev)
+
+            def launch():
+                return eng.process_batch_device_bgr(cur3, prev3)[2]
+        else:
+            def launch():
+                return eng.process_batch_device(cur, prev)[2]
 
     if graph:
         eager_launch = launch

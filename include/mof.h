@@ -190,6 +190,13 @@ int mof_bm_refine(mof_bm_engine* e, int fullpix_x, int fullpix_y, int passes, in
 int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                 size_t prev_stride, size_t pitch, int n_pairs, int8_t* d_dx, int8_t* d_dy,
                                 int8_t* d_mode, void* stream);
+/* Front-end fusion for the block matchers, as mof_fft_process_batch_device_bgr: the frames are
+ * interleaved BGR8 (3 bytes per pixel, `pitch` bytes per row >= 3 * frame_width), cv::cvtColor(.., CV_RGB2GRAY) as the
+ * node applies it (optic_flow.cpp:1622, on BGR data) happens inside the kernels' staging loads. Same results, to the
+ * bit, as the gray entry on the converted frames. */
+int mof_bm_process_batch_device_bgr(mof_bm_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                    size_t prev_stride, size_t pitch, int n_pairs, int8_t* d_dx, int8_t* d_dy,
+                                    int8_t* d_mode, void* stream);
 int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
                               size_t prev_stride, size_t pitch, int n_pairs, int8_t* dx, int8_t* dy, int8_t* mode);
 int mof_bm_sync(mof_bm_engine* e);

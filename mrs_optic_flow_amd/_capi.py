@@ -81,6 +81,7 @@ SYMBOLS = {
     "mof_bm_process": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP]),
     "mof_bm_refine": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "mof_bm_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP, _VP, _VP]),
+    "mof_bm_process_batch_device_bgr": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP, _VP, _VP]),
     "mof_bm_process_batch_host": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP, _VP]),
     "mof_bm_sync": (_I, [_VP]),
     "mof_sr_create": (_I, [C.POINTER(SrConfig), C.POINTER(_VP)]),

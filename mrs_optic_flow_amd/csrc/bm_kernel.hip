@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "mof_kernels.h"
+#include "pc_common.hpp"  // rgb2gray_fixed, gray16_from_bgr48
 
 namespace mof {
 
@@ -70,6 +71,27 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ uint32_t fast_div(uint32_t i, uint32_t m) { return m ? __umulhi(i, m) : i; }
 __device__ __forceinline__ uint32_t div_magic(uint32_t d) { return d == 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
 
+// four gray pixels (packed u8x4) from 4 gray bytes or 12 interleaved BGR bytes, any alignment
+__device__ __forceinline__ uint32_t load_gray4(const uint8_t* p, int channels) {
+  if (channels == 1) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+  }
+  uint32_t w[3];
+  __builtin_memcpy(w, p, 12);
+  uint32_t packed = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int i = 3 * b;
+    const uint32_t c0 = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+    const uint32_t c1 = (w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xffu;
+    const uint32_t c2 = (w[(i + 2) >> 2] >> (8 * ((i + 2) & 3))) & 0xffu;
+    packed |= rgb2gray_fixed(c0, c1, c2) << (8 * b);
+  }
+  return packed;
+}
+
 template <int XB, int G>
 __global__ void __launch_bounds__(BM_THREADS_MAX) bm_scan_kernel(BmArgs a, int bpw, int groups_per_row, int WPD, int slot_dwords) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -93,8 +115,9 @@ __global__ void __launch_bounds__(BM_THREADS_MAX) bm_scan_kernel(BmArgs a, int b
   // per lane). A dword that straddles the window's right edge is loaded ending AT the edge and shifted down, so bytes
   // beyond the window width are zero and nothing outside the window is touched.
   {
-    const uint8_t* prev0 = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + bx0 * S;
-    const uint8_t* cur0 = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + r) * a.pitch + (bx0 * S + r);
+    const int CH = a.channels;  // 3: BGR8 frames, gray conversion on the way into LDS
+    const uint8_t* prev0 = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + (size_t)(bx0 * S) * CH;
+    const uint8_t* cur0 = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + r) * a.pitch + (size_t)(bx0 * S + r) * CH;
     const uint32_t win_dwords = (uint32_t)(WW * WPD), blk_dwords = (uint32_t)(sps * CPD);
     const uint32_t m_win = div_magic(win_dwords), m_wpd = div_magic((uint32_t)WPD);
     const uint32_t m_blk = div_magic(blk_dwords), m_cpd = div_magic((uint32_t)CPD);
@@ -105,7 +128,7 @@ __global__ void __launch_bounds__(BM_THREADS_MAX) bm_scan_kernel(BmArgs a, int b
       uint32_t v = 0;
       if ((int)x < WW) {
         const uint32_t off = (int)x + 4 <= WW ? x : (uint32_t)(WW - 4);
-        __builtin_memcpy(&v, prev0 + (size_t)y * a.pitch + s * (uint32_t)S + off, 4);  // any alignment
+        v = load_gray4(prev0 + (size_t)y * a.pitch + (size_t)(s * (uint32_t)S + off) * CH, CH);  // any alignment
         v >>= 8 * (x - off);
       }
       lds[s * (uint32_t)slot_dwords + rem] = v;
@@ -114,9 +137,7 @@ __global__ void __launch_bounds__(BM_THREADS_MAX) bm_scan_kernel(BmArgs a, int b
     for (uint32_t i = tid; i < (uint32_t)nb * blk_dwords; i += nthreads) {
       const uint32_t s = fast_div(i, m_blk), rem = i - s * blk_dwords;
       const uint32_t y = fast_div(rem, m_cpd), x = 4 * (rem - y * (uint32_t)CPD);
-      uint32_t v;
-      __builtin_memcpy(&v, cur0 + (size_t)y * a.pitch + s * (uint32_t)S + x, 4);
-      lds[s * (uint32_t)slot_dwords + win_dwords + rem] = v;
+      lds[s * (uint32_t)slot_dwords + win_dwords + rem] = load_gray4(cur0 + (size_t)y * a.pitch + (size_t)(s * (uint32_t)S + x) * CH, CH);
     }
   }
   if (tid < nb) keys[tid] = ~0ull;
@@ -291,8 +312,9 @@ __global__ void __launch_bounds__(64) bm_scan16_kernel(BmArgs a, int strip_dword
   const int nb = (gx - b0 < bpw) ? gx - b0 : bpw;        // blocks of this wave (>= 1)
   uint32_t* strip = lds;                                 // [WW][strip_dwords]
   uint32_t* keys = strip + WW * strip_dwords;            // [64]
-  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + b0 * S;
-  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + R) * a.pitch + R + b0 * S;
+  const int CH = a.channels;  // 3: BGR8 frames, gray conversion inside the loads
+  const uint8_t* prev = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + (size_t)(b0 * S) * CH;
+  const uint8_t* cur = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + R) * a.pitch + (size_t)(R + b0 * S) * CH;
   const int strip_w = (nb - 1) * S + WW;  // bytes of the frame rows this wave needs
 
   const int b = lane / XG, xg = lane % XG;      // block within the wave, group of four x-shifts
@@ -303,13 +325,17 @@ __global__ void __launch_bounds__(64) bm_scan16_kernel(BmArgs a, int strip_dword
   uint32_t cb[SPS][4];
 #pragma unroll
   for (int j = 0; j < SPS; ++j) {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 t;
-    __builtin_memcpy(&t, cur + (size_t)j * a.pitch + bc * S, 16);  // one global_load_dwordx4, any alignment
-    cb[j][0] = t.x;
-    cb[j][1] = t.y;
-    cb[j][2] = t.z;
-    cb[j][3] = t.w;
+    if (CH == 1) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 t;
+      __builtin_memcpy(&t, cur + (size_t)j * a.pitch + bc * S, 16);  // one global_load_dwordx4, any alignment
+      cb[j][0] = t.x;
+      cb[j][1] = t.y;
+      cb[j][2] = t.z;
+      cb[j][3] = t.w;
+    } else {
+      gray16_from_bgr48(cur + (size_t)j * a.pitch + (size_t)(bc * S) * 3, cb[j]);
+    }
   }
 
   // ---- stage the strip: 16-byte loads at any byte alignment (global_load_dwordx4 -> ds_write_b128);
@@ -327,7 +353,13 @@ __global__ void __launch_bounds__(64) bm_scan16_kernel(BmArgs a, int strip_dword
       u32x4 v = {0u, 0u, 0u, 0u};
       if (x < strip_w) {
         const int off = x + 16 <= strip_w ? x : strip_w - 16;
-        __builtin_memcpy(&v, prev + (size_t)y * a.pitch + off, 16);
+        if (CH == 1) {
+          __builtin_memcpy(&v, prev + (size_t)y * a.pitch + off, 16);
+        } else {
+          uint32_t g4[4];
+          gray16_from_bgr48(prev + (size_t)y * a.pitch + (size_t)off * 3, g4);
+          v = u32x4{g4[0], g4[1], g4[2], g4[3]};
+        }
         const int d = x - off;  // 0, or 1..15 bytes for the edge chunk
         if (d) {
           const int q = d >> 2;

@@ -504,8 +504,9 @@ static int validate_bm(const mof_bm_config* c) {
 }
 
 static mof::BmArgs bm_args(const mof_bm_engine* e, const uint8_t* cur, size_t cs, const uint8_t* prev, size_t ps,
-                           size_t pitch, int8_t* dx, int8_t* dy, int8_t* mode) {
+                           size_t pitch, int8_t* dx, int8_t* dy, int8_t* mode, int channels = 1) {
   mof::BmArgs a{};
+  a.channels = channels;
   a.cur = cur;
   a.prev = prev;
   a.cur_stride = cs;
@@ -693,6 +694,25 @@ int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t c
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   mof::BmArgs a = bm_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_dx, d_dy, d_mode);
+  HIP_TRY(mof::launch_bm_scan(a, n_pairs, s));
+  HIP_TRY(mof::launch_bm_mode(a, n_pairs, s));
+  return MOF_OK;
+}
+
+int mof_bm_process_batch_device_bgr(mof_bm_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
+                                    size_t prev_stride, size_t pitch, int n_pairs, int8_t* d_dx, int8_t* d_dy,
+                                    int8_t* d_mode, void* stream) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_pairs == 0) return MOF_OK;
+  if (!d_cur || !d_prev || !d_dx || !d_dy || !d_mode || n_pairs < 0 || pitch < 3 * (size_t)e->cfg.frame_width)
+    return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
+  if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
+    return fail(MOF_ERR_BAD_ARG, "batch too large for one launch");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  mof::BmArgs a = bm_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_dx, d_dy, d_mode, 3);
   HIP_TRY(mof::launch_bm_scan(a, n_pairs, s));
   HIP_TRY(mof::launch_bm_mode(a, n_pairs, s));
   return MOF_OK;

@@ -49,6 +49,7 @@ struct BmArgs {
   int grid_x, grid_y;
   int block, step, radius;
   int low_contrast_rule;
+  int channels;  // 1: gray frames; 3: interleaved BGR8, CV_RGB2GRAY fused into the staging loads
   int8_t* dx;    // [pair][by*grid_x+bx]
   int8_t* dy;
   int8_t* mode;  // [pair][8]

@@ -306,6 +306,22 @@ class _BmBase:
                                                     mode.data_ptr(), _stream_ptr(s)))
         return dx, dy, mode
 
+    def process_batch_device_bgr(self, cur, prev, stream=None):
+        """cur, prev: torch uint8 [n, H, W, 3] BGR8 views (W-stride 3, any row pitch): CV_RGB2GRAY (as the node applies it to
+        BGR data) is fused into the kernels' staging loads; same bits as the gray entry on the converted frames."""
+        import torch
+
+        _check_device_batch(cur, prev, (self.cfg.frame_height, self.cfg.frame_width), self.cfg.device, channels=3)
+        n = cur.shape[0]
+        dx = torch.empty((n, self.cfg.grid_y, self.cfg.grid_x), dtype=torch.int8, device=cur.device)
+        dy = torch.empty_like(dx)
+        mode = torch.empty((n, 8), dtype=torch.int8, device=cur.device)
+        s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        check(self._lib.mof_bm_process_batch_device_bgr(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
+                                                        prev.stride(0), cur.stride(1), n, dx.data_ptr(), dy.data_ptr(),
+                                                        mode.data_ptr(), _stream_ptr(s)))
+        return dx, dy, mode
+
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
             self._lib.mof_bm_destroy(self._h)

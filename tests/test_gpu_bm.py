@@ -153,6 +153,38 @@ def test_random_geometries_bit_exact(gpu):
             assert tuple(mode[k, :2]) == wmode
 
 
+@pytest.mark.parametrize("block,step,radius", [(16, 8, 16), (16, 4, 8), (24, 4, 5), (120, 24, 21), (32, 0, 8), (12, 4, 3)])
+def test_bgr_front_end_fused_into_the_block_scans(gpu, block, step, radius):
+    """SURVEY N2 for K2: interleaved BGR8 camera frames (a crop of a larger frame, odd byte offsets), CV_RGB2GRAY as the node
+    applies it (optic_flow.cpp:1622) inside the staging loads of both scan kernels: the same bits as the gray entry on the
+    converted crop, and the oracle's shifts."""
+    B, h, w, xi, yi = 3, 150 + 2 * radius, 260 + 2 * radius, 7, 5
+    if block == 120:
+        h, w = 330, 480
+    H, W = h + 11, w + 19
+    rng = np.random.default_rng(block * 100 + radius)
+    base = [synth.pair_np(30 + k, H, W, 2 + k, -k) for k in range(B)]
+
+    def colour(g):
+        g = g.astype(np.int32)
+        ch = np.stack([g, 255 - g // 2, (g * 3 // 4 + 20)], axis=-1) + rng.integers(-2, 3, g.shape + (3,))
+        return np.clip(ch, 0, 255).astype(np.uint8)
+    cur = np.stack([colour(c) for c, _ in base])
+    prev = np.stack([colour(p) for _, p in base])
+    eng = FastSpacedBMMethod(block, radius, step, (h, w))
+    cfg = O.bm_config_fast_spaced(w, h, block, step, radius)
+    tc, tp = torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)
+    dx, dy, mode = eng.process_batch_device_bgr(tc[:, yi:yi + h, xi:xi + w], tp[:, yi:yi + h, xi:xi + w])
+    dx, dy, mode = dx.cpu().numpy(), dy.cpu().numpy(), mode.cpu().numpy()
+    for k in range(B):
+        gc, gp = O.rgb2gray(cur[k, yi:yi + h, xi:xi + w]), O.rgb2gray(prev[k, yi:yi + h, xi:xi + w])
+        wdx, wdy, wmode = O.bm_process(gc, gp, cfg)
+        assert (dx[k] == wdx).all() and (dy[k] == wdy).all() and tuple(mode[k, :2]) == wmode, k
+        gx, gy, gm = eng.process_batch_device(torch.from_numpy(gc[None]).to(gpu), torch.from_numpy(gp[None]).to(gpu))
+        assert torch.equal(gx[0].cpu(), torch.from_numpy(dx[k])) and torch.equal(gy[0].cpu(), torch.from_numpy(dy[k]))
+        assert np.array_equal(gm[0].cpu().numpy(), mode[k])
+
+
 def test_refine_matches_oracle(gpu):
     """mof_bm_refine (BlockMethod::Refine, faithful and repaired) on the frames of the last processImage call."""
     fs = 144
