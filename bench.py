@@ -38,12 +38,17 @@ COMPUTE_PIPE_NOTE = "VALU fp32 (Stockham passes in LDS; MFMA row-DFT variant: se
 def binding_note(name: str, wl) -> str:
     """What actually bounds the dominant kernel of a workload (measured)."""
     if wl["kind"] == "bm":
-        return "integer VALU: v_qsad_pk_u16_u8 at 1 byte-difference per lane per cycle, VALU 86 % active; not HBM"
+        if wl["block"] == 16 and wl["radius"] in (8, 16) and not wl.get("block_method"):
+            return ("integer VALU: v_qsad_pk_u16_u8 at 1 byte-difference per lane per cycle; the wave's instruction stream runs at "
+                    "92 % of its issue time, 75-77 % of the instruction's ceiling; not HBM (DESIGN.md section 4, K2)")
+        return ("integer VALU: generic block scan 97 % VALU-busy, 81 % of those cycles in v_qsad_pk_u16_u8 (the rest: one "
+                "v_pk_mov per odd window pair, widening); small geometries (c1) are staging-latency-bound; not HBM")
     if wl["kind"] == "fft+rt":
         return "K1 as in ref + the getRT tail (one wavefront per pair, fp64 recurrences: 0.35 ms per 1024 pairs); not HBM"
     if wl["kind"] == "fft+sr":
-        return ("scale/rotation pipeline K4-K8 (log-polar gather + whole-frame phase correlation through cache-resident "
-                "scratch) takes 90 % of the step; K1 as in c2; not HBM")
+        return ("scale/rotation pipeline K4-K8 takes 79 % of the step: log-polar gathers (v_dot4c taps on LDS-staged source "
+                "boxes; VALU + L1 look-ups) 34 %, whole-frame transforms through Zt / Dt (2.2-2.8 TB/s of HBM traffic) 43 %; "
+                "K1 as in c2; DESIGN.md section 4 (K4-K8)")
     if wl["n"] >= 120:
         return ("one persistent workgroup per CU (the tile fills the LDS): latency of the per-patch phase chain, "
                 "VALU 77-79 % active, LDS pipe 35-59 %; not HBM")
