@@ -111,34 +111,39 @@ __global__ void __launch_bounds__(BM_THREADS_MAX) bm_scan_kernel(BmArgs a, int b
   const int bx0 = grp * bpw;
   const int nb = (a.grid_x - bx0 < bpw) ? a.grid_x - bx0 : bpw;  // blocks of this workgroup (>= 1)
 
-  // ---- stage windows + blocks in LDS: one flat loop over every slot's dwords (independent loads, several in flight
-  // per lane). A dword that straddles the window's right edge is loaded ending AT the edge and shifted down, so bytes
-  // beyond the window width are zero and nothing outside the window is touched.
+  // ---- stage windows + blocks in LDS. Lanes run along a row (a power-of-two count >= the row's data dwords, so the
+  // index arithmetic is shifts and masks) and step down the rows of all slots; every load is independent, several are
+  // in flight per lane. A dword that straddles the window's right edge is loaded ending AT the edge and shifted down.
+  // The padding dwords of a window row (look-ahead of the sliding register window) are NOT written: they only feed
+  // x-shifts >= D, whose sums are discarded (the four sums of a v_qsad are separate 16-bit fields).
+  // (The first r02 form walked a flat index with two divisions per dword: 25 VALU instructions per staged dword, as
+  // many instructions as the whole scan at c1's 32 x 32 blocks.)
   {
     const int CH = a.channels;  // 3: BGR8 frames, gray conversion on the way into LDS
     const uint8_t* prev0 = a.prev + (size_t)pair * a.prev_stride + (size_t)(by * S) * a.pitch + (size_t)(bx0 * S) * CH;
     const uint8_t* cur0 = a.cur + (size_t)pair * a.cur_stride + (size_t)(by * S + r) * a.pitch + (size_t)(bx0 * S + r) * CH;
-    const uint32_t win_dwords = (uint32_t)(WW * WPD), blk_dwords = (uint32_t)(sps * CPD);
-    const uint32_t m_win = div_magic(win_dwords), m_wpd = div_magic((uint32_t)WPD);
-    const uint32_t m_blk = div_magic(blk_dwords), m_cpd = div_magic((uint32_t)CPD);
-#pragma unroll 4
-    for (uint32_t i = tid; i < (uint32_t)nb * win_dwords; i += nthreads) {
-      const uint32_t s = fast_div(i, m_win), rem = i - s * win_dwords;
-      const uint32_t y = fast_div(rem, m_wpd), x = 4 * (rem - y * (uint32_t)WPD);
-      uint32_t v = 0;
-      if ((int)x < WW) {
-        const uint32_t off = (int)x + 4 <= WW ? x : (uint32_t)(WW - 4);
-        v = load_gray4(prev0 + (size_t)y * a.pitch + (size_t)(s * (uint32_t)S + off) * CH, CH);  // any alignment
-        v >>= 8 * (x - off);
+    const int win_dwords = WW * WPD;
+    auto stage = [&](const uint8_t* base, int rows, int row_px, int row_pitch_dw, int lds_off) {
+      const int dw = (row_px + 3) / 4;  // data dwords of a row
+      int xsh = 0;
+      while ((1 << xsh) < dw) ++xsh;
+      const int xd = tid & ((1 << xsh) - 1), rstep = nthreads >> xsh;
+      if (xd >= dw) return;
+      const int x = 4 * xd, off = x + 4 <= row_px ? x : row_px - 4;
+      const uint32_t sh = 8u * (uint32_t)(x - off);
+      int y = tid >> xsh, sl = 0;  // row within the slot, slot
+      while (y >= rows) y -= rows, ++sl;
+#pragma unroll 2
+      for (; sl < nb;) {
+        uint32_t v = load_gray4(base + (size_t)y * a.pitch + (size_t)(sl * S + off) * CH, CH);  // any alignment
+        v >>= sh;
+        lds[sl * slot_dwords + lds_off + y * row_pitch_dw + xd] = v;
+        y += rstep;
+        while (y >= rows) y -= rows, ++sl;
       }
-      lds[s * (uint32_t)slot_dwords + rem] = v;
-    }
-#pragma unroll 4
-    for (uint32_t i = tid; i < (uint32_t)nb * blk_dwords; i += nthreads) {
-      const uint32_t s = fast_div(i, m_blk), rem = i - s * blk_dwords;
-      const uint32_t y = fast_div(rem, m_cpd), x = 4 * (rem - y * (uint32_t)CPD);
-      lds[s * (uint32_t)slot_dwords + win_dwords + rem] = load_gray4(cur0 + (size_t)y * a.pitch + (size_t)(s * (uint32_t)S + x) * CH, CH);
-    }
+    };
+    stage(prev0, WW, WW, WPD, 0);
+    stage(cur0, sps, sps, CPD, win_dwords);
   }
   if (tid < nb) keys[tid] = ~0ull;
   __syncthreads();
