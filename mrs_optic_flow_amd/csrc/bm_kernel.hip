@@ -620,7 +620,8 @@ static BmPlan bm_plan_search(int block, int radius, int grid_x) {
         const int waves_per_cu = waves * (wgs_per_cu < 1 ? 1 : wgs_per_cu);
         // per row step and wave: xb v_qsad (16 cycles each on its SIMD); one window + one block dword from the CU's LDS
         const double valu = 16.0 * xb;
-        const double ldsc = 4.0 * (bm_window_read_cycles(D, XGL, xb, wpd, slot, items) + 2.0);  // four SIMDs share the LDS
+        // four SIMDs share the LDS; the block row is read 8 bytes at a time when its pitch allows (half the cycles per dword)
+        const double ldsc = 4.0 * (bm_window_read_cycles(D, XGL, xb, wpd, slot, items) + ((CPD & 1) == 0 && ((WW * wpd) & 1) == 0 ? 1.0 : 2.0));
         double c = (valu > ldsc ? valu : ldsc) / xb;
         c *= (double)(XGL * xb) / XG;                       // padded x-shift groups
         c *= (double)(4 * XG) / D;                          // padded x-shifts of the last group
@@ -630,6 +631,7 @@ static BmPlan bm_plan_search(int block, int radius, int grid_x) {
         if (waves_per_cu < 8) c *= 1.0 + 0.08 * (8 - waves_per_cu);  // little left to hide the staging phase behind
         if (wgs_per_cu <= 1) c *= 1.3;                               // ... and nothing at all with one workgroup per CU
         else if (wgs_per_cu == 2) c *= 1.08;
+        c *= 1.0 + 0.015 * waves;  // a workgroup's waves wait for one another around the staging phase: smaller ones overlap better
         c *= 1.0 + 0.002 * pad;
         if (c < best.cost) {
           best.cost = c;
