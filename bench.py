@@ -269,9 +269,15 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(g, stream=side):
-                graph_result = eager_launch()
+        import gc
+        gc.collect()
+        gc.disable()  # a finalizer that frees device memory inside the capture would invalidate it (global capture mode)
+        try:
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    graph_result = eager_launch()
+        finally:
+            gc.enable()
 
         def launch(keep=(eager_launch, side)):  # the captured graph uses the engines' scratch: keep every engine alive
             g.replay()

@@ -235,6 +235,8 @@ int mof_sr_reset(mof_sr_engine* e);
  * batch. Needed before a batch is CAPTURED into a HIP graph on an engine that has not run a batch yet (allocation is
  * not capturable: the batch call then fails with MOF_ERR_BAD_ARG). No reference counterpart. */
 int mof_sr_reserve(mof_sr_engine* e, int n_pairs);
+/* Note for graph users: mof_*_destroy frees device memory; under HIP's default (global) capture mode a free on ANY thread
+ * while a stream is capturing invalidates that capture -- do not destroy engines (or let a garbage collector do it) during one. */
 
 /* scaleRotationEstimator::processImage (scaleRotationEstimator.cpp:34-148), synchronous. frame: resolution^2
  * CV_8UC1. out_scale_rot[2] = (scale, rotation in rad): first call -> log-polar (INTER_CUBIC) kept as the previous

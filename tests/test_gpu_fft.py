@@ -289,10 +289,19 @@ def test_batch_entry_points_are_hip_graph_capturable(gpu):
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        with torch.cuda.graph(g, stream=side):
-            fm.process_batch_device(tc, tp, out=out)
-            sr_out = sr.process_batch_device(tc, tp)
+    # Engines of earlier tests may still await Python's cyclic collector; a finalizer that runs INSIDE the capture frees
+    # device memory (hipFree in mof_*_destroy), which HIP's global capture mode answers by invalidating the capture
+    # (seen as a flaky hipErrorStreamCaptureInvalidated): collect now, and keep the collector off while capturing.
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                fm.process_batch_device(tc, tp, out=out)
+                sr_out = sr.process_batch_device(tc, tp)
+    finally:
+        gc.enable()
     out.zero_()
     for _ in range(3):
         g.replay()
