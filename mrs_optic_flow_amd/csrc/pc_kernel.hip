@@ -37,6 +37,9 @@
 #ifndef MOF_FUSE_XPOW
 #define MOF_FUSE_XPOW 1  // 1: where it pays (PcTraits::FUSE_XPOW), the cross-power spectrum is formed inside the inverse row pass
 #endif
+#ifndef MOF_XPOW_SPLIT
+#define MOF_XPOW_SPLIT 1  // the inverse row pass of the waves that do not own row 0 carries no select for the packed row
+#endif
 #ifndef MOF_FUSED_TW
 #define MOF_FUSED_TW 1  // twiddles of the radix-8 second stage fused into its first layer (butterfly8_tw)
 #endif
@@ -163,7 +166,8 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
 // forward spectrum, forms conj(C[v][u]) in registers and goes straight into the first butterfly. The separate
 // cross-power pass (a tile read and half a tile write, one workgroup barrier) disappears. Partner rows are N-1..H+1,
 // which nobody writes in this phase; row 0 (packed with row H by the owning wave beforehand) is taken as it is.
-template <int N, int PK>
+// HAS_ROW0: the wave that owns row 0 (wave 0); the others never meet the packed row and carry no per-element select for it.
+template <int N, int PK, bool HAS_ROW0>
 __device__ __forceinline__ void row_pass_xpow(cf* __restrict__ z, int line0, int lane, const cf* tw_row) {
   using P = PcTraits<N>;
   constexpr int R1 = P::R1, R2 = P::R2, LINES = P::LI;
@@ -176,7 +180,7 @@ __device__ __forceinline__ void row_pass_xpow(cf* __restrict__ z, int line0, int
       const int q = lane + 64 * b;
       const int line = line0 + q / R2, x = q % R2;
       const int pline = (N - line) % N;
-      const bool packed = line == 0;
+      const bool packed = HAS_ROW0 && line == 0;
 #pragma unroll
       for (int k = 0; k < R1; ++k) {
         const int u = x + k * R2, um = (N - u) % N;
@@ -536,7 +540,12 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   }
   // ---- inverse (unscaled) of the Hermitian spectrum: forward transforms of conj(C); rows 0..H-1 only,
   //      then column pairs  (idft :1497)
-  if (wave < P::WI) row_pass_xpow<N, PK>(z, wave * P::LI, lane, tw_row);
+#if MOF_XPOW_SPLIT
+  if (wave == 0) row_pass_xpow<N, PK, true>(z, 0, lane, tw_row);
+  else if (wave < P::WI) row_pass_xpow<N, PK, false>(z, wave * P::LI, lane, tw_row);
+#else
+  if (wave < P::WI) row_pass_xpow<N, PK, true>(z, wave * P::LI, lane, tw_row);
+#endif
   } else {
 #ifndef MOF_ABLATE_NOPW
   {
