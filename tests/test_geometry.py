@@ -269,3 +269,19 @@ def test_argument_checks():
         G.get_2dt(np.zeros((1, 2)), G.Layout(1, 1, 0, 0, 120, 120, 120), G.Camera(0, 1, 0, 0, 0, 0, 0, 0, 0), G.T2dParams(1, 1, 0, 0, 0))
     L = G.reference_layout(480, 120)
     assert (L.grid_x, L.grid_y, L.stride_x, L.patch_size) == (4, 4, 120, 120)
+
+
+def test_unrolled_elimination_equals_the_indexed_form_bit_for_bit():
+    """The device's RANSAC hypotheses solve their 8 x 9 minimal-set system with solve_linear_unrolled (every index a
+    compile-time constant: the matrix stays in registers), the host form and the oracle-facing tests with solve_linear.
+    tests/cpp/test_geom_core.cpp runs both on 4500 random systems (pivoting, singular and exact-zero cases) on the
+    host and demands identical bits."""
+    import os
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    binary = os.path.join(here, "cpp", "test_geom_core")
+    if not os.path.exists(binary):
+        subprocess.check_call(["make", "-C", os.path.join(here, "cpp"), "-s", "test_geom_core"])
+    r = subprocess.run([binary], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("geom core ok"), r.stdout + r.stderr
