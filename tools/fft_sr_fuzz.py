@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Random FftMethod layouts (N in 32 / 64 / 120 / 128, any grid, origin, stride, frame size, batch classes) and random
+scale / rotation estimator settings (resolution, M, both OpenCV generations, both interpolations) through the GPU path
+against the oracle: shifts within 1e-4 px wherever the correlation surface has a stable arg-max, remap to the byte.
+usage (GPU box): python tools/fft_sr_fuzz.py [seed] [fft_trials] [sr_trials]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+import torch
+
+import oracle_lib as O
+import sr_scenes
+from mrs_optic_flow_amd import FftMethod, ScaleRotationEstimator, synth
+from mrs_optic_flow_amd.engine import INTER_CUBIC, INTER_LANCZOS4
+
+TOL = 1e-4
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n_fft = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+n_sr = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda")
+bad = checked = total = 0
+for trial in range(n_fft):
+    n = int(rng.choice([32, 64, 64, 120, 128]))
+    gx, gy = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+    sx, sy = int(rng.integers(max(1, n // 3), n + 40)), int(rng.integers(max(1, n // 3), n + 40))
+    ox, oy = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+    w = ox + (gx - 1) * sx + n + int(rng.integers(0, 13))
+    h = oy + (gy - 1) * sy + n + int(rng.integers(0, 13))
+    B = 3
+    cur, prev, shifts, kinds = synth.batch_np(B, h, w, max(1, n // 8), k0=int(rng.integers(0, 1000)))
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(ox, oy), stride=(sx, sy))
+    got = fm.process_batch_device(torch.from_numpy(cur).to(dev), torch.from_numpy(prev).to(dev)).cpu().numpy()
+    lay = O.fft_layout(w, h, n, gx, gy, (ox, oy), (sx, sy))
+    for k in range(B):
+        want64, _, diags = O.fft_process(cur[k], prev[k], lay, 64, want_diag=True)
+        want32, _ = O.fft_process(cur[k], prev[k], lay, 32)
+        for p in range(want64.shape[0]):
+            total += 1
+            stable = diags[p].second_value < 0.5 * diags[p].peak_value or (
+                np.array_equal(np.isnan(want64[p]), np.isnan(want32[p])) and np.allclose(want64[p], want32[p], rtol=0, atol=TOL, equal_nan=True))
+            if not stable:
+                continue
+            checked += 1
+            if not np.allclose(got[k, p], want64[p], rtol=0, atol=TOL, equal_nan=True):
+                bad += 1
+                print("FFT MISMATCH", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), k, p, got[k, p], want64[p])
+print(f"fft: {checked}/{total} patches with a stable arg-max checked, mismatches {bad}")
+sr_bad = 0
+for trial in range(n_sr):
+    res = int(rng.choice([240, 256, 480]))
+    M = float(rng.uniform(28.0, 90.0)) * res / 480.0
+    variant = int(rng.integers(0, 2))
+    interp = INTER_CUBIC if rng.integers(0, 2) else INTER_LANCZOS4
+    n_img = int(rng.choice([1, 4, 7, 21]))
+    base = sr_scenes.canvas(int(rng.integers(0, 1000)), res)
+    frames = np.stack([sr_scenes.view(base, res, float(rng.uniform(0.85, 1.2)), float(rng.uniform(-40, 40))) for _ in range(n_img)])
+    frames[0, :5, :] = 255
+    frames[-1, :, -3:] = 0
+    pad_x = int(rng.choice([0, 8, 24, 5]))
+    big = torch.zeros((n_img, res + 2, res + pad_x), dtype=torch.uint8, device=dev)
+    big[:, 1:1 + res, :res] = torch.from_numpy(frames).to(dev)
+    est = ScaleRotationEstimator(res, M, logpolar_variant=variant)
+    got = est.logpolar_batch_device(big[:, 1:1 + res, :res], interp).cpu().numpy()
+    for k in range(n_img):
+        want = O.logpolar(frames[k], M, interp, variant=variant)
+        if not np.array_equal(got[k], want):
+            sr_bad += 1
+            print("SR MISMATCH", trial, res, M, variant, interp, n_img, pad_x, k, int((got[k] != want).sum()))
+    if n_img >= 2:
+        pt = est.process_batch_device(big[1:, 1:1 + res, :res], big[:-1, 1:1 + res, :res]).cpu().numpy()
+        for k in range(min(n_img - 1, 3)):
+            ref = O.ScaleRotationEstimator(res, M, 64, variant=variant)
+            ref.processImage(frames[k])
+            ref.processImage(frames[k + 1])
+            if not np.allclose(pt[k, 2:], ref.pt, rtol=0, atol=TOL):
+                sr_bad += 1
+                print("SR PT MISMATCH", trial, res, M, variant, k, pt[k], ref.pt)
+print(f"sr: {n_sr} settings, mismatches {sr_bad}")
+sys.exit(1 if bad or sr_bad else 0)
