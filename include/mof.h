@@ -212,8 +212,9 @@ typedef struct mof_sr_config {
   int logpolar_variant; /* MOF_LOGPOLAR_CV4 (0, default) or MOF_LOGPOLAR_CV3: see below              */
   /* Batched mode only (no reference counterpart; zero-initialise for the defaults):                 */
   int batch_chunk;      /* frame pairs per pipeline pass, 0 = default (512; 1..4096). From its first      */
-                        /* batch on the engine owns batch_chunk * (4 res^2 + 8 res^2 + 8 res (res/2+1))   */
-                        /* bytes of scratch (1.9 GB at 480^2 and 512 pairs); until then one pair's worth  */
+                        /* batch on the engine owns scratch for min(batch size rounded up to a power of   */
+                        /* two, batch_chunk) pairs at 4 res^2 + 8 res^2 + 8 res (res/2+1) bytes each      */
+                        /* (1.9 GB at 480^2 and 512 pairs); until then one pair's worth                   */
   int pipeline_lanes;   /* 0 = default (1), 1 = every pass on the caller's stream, 2 = the remap of pass  */
                         /* k+1 runs beside the transforms of pass k on a second stream of the engine      */
 } mof_sr_config;

@@ -573,8 +573,10 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
   hipStream_t s = (hipStream_t)stream;
   const size_t nn = (size_t)res * res;
   {
-    // a whole pass at once (a batch that grows the scratch pair by pair would re-allocate on every call)
-    const int rc = scratch_reserve(e, n_pairs > 1 ? e->chunk : 1, s);
+    // what this batch needs, rounded up to a power of two (growing batches re-allocate O(log) times), a pass at most
+    int want = 1;
+    while (want < n_pairs && want < e->chunk) want <<= 1;
+    const int rc = scratch_reserve(e, want < e->chunk ? want : e->chunk, s);
     if (rc != MOF_OK) return rc;
   }
   SR_TRY(scratch_acquire(e, s));
