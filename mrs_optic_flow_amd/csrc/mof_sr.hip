@@ -332,6 +332,14 @@ hipError_t scratch_alloc(mof_sr_engine* e, int pairs) {
   return hipSuccess;
 }
 
+// Pairs per pass a batch of n pairs needs: n rounded up to a power of two (growing batches re-allocate O(log) times),
+// a whole pass at most. mof_sr_reserve and the batch entry use the same rule.
+int scratch_want(const mof_sr_engine* e, int n_pairs) {
+  int want = 1;
+  while (want < n_pairs && want < e->chunk) want <<= 1;
+  return want < e->chunk ? want : e->chunk;
+}
+
 // Makes sure the scratch holds a pass of `pairs` pairs. Growing frees and re-allocates: not possible while `s` is
 // being captured into a graph (run one batch, or mof_sr_reserve, before the capture), and only after every earlier
 // user of the scratch has finished. Returns a MOF status.
@@ -363,7 +371,7 @@ int mof_sr_reserve(mof_sr_engine* e, int n_pairs) {
   BusyGuard g(e->busy);
   if (!g.owned) return mof::capi_fail(MOF_ERR_BUSY, "engine busy");
   if (hipSetDevice(e->cfg.device) != hipSuccess) return mof::capi_fail(MOF_ERR_HIP, "hipSetDevice failed");
-  return scratch_reserve(e, n_pairs < e->chunk ? (n_pairs < 1 ? 1 : n_pairs) : e->chunk, e->stream);
+  return scratch_reserve(e, scratch_want(e, n_pairs), e->stream);
 }
 
 void mof_sr_destroy(mof_sr_engine* e) {
@@ -573,10 +581,7 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
   hipStream_t s = (hipStream_t)stream;
   const size_t nn = (size_t)res * res;
   {
-    // what this batch needs, rounded up to a power of two (growing batches re-allocate O(log) times), a pass at most
-    int want = 1;
-    while (want < n_pairs && want < e->chunk) want <<= 1;
-    const int rc = scratch_reserve(e, want < e->chunk ? want : e->chunk, s);
+    const int rc = scratch_reserve(e, scratch_want(e, n_pairs), s);
     if (rc != MOF_OK) return rc;
   }
   SR_TRY(scratch_acquire(e, s));
