@@ -43,6 +43,9 @@ def binding_note(name: str, wl) -> str:
                     "92 % of its issue time, 75-77 % of the instruction's ceiling; not HBM (DESIGN.md section 4, K2)")
         return ("integer VALU: generic block scan 97 % VALU-busy, 81 % of those cycles in v_qsad_pk_u16_u8 (the rest: one "
                 "v_pk_mov per odd window pair, widening); small geometries (c1) are staging-latency-bound; not HBM")
+    if wl["kind"] == "fft+2dt":
+        return ("1/4-scale resize fused into K1's load (half of the frame rows are fetched) + one 120 x 120 patch per pair: "
+                "0.10 ms per 1024 pairs, the one path here whose time is mostly frame fetch")
     if wl["kind"] == "fft+rt":
         return "K1 as in ref + the getRT tail (one wavefront per pair, fp64 recurrences: 0.35 ms per 1024 pairs); not HBM"
     if wl["kind"] == "fft+sr":
@@ -82,6 +85,12 @@ WORKLOADS = {
     "refrt": dict(kind="fft+rt", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
                   name="refrt: ref + the getRT geometry tail on the device (frames -> rotation, velocity), batch=1024 per GPU",
                   bytes_per_pair=2 * 480 * 480 + 64),
+    # the take-off mode: quarter-scale frames -> one long-range shift -> get2DT (closed form), on the device
+    "reflr": dict(kind="fft+2dt", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
+                  name="reflr: processImageLongRange (1/4-scale frames, one 120x120 patch) + get2DT on the device, batch=1024 per GPU",
+                  # cv::resize(1/4, INTER_LINEAR) taps pixels (4x+1, 4x+2) x (4y+1, 4y+2): half of the rows are needed (whole
+                  # 64-byte sectors of them), the other half never leaves HBM
+                  bytes_per_pair=2 * 480 * 240 + 64),
     # c2 with the node's front end fused in: interleaved BGR8 frames, CV_RGB2GRAY inside the load
     "c2bgr": dict(kind="fft", bgr=True, h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=512, s=8,
                   name="c2bgr: c2 on interleaved BGR8 frames, CV_RGB2GRAY fused into the load, batch=512 per GPU",
@@ -135,6 +144,16 @@ def cpu_baseline(wl, budget_s: float = 12.0):
             est.processImage(prev[k % n_gen][:r, x0:x0 + r])
             est.processImage(cur[k % n_gen][:r, x0:x0 + r])
         what = "f32 oracle (oracle/pc_ref.c + lp_ref.c)"
+    elif wl["kind"] == "fft+2dt":
+        lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
+        ocam = O.GeomCamera(400.0, 400.0, 240.0, 240.0, -0.01, 0.002, 0.0, 0.0, 0.0)
+        ol = O.GeomLayout(1, 1, 0, 0, wl["n"], wl["n"], wl["n"])
+        opar = O.Geom2dtParams(3.0, 0.02, 0.01, -0.02, 0.3)
+
+        def run(k):
+            flow, _ = O.fft_process_long_range(cur[k % n_gen], prev[k % n_gen], lay, 32)
+            O.geom_get_2dt(flow, ol, ocam, opar)
+        what = "f32 oracle long-range (oracle/pc_ref.c) + get2DT (oracle/geom_ref.c)"
     elif wl["kind"] == "fft+rt":
         import ctypes as C
         lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
@@ -201,7 +220,7 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
     # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
     cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
     state = {"out": None}
-    if wl["kind"] in ("fft", "fft+sr", "fft+rt"):
+    if wl["kind"] in ("fft", "fft+sr", "fft+rt", "fft+2dt"):
         eng = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"],
                         origin=wl["origin"], stride=wl["stride"], device=local_rank)
         state["out"] = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
@@ -214,6 +233,20 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
                 eng.process_batch_device(cur, prev, out=state["out"])
                 srout = sr.process_batch_device(cur_c, prev_c)
                 return torch.cat([state["out"].reshape(B, -1), srout], dim=1)
+        elif wl["kind"] == "fft+2dt":
+            import numpy as np
+
+            from mrs_optic_flow_amd import geometry as G
+            gcam = G.Camera(400.0, 400.0, 240.0, 240.0, -0.01, 0.002, 0.0, 0.0, 0.0)
+            n_lr = eng._lib.mof_fft_long_range_patches(eng._h)
+            gl = G.Layout(1, 1, 0, 0, wl["n"], wl["n"], wl["n"]) if n_lr == 1 else None  # the quarter image is one patch
+            assert gl is not None, "reflr expects the reference geometry (one long-range patch)"
+            row = np.frombuffer(bytes(G.T2dParams(3.0, 0.02, 0.01, -0.02, 0.3)), dtype=np.float64).copy()
+            d_par = torch.from_numpy(np.repeat(row[None, :], B, axis=0)).to(dev)
+
+            def launch():
+                flow = eng.process_long_range_batch_device(cur, prev)
+                return G.get_2dt_batch_device(flow, gl, gcam, d_par)
         elif wl["kind"] == "fft+rt":
             import ctypes as C
 
@@ -471,6 +504,7 @@ def main() -> None:
         line = {
             "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fft+sr": "_fft_phase_corr_plus_scale_rotation",
                                              "fft+rt": "_fft_phase_corr_plus_get_rt",
+                                             "fft+2dt": "_long_range_plus_get_2dt",
                                              "bm": "_block_method" if wl.get("block_method") else "_fast_spaced_bm"}[wl["kind"]],
             "value": pairs / elapsed,
             "unit": "frame-pairs/s",
@@ -497,7 +531,7 @@ def main() -> None:
             torch.cuda.empty_cache()
             # driver-visible records of the other BASELINE configurations (same protocol, fewer steps)
             line["other_workloads"] = {tag: measure_other(tag, dev, st, 5)
-                                       for tag, st in (("c3", 50), ("c4", 10), ("c5", 20), ("ref", 50), ("bmref", 50), ("refrt", 50))}
+                                       for tag, st in (("c3", 50), ("c4", 10), ("c5", 20), ("ref", 50), ("bmref", 50), ("refrt", 50), ("reflr", 50))}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
