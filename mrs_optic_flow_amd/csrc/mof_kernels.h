@@ -84,6 +84,8 @@ struct SrLpArgs {
   const SrMapEntry* map;   // res*res
   const int16_t* weights;  // [1024][K*K]
   const uint32_t* wplanes; // [1024][K*K/2 + 2]: signed-byte planes of the same weights (sr_weight_planes), staged kernel
+  const SrTileBox* sboxes; // [res/16 * res/16]: boxes of the 16 x 16 super-tiles (four 8 x 8 tiles of one workgroup), or null
+  int sbox_dwords_max;     // dwords of the largest super-tile box as the kernel lays it out
   int res;
   int zero_invalid;        // 1: pixels mapped outside the source are written as 0 (destination known to start as zeros)
   const SrTileBox* boxes;  // [tiles*tiles] for THIS interpolation's footprint size
@@ -112,7 +114,8 @@ std::vector<int16_t> sr_weight_table(int ksize /* 4 cubic, 8 Lanczos4 */);  // [
 // hi would be 128 (kept at 127; -1 if none): sum w p = 256 sum hi p' + sum lo p' + 128 sum w [+ 256 p'(tap)].
 std::vector<uint32_t> sr_weight_planes(const std::vector<int16_t>& weights, int ksize);
 // per-tile footprint boxes for a ksize x ksize kernel; *lds_per_wave receives the LDS bytes of the largest one
-std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave);
+// tile = 8 (per-wave boxes) or 16 (super-tile boxes shared by a workgroup)
+std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave, int tile_px);
 
 bool sr_resolution_supported(int res);
 int sr_candidates(int res);

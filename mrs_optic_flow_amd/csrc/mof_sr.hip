@@ -191,15 +191,15 @@ std::vector<uint32_t> sr_weight_planes(const std::vector<int16_t>& weights, int 
   return out;
 }
 
-std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave) {
-  const int tiles = (res + 7) / 8, half = ksize / 2 - 1;
+std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave, int tile_px) {
+  const int tiles = (res + tile_px - 1) / tile_px, half = ksize / 2 - 1;
   std::vector<SrTileBox> boxes((size_t)tiles * tiles, SrTileBox{0, 0, 0, 0});
   int worst = 16;
   for (int ty = 0; ty < tiles; ++ty)
     for (int tx = 0; tx < tiles; ++tx) {
       int x0 = 1 << 20, y0 = 1 << 20, x1 = -1, y1 = -1;
-      for (int l = 0; l < 64; ++l) {
-        const int rho = tx * 8 + (l & 7), phi = ty * 8 + (l >> 3);
+      for (int l = 0; l < tile_px * tile_px; ++l) {
+        const int rho = tx * tile_px + l % tile_px, phi = ty * tile_px + l / tile_px;
         if (rho >= res || phi >= res) continue;
         const SrMapEntry& m = map[(size_t)phi * res + rho];
         const int sx = m.ax - half, sy = m.ay - half;
@@ -252,6 +252,8 @@ struct mof_sr_engine {
   int16_t* d_w_cubic = nullptr;
   int16_t* d_w_lanczos = nullptr;
   uint32_t* d_wp[2] = {nullptr, nullptr};  // byte planes of the two tables (cubic, Lanczos4)
+  mof::SrTileBox* d_sboxes[2] = {nullptr, nullptr};  // super-tile boxes (cubic, Lanczos4); null when res % 16 != 0
+  int sbox_dwords[2] = {0, 0};
   float* d_twiddles = nullptr;
   uint8_t* d_frame = nullptr;    // staging for the stateful path (res*res)
   uint8_t* d_temp_im = nullptr;  // tempIm, :27
@@ -379,7 +381,7 @@ void mof_sr_destroy(mof_sr_engine* e) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
-  void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_wp[0], e->d_wp[1], e->d_twiddles, e->d_frame, e->d_temp_im, e->d_prev_lp,
+  void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_sboxes[0], e->d_sboxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_wp[0], e->d_wp[1], e->d_twiddles, e->d_frame, e->d_temp_im, e->d_prev_lp,
                  e->d_lp,  e->d_Zt,      e->d_Dt,        e->d_cand,     e->d_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -416,7 +418,14 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   const std::vector<mof::SrMapEntry> map = mof::sr_logpolar_map(res, cfg->magnitude, cfg->logpolar_variant);
   const std::vector<int16_t> wc = weight_table(4), wl = weight_table(8);
   int lds_c = 0, lds_l = 0;
-  const std::vector<mof::SrTileBox> bc = mof::sr_tile_boxes(map, res, 4, &lds_c), bl = mof::sr_tile_boxes(map, res, 8, &lds_l);
+  const std::vector<mof::SrTileBox> bc = mof::sr_tile_boxes(map, res, 4, &lds_c, 8), bl = mof::sr_tile_boxes(map, res, 8, &lds_l, 8);
+  // boxes of the 16 x 16 super-tiles (one workgroup = four tiles sharing a staged box)
+  int slds_c = 0, slds_l = 0;
+  std::vector<mof::SrTileBox> sbc, sbl;
+  if (res % 16 == 0) {
+    sbc = mof::sr_tile_boxes(map, res, 4, &slds_c, 16);
+    sbl = mof::sr_tile_boxes(map, res, 8, &slds_l, 16);
+  }
   std::vector<float> tw(2 * (size_t)res);
   mof_sr_engine* e = new (std::nothrow) mof_sr_engine();
   if (!e) return mof::capi_fail(MOF_ERR_NO_MEMORY, "out of host memory");
@@ -459,6 +468,14 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   CREATE_TRY(hipMemcpy(e->d_boxes[0], bc.data(), bc.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_boxes[1], bl.size() * sizeof(mof::SrTileBox)));
   CREATE_TRY(hipMemcpy(e->d_boxes[1], bl.data(), bl.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
+  if (!sbc.empty()) {
+    e->sbox_dwords[0] = slds_c / 4;
+    e->sbox_dwords[1] = slds_l / 4;
+    CREATE_TRY(hipMalloc(&e->d_sboxes[0], sbc.size() * sizeof(mof::SrTileBox)));
+    CREATE_TRY(hipMemcpy(e->d_sboxes[0], sbc.data(), sbc.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&e->d_sboxes[1], sbl.size() * sizeof(mof::SrTileBox)));
+    CREATE_TRY(hipMemcpy(e->d_sboxes[1], sbl.data(), sbl.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
+  }
   CREATE_TRY(hipMalloc(&e->d_w_cubic, wc.size() * sizeof(int16_t)));
   CREATE_TRY(hipMemcpy(e->d_w_cubic, wc.data(), wc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_w_lanczos, wl.size() * sizeof(int16_t)));
@@ -502,6 +519,8 @@ static void lp_tables(const mof_sr_engine* e, int interp, mof::SrLpArgs* lp) {
   const int k = interp == 2 ? 0 : 1;
   lp->weights = k == 0 ? e->d_w_cubic : e->d_w_lanczos;
   lp->wplanes = e->d_wp[k];
+  lp->sboxes = e->d_sboxes[k];
+  lp->sbox_dwords_max = e->sbox_dwords[k];
   lp->boxes = e->d_boxes[k];
   lp->lds_per_wave = e->lds_per_wave[k];
   lp->box_dwords_max = e->lds_per_wave[k] / 4;

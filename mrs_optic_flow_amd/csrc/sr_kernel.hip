@@ -294,13 +294,32 @@ __host__ __device__ inline int lp_box_capacity(int box_dwords_max) {
 #else
 #define MOF_LP_ATTR
 #endif
-template <int K, int NR>
+// SUPER: the four waves of a workgroup own the four 8 x 8 tiles of one 16 x 16 SUPER-TILE and share ONE staged box (the
+// bounding box of all their footprints, a.sboxes): the texture addresser was what bound the per-wave form (TA_BUSY 84-89 %:
+// every box row is a cache line of its own), and one shared box has 2.2-2.5x fewer rows than four separate ones. The
+// lanes of all four waves stage it together (slot = thread + 256 t) and meet at a raw s_barrier (a __syncthreads would
+// drain the ring's loads in flight).
+template <int K, int NR, bool SUPER>
 __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave, int xcd_groups) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lp_lds[];
-  const int res = a.res, tiles = (res + 7) / 8, n_tiles = tiles * tiles;
+  const int res = a.res, tiles = (res + 7) / 8, n_tiles = SUPER ? (tiles / 2) * (tiles / 2) : tiles * tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NT = SUPER ? 256 : 64;                 // threads that stage one box
+  const int st_tid = SUPER ? (int)threadIdx.x : lane;  // this thread's staging index
   int tile, img0;
-  if (xcd_groups > 0) {
+  if constexpr (SUPER) {
+    // one workgroup per (super-tile, image group); same XCD-aware order
+    if (xcd_groups > 0) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+      const int g = xcd + 8 * (j / n_tiles);
+      tile = j % n_tiles;
+      img0 = g * img_per_wave;
+      if (g >= xcd_groups) return;
+    } else {
+      tile = blockIdx.x % n_tiles;
+      img0 = (blockIdx.x / n_tiles) * img_per_wave;
+    }
+  } else if (xcd_groups > 0) {
     // XCD-aware order (speed only): workgroups b, b + 8, b + 16, .. share an XCD and its L2, so image group g goes to
     // the workgroups with b % 8 == g % 8 -- every image is then fetched into ONE L2 instead of up to eight
     // (r02: 3.3x the image bytes in FETCH_SIZE with the plain order)
@@ -316,7 +335,8 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
   }
   if (img0 >= n_images) return;
   const int img1 = img0 + img_per_wave < n_images ? img0 + img_per_wave : n_images;
-  const int rho = (tile % tiles) * 8 + (lane & 7), phi = (tile / tiles) * 8 + (lane >> 3);
+  const int rho = SUPER ? (tile % (tiles / 2)) * 16 + (wave & 1) * 8 + (lane & 7) : (tile % tiles) * 8 + (lane & 7);
+  const int phi = SUPER ? (tile / (tiles / 2)) * 16 + (wave >> 1) * 8 + (lane >> 3) : (tile / tiles) * 8 + (lane >> 3);
   const bool inside = rho < res && phi < res;
   const int pix = phi * res + rho;
   SrMapEntry m{0, 0, 0, 0};
@@ -325,7 +345,14 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
   constexpr int HALF = K / 2 - 1;
   const int sx = m.ax - HALF, sy = m.ay - HALF;
   uint8_t* dst = a.dst + (size_t)img0 * a.dst_stride + pix;
-  if (__ballot(valid) == 0ull) {  // the whole tile maps outside the source (rho beyond the corners)
+  const bool wave_valid = __ballot(valid) != 0ull;
+  // SUPER: the 16 x 16 output tile leaves through LDS -- every lane drops its byte, sixteen lanes of wave 0 pick up a row
+  // each and store 16 bytes: one store instruction and 16 cache lines per image instead of four and 32 (the cubic
+  // kernel's texture addresser was 84 % busy, half of it stores). BORDER_TRANSPARENT tiles that must keep destination
+  // pixels (no zero_invalid, some lane invalid) store per lane.
+  bool row_store = false;
+  if constexpr (SUPER) row_store = a.zero_invalid || __syncthreads_and((int)valid) != 0;
+  if (SUPER ? __syncthreads_or((int)valid) == 0 : !wave_valid) {  // the whole (super-)tile maps outside the source
     if (a.zero_invalid && inside)
       for (int img = img0; img < img1; ++img, dst += a.dst_stride) *dst = 0;
     return;
@@ -350,7 +377,7 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
     rem_k = valid ? (int)t[K * K / 2 + 1] : -1;
   }
   // the box: bw x bh source pixels at (bx, by); LDS rows of lpd dwords; every row starts `mis` bytes into its first dword
-  const SrTileBox box = a.boxes[tile];
+  const SrTileBox box = SUPER ? a.sboxes[tile] : a.boxes[tile];
   const int bx = box.x0, by = box.y0, bw = box.w, bh = box.h;
   const int lpd = (bw + 3 + 3) / 4 + 1, cnt = bh * lpd;
   const uint8_t* src = a.src + (size_t)img0 * a.src_stride;
@@ -359,15 +386,15 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
   // Box dword i = lane + 64 t comes from byte offset goff[t]. Slots past the box, or past the last needed byte of a
   // row (they may lie outside the buffer), re-read the box's first dword and park it in a dump slot behind the box, so
   // that the T = ceil(cnt / 64) loads and LDS writes of a box are unconditional for the whole wave.
-  const int T = __builtin_amdgcn_readfirstlane((cnt + 63) / 64);
+  const int T = __builtin_amdgcn_readfirstlane((cnt + NT - 1) / NT);
   uint32_t goff[NR];
   {
-    // (row, dword) of slot lane + 64 t, advanced by 64 slots per step: two integer divisions per wave instead of 2 NR
-    int r = lane / lpd, j = lane % lpd;
-    const int dr = 64 / lpd, dj = 64 % lpd;
+    // (row, dword) of slot st_tid + NT t, advanced by NT slots per step: two integer divisions per lane instead of 2 NR
+    int r = st_tid / lpd, j = st_tid % lpd;
+    const int dr = NT / lpd, dj = NT % lpd;
 #pragma unroll
     for (int t = 0; t < NR; ++t) {
-      const bool ok = lane + 64 * t < cnt && 4 * j < (int)mis + bw;
+      const bool ok = st_tid + NT * t < cnt && 4 * j < (int)mis + bw;
       goff[t] = ok ? (uint32_t)r * (uint32_t)a.pitch + 4u * (uint32_t)j : 0u;
       j += dj;
       r += dr;
@@ -377,8 +404,8 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
       }
     }
   }
-  const int box_dwords = lp_box_capacity(a.box_dwords_max);
-  uint32_t* L = lp_lds + (size_t)wave * box_dwords;  // the wave's box: one image at a time
+  const int box_dwords = SUPER ? 4 * lp_box_capacity((a.sbox_dwords_max + 3) / 4) : lp_box_capacity(a.box_dwords_max);
+  uint32_t* L = SUPER ? lp_lds : lp_lds + (size_t)wave * 2 * box_dwords;  // two boxes: the image being gathered and the next one
   // Footprints that cross the border take BORDER_REFLECT_101 taps. They go through the SAME code as interior ones:
   // tap row k1 is source row reflect(sy + k1); the K taps of a row are read as the K-byte window starting at
   // wx = clamp(sx, 0, res - K) -- it holds every reflected column -- and put in tap order by one byte permute
@@ -425,6 +452,8 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
   auto gather = [&](auto border_c, const uint32_t* Lu) -> int {
     constexpr bool BORDER = decltype(border_c)::value;
     int s_hi = 0, s_lo = 0;
+    // (issuing every tap row's LDS reads before the first dot product instead of the compiler's row-by-row order:
+    // same-box A/B, no change)
 #pragma unroll
     for (int k1 = 0; k1 < K; ++k1) {
       const uint32_t* p = Lu + rowoff[k1] + lcol;
@@ -475,7 +504,15 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
   }
   const size_t img_stride = a.src_stride;
   const int n_img = __builtin_amdgcn_readfirstlane(img1 - img0);  // wave-uniform (the analysis cannot see it: img0 depends on the wave index)
+  // top-left pixel of the super-tile in image img0 of the destination (row stores)
+  uint8_t* dst_tile = a.dst + (size_t)img0 * a.dst_stride + (size_t)(SUPER ? (tile / (tiles / 2)) * 16 : 0) * res + (SUPER ? (tile % (tiles / 2)) * 16 : 0);
   uint32_t ring[NR];
+  // the lanes that share a box meet here: one wave (its DS instructions execute in order), or the workgroup at a raw
+  // s_barrier behind its own LDS traffic -- NOT __syncthreads(), whose fence would also drain the ring's loads in flight
+  auto box_sync = [&]() {
+    if constexpr (SUPER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else wave_sync();
+  };
   auto pipeline = [&](auto tc_c) {
     constexpr int TC = decltype(tc_c)::value, D = NR / TC < 4 ? NR / TC : 4;
     auto fetch = [&](auto slot_c, int i) {  // image i (clamped to the wave's last) into ring slot `slot`
@@ -490,21 +527,39 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
       fetch(q, (int)decltype(q)::value);
       __builtin_amdgcn_sched_barrier(0);
     });
+    auto commit = [&](auto slot_c, uint32_t* Lb) {
+      constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+      for (int t = 0; t < TC; ++t) Lb[st_tid + NT * t] = ring[slot * TC + t] ^ 0x80808080u;
+    };
+    // Two LDS boxes: the box of image i + 1 is committed while image i is gathered, so the lanes that share a box meet
+    // ONCE per image (after both), and the freed ring slot is refilled right away.
+    commit(std::integral_constant<int, 0>{}, L);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(std::integral_constant<int, 0>{}, D);
+    __builtin_amdgcn_sched_barrier(0);
+    box_sync();
     for (int i = 0; i < n_img; i += D) {
       static_for<0, D>([&](auto q) {
-        constexpr int slot = decltype(q)::value;
+        constexpr int slot = decltype(q)::value, next = (slot + 1) % D;
         const int cur = i + slot;
-        wave_sync();  // every lane is done with the previous image's box
-#pragma unroll
-        for (int t = 0; t < TC; ++t) L[lane + 64 * t] = ring[slot * TC + t] ^ 0x80808080u;
-        wave_sync();
+        uint32_t* Lc = L + (cur & 1) * box_dwords;
+        commit(std::integral_constant<int, next>{}, L + ((cur + 1) & 1) * box_dwords);  // image cur + 1 (ring slot `next`)
         __builtin_amdgcn_sched_barrier(0);
-        fetch(q, cur + D);
+        fetch(std::integral_constant<int, next>{}, cur + 1 + D);
         __builtin_amdgcn_sched_barrier(0);
+        uint8_t* Lout = reinterpret_cast<uint8_t*>(L + 2 * box_dwords) + (cur & 1) * 256;
         if (cur < n_img) {
           int v = 0;
-          if (valid) v = wave_border ? gather(std::true_type{}, L) : gather(std::false_type{}, L);
-          if (valid || (a.zero_invalid && inside)) dst[(size_t)cur * a.dst_stride] = (uint8_t)v;
+          if (valid) v = wave_border ? gather(std::true_type{}, Lc) : gather(std::false_type{}, Lc);
+          if (SUPER && row_store) Lout[((wave >> 1) * 8 + (lane >> 3)) * 16 + (wave & 1) * 8 + (lane & 7)] = (uint8_t)v;
+          else if (valid || (a.zero_invalid && inside)) dst[(size_t)cur * a.dst_stride] = (uint8_t)v;
+        }
+        box_sync();  // image cur + 1 is staged, everyone is done with image cur (and its output tile is complete)
+        if (SUPER && row_store && cur < n_img && threadIdx.x < 16) {
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 rowv = *reinterpret_cast<const u32x4*>(Lout + 16 * threadIdx.x);
+          __builtin_memcpy(dst_tile + (size_t)cur * a.dst_stride + (size_t)threadIdx.x * res, &rowv, 16);
         }
       });
     }
@@ -818,11 +873,23 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
     const int nq = (n_tiles + 3) / 4;
     const int xcd_groups = (groups >= 8 && !xcd_off) ? groups : 0;  // fewer than 8 groups would leave XCDs idle
     const unsigned blocks = xcd_groups ? (unsigned)(8 * ((groups + 7) / 8) * nq) : (unsigned)(((long)n_tiles * groups + 3) / 4);
-    const size_t lds = (size_t)4 * sizeof(uint32_t) * lp_box_capacity(a.box_dwords_max);
+    // shared box per 16 x 16 super-tile (four waves) where the map's largest one fits the staging ring (256 x NR dwords)
+    static const bool super_off = [] { const char* e = getenv("MOF_SR_LP_SUPER"); return e && atoi(e) == 0; }();
+    if (!super_off && a.sboxes && a.res % 16 == 0 && a.sbox_dwords_max <= 256 * NR) {
+      const int n_super = (tiles / 2) * (tiles / 2);
+      const unsigned sblocks = xcd_groups ? (unsigned)(8 * ((groups + 7) / 8) * n_super) : (unsigned)((long)n_super * groups);
+      const size_t slds = sizeof(uint32_t) * (size_t)2 * 4 * lp_box_capacity((a.sbox_dwords_max + 3) / 4) + 512;  // two boxes + two output tiles
+      if (interp == 2)
+        hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
+      else
+        hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
+      return hipGetLastError();
+    }
+    const size_t lds = (size_t)4 * 2 * sizeof(uint32_t) * lp_box_capacity(a.box_dwords_max);
     if (interp == 2)
-      hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, false>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
     else
-      hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, false>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
     return hipGetLastError();
   }
   if (!global_w && n_images >= 4) return interp == 2 ? launch_lp_lds<4>(a, n_images, stream) : launch_lp_lds<8>(a, n_images, stream);
