@@ -229,9 +229,25 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
             x0, r = wl["sr_x0"], wl["sr_res"]
             cur_c, prev_c = cur[:, :r, x0:x0 + r], prev[:, :r, x0:x0 + r]
 
+            side_mode = int(os.environ.get("MOF_C5_SIDE", "0"))  # experiment: K1 on a second stream beside the estimator
+            side = torch.cuda.Stream(priority=0 if side_mode < 2 else -1) if side_mode else None
+
             def launch():
-                eng.process_batch_device(cur, prev, out=state["out"])
-                srout = sr.process_batch_device(cur_c, prev_c)
+                if side is None:
+                    eng.process_batch_device(cur, prev, out=state["out"])
+                    srout = sr.process_batch_device(cur_c, prev_c)
+                else:
+                    main = torch.cuda.current_stream()
+                    side.wait_stream(main)
+                    if side_mode == 3:  # the estimator on the side stream, K1 on the main one
+                        with torch.cuda.stream(side):
+                            srout = sr.process_batch_device(cur_c, prev_c)
+                        eng.process_batch_device(cur, prev, out=state["out"])
+                    else:
+                        with torch.cuda.stream(side):
+                            eng.process_batch_device(cur, prev, out=state["out"])
+                        srout = sr.process_batch_device(cur_c, prev_c)
+                    main.wait_stream(side)
                 return torch.cat([state["out"].reshape(B, -1), srout], dim=1)
         elif wl["kind"] == "fft+2dt":
             import numpy as np
@@ -302,17 +318,11 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
-        import gc
-        gc.collect()
-        gc.disable()  # a finalizer that frees device memory inside the capture would invalidate it (global capture mode)
-        try:
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(g, stream=side):
-                    graph_result = eager_launch()
-        finally:
-            gc.enable()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                graph_result = eager_launch()
 
-        def launch(keep=(eager_launch, side)):  # the captured graph uses the engines' scratch: keep every engine alive
+        def launch():  # (the captured engines are pinned by the library and by engine._CAPTURED until release_captured())
             g.replay()
             return graph_result
 
@@ -476,7 +486,8 @@ def main() -> None:
         if i is not None and i < len(ev1):
             ev1[i].record()
         if ag is not None:
-            return ag.submit()
+            ag.submit().done()  # nobody reads the gathered vectors here: released at once (sharding.Gathered)
+            return None
         if world > 1:
             res = sharding.gather_results(res, B * world)
         return res

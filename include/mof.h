@@ -54,6 +54,23 @@ const char* mof_last_error(void);
 /* Number of usable HIP devices (0 when there is none; never negative). */
 int mof_device_count(void);
 
+/* HIP graphs. Every *_batch_device entry point can be captured into a HIP graph on the caller's stream (no allocation,
+ * synchronisation or host read-back inside). A captured kernel node holds raw pointers to engine-owned device memory
+ * (FftMethod: the twiddle table; the scale/rotation estimator: its whole pipeline scratch), so a call made while `stream`
+ * is capturing PINS its engine:
+ *   - while pinned, the estimator's scratch never moves: a later batch that would need more pairs per pass than the
+ *     scratch holds fails with MOF_ERR_BUSY instead of re-allocating under the graph (mof_sr_reserve the largest batch
+ *     BEFORE capturing);
+ *   - mof_*_destroy of a pinned engine does not free anything: the engine is parked on a process-wide list, and replays of
+ *     the graph stay valid. mof_purge_deferred() frees the parked engines (call it when the graphs are destroyed);
+ *   - mof_*_release_graphs(e) un-pins a live engine: the caller states that no graph that captured it will be replayed.
+ * The library's own allocations and frees (create, destroy, reserve, the *_batch_host temporaries) run under
+ * hipStreamCaptureModeRelaxed on the calling thread, so creating or destroying an engine on one thread does not
+ * invalidate a capture that is running on another (or on the same) thread. Block-matching batches read no engine memory
+ * and do not pin. There is no reference counterpart: the reference is one synchronous call per frame. */
+int mof_purge_deferred(void);  /* frees every parked engine; returns how many */
+int mof_deferred_count(void);  /* engines parked now */
+
 /* ------------------------------------------------------------------------------------------ */
 /* FFT phase correlation (FftMethod)                                                          */
 /* ------------------------------------------------------------------------------------------ */
@@ -92,10 +109,13 @@ int mof_fft_config_reference(mof_fft_config* cfg, int frame_size, int sample_poi
 typedef struct mof_fft_engine mof_fft_engine;
 
 int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out);
-/* Diagnostics: name of the kernel formulation the engine launches ("stockham" -- pc_kernel.hip / pc_kernel_mixed.hip --
- * or "quad", pc_kernel_quad.hip, selected for 64 x 64 patches by the environment variable MOF_PC_QUAD=1 at load time). */
+/* Diagnostics: name of the kernel formulation the engine launches: "stockham" (pc_kernel.hip / pc_kernel_mixed.hip) in
+ * the product library; "quad" only in the A/B build csrc/ab/libmof_hip_quad.so with MOF_PC_QUAD=1 (pc_kernel_quad.hip,
+ * a measured-slower alternative kept for comparison, not shipped). */
 const char* mof_fft_kernel_variant(const mof_fft_engine* e);
 void mof_fft_destroy(mof_fft_engine* e);
+int mof_fft_release_graphs(mof_fft_engine* e);      /* see "HIP graphs" above */
+int mof_fft_graph_pinned(const mof_fft_engine* e);  /* 1 while pinned */
 
 /* setImPrev (OpticFlowCalc.h:14-16): host frame copied to the device-resident previous frame.
  * As in the reference, the first process() call after create()/reset() still correlates the
@@ -168,6 +188,8 @@ typedef struct mof_bm_engine mof_bm_engine;
 
 int mof_bm_create(const mof_bm_config* cfg, mof_bm_engine** out);
 void mof_bm_destroy(mof_bm_engine* e);
+int mof_bm_release_graphs(mof_bm_engine* e);      /* block-matching batches never pin; kept for symmetry */
+int mof_bm_graph_pinned(const mof_bm_engine* e);
 int mof_bm_set_prev(mof_bm_engine* e, const uint8_t* frame, size_t pitch);
 int mof_bm_reset(mof_bm_engine* e);
 
@@ -236,8 +258,8 @@ int mof_sr_reset(mof_sr_engine* e);
  * batch. Needed before a batch is CAPTURED into a HIP graph on an engine that has not run a batch yet (allocation is
  * not capturable: the batch call then fails with MOF_ERR_BAD_ARG). No reference counterpart. */
 int mof_sr_reserve(mof_sr_engine* e, int n_pairs);
-/* Note for graph users: mof_*_destroy frees device memory; under HIP's default (global) capture mode a free on ANY thread
- * while a stream is capturing invalidates that capture -- do not destroy engines (or let a garbage collector do it) during one. */
+int mof_sr_release_graphs(mof_sr_engine* e);      /* see "HIP graphs" at the top of this header */
+int mof_sr_graph_pinned(const mof_sr_engine* e);
 
 /* scaleRotationEstimator::processImage (scaleRotationEstimator.cpp:34-148), synchronous. frame: resolution^2
  * CV_8UC1. out_scale_rot[2] = (scale, rotation in rad): first call -> log-polar (INTER_CUBIC) kept as the previous
@@ -254,10 +276,11 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
  * call's last kernel, so back-to-back batches on different streams are safe but do not overlap. While `stream` is
  * being captured into a HIP graph no cross-stream dependency is taken or left: replays of graphs that contain calls
  * on one engine must be ordered by the caller.
- * Batches longer than one pipeline pass (256 pairs) run as two lanes -- the log-polar remaps of pass k+1 on a stream of
- * the engine's own, beside the transforms of pass k on `stream`, handed over with events; everything is complete when
- * `stream` is. Under graph capture the engine's stream joins the capture (fork / join by events) and the graph replays
- * with the same two lanes. A captured graph uses the engine's scratch: the engine must outlive it. */
+ * A batch runs in pipeline passes of batch_chunk pairs (default 512) on `stream`. With pipeline_lanes = 2 (not the
+ * default) the log-polar remaps of pass k+1 run on a stream of the engine's own beside the transforms of pass k, handed
+ * over with events; everything is complete when `stream` is. Under graph capture the engine's stream joins the capture
+ * (fork / join by events) and the graph replays with the same lanes. A captured call pins the engine ("HIP graphs" at
+ * the top of this header): its scratch stays put and its destroy is deferred while a graph may replay through it. */
 int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                 size_t prev_stride, size_t pitch, int n_pairs, double* d_out, void* stream);
 

@@ -58,6 +58,14 @@ SYMBOLS = {
     "mof_version": (C.c_char_p, []),
     "mof_last_error": (C.c_char_p, []),
     "mof_device_count": (_I, []),
+    "mof_purge_deferred": (_I, []),
+    "mof_deferred_count": (_I, []),
+    "mof_fft_release_graphs": (_I, [_VP]),
+    "mof_fft_graph_pinned": (_I, [_VP]),
+    "mof_bm_release_graphs": (_I, [_VP]),
+    "mof_bm_graph_pinned": (_I, [_VP]),
+    "mof_sr_release_graphs": (_I, [_VP]),
+    "mof_sr_graph_pinned": (_I, [_VP]),
     "mof_fft_config_reference": (_I, [C.POINTER(FftConfig), _I, _I, C.c_double]),
     "mof_fft_create": (_I, [C.POINTER(FftConfig), C.POINTER(_VP)]),
     "mof_fft_kernel_variant": (C.c_char_p, [_VP]),

@@ -560,6 +560,13 @@ MOF_HD bool homography_fit(const double* a, const double* b, const unsigned char
 }
 
 // ---- cv::decomposeHomographyMat(H, I) ------------------------------------------------------------------------------
+// ATTRIBUTION. This block (signd, opposite_of_minor, rmat_from_tstar_n, decompose_homography) is a restatement, written from
+// memory, of OpenCV's modules/calib3d/src/homography_decomp.cpp -- class HomographyDecompInria, the analytical method of
+// E. Malis and M. Vargas, "Deeper understanding of the homography decomposition for vision-based control", INRIA RR-6303
+// (2007) -- including that file's variable naming (M00.., rtM00.., e12.., npa / npb, ESii, r_2, nt_2). OpenCV is
+// third-party code under the Apache-2.0 (4.5+) / 3-clause BSD (3.x, 4.0-4.4) licence, Copyright (C) 2014 Samson Yilma and
+// the OpenCV contributors; it is NOT part of /root/reference, which only calls it (optic_flow.cpp:595). Nothing here was
+// checked against a real OpenCV build (parity unpinned).
 
 MOF_HD int signd(double x) { return x >= 0 ? 1 : -1; }
 

@@ -13,9 +13,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
+#include "capi_graph.hpp"
 #include "mof_kernels.h"
 
 namespace {
@@ -40,6 +42,35 @@ int capi_fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+namespace {
+struct Parked {
+  void (*destroy_now)(void*);
+  void* engine;
+};
+std::mutex g_parked_mutex;
+std::vector<Parked> g_parked;
+}  // namespace
+
+void park_engine(void (*destroy_now)(void*), void* engine) {
+  std::lock_guard<std::mutex> lock(g_parked_mutex);
+  g_parked.push_back(Parked{destroy_now, engine});
+}
+
+int purge_parked() {
+  std::vector<Parked> todo;
+  {
+    std::lock_guard<std::mutex> lock(g_parked_mutex);
+    todo.swap(g_parked);
+  }
+  for (const Parked& p : todo) p.destroy_now(p.engine);
+  return (int)todo.size();
+}
+
+int parked_count() {
+  std::lock_guard<std::mutex> lock(g_parked_mutex);
+  return (int)g_parked.size();
 }
 }  // namespace mof
 
@@ -86,6 +117,7 @@ struct mof_fft_engine {
   uint8_t* h_stage = nullptr;    // pinned upload staging (tightly packed frame)
   bool first = true;             // FftMethod.cpp:1761
   std::atomic<bool> busy{false};
+  std::atomic<bool> graph_pinned{false};  // a batch call was captured into a HIP graph (capi_graph.hpp)
 };
 
 struct mof_bm_engine {
@@ -105,6 +137,7 @@ struct mof_bm_engine {
   unsigned long long* h_sad9 = nullptr;
   bool have_pair = false;      // a processImage call has been made (both frame slots are meaningful)
   std::atomic<bool> busy{false};
+  std::atomic<bool> graph_pinned{false};
 };
 
 extern "C" {
@@ -168,6 +201,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   if (rc) return rc;
   rc = select_device(cfg->device);
   if (rc) return rc;
+  mof::RelaxedCapture relaxed;  // allocating an engine must not invalidate a capture on another thread
   const int n = cfg->patch_size;
   const size_t res = (size_t)cfg->grid_x * cfg->grid_y * 2;
   // twiddles W_N^k = exp(-2 pi i k / N), double -> float, axis values exact
@@ -216,8 +250,9 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
 
 const char* mof_fft_kernel_variant(const mof_fft_engine* e) { return e ? mof::pc_kernel_variant(e->cfg.patch_size) : ""; }
 
-void mof_fft_destroy(mof_fft_engine* e) {
-  if (!e) return;
+static void fft_destroy_now(void* p) {
+  mof_fft_engine* e = static_cast<mof_fft_engine*>(p);
+  mof::RelaxedCapture relaxed;  // frees must not invalidate a capture running on another thread
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->d_twiddles) (void)hipFree(e->d_twiddles);
@@ -229,6 +264,26 @@ void mof_fft_destroy(mof_fft_engine* e) {
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
+
+void mof_fft_destroy(mof_fft_engine* e) {
+  if (!e) return;
+  if (e->graph_pinned.load()) {  // a captured graph may still read the twiddles: keep them until the owner releases
+    mof::park_engine(&fft_destroy_now, e);
+    return;
+  }
+  fft_destroy_now(e);
+}
+
+int mof_fft_release_graphs(mof_fft_engine* e) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  e->graph_pinned.store(false);
+  return MOF_OK;
+}
+
+int mof_fft_graph_pinned(const mof_fft_engine* e) { return e && e->graph_pinned.load() ? 1 : 0; }
+
+int mof_purge_deferred(void) { return mof::purge_parked(); }
+int mof_deferred_count(void) { return mof::parked_count(); }
 
 static void pack_frame(uint8_t* dst, const uint8_t* src, size_t pitch, int w, int h) {
   for (int y = 0; y < h; ++y) std::memcpy(dst + (size_t)y * w, src + (size_t)y * pitch, (size_t)w);
@@ -375,6 +430,7 @@ int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_
   mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
   int rc = long_range_args(e, &a);
   if (rc) return rc;
+  if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
   HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
@@ -391,6 +447,7 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
   if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
   HIP_TRY(hipSetDevice(e->cfg.device));
   mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
+  if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
   HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
@@ -408,6 +465,7 @@ int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, si
   HIP_TRY(hipSetDevice(e->cfg.device));
   mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
   a.channels = 3;
+  if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
   HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
@@ -419,6 +477,7 @@ int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur
   if (!cur || !prev || !out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  mof::RelaxedCapture relaxed;  // the temporaries below must not disturb a capture on another thread
   const size_t fb = e->frame_bytes, res = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
   uint8_t *d_c = nullptr, *d_p = nullptr;
   double* d_o = nullptr;
@@ -531,6 +590,7 @@ int mof_bm_create(const mof_bm_config* cfg, mof_bm_engine** out) {
   if (rc) return rc;
   rc = select_device(cfg->device);
   if (rc) return rc;
+  mof::RelaxedCapture relaxed;
   mof_bm_engine* e = new (std::nothrow) mof_bm_engine();
   if (!e) return fail(MOF_ERR_NO_MEMORY, "out of host memory");
   e->cfg = *cfg;
@@ -560,8 +620,9 @@ int mof_bm_create(const mof_bm_config* cfg, mof_bm_engine** out) {
   return MOF_OK;
 }
 
-void mof_bm_destroy(mof_bm_engine* e) {
-  if (!e) return;
+static void bm_destroy_now(void* p) {
+  mof_bm_engine* e = static_cast<mof_bm_engine*>(p);
+  mof::RelaxedCapture relaxed;
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->d_frames[0]) (void)hipFree(e->d_frames[0]);
@@ -578,6 +639,23 @@ void mof_bm_destroy(mof_bm_engine* e) {
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
+
+void mof_bm_destroy(mof_bm_engine* e) {
+  if (!e) return;
+  if (e->graph_pinned.load()) {
+    mof::park_engine(&bm_destroy_now, e);
+    return;
+  }
+  bm_destroy_now(e);
+}
+
+int mof_bm_release_graphs(mof_bm_engine* e) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  e->graph_pinned.store(false);
+  return MOF_OK;
+}
+
+int mof_bm_graph_pinned(const mof_bm_engine* e) { return e && e->graph_pinned.load() ? 1 : 0; }
 
 int mof_bm_set_prev(mof_bm_engine* e, const uint8_t* frame, size_t pitch) {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
@@ -639,6 +717,7 @@ int mof_bm_refine(mof_bm_engine* e, int fullpix_x, int fullpix_y, int passes, in
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int w = e->cfg.frame_width, h = e->cfg.frame_height, W2 = 2 * w, H2 = 2 * h;
   if (!e->d_up[0]) {
+    mof::RelaxedCapture relaxed;
     HIP_TRY(hipMalloc(&e->d_up[0], (size_t)W2 * H2));
     HIP_TRY(hipMalloc(&e->d_up[1], (size_t)W2 * H2));
     HIP_TRY(hipMalloc(&e->d_sad9, 9 * sizeof(unsigned long long)));
@@ -692,7 +771,7 @@ int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t c
   BusyGuard g(e->busy);
   if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t s = (hipStream_t)stream;  // (a captured block-matching batch reads no engine-owned memory: no pin)
   mof::BmArgs a = bm_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_dx, d_dy, d_mode);
   HIP_TRY(mof::launch_bm_scan(a, n_pairs, s));
   HIP_TRY(mof::launch_bm_mode(a, n_pairs, s));
@@ -711,7 +790,7 @@ int mof_bm_process_batch_device_bgr(mof_bm_engine* e, const uint8_t* d_cur, size
   BusyGuard g(e->busy);
   if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t s = (hipStream_t)stream;  // (a captured block-matching batch reads no engine-owned memory: no pin)
   mof::BmArgs a = bm_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_dx, d_dy, d_mode, 3);
   HIP_TRY(mof::launch_bm_scan(a, n_pairs, s));
   HIP_TRY(mof::launch_bm_mode(a, n_pairs, s));
@@ -725,6 +804,7 @@ int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_s
   if (!cur || !prev || !dx || !dy || !mode || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  mof::RelaxedCapture relaxed;
   const size_t fb = e->frame_bytes, nb = (size_t)e->cfg.grid_x * e->cfg.grid_y;
   std::vector<uint8_t> pc(fb * n_pairs), pp(fb * n_pairs);
   for (int k = 0; k < n_pairs; ++k) {

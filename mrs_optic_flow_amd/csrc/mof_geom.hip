@@ -371,9 +371,16 @@ __global__ void __launch_bounds__(64) geom_get_rt_kernel(const double* __restric
   const RtParams p = params[pair];
   const double* sh = shifts + (size_t)pair * total * 2;
   double* o = out + (size_t)pair * 8;
-  if (lane < 8) o[lane] = lane == 3 ? 1.0 : 0.0;  // identity rotation, zero translation unless the call succeeds
+  // every exit path writes the 8 outputs exactly once, from lane 0: identity rotation and zero translation unless
+  // the call succeeds, then the status
+  auto leave = [&](int status) {
+    if (lane == 0) {
+      for (int k = 0; k < 7; ++k) o[k] = k == 3 ? 1.0 : 0.0;
+      o[7] = (double)status;
+    }
+  };
   if (!finite_d(1.0 / p.dt)) {
-    if (lane == 0) o[7] = (double)kBadDuration;
+    leave(kBadDuration);
     return;
   }
   // ordered compaction of the valid patches, undistorted on the way
@@ -400,7 +407,7 @@ __global__ void __launch_bounds__(64) geom_get_rt_kernel(const double* __restric
   }
   __syncthreads();
   if (thr < 0 || n < thr) {
-    if (lane == 0) o[7] = (double)kTooFewPoints;
+    leave(kTooFewPoints);
     return;
   }
 #ifdef MOF_GEOM_PROF  // diagnostic build (tools/geom_stage_cycles.py): stage cycle counts instead of results
@@ -442,7 +449,7 @@ __global__ void __launch_bounds__(64) geom_get_rt_kernel(const double* __restric
   int remaining = 0;
   for (int i = 0; i < n; ++i) remaining += mask[i];
   if (remaining < thr || !found) {
-    if (lane == 0) o[7] = (double)(remaining < thr ? kTooFewInliers : kNoHomography);
+    leave(remaining < thr ? kTooFewInliers : kNoHomography);
     return;
   }
 #ifdef MOF_GEOM_PROF
@@ -468,8 +475,12 @@ __global__ void __launch_bounds__(64) geom_get_rt_kernel(const double* __restric
 #ifdef MOF_GEOM_PROF
     res[0] = (double)(t_b - t_a), res[1] = (double)(t_c - t_b), res[2] = (double)(__builtin_readcyclecounter() - t_c);
 #endif
-    if (status == kOk)
-      for (int k = 0; k < 7; ++k) o[k] = res[k];
+#ifdef MOF_GEOM_PROF
+    const bool keep = true;
+#else
+    const bool keep = status == kOk;
+#endif
+    for (int k = 0; k < 7; ++k) o[k] = keep ? res[k] : (k == 3 ? 1.0 : 0.0);
     o[7] = (double)status;
   }
 }
@@ -487,6 +498,28 @@ __global__ void __launch_bounds__(64) geom_get_2dt_kernel(const double* __restri
   o[7] = 0.0;
 }
 
+}  // namespace
+
+namespace {
+// The geometry ABI carries no device ordinal: launch on the device that owns the output buffer (the stream and the
+// other pointers must belong to it too), leaving the calling thread's current device as it was.
+struct DeviceOf {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceOf(const void* p) {
+    hipPointerAttribute_t at{};
+    err = hipPointerGetAttributes(&at, p);
+    if (err != hipSuccess) return;
+    int cur = 0;
+    if ((err = hipGetDevice(&cur)) != hipSuccess) return;
+    if (cur != at.device) {
+      if ((err = hipSetDevice(at.device)) == hipSuccess) prev = cur;
+    }
+  }
+  ~DeviceOf() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 }  // namespace
 
 extern "C" {
@@ -582,6 +615,8 @@ int mof_geom_get_rt_batch_device(const double* d_shifts_xy, const mof_geom_layou
   Camera c;
   std::memcpy(&L, layout, sizeof(L));
   std::memcpy(&c, cam, sizeof(c));
+  DeviceOf dev(d_out);
+  if (dev.err != hipSuccess) return mof::capi_fail(MOF_ERR_BAD_ARG, "d_out is not a device pointer: %s", hipGetErrorString(dev.err));
   const int total = L.grid_x * L.grid_y;
   size_t lds = (size_t)(4 * total + (total + 7) / 8) * sizeof(double);  // a, b (2 doubles per point each) + mask bytes
   const int wave_fit = total <= kWaveFitPoints;
@@ -605,6 +640,8 @@ int mof_geom_get_2dt_batch_device(const double* d_shifts_xy, const mof_geom_layo
   Camera c;
   std::memcpy(&L, layout, sizeof(L));
   std::memcpy(&c, cam, sizeof(c));
+  DeviceOf dev(d_out);
+  if (dev.err != hipSuccess) return mof::capi_fail(MOF_ERR_BAD_ARG, "d_out is not a device pointer: %s", hipGetErrorString(dev.err));
   hipLaunchKernelGGL(geom_get_2dt_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                      d_shifts_xy, L, c, reinterpret_cast<const T2dParams*>(d_params), n_pairs, d_out);
   const hipError_t e = hipGetLastError();

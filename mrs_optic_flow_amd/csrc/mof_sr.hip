@@ -19,6 +19,7 @@
 #include <new>
 #include <vector>
 
+#include "capi_graph.hpp"
 #include "mof.h"
 #include "mof_kernels.h"
 
@@ -269,6 +270,9 @@ struct mof_sr_engine {
   bool two_lanes = false;        // remap of pass k+1 beside the transforms of pass k (mof_sr_config.pipeline_lanes == 2)
   bool first = true;             // :31
   std::atomic<bool> busy{false};
+  // a batch call was captured into a HIP graph: the graph's kernel nodes hold raw pointers into the scratch below, so
+  // from then on the scratch neither grows nor is freed until mof_sr_release_graphs (capi_graph.hpp)
+  std::atomic<bool> graph_pinned{false};
   // Ordering of the engine-owned scratch (d_lp, d_Zt, d_Dt, d_cand, d_out) across streams: every call that
   // touches it records `scratch_ev` behind its last kernel; a later call on a DIFFERENT stream first makes its
   // stream wait for that event (same-stream calls are ordered by the stream itself).
@@ -316,6 +320,7 @@ hipError_t scratch_release(mof_sr_engine* e, hipStream_t s) {
 
 // The pipeline scratch (log-polar images of two passes, Zt, Dt, peak candidates, results) for `pairs` pairs per pass.
 hipError_t scratch_alloc(mof_sr_engine* e, int pairs) {
+  mof::RelaxedCapture relaxed;  // allocation / release must not invalidate a capture on another thread
   const int res = e->cfg.resolution;
   const size_t nn = (size_t)res * res;
   void** bufs[] = {(void**)&e->d_lp, (void**)&e->d_Zt, (void**)&e->d_Dt, (void**)&e->d_cand, (void**)&e->d_out};
@@ -347,6 +352,10 @@ int scratch_want(const mof_sr_engine* e, int n_pairs) {
 // user of the scratch has finished. Returns a MOF status.
 int scratch_reserve(mof_sr_engine* e, int pairs, hipStream_t s) {
   if (pairs <= e->scratch_pairs) return MOF_OK;
+  if (e->graph_pinned.load())
+    return mof::capi_fail(MOF_ERR_BUSY, "the estimator's scratch would have to grow from %d to %d pairs per pass, but a captured HIP graph "
+                                         "still points into it: reserve the largest batch before capturing, or call "
+                                         "mof_sr_release_graphs once the graphs are gone", e->scratch_pairs, pairs);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
     return mof::capi_fail(MOF_ERR_BAD_ARG, "the estimator's scratch must grow to %d pairs per pass, which cannot happen inside a graph capture: "
@@ -376,8 +385,9 @@ int mof_sr_reserve(mof_sr_engine* e, int n_pairs) {
   return scratch_reserve(e, scratch_want(e, n_pairs), e->stream);
 }
 
-void mof_sr_destroy(mof_sr_engine* e) {
-  if (!e) return;
+static void sr_destroy_now(void* p) {
+  mof_sr_engine* e = static_cast<mof_sr_engine*>(p);
+  mof::RelaxedCapture relaxed;
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
@@ -396,6 +406,23 @@ void mof_sr_destroy(mof_sr_engine* e) {
   delete e;
 }
 
+void mof_sr_destroy(mof_sr_engine* e) {
+  if (!e) return;
+  if (e->graph_pinned.load()) {  // replays of a captured graph would run through freed scratch: park until released
+    mof::park_engine(&sr_destroy_now, e);
+    return;
+  }
+  sr_destroy_now(e);
+}
+
+int mof_sr_release_graphs(mof_sr_engine* e) {
+  if (!e) return mof::capi_fail(MOF_ERR_NOT_INIT, "null engine");
+  e->graph_pinned.store(false);
+  return MOF_OK;
+}
+
+int mof_sr_graph_pinned(const mof_sr_engine* e) { return e && e->graph_pinned.load() ? 1 : 0; }
+
 int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   if (!out) return mof::capi_fail(MOF_ERR_BAD_ARG, "null out");
   *out = nullptr;
@@ -413,6 +440,7 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   }
   if (cfg->device < 0 || cfg->device >= ndev) return mof::capi_fail(MOF_ERR_BAD_ARG, "device %d out of range", cfg->device);
   SR_TRY(hipSetDevice(cfg->device));
+  mof::RelaxedCapture relaxed;  // allocating an engine must not invalidate a capture on another thread
   const int res = cfg->resolution;
   const size_t nn = (size_t)res * res;
   const std::vector<mof::SrMapEntry> map = mof::sr_logpolar_map(res, cfg->magnitude, cfg->logpolar_variant);
@@ -604,6 +632,7 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
     if (rc != MOF_OK) return rc;
   }
   SR_TRY(scratch_acquire(e, s));
+  if (mof::stream_capturing(s)) e->graph_pinned.store(true);
   const int kChunk = e->chunk;
   // Under graph capture the fork / join below pulls the engine's stream into the caller's capture (event record on the
   // capturing stream, wait on the other), so a captured batch replays with the same two lanes.
@@ -671,6 +700,7 @@ int mof_sr_logpolar_batch_device(mof_sr_engine* e, const uint8_t* d_src, size_t 
   lp.map = e->d_map;
   lp.res = res;
   lp_tables(e, interpolation, &lp);
+  if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);  // the map and the tables are the engine's
   SR_TRY(mof::launch_sr_logpolar(lp, interpolation, n_images, (hipStream_t)stream));  // touches no engine scratch
   return MOF_OK;
 }

@@ -699,12 +699,16 @@ static hipError_t launch_n(const PcArgs& a_in, int n_pairs, hipStream_t stream) 
   return hipGetLastError();
 }
 
-// MOF_PC_QUAD=1 routes N = 64 to the quad-per-line formulation of pc_kernel_quad.hip (an evaluated alternative: a third
-// of the LDS traffic, 35 % more VALU instructions, 8 % slower on MI355X -- DESIGN.md §4, K1).
+// The quad-per-line formulation of pc_kernel_quad.hip (an evaluated alternative: a third of the LDS traffic, 35 % more
+// VALU instructions, 8 % slower on MI355X -- DESIGN.md section 4, K1) is NOT part of the product library: only the A/B
+// build `make quad` (-DMOF_WITH_QUAD -> csrc/ab/libmof_hip_quad.so, loaded through MOF_LIB_PATH) links it, and there
+// MOF_PC_QUAD=1 routes N = 64 to it.
+#ifdef MOF_WITH_QUAD
 static bool classic64() {
   static const bool v = [] { const char* e = getenv("MOF_PC_QUAD"); return !(e && atoi(e) != 0); }();
   return v;
 }
+#endif
 
 hipError_t pc_configure(int patch_size) {
   int dev = 0;
@@ -714,7 +718,10 @@ hipError_t pc_configure(int patch_size) {
     case 32: return configure_n<32>();
     case 64: {
       hipError_t e = configure_n<64>();
-      return e != hipSuccess ? e : pc_configure_quad64();
+#ifdef MOF_WITH_QUAD
+      if (e == hipSuccess) e = pc_configure_quad64();
+#endif
+      return e;
     }
     case 128: return configure_n<128>();
     case 120: return pc_configure_120();
@@ -725,14 +732,23 @@ hipError_t pc_configure(int patch_size) {
 hipError_t launch_pc_field(const PcArgs& a, int patch_size, int n_pairs, hipStream_t stream) {
   switch (patch_size) {
     case 32: return launch_n<32>(a, n_pairs, stream);
-    case 64: return classic64() ? launch_n<64>(a, n_pairs, stream) : launch_pc_field_quad64(a, n_pairs, stream);
+    case 64:
+#ifdef MOF_WITH_QUAD
+      if (!classic64()) return launch_pc_field_quad64(a, n_pairs, stream);
+#endif
+      return launch_n<64>(a, n_pairs, stream);
     case 128: return launch_n<128>(a, n_pairs, stream);
     case 120: return launch_pc_field_120(a, n_pairs, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
-const char* pc_kernel_variant(int patch_size) { return (patch_size == 64 && !classic64()) ? "quad" : "stockham"; }
+const char* pc_kernel_variant(int patch_size) {
+#ifdef MOF_WITH_QUAD
+  if (patch_size == 64 && !classic64()) return "quad";
+#endif
+  return "stockham";
+}
 
 bool pc_patch_size_supported(int n) { return n == 32 || n == 64 || n == 128 || n == 120; }
 

@@ -34,6 +34,32 @@ def _stream_ptr(stream):
     return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
 
 
+# Engines that a HIP graph captured (include/mof.h, "HIP graphs"): a captured kernel node holds raw pointers into the
+# engine's device memory, so the Python handle must not be collected while the graph can replay. Every *_device call made
+# while the stream is capturing puts its engine here; release_captured() (per engine or for all) lets go again.
+_CAPTURED: set = set()
+
+
+def _pin_if_capturing(engine, stream) -> None:
+    import torch
+
+    if torch.cuda.is_current_stream_capturing() or (stream is not None and hasattr(stream, "is_capturing")
+                                                      and stream.is_capturing()):
+        _CAPTURED.add(engine)
+
+
+def release_captured(engine=None) -> int:
+    """The caller states that the graphs which captured ``engine`` (default: every captured engine) are gone: the
+    engines may be collected, and the estimator's scratch may grow, again. Returns how many engines were released."""
+    todo = list(_CAPTURED) if engine is None else [e for e in (engine,) if e in _CAPTURED]
+    for e in todo:
+        _CAPTURED.discard(e)
+        e._release_graphs()
+    lib = _capi.load()
+    lib.mof_purge_deferred()
+    return len(todo)
+
+
 PEAK_OPENCV, PEAK_OCL = 0, 1  # include/mof.h
 INTER_CUBIC, INTER_LANCZOS4 = 2, 4  # include/mof.h (cv::INTER_CUBIC, cv::INTER_LANCZOS4)
 LOGPOLAR_CV4, LOGPOLAR_CV3 = 0, 1  # include/mof.h
@@ -158,6 +184,7 @@ class FftMethod:
         n = cur.shape[0]
         out = torch.empty((n, n_lr, 2), dtype=torch.float64, device=cur.device)
         s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        _pin_if_capturing(self, s)
         check(self._lib.mof_fft_process_long_range_batch_device(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
                                                                 prev.stride(0), cur.stride(1), n, out.data_ptr(),
                                                                 _stream_ptr(s)))
@@ -191,6 +218,7 @@ class FftMethod:
                 and out.numel() == n * self.n_patches * 2):
             raise ValueError("out must be a dense float64 tensor of n * patches * 2 elements on the engine's device")
         s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        _pin_if_capturing(self, s)
         check(self._lib.mof_fft_process_batch_device(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
                                                      prev.stride(0), cur.stride(1), n, out.data_ptr(), _stream_ptr(s)))
         return out
@@ -204,6 +232,7 @@ class FftMethod:
         n = cur.shape[0]
         out = torch.empty((n, self.n_patches, 2), dtype=torch.float64, device=cur.device)
         s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        _pin_if_capturing(self, s)
         check(self._lib.mof_fft_process_batch_device_bgr(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
                                                          prev.stride(0), cur.stride(1), n, out.data_ptr(),
                                                          _stream_ptr(s)))
@@ -214,9 +243,13 @@ class FftMethod:
             raise ValueError(f"frame is {tuple(f.shape[-2:])}, engine expects "
                              f"{(self.cfg.frame_height, self.cfg.frame_width)}")
 
+    def _release_graphs(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            check(self._lib.mof_fft_release_graphs(self._h))
+
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
-            self._lib.mof_fft_destroy(self._h)
+            self._lib.mof_fft_destroy(self._h)  # deferred by the library while a captured graph pins the engine
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -322,6 +355,10 @@ class _BmBase:
                                                         mode.data_ptr(), _stream_ptr(s)))
         return dx, dy, mode
 
+    def _release_graphs(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            check(self._lib.mof_bm_release_graphs(self._h))
+
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
             self._lib.mof_bm_destroy(self._h)
@@ -393,6 +430,7 @@ class ScaleRotationEstimator:
         n = cur.shape[0]
         out = torch.empty((n, 4), dtype=torch.float64, device=cur.device)
         s = stream if stream is not None else torch.cuda.current_stream(cur.device)
+        _pin_if_capturing(self, s)
         check(self._lib.mof_sr_process_batch_device(self._h, cur.data_ptr(), cur.stride(0), prev.data_ptr(),
                                                     prev.stride(0), cur.stride(1), n, out.data_ptr(), _stream_ptr(s)))
         return out
@@ -410,13 +448,22 @@ class ScaleRotationEstimator:
                 and tuple(dst.shape) == (n, res, res)):
             raise ValueError("dst must be a dense uint8 [n, res, res] tensor on the engine's device")
         s = stream if stream is not None else torch.cuda.current_stream(src.device)
+        _pin_if_capturing(self, s)
         check(self._lib.mof_sr_logpolar_batch_device(self._h, src.data_ptr(), src.stride(0), src.stride(1), n,
                                                      int(interpolation), dst.data_ptr(), _stream_ptr(s)))
         return dst
 
+    def _release_graphs(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            check(self._lib.mof_sr_release_graphs(self._h))
+
+    @property
+    def graph_pinned(self) -> bool:
+        return bool(self._lib.mof_sr_graph_pinned(self._h))
+
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
-            self._lib.mof_sr_destroy(self._h)
+            self._lib.mof_sr_destroy(self._h)  # deferred by the library while a captured graph pins the engine
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -51,9 +51,37 @@ def gather_results(local, n_pairs: int, group=None):
     return out[:n_pairs]
 
 
+class GatherBufferInUse(RuntimeError):
+    """A gathered buffer is about to be overwritten while the consumer it was handed to has not released it."""
+
+
+class Gathered:
+    """What AsyncGather.submit() hands out: the gathered tensor of one batch plus its hand-over protocol.
+    ``wait()`` -- the gather has landed (torch's current stream is ordered behind it); ``tensor`` -- [n_pairs, ...];
+    ``done()`` -- the consumer is finished: work it queued on the current stream so far is what the buffer's next
+    gather will wait for. A buffer whose consumer never called done() is not re-used (GatherBufferInUse)."""
+
+    def __init__(self, tensor, work):
+        self.tensor, self._work, self._event, self._done = tensor, work, None, False
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+        return self.tensor
+
+    def done(self):
+        import torch
+
+        if not self._done:
+            self._event = torch.cuda.Event()
+            self._event.record()
+            self._done = True
+
+
 class AsyncGather:
     """Double-buffered, non-blocking gather for back-to-back batches: the all-gather of batch i (RCCL, its own
-    stream) overlaps the kernels of batch i+1; a buffer is waited for only right before it is reused."""
+    stream) overlaps the kernels of batch i+1; a local buffer is waited for only right before it is reused, and a
+    gathered buffer is overwritten only after the consumer it was handed to has released it (Gathered.done())."""
 
     def __init__(self, shard_shape, dtype, device, n_pairs: int, group=None, depth: int = 2):
         import torch
@@ -67,6 +95,7 @@ class AsyncGather:
         self.full = [torch.empty((self.world * self.per,) + tuple(shard_shape[1:]), dtype=dtype, device=device)
                      for _ in range(depth)]
         self.work = [None] * depth
+        self.handed = [None] * depth
         self.i = 0
 
     def slot(self):
@@ -77,13 +106,22 @@ class AsyncGather:
             self.work[k] = None
         return self.local[k]
 
-    def submit(self):
+    def submit(self) -> Gathered:
+        import torch
         import torch.distributed as dist
 
         k = self.i % self.depth
+        prev = self.handed[k]
+        if prev is not None:
+            if not prev._done:
+                raise GatherBufferInUse(f"gathered buffer {k} (batch {self.i - self.depth}) is still held by its consumer: "
+                                        "call done() on the handle submit() returned before this buffer comes round again")
+            # the collective is ordered behind the current stream: make that stream wait for the consumer's last read
+            torch.cuda.current_stream().wait_event(prev._event)
         self.work[k] = dist.all_gather_into_tensor(self.full[k], self.local[k], group=self.group, async_op=True)
+        self.handed[k] = Gathered(self.full[k][: self.n_pairs], self.work[k])
         self.i += 1
-        return self.full[k]
+        return self.handed[k]
 
     def drain(self):
         for k in range(self.depth):

@@ -345,6 +345,9 @@ int oracle_find_homography(const double* a, const double* b, int n, double* H, u
 }
 
 /* ---------------------------------------------------------------------------------------------------------------- */
+/* ATTRIBUTION: restated from memory after OpenCV's modules/calib3d/src/homography_decomp.cpp (HomographyDecompInria:
+ * Malis & Vargas, INRIA RR-6303, 2007; third-party, Apache-2.0 / BSD, (C) 2014 Samson Yilma and the OpenCV contributors),
+ * not from /root/reference, which only calls it (optic_flow.cpp:595). Unpinned against a real OpenCV.                  */
 /* cv::decomposeHomographyMat(H, I): HomographyDecompInria                                                            */
 /* ---------------------------------------------------------------------------------------------------------------- */
 static int sgn(double x) { return x >= 0 ? 1 : -1; }

@@ -289,19 +289,12 @@ def test_batch_entry_points_are_hip_graph_capturable(gpu):
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
-    # Engines of earlier tests may still await Python's cyclic collector; a finalizer that runs INSIDE the capture frees
-    # device memory (hipFree in mof_*_destroy), which HIP's global capture mode answers by invalidating the capture
-    # (seen as a flaky hipErrorStreamCaptureInvalidated): collect now, and keep the collector off while capturing.
-    import gc
-    gc.collect()
-    gc.disable()
-    try:
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(g, stream=side):
-                fm.process_batch_device(tc, tp, out=out)
-                sr_out = sr.process_batch_device(tc, tp)
-    finally:
-        gc.enable()
+    # (engines of earlier tests may be finalised by Python's collector INSIDE this capture: the library frees under the
+    # relaxed capture mode, so that does not invalidate it -- no gc.disable() here any more)
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            fm.process_batch_device(tc, tp, out=out)
+            sr_out = sr.process_batch_device(tc, tp)
     out.zero_()
     for _ in range(3):
         g.replay()
@@ -393,11 +386,15 @@ def test_ocl_peak_model_mask_constant_and_modes(gpu):
 
 
 def test_quad_formulation_of_k1_passes_the_same_parity_tests(gpu):
-    """pc_kernel_quad.hip (MOF_PC_QUAD=1, read once at load time) is an opt-in alternative formulation for 64 x 64
-    patches; it has to stay correct. One child process re-runs this file's N = 64 parity cases with it selected."""
+    """pc_kernel_quad.hip is a measured-slower alternative formulation for 64 x 64 patches, kept out of the product
+    library: only the A/B build csrc/ab/libmof_hip_quad.so (`make quad`) links it, and MOF_PC_QUAD=1 selects it there.
+    It has to stay correct: one child process re-runs this file's N = 64 parity cases on that library."""
     import subprocess
     import sys
-    env = dict(os.environ, MOF_PC_QUAD="1", MOF_EXPECT_VARIANT="quad")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    quad_lib = os.path.join(root, "mrs_optic_flow_amd", "csrc", "ab", "libmof_hip_quad.so")
+    assert os.path.exists(quad_lib), "build it with `make -C mrs_optic_flow_amd/csrc quad` (__graft_entry__.build() does)"
+    env = dict(os.environ, MOF_PC_QUAD="1", MOF_EXPECT_VARIANT="quad", MOF_LIB_PATH=quad_lib)
     sel = "golden or seeded or ocl_peak or bgr or long_range or gating or circular or expected_variant"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel,
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)

@@ -8,7 +8,7 @@ dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 ag = sharding.AsyncGather((8, 4, 2), torch.float64, dev, 8)
 for i in range(5):
-    buf = ag.slot(); buf.fill_(float(i)); full = ag.submit()
+    buf = ag.slot(); buf.fill_(float(i)); ag.submit().done()
 ag.drain(); torch.cuda.synchronize()
 print("async gather ok", [float(f[0, 0, 0]) for f in ag.full])
 x = torch.arange(6, dtype=torch.float64, device=dev).reshape(3, 2)

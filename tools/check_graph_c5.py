@@ -6,11 +6,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-import gc
 
 import torch
 
-gc.disable()  # a finalizer that frees device memory inside a capture invalidates it (global capture mode)
 
 from mrs_optic_flow_amd import FftMethod, ScaleRotationEstimator, synth
 

@@ -7,12 +7,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-import gc
 
 import numpy as np
 import torch
 
-gc.disable()  # a finalizer that frees device memory inside a capture invalidates it (global capture mode)
 
 import sr_scenes
 from mrs_optic_flow_amd import ScaleRotationEstimator
