@@ -48,6 +48,9 @@ def binding_note(name: str, wl) -> str:
                 "0.10 ms per 1024 pairs, the one path here whose time is mostly frame fetch")
     if wl["kind"] == "fft+rt":
         return "K1 as in ref + the getRT tail (one wavefront per pair, fp64 recurrences: 0.35 ms per 1024 pairs); not HBM"
+    if wl["kind"] == "fft+srseq":
+        return ("c5 on a video: one Lanczos4 remap and one real row transform per frame (K5s), column pass walking pairs in "
+                "time with the previous spectra in registers (K6s); DESIGN.md section 4 (sequence mode)")
     if wl["kind"] == "fft+sr":
         return ("scale/rotation pipeline K4-K8 takes 79 % of the step: log-polar gathers (v_dot4c taps on LDS-staged source "
                 "boxes; VALU + L1 look-ups) 34 %, whole-frame transforms through Zt / Dt (2.2-2.8 TB/s of HBM traffic) 43 %; "
@@ -106,6 +109,14 @@ WORKLOADS = {
                     "phase correlation), 752x480, batch=1024 frame pairs per GPU",
                # 2*W*H u8 in + flow vectors + (scale, rot)
                bytes_per_pair=2 * 752 * 480 + 64 * 8 + 8),
+    # c5 on a VIDEO (the node's real workload, scaleRotationEstimator.cpp:34-148 steady state): B + 1 consecutive frames,
+    # K1 on the B consecutive pairs, the estimator in sequence mode (every frame remapped and row-transformed once)
+    "c5seq": dict(kind="fft+srseq", h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=1024, s=8,
+                  sr_res=480, sr_m=49.9, sr_x0=136,
+                  name="c5seq: c5 on a video -- FftMethod on 1024 consecutive frame pairs + scaleRotationEstimator in sequence "
+                       "mode (first frame INTER_CUBIC, then INTER_LANCZOS4 once per frame), 752x480, 1025 frames per GPU",
+                  # one NEW frame per pair (the other one was the previous pair's) + flow vectors + (scale, rot)
+                  bytes_per_pair=752 * 480 + 64 * 8 + 8),
     # BASELINE c1 geometry (the CPU plumbing config) on the GPU: BlockMethod, 272x272 crop, 8x8 blocks of 32x32, +-8 px
     "c1": dict(kind="bm", block_method=True, h=272, w=272, block=32, step=0, radius=8, batch=1024, s=6,
                name="c1: BlockMethod 272x272 crop, 8x8 grid of 32x32 blocks, scanRadius=8, batch=1024 per GPU",
@@ -134,7 +145,17 @@ def cpu_baseline(wl, budget_s: float = 12.0):
 
     n_gen = 4
     cur, prev, _, _ = synth.batch_np(n_gen, wl["h"], wl["w"], wl["s"], classes=False, k0=1)
-    if wl["kind"] == "fft+sr":
+    if wl["kind"] == "fft+srseq":
+        lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
+        x0, r = wl["sr_x0"], wl["sr_res"]
+        seq_est = O.ScaleRotationEstimator(r, wl["sr_m"], 32)
+        seq_est.processImage(prev[0][:r, x0:x0 + r])
+
+        def run(k):  # one new frame: K1 against the previous frame, one stateful estimator call
+            O.fft_process(cur[k % n_gen], prev[k % n_gen], lay, 32)
+            seq_est.processImage(cur[k % n_gen][:r, x0:x0 + r])
+        what = "f32 oracle (oracle/pc_ref.c + lp_ref.c, stateful estimator: one remap + correlation per frame)"
+    elif wl["kind"] == "fft+sr":
         lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
         x0, r = wl["sr_x0"], wl["sr_res"]
 
@@ -217,14 +238,29 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
     from mrs_optic_flow_amd import FastSpacedBMMethod, FftMethod, ScaleRotationEstimator, synth
 
     B = wl["batch"]
-    # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
-    cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
     state = {"out": None}
-    if wl["kind"] in ("fft", "fft+sr", "fft+rt", "fft+2dt"):
+    if wl["kind"] == "fft+srseq":
+        # every rank owns its own video (texture index = rank): B + 1 frames = B consecutive pairs
+        video, _ = synth.video_torch(B + 1, wl["h"], wl["w"], dev, k=rank)
+        cur, prev = video[1:], video[:-1]  # a video needs no copy: cur = frames + 1, prev = frames
+    else:
+        # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
+        cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
+    if wl["kind"] in ("fft", "fft+sr", "fft+srseq", "fft+rt", "fft+2dt"):
         eng = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"],
                         origin=wl["origin"], stride=wl["stride"], device=local_rank)
         state["out"] = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
-        if wl["kind"] == "fft+sr":
+        if wl["kind"] == "fft+srseq":
+            sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank)
+            x0, r = wl["sr_x0"], wl["sr_res"]
+            crop = video[:, :r, x0:x0 + r]
+            sr.process_sequence_device(crop[:2])  # arm the steady state: every timed frame goes through INTER_LANCZOS4
+
+            def launch():
+                eng.process_batch_device(cur, prev, out=state["out"])
+                srout = sr.process_sequence_device(crop[1:], resolve_gate=False)  # B new frames = B pairs
+                return torch.cat([state["out"].reshape(B, -1), srout], dim=1)
+        elif wl["kind"] == "fft+sr":
             sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank)
             x0, r = wl["sr_x0"], wl["sr_res"]
             cur_c, prev_c = cur[:, :r, x0:x0 + r], prev[:, :r, x0:x0 + r]
@@ -514,6 +550,7 @@ def main() -> None:
         pairs = B * world * args.steps
         line = {
             "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fft+sr": "_fft_phase_corr_plus_scale_rotation",
+                                             "fft+srseq": "_fft_phase_corr_plus_scale_rotation_sequence",
                                              "fft+rt": "_fft_phase_corr_plus_get_rt",
                                              "fft+2dt": "_long_range_plus_get_2dt",
                                              "bm": "_block_method" if wl.get("block_method") else "_fast_spaced_bm"}[wl["kind"]],

@@ -284,6 +284,26 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
 int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                 size_t prev_stride, size_t pitch, int n_pairs, double* d_out, void* stream);
 
+/* A VIDEO on the device: exactly what n_frames consecutive mof_sr_process calls would return, continuing the engine's
+ * stateful sequence (`first`, the previous image) and leaving it as those calls would -- the reference's steady state
+ * (scaleRotationEstimator.cpp:34-148): the very first frame after create / reset goes through INTER_CUBIC (:45) and
+ * returns (1, 0) (:74); every later frame goes through INTER_LANCZOS4 (:112) ONCE and is correlated with the previous
+ * frame's log-polar image (:117), which is what it then becomes itself (:128). Frame i at d_frames + i*frame_stride
+ * (the top-left pixel of the resolution^2 crop, `pitch` bytes per row). d_out receives n_frames * 4 doubles:
+ * scale, rot, pt.x, pt.y (first frame: 1, 0, 0, 0). Same bits as the frame-by-frame calls (the same kernels run).
+ * The gate (:119-121): a frame whose |pt.x| > resolution/2 returns (1, 0) and does NOT replace the previous image, so
+ * the next frame is correlated with an older one -- a serial dependency through a result.
+ *   n_gated != NULL: the call resolves it (per pipeline pass it reads the pass's results back, re-runs the pairs that
+ *     sit behind a gated frame against the right partner) and is SYNCHRONOUS; *n_gated = number of gated frames.
+ *   n_gated == NULL: asynchronous on `stream` and capturable into a HIP graph; every frame is correlated with its
+ *     immediate predecessor. Identical unless some frame is gated, which the caller can see in d_out (|pt.x| >
+ *     resolution/2 with scale == 1, rot == 0) -- a degenerate case (constant or wrapped images).
+ * Each frame is remapped and row-transformed once (K5s), the column pass walks consecutive pairs in time (K6s,
+ * csrc/sr_seq_kernel.hip): about half the remap work and a third less spectrum traffic than n_frames - 1 independent
+ * pairs through mof_sr_process_batch_device. Uses the engine's scratch like the batch entry. */
+int mof_sr_process_sequence_device(mof_sr_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch,
+                                   int n_frames, double* d_out, void* stream, int* n_gated);
+
 /* The remap stage alone: cv::logPolar(src, dst, Point2f(res/2, res/2), M, interpolation) (scaleRotationEstimator.cpp:45
  * INTER_CUBIC, :112 INTER_LANCZOS4) on n_images res x res CV_8UC1 crops (image i at d_src + i*src_stride, `pitch` bytes
  * per row) into tightly packed res*res outputs at d_dst + i*res*res. As with cv::remap's BORDER_TRANSPARENT,

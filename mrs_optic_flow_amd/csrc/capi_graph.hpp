@@ -28,6 +28,18 @@ inline bool stream_capturing(hipStream_t s) {
   return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
 
+// Synchronous copy / fill on a stream of the engine's own (non-blocking): hipMemcpy / hipMemset run on the legacy stream,
+// which implicitly joins every blocking stream -- a capturing one included ("operation would make the legacy stream depend
+// on a capturing blocking stream"), so they cannot be used by a library that may be called beside a capture.
+inline hipError_t copy_on(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+  return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+inline hipError_t fill_on(hipStream_t s, void* dst, int value, size_t bytes) {
+  const hipError_t e = hipMemsetAsync(dst, value, bytes, s);
+  return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+
 // engines whose destroy was deferred because a captured graph may still use their device memory
 void park_engine(void (*destroy_now)(void*), void* engine);  // mof_capi.hip
 int purge_parked();                                          // frees every parked engine, returns how many

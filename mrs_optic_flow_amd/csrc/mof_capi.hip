@@ -232,11 +232,11 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   } while (0)
   CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc(&e->d_twiddles, tw.size() * sizeof(float)));
-  CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+  CREATE_TRY(mof::copy_on(e->stream, e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_frames[0], e->frame_bytes));
   CREATE_TRY(hipMalloc(&e->d_frames[1], e->frame_bytes));
-  CREATE_TRY(hipMemset(e->d_frames[0], 0, e->frame_bytes));
-  CREATE_TRY(hipMemset(e->d_frames[1], 0, e->frame_bytes));
+  CREATE_TRY(mof::fill_on(e->stream, e->d_frames[0], 0, e->frame_bytes));
+  CREATE_TRY(mof::fill_on(e->stream, e->d_frames[1], 0, e->frame_bytes));
   CREATE_TRY(hipMalloc(&e->d_out, res * sizeof(double)));
   CREATE_TRY(hipHostMalloc(&e->h_out, res * sizeof(double), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
@@ -490,14 +490,14 @@ int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur
   hipError_t he;
   if ((he = hipMalloc(&d_c, fb * n_pairs)) != hipSuccess || (he = hipMalloc(&d_p, fb * n_pairs)) != hipSuccess ||
       (he = hipMalloc(&d_o, res * n_pairs * sizeof(double))) != hipSuccess ||
-      (he = hipMemcpy(d_c, pc.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess ||
-      (he = hipMemcpy(d_p, pp.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess) {
+      (he = mof::copy_on(e->stream, d_c, pc.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess ||
+      (he = mof::copy_on(e->stream, d_p, pp.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess) {
     rc = fail(MOF_ERR_HIP, "batch upload: %s", hipGetErrorString(he));
   }
   if (rc == MOF_OK)
     rc = mof_fft_process_batch_device(e, d_c, fb, d_p, fb, (size_t)e->cfg.frame_width, n_pairs, d_o, e->stream);
   if (rc == MOF_OK && ((he = hipStreamSynchronize(e->stream)) != hipSuccess ||
-                       (he = hipMemcpy(out_xy, d_o, res * n_pairs * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess))
+                       (he = mof::copy_on(e->stream, out_xy, d_o, res * n_pairs * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess))
     rc = fail(MOF_ERR_HIP, "batch download: %s", hipGetErrorString(he));
   if (d_c) (void)hipFree(d_c);
   if (d_p) (void)hipFree(d_p);
@@ -608,8 +608,8 @@ int mof_bm_create(const mof_bm_config* cfg, mof_bm_engine** out) {
   CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc(&e->d_frames[0], e->frame_bytes));
   CREATE_TRY(hipMalloc(&e->d_frames[1], e->frame_bytes));
-  CREATE_TRY(hipMemset(e->d_frames[0], 0, e->frame_bytes));  // imPrev = Scalar(0), BlockMethod.cpp:17-18
-  CREATE_TRY(hipMemset(e->d_frames[1], 0, e->frame_bytes));
+  CREATE_TRY(mof::fill_on(e->stream, e->d_frames[0], 0, e->frame_bytes));  // imPrev = Scalar(0), BlockMethod.cpp:17-18
+  CREATE_TRY(mof::fill_on(e->stream, e->d_frames[1], 0, e->frame_bytes));
   CREATE_TRY(hipMalloc(&e->d_dx, nb));
   CREATE_TRY(hipMalloc(&e->d_dy, nb));
   CREATE_TRY(hipMalloc(&e->d_mode, 8));
@@ -818,15 +818,15 @@ int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_s
   if ((he = hipMalloc(&d_c, fb * n_pairs)) != hipSuccess || (he = hipMalloc(&d_p, fb * n_pairs)) != hipSuccess ||
       (he = hipMalloc(&d_x, nb * n_pairs)) != hipSuccess || (he = hipMalloc(&d_y, nb * n_pairs)) != hipSuccess ||
       (he = hipMalloc(&d_m, 8 * (size_t)n_pairs)) != hipSuccess ||
-      (he = hipMemcpy(d_c, pc.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess ||
-      (he = hipMemcpy(d_p, pp.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess)
+      (he = mof::copy_on(e->stream, d_c, pc.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess ||
+      (he = mof::copy_on(e->stream, d_p, pp.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess)
     rc = fail(MOF_ERR_HIP, "batch upload: %s", hipGetErrorString(he));
   if (rc == MOF_OK)
     rc = mof_bm_process_batch_device(e, d_c, fb, d_p, fb, (size_t)e->cfg.frame_width, n_pairs, d_x, d_y, d_m, e->stream);
   if (rc == MOF_OK && ((he = hipStreamSynchronize(e->stream)) != hipSuccess ||
-                       (he = hipMemcpy(dx, d_x, nb * n_pairs, hipMemcpyDeviceToHost)) != hipSuccess ||
-                       (he = hipMemcpy(dy, d_y, nb * n_pairs, hipMemcpyDeviceToHost)) != hipSuccess ||
-                       (he = hipMemcpy(mode, d_m, 8 * (size_t)n_pairs, hipMemcpyDeviceToHost)) != hipSuccess))
+                       (he = mof::copy_on(e->stream, dx, d_x, nb * n_pairs, hipMemcpyDeviceToHost)) != hipSuccess ||
+                       (he = mof::copy_on(e->stream, dy, d_y, nb * n_pairs, hipMemcpyDeviceToHost)) != hipSuccess ||
+                       (he = mof::copy_on(e->stream, mode, d_m, 8 * (size_t)n_pairs, hipMemcpyDeviceToHost)) != hipSuccess))
     rc = fail(MOF_ERR_HIP, "batch download: %s", hipGetErrorString(he));
   if (d_c) (void)hipFree(d_c);
   if (d_p) (void)hipFree(d_p);

@@ -121,5 +121,18 @@ bool sr_resolution_supported(int res);
 int sr_candidates(int res);
 hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp /*2 cubic, 4 lanczos4*/, int n_images, hipStream_t stream);
 hipError_t launch_sr_phase_correlate(const SrPcArgs& a, int res, int n_pairs, hipStream_t stream);
+// K7 + K8 alone (uses a.Dt, a.cand, a.twiddles, a.M, a.out)
+hipError_t launch_sr_peak(const SrPcArgs& a, int res, int n_pairs, hipStream_t stream);
+// Sequence pipeline (sr_seq_kernel.hip). Zh = the row half-spectra of ONE log-polar image, doubled and transposed:
+// [(res/2 + 1) u][res v] complex floats = sr_zh_floats(res) floats.
+size_t sr_zh_floats(int res);
+hipError_t launch_sr_identity(double* out4, hipStream_t stream);  // (1, 0, 0, 0): the first frame's result (:74)
+// K5s: images lp + f * lp_stride (res * res u8, tightly packed rows) -> zh + f * zh_stride (strides: bytes / floats)
+hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float* twiddles, float* zh, size_t zh_stride, int res,
+                               int n_frames, hipStream_t stream);
+// K6s: pair p = (cur: zh_cur + p * zh_stride, prev: zh_prev + p * zh_stride) -> Dt[p]; `run` > 1 lets one wave walk that
+// many consecutive pairs re-using cur(p) as prev(p + 1) -- only valid when zh_cur == zh_prev + zh_stride (a sequence)
+hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* twiddles, float* Dt, int res,
+                              int n_pairs, int run, hipStream_t stream);
 
 }  // namespace mof

@@ -258,13 +258,16 @@ struct mof_sr_engine {
   float* d_twiddles = nullptr;
   uint8_t* d_frame = nullptr;    // staging for the stateful path (res*res)
   uint8_t* d_temp_im = nullptr;  // tempIm, :27
-  uint8_t* d_prev_lp = nullptr;  // prevIm_F32 (kept as the u8 image it was converted from)
+  float* d_zh_prev = nullptr;    // prevIm_F32 (:48, :128), kept as what the correlation needs of it: its row half-spectra
+                                 // (sr_seq_kernel.hip, K5s) -- each frame is remapped and row-transformed ONCE
   uint8_t* d_lp = nullptr;       // batch: [kChunk][2][res*res] log-polar images (cur, prev)
   float *d_Zt = nullptr, *d_Dt = nullptr;
   float2* d_cand = nullptr;
   double* d_out = nullptr;       // [kChunk][4]
   uint8_t* h_stage = nullptr;
   double* h_out = nullptr;
+  double* h_seq = nullptr;       // pinned [chunk][4]: a pass's results, read back when a sequence call resolves the gate
+  int seq_run = 8;               // pairs one wave of K6s walks in time (MOF_SR_SEQ_RUN overrides)
   int chunk = 0;                 // frame pairs per pipeline pass
   int scratch_pairs = 0;         // pairs per pass the scratch holds now (1 after create, `chunk` after the first batch)
   bool two_lanes = false;        // remap of pass k+1 beside the transforms of pass k (mof_sr_config.pipeline_lanes == 2)
@@ -331,7 +334,11 @@ hipError_t scratch_alloc(mof_sr_engine* e, int pairs) {
   e->scratch_pairs = 0;
   hipError_t err;
   if ((err = hipMalloc(&e->d_lp, (size_t)2 * pairs * 2 * nn)) != hipSuccess) return err;  // two passes: remap of pass k+1 beside the transforms of pass k
-  if ((err = hipMalloc(&e->d_Zt, (size_t)pairs * nn * 2 * sizeof(float))) != hipSuccess) return err;
+  {
+    // pair pipeline: packed row spectra Zt, nn complex per pair; sequence pipeline: (pairs + 1) frames of half spectra
+    const size_t zt = (size_t)pairs * nn * 2 * sizeof(float), zh = (size_t)(pairs + 1) * mof::sr_zh_floats(res) * sizeof(float);
+    if ((err = hipMalloc(&e->d_Zt, zt > zh ? zt : zh)) != hipSuccess) return err;
+  }
   if ((err = hipMalloc(&e->d_Dt, (size_t)pairs * res * (res / 2 + 1) * 2 * sizeof(float))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_cand, (size_t)pairs * mof::sr_candidates(res) * sizeof(float2))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_out, (size_t)pairs * 4 * sizeof(double))) != hipSuccess) return err;
@@ -391,12 +398,13 @@ static void sr_destroy_now(void* p) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
-  void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_sboxes[0], e->d_sboxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_wp[0], e->d_wp[1], e->d_twiddles, e->d_frame, e->d_temp_im, e->d_prev_lp,
+  void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_sboxes[0], e->d_sboxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_wp[0], e->d_wp[1], e->d_twiddles, e->d_frame, e->d_temp_im, e->d_zh_prev,
                  e->d_lp,  e->d_Zt,      e->d_Dt,        e->d_cand,     e->d_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   if (e->h_out) (void)hipHostFree(e->h_out);
+  if (e->h_seq) (void)hipHostFree(e->h_seq);
   if (e->scratch_ev) (void)hipEventDestroy(e->scratch_ev);
   if (e->remap_stream) (void)hipStreamSynchronize(e->remap_stream);
   for (hipEvent_t ev : {e->ev_fork, e->ev_lp[0], e->ev_lp[1], e->ev_fft[0], e->ev_fft[1]})
@@ -489,42 +497,47 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_fft[b], hipEventDisableTiming));
   }
   CREATE_TRY(hipMalloc(&e->d_map, map.size() * sizeof(mof::SrMapEntry)));
-  CREATE_TRY(hipMemcpy(e->d_map, map.data(), map.size() * sizeof(mof::SrMapEntry), hipMemcpyHostToDevice));
+  CREATE_TRY(mof::copy_on(e->stream, e->d_map, map.data(), map.size() * sizeof(mof::SrMapEntry), hipMemcpyHostToDevice));
   e->lds_per_wave[0] = lds_c;
   e->lds_per_wave[1] = lds_l;
   CREATE_TRY(hipMalloc(&e->d_boxes[0], bc.size() * sizeof(mof::SrTileBox)));
-  CREATE_TRY(hipMemcpy(e->d_boxes[0], bc.data(), bc.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
+  CREATE_TRY(mof::copy_on(e->stream, e->d_boxes[0], bc.data(), bc.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_boxes[1], bl.size() * sizeof(mof::SrTileBox)));
-  CREATE_TRY(hipMemcpy(e->d_boxes[1], bl.data(), bl.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
+  CREATE_TRY(mof::copy_on(e->stream, e->d_boxes[1], bl.data(), bl.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
   if (!sbc.empty()) {
     e->sbox_dwords[0] = slds_c / 4;
     e->sbox_dwords[1] = slds_l / 4;
     CREATE_TRY(hipMalloc(&e->d_sboxes[0], sbc.size() * sizeof(mof::SrTileBox)));
-    CREATE_TRY(hipMemcpy(e->d_sboxes[0], sbc.data(), sbc.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
+    CREATE_TRY(mof::copy_on(e->stream, e->d_sboxes[0], sbc.data(), sbc.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&e->d_sboxes[1], sbl.size() * sizeof(mof::SrTileBox)));
-    CREATE_TRY(hipMemcpy(e->d_sboxes[1], sbl.data(), sbl.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
+    CREATE_TRY(mof::copy_on(e->stream, e->d_sboxes[1], sbl.data(), sbl.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
   }
   CREATE_TRY(hipMalloc(&e->d_w_cubic, wc.size() * sizeof(int16_t)));
-  CREATE_TRY(hipMemcpy(e->d_w_cubic, wc.data(), wc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  CREATE_TRY(mof::copy_on(e->stream, e->d_w_cubic, wc.data(), wc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_w_lanczos, wl.size() * sizeof(int16_t)));
-  CREATE_TRY(hipMemcpy(e->d_w_lanczos, wl.data(), wl.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  CREATE_TRY(mof::copy_on(e->stream, e->d_w_lanczos, wl.data(), wl.size() * sizeof(int16_t), hipMemcpyHostToDevice));
   {
     const std::vector<uint32_t> pc = mof::sr_weight_planes(wc, 4), pl = mof::sr_weight_planes(wl, 8);
     CREATE_TRY(hipMalloc(&e->d_wp[0], pc.size() * sizeof(uint32_t)));
-    CREATE_TRY(hipMemcpy(e->d_wp[0], pc.data(), pc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CREATE_TRY(mof::copy_on(e->stream, e->d_wp[0], pc.data(), pc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&e->d_wp[1], pl.size() * sizeof(uint32_t)));
-    CREATE_TRY(hipMemcpy(e->d_wp[1], pl.data(), pl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CREATE_TRY(mof::copy_on(e->stream, e->d_wp[1], pl.data(), pl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   CREATE_TRY(hipMalloc(&e->d_twiddles, tw.size() * sizeof(float)));
-  CREATE_TRY(hipMemcpy(e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+  CREATE_TRY(mof::copy_on(e->stream, e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_frame, nn));
   CREATE_TRY(hipMalloc(&e->d_temp_im, nn));
-  CREATE_TRY(hipMalloc(&e->d_prev_lp, nn));
-  CREATE_TRY(hipMemset(e->d_temp_im, 0, nn));  // tempIm = cv::Mat::zeros, :27
-  CREATE_TRY(hipMemset(e->d_prev_lp, 0, nn));
+  CREATE_TRY(hipMalloc(&e->d_zh_prev, mof::sr_zh_floats(res) * sizeof(float)));
+  CREATE_TRY(mof::fill_on(e->stream, e->d_temp_im, 0, nn));  // tempIm = cv::Mat::zeros, :27
+  CREATE_TRY(mof::fill_on(e->stream, e->d_zh_prev, 0, mof::sr_zh_floats(res) * sizeof(float)));
   CREATE_TRY(scratch_alloc(e, 1));  // the stateful call needs one pair; a batch grows it to a whole pass (scratch_reserve)
   CREATE_TRY(hipHostMalloc(&e->h_stage, nn, hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_out, 4 * sizeof(double), hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc(&e->h_seq, (size_t)e->chunk * 4 * sizeof(double), hipHostMallocDefault));
+  {
+    const char* v = getenv("MOF_SR_SEQ_RUN");
+    if (v && atoi(v) >= 1 && atoi(v) <= 4096) e->seq_run = atoi(v);
+  }
 #undef CREATE_TRY
   *out = e;
   return MOF_OK;
@@ -570,6 +583,15 @@ static mof::SrPcArgs pc_args(const mof_sr_engine* e, const uint8_t* lp_cur, cons
   return a;
 }
 
+// One pair through the sequence kernels: (cur spectra, prev spectra) -> Dt slot 0 -> (scale, rot, pt) at `out`
+static hipError_t seq_one_pair(mof_sr_engine* e, const float* zh_prev, const float* zh_cur, double* out, hipStream_t s) {
+  const int res = e->cfg.resolution;
+  hipError_t err = mof::launch_sr_cols_seq(zh_prev, zh_cur, 0, e->d_twiddles, e->d_Dt, res, 1, 1, s);
+  if (err != hipSuccess) return err;
+  mof::SrPcArgs a = pc_args(e, nullptr, nullptr, 0, out);
+  return mof::launch_sr_peak(a, res, 1, s);
+}
+
 int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double* out_scale_rot) {
   if (!e) return mof::capi_fail(MOF_ERR_NOT_INIT, "null engine");
   const int res = e->cfg.resolution;
@@ -577,7 +599,7 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
   BusyGuard g(e->busy);
   if (!g.owned) return mof::capi_fail(MOF_ERR_BUSY, "engine busy");
   SR_TRY(hipSetDevice(e->cfg.device));
-  const size_t nn = (size_t)res * res;
+  const size_t nn = (size_t)res * res, zh_bytes = mof::sr_zh_floats(res) * sizeof(float);
   for (int y = 0; y < res; ++y) std::memcpy(e->h_stage + (size_t)y * res, frame + (size_t)y * pitch, (size_t)res);
   SR_TRY(hipMemcpyAsync(e->d_frame, e->h_stage, nn, hipMemcpyHostToDevice, e->stream));
   mof::SrLpArgs lp{};
@@ -588,30 +610,125 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
   lp.dst_stride = 0;
   lp.map = e->d_map;
   lp.res = res;
+  const int interp = e->first ? 2 : 4;  // INTER_CUBIC for the very first frame (:45), INTER_LANCZOS4 from then on (:112)
+  lp_tables(e, interp, &lp);
+  SR_TRY(mof::launch_sr_logpolar(lp, interp, 1, e->stream));
+  SR_TRY(scratch_acquire(e, e->stream));
+  // tempIm.convertTo(CV_32FC1) (:47, :115) + the row half of the forward DFT of cv::phaseCorrelate (:117): K5s
+  SR_TRY(mof::launch_sr_rows_real(e->d_temp_im, 0, e->d_twiddles, e->d_Zt, 0, res, 1, e->stream));
   if (e->first) {
-    lp_tables(e, 2, &lp);
-    SR_TRY(mof::launch_sr_logpolar(lp, 2, 1, e->stream));  // INTER_CUBIC, :45
-    SR_TRY(hipMemcpyAsync(e->d_prev_lp, e->d_temp_im, nn, hipMemcpyDeviceToDevice, e->stream));  // :48
+    SR_TRY(hipMemcpyAsync(e->d_zh_prev, e->d_Zt, zh_bytes, hipMemcpyDeviceToDevice, e->stream));  // prevIm_F32 = .., :48
+    SR_TRY(scratch_release(e, e->stream));
     SR_TRY(hipStreamSynchronize(e->stream));
     e->first = false;  // :73
     out_scale_rot[0] = 1.0;
     out_scale_rot[1] = 0.0;  // :74
     return MOF_OK;
   }
-  lp_tables(e, 4, &lp);
-  SR_TRY(mof::launch_sr_logpolar(lp, 4, 1, e->stream));  // INTER_LANCZOS4, :112
-  mof::SrPcArgs a = pc_args(e, e->d_temp_im, e->d_prev_lp, 0, e->d_out);
-  SR_TRY(scratch_acquire(e, e->stream));
-  SR_TRY(mof::launch_sr_phase_correlate(a, res, 1, e->stream));  // :117
+  SR_TRY(seq_one_pair(e, e->d_zh_prev, e->d_Zt, e->d_out, e->stream));  // :117
   SR_TRY(hipMemcpyAsync(e->h_out, e->d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  SR_TRY(scratch_release(e, e->stream));
   SR_TRY(hipStreamSynchronize(e->stream));
   out_scale_rot[0] = e->h_out[0];
   out_scale_rot[1] = e->h_out[1];
   // the reference returns early on the gate, BEFORE prevIm_F32 = tempIm_F32.clone() (:119-121 vs :128)
-  if (!(std::fabs(e->h_out[2]) > (double)(res / 2))) {
-    SR_TRY(hipMemcpyAsync(e->d_prev_lp, e->d_temp_im, nn, hipMemcpyDeviceToDevice, e->stream));
-    SR_TRY(hipStreamSynchronize(e->stream));
+  if (!(std::fabs(e->h_out[2]) > (double)(res / 2)))
+    SR_TRY(hipMemcpyAsync(e->d_zh_prev, e->d_Zt, zh_bytes, hipMemcpyDeviceToDevice, e->stream));
+  SR_TRY(scratch_release(e, e->stream));
+  SR_TRY(hipStreamSynchronize(e->stream));
+  return MOF_OK;
+}
+
+// A video on the device = n_frames consecutive mof_sr_process calls (see mof.h). Per pass of up to `chunk` new frames the
+// scratch holds slot 0 = the spectra the first new frame is correlated with, slots 1..m = the new frames.
+int mof_sr_process_sequence_device(mof_sr_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch, int n_frames,
+                                   double* d_out, void* stream, int* n_gated) {
+  if (!e) return mof::capi_fail(MOF_ERR_NOT_INIT, "null engine");
+  const int res = e->cfg.resolution;
+  if (n_gated) *n_gated = 0;
+  if (n_frames == 0) return MOF_OK;
+  if (!d_frames || !d_out || n_frames < 0 || pitch < (size_t)res) return mof::capi_fail(MOF_ERR_BAD_ARG, "bad sequence arguments");
+  BusyGuard g(e->busy);
+  if (!g.owned) return mof::capi_fail(MOF_ERR_BUSY, "engine busy");
+  SR_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const bool capturing = mof::stream_capturing(s);
+  if (capturing && n_gated)
+    return mof::capi_fail(MOF_ERR_BAD_ARG, "resolving the gate reads results back on the host: pass n_gated = NULL while capturing");
+  const size_t nn = (size_t)res * res, zhf = mof::sr_zh_floats(res), zh_bytes = zhf * sizeof(float);
+  {
+    const int rc = scratch_reserve(e, scratch_want(e, n_frames), s);
+    if (rc != MOF_OK) return rc;
+  }
+  SR_TRY(scratch_acquire(e, s));
+  if (capturing) e->graph_pinned.store(true);
+  const int C = e->scratch_pairs < e->chunk ? e->scratch_pairs : e->chunk;  // new frames per pass
+  float* zh = e->d_Zt;
+  mof::SrLpArgs lp{};
+  lp.zero_invalid = 1;  // tempIm starts as zeros (:27) and transparent pixels never change: write the zeros here
+  lp.pitch = pitch;
+  lp.map = e->d_map;
+  lp.res = res;
+  lp.src_stride = frame_stride;
+  lp.dst_stride = nn;
+  int done = 0, gated_total = 0;
+  int carry = -1;  // slot of the previous pass whose spectra are `prev` for the next frame (-1: the engine's state)
+  while (done < n_frames) {
+    if (e->first) {  // the very first frame: INTER_CUBIC (:45), becomes prev (:48), returns (1, 0) (:74)
+      lp.src = d_frames + (size_t)done * frame_stride;
+      lp.dst = e->d_lp;
+      lp_tables(e, 2, &lp);
+      SR_TRY(mof::launch_sr_logpolar(lp, 2, 1, s));
+      SR_TRY(mof::launch_sr_rows_real(e->d_lp, nn, e->d_twiddles, zh, zhf, res, 1, s));
+      SR_TRY(mof::launch_sr_identity(d_out + 4 * (size_t)done, s));
+      e->first = false;  // :73
+      ++done;
+    } else if (carry < 0) {
+      SR_TRY(hipMemcpyAsync(zh, e->d_zh_prev, zh_bytes, hipMemcpyDeviceToDevice, s));
+    } else if (carry > 0) {
+      SR_TRY(hipMemcpyAsync(zh, zh + (size_t)carry * zhf, zh_bytes, hipMemcpyDeviceToDevice, s));
+    }
+    const int m = n_frames - done < C ? n_frames - done : C;
+    carry = 0;
+    if (m > 0) {
+      lp.src = d_frames + (size_t)done * frame_stride;
+      lp.dst = e->d_lp + nn;
+      lp_tables(e, 4, &lp);
+      SR_TRY(mof::launch_sr_logpolar(lp, 4, m, s));  // INTER_LANCZOS4, :112 -- every frame once
+      SR_TRY(mof::launch_sr_rows_real(e->d_lp + nn, nn, e->d_twiddles, zh + zhf, zhf, res, m, s));
+      SR_TRY(mof::launch_sr_cols_seq(zh, zh + zhf, zhf, e->d_twiddles, e->d_Dt, res, m, e->seq_run, s));
+      mof::SrPcArgs a = pc_args(e, nullptr, nullptr, 0, d_out + 4 * (size_t)done);
+      SR_TRY(mof::launch_sr_peak(a, res, m, s));
+      carry = m;
+      if (n_gated) {
+        // The gate (:119-121): a frame whose |pt.x| > res/2 returns (1, 0) and does NOT become prev. The pass above
+        // correlated every frame with its immediate predecessor; behind a gated frame that is the wrong partner, so
+        // walk the results in order and redo the (rare) pairs whose reference partner is an older frame.
+        SR_TRY(hipMemcpyAsync(e->h_seq, d_out + 4 * (size_t)done, (size_t)m * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+        SR_TRY(hipStreamSynchronize(s));
+        int prev_slot = 0;
+        for (int i = 1; i <= m; ++i) {
+          double ptx = e->h_seq[4 * (size_t)(i - 1) + 2];
+          if (prev_slot != i - 1) {
+            double* o = d_out + 4 * (size_t)(done + i - 1);
+            SR_TRY(seq_one_pair(e, zh + (size_t)prev_slot * zhf, zh + (size_t)i * zhf, o, s));
+            SR_TRY(hipMemcpyAsync(e->h_out, o, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            SR_TRY(hipStreamSynchronize(s));
+            ptx = e->h_out[2];
+          }
+          if (std::fabs(ptx) > (double)(res / 2)) ++gated_total;
+          else prev_slot = i;
+        }
+        carry = prev_slot;
+      }
+      done += m;
+    }
+  }
+  // prevIm_F32 <- the last frame that passed the gate (:128)
+  if (carry >= 0) SR_TRY(hipMemcpyAsync(e->d_zh_prev, zh + (size_t)carry * zhf, zh_bytes, hipMemcpyDeviceToDevice, s));
+  SR_TRY(scratch_release(e, s));
+  if (n_gated) {
+    SR_TRY(hipStreamSynchronize(s));
+    *n_gated = gated_total;
   }
   return MOF_OK;
 }

@@ -267,13 +267,12 @@ __device__ __forceinline__ void gray16_from_bgr48(const uint8_t* p, uint32_t* g 
 //
 // PK = 1 is the useOCL=true normalisation (cl/FftMethod.cl:971-982, :1024-1031): C = P rsqrt(|P|^2 + eps)
 // for every pair and 1 / (a b) in the four real-only slots.
+// cross_power_ab takes the two spectra already separated (and doubled): A2 = 2A, B2 = 2B.
 template <int PK = 0>
-__device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
+__device__ __forceinline__ cf cross_power_ab(cf A, cf B, bool real_only) {
   // Worked on 2A = Z[k] + conj(Z[-k]) and 2B = -i (Z[k] - conj(Z[-k])): P' = 2A conj(2B) = 4P, and
   //   P |P| / (|P|^2 + eps)  ==  P' |P'| / (|P'|^2 + 16 eps)   exactly (powers of two), four multiplies fewer per bin.
   const float eps16 = 16.f * 1.1920928955078125e-07f;  // 16 * FLT_EPSILON, :1117
-  const cf A = {zk.x + zm.x, zk.y - zm.y};
-  const cf B = {zk.y + zm.y, zm.x - zk.x};
   if (real_only) {
     // P = A.x B.x / 4 ; C = P / (P^2 + eps) = 4 P' / (P'^2 + 16 eps)
     const float p4 = A.x * B.x;
@@ -296,6 +295,19 @@ __device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
   if (__builtin_amdgcn_ballot_w64(!(q >= 1024.f)) != 0)
     s = (q >= 1024.f) ? s : __builtin_amdgcn_sqrtf(q) * __builtin_amdgcn_rcpf(q + eps16);
   return {pr * s, pim * s};
+}
+
+// The two real images ride one complex transform (z = cur + i prev): untangle bin k from Z[k] and Z[-k], doubled
+__device__ __forceinline__ void untangle2(cf zk, cf zm, cf* A2, cf* B2) {
+  *A2 = {zk.x + zm.x, zk.y - zm.y};
+  *B2 = {zk.y + zm.y, zm.x - zk.x};
+}
+
+template <int PK = 0>
+__device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
+  cf A, B;
+  untangle2(zk, zm, &A, &B);
+  return cross_power_ab<PK>(A, B, real_only);
 }
 
 // Weighted centroid in double + validity gate, executed by ONE wave in two steps so that the tile can be recycled in

@@ -1,0 +1,116 @@
+// sr_common.hpp -- the in-register two-stage 1-D transform shared by the scale/rotation kernels (sr_kernel.hip: independent
+// pairs; sr_seq_kernel.hip: video sequences). Device code only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "pc_common.hpp"
+
+namespace mof {
+namespace {
+
+template <int N>
+struct SrPlan;
+// LINE = complex elements per line buffer: >= R1 * Y2 (the padded stage-1 output), odd so that the 8 lines of a
+// workgroup start on different banks; Y2 = row pitch of the stage-1 output (R2 + 1: stride-Y2 reads hit distinct banks)
+template <>
+struct SrPlan<480> {
+  static constexpr int R1 = 15, R2 = 32, Y2 = 33, LINE = 497;
+};
+template <>
+struct SrPlan<240> {
+  static constexpr int R1 = 15, R2 = 16, Y2 = 17, LINE = 257;
+};
+template <>
+struct SrPlan<256> {
+  static constexpr int R1 = 16, R2 = 16, Y2 = 17, LINE = 273;
+};
+
+template <int R>
+__device__ __forceinline__ void bfly(cf* v) {
+  if constexpr (R == 15) butterfly15(v);
+  else if constexpr (R == 32) butterfly32(v);
+  else butterfly<R>(v);
+}
+
+constexpr int SR_LINES = 8;      // lines per workgroup in K5 / K7 (8 rows, 8 row pairs) and in K6 (4 columns + 4 mirrors)
+constexpr int SR_T = 128;        // two waves, four lines each
+constexpr int COLS_CW = SR_LINES / 2;
+
+// Inter-stage twiddles of the lane's stage-1 slot: W_N^{n2 k1}, k1 = 1..R1-1, n2 = lane % R2 (the same for every line
+// the lane ever transforms, so they are fetched once per kernel).
+template <int N>
+struct SrTw {
+  cf w[SrPlan<N>::R1 - 1];
+  __device__ __forceinline__ void load(const float* __restrict__ table, int lane) {
+    const int n2 = lane % SrPlan<N>::R2;
+#pragma unroll
+    for (int k1 = 1; k1 < SrPlan<N>::R1; ++k1) {
+      const float2 t = *reinterpret_cast<const float2*>(table + 2 * (n2 * k1));  // n2 * k1 < N
+      w[k1 - 1] = {t.x, t.y};
+    }
+  }
+};
+
+// Forward DFT of `nl` (2 or 4) lines of length N owned by ONE wave, in place, natural order in and out.
+//   stage 1: lane = (line, n2): radix R1 over x[R2 n1 + n2], twiddle W_N^{n2 k1}, stored at y[Y2 k1 + n2]
+//   stage 2: lane = (line, k1): radix R2 over y[Y2 k1 + n2], X[k1 + R1 k2] stored in natural order (or handed to
+//            `sink(line, k1, v)` instead when the caller consumes the result from registers).
+// A wave's LDS instructions execute in order and every lane reads all its inputs before it writes, so in place is safe.
+template <int N, class Sink>
+__device__ __forceinline__ void wave_fft(cf* __restrict__ z, int nl, int lane, const SrTw<N>& tw, Sink sink) {
+  using P = SrPlan<N>;
+  constexpr int LP1 = 64 / P::R2;  // lines per stage-1 pass
+  for (int l0 = 0; l0 < nl; l0 += LP1) {
+    const int l = l0 + lane / P::R2, n2 = lane % P::R2;
+    if (l < nl) {  // (R2 = 16 packs four lines into a pass; a two-line call leaves half the wave idle)
+      cf* line = z + l * P::LINE;
+      cf v[P::R1];
+#pragma unroll
+      for (int n1 = 0; n1 < P::R1; ++n1) v[n1] = lds_read(&line[P::R2 * n1 + n2]);
+      bfly<P::R1>(v);
+      line[n2] = v[0];
+#pragma unroll
+      for (int k1 = 1; k1 < P::R1; ++k1) line[P::Y2 * k1 + n2] = cmul(v[k1], tw.w[k1 - 1]);
+    }
+  }
+  wave_sync();
+  {
+    // 16 lanes per line (15 of them active when R1 = 15); nl = 2 leaves the upper half of the wave idle
+    const int l = lane >> 4, k1 = lane & 15;
+    const bool on = l < nl && k1 < P::R1;
+    cf* line = z + l * P::LINE;
+    cf v[P::R2];
+    if (on) {
+#pragma unroll
+      for (int n2 = 0; n2 < P::R2; ++n2) v[n2] = lds_read(&line[P::Y2 * k1 + n2]);
+      bfly<P::R2>(v);
+      sink(line, l, k1, v);
+    }
+  }
+  wave_sync();
+}
+
+// default sink: natural-order store
+template <int N>
+struct StoreNatural {
+  __device__ __forceinline__ void operator()(cf* line, int, int k1, const cf* v) const {
+#pragma unroll
+    for (int k2 = 0; k2 < SrPlan<N>::R2; ++k2) line[k1 + SrPlan<N>::R1 * k2] = v[k2];
+  }
+};
+
+// compile-time loop: the body sees its index as an integral_constant
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+}  // namespace
+
+}  // namespace mof

@@ -1,0 +1,246 @@
+// sr_seq_kernel.hip -- the scale/rotation estimator's transforms for FRAME SEQUENCES (K5s, K6s) on gfx950.
+//
+// scaleRotationEstimator::processImage (/root/reference/src/scaleRotationEstimator.cpp:34-148) is a stream processor: from
+// the second call on, every frame's log-polar image is `cur` once (:112-117) and -- unless the gate of :119-121 fires --
+// `prev` once (:128). The pair kernels of sr_kernel.hip pack (cur, prev) into one complex transform, which is the cheapest
+// form for INDEPENDENT pairs but transforms every frame of a video twice. Here the unit is the frame:
+//   K5s sr_rows_real : one log-polar image -> its row half-spectra, two real rows per complex transform, untangled and
+//                      written transposed and DOUBLED: Zh[u][v] = 2 * rowDFT(v)[u], u = 0..N/2 (925 KB per 480^2 frame
+//                      instead of 1.84 MB of packed Zt per pair)
+//   K6s sr_cols_seq  : ONE WAVE owns four columns u and walks a run of consecutive pairs in time: the column spectra of
+//                      the previous frame stay in its registers (60 VGPRs), per new frame it reads four lines of Zh,
+//                      transforms them in LDS, forms the normalised cross-power spectrum against the registers (same
+//                      rules as K6 / K1, pc_common.hpp), transforms back and writes the same Dt that K7 / K8 of
+//                      sr_kernel.hip consume. No workgroup barrier; per pair and column group 8 line transforms instead of
+//                      K6's 12, and each Zh line is read (1 + 1/run) times instead of twice.
+// The stateful single-frame entry (mof_sr_process) runs the SAME kernels with one pair per launch, so a sequence processed
+// in one call and the same frames fed one at a time produce identical bits.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mof_kernels.h"
+#include "pc_common.hpp"
+#include "sr_common.hpp"
+
+namespace mof {
+
+namespace {
+
+// ---- K5s: row half-spectra of one real image -------------------------------------------------------------------------
+// ROWS image rows per workgroup = ROWS / 2 packed lines, four lines per wave. The transposed store writes ROWS * 8
+// contiguous bytes per u.
+template <int N>
+struct RowsReal {
+  static constexpr int ROWS = (N % 32 == 0) ? 32 : 16;
+  static constexpr int LINES = ROWS / 2;
+  static constexpr int T = LINES * 16;
+};
+
+template <int N>
+__global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint8_t* __restrict__ lp, size_t lp_stride,
+                                                                       const float* __restrict__ twiddles,
+                                                                       float* __restrict__ zh, size_t zh_stride) {
+  using P = SrPlan<N>;
+  using R = RowsReal<N>;
+  constexpr int H = N / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char rr_lds[];
+  cf* z = reinterpret_cast<cf*>(rr_lds);  // [LINES][LINE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frame = blockIdx.y, row0 = blockIdx.x * R::ROWS;
+  SrTw<N> tw;
+  tw.load(twiddles, lane);
+  // wave w owns rows row0 + 8w .. +7 = lines 4w .. 4w+3: line l = rows (2l, 2l+1) as real and imaginary part
+  const uint8_t* img = lp + (size_t)frame * lp_stride + (size_t)(row0 + 8 * wave) * N;
+  cf* mine = z + 4 * wave * P::LINE;
+  {
+    constexpr int ND = N / 4, NL = (4 * ND + 63) / 64;  // dwords per row; (even, odd) dword pairs per lane
+    uint32_t c[NL], p[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {  // all loads first, then the conversion (convertTo CV_32FC1, :115)
+      const int i = lane + 64 * k;
+      if (i < 4 * ND) {
+        const int l = i / ND, d = i % ND;
+        c[k] = *reinterpret_cast<const uint32_t*>(img + (size_t)(2 * l) * N + 4 * d);
+        p[k] = *reinterpret_cast<const uint32_t*>(img + (size_t)(2 * l + 1) * N + 4 * d);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = lane + 64 * k;
+      if (i < 4 * ND) {
+        const int l = i / ND, d = i % ND;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          mine[l * P::LINE + 4 * d + q] = {(float)((c[k] >> (8 * q)) & 0xffu), (float)((p[k] >> (8 * q)) & 0xffu)};
+      }
+    }
+  }
+  wave_sync();
+  wave_fft<N>(mine, 4, lane, tw, StoreNatural<N>{});
+  __syncthreads();
+  // untangle the two rows of every line and store transposed: Zh[u][row0 + 2j], Zh[u][row0 + 2j + 1] are neighbours
+  cf* out = reinterpret_cast<cf*>(zh + (size_t)frame * zh_stride) + row0;
+  for (int i = tid; i < R::LINES * (H + 1); i += R::T) {
+    const int u = i / R::LINES, j = i % R::LINES;
+    const cf zk = z[j * P::LINE + u], zm = z[j * P::LINE + (N - u) % N];
+    cf a2, b2;
+    untangle2(zk, zm, &a2, &b2);  // 2 * DFT(row 2j)[u], 2 * DFT(row 2j + 1)[u]
+    *reinterpret_cast<float4*>(out + (size_t)u * N + 2 * j) = make_float4(a2.x, a2.y, b2.x, b2.y);
+  }
+}
+
+// ---- K6s: column transforms + cross-power + inverse columns, one wave walking a run of pairs -------------------------
+constexpr int SEQ_CW = 4;  // columns per wave
+
+template <int N>
+__global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur,
+                                                         size_t zh_stride, const float* __restrict__ twiddles,
+                                                         float* __restrict__ Dt, int n_pairs, int run) {
+  using P = SrPlan<N>;
+  constexpr int H = N / 2, CW = SEQ_CW;
+  constexpr int MV = (N + 63) / 64;       // bins per lane and line (v = lane + 64 m)
+  constexpr int MQ = (N / 2 + 63) / 64;   // 16-byte pieces per lane and line
+  __shared__ cf z[CW * P::LINE];
+  const int lane = threadIdx.x, u0 = blockIdx.x * CW, p0 = blockIdx.y * run;
+  const int np = n_pairs - p0 < run ? n_pairs - p0 : run;
+  SrTw<N> tw;
+  tw.load(twiddles, lane);
+
+  // four lines of one frame's Zh (columns u0 .. u0+3, clamped in the tail group) -> LDS -> column transforms in place
+  auto load_cols = [&](const float* frame) {
+    const cf* Zf = reinterpret_cast<const cf*>(frame);
+    float4 t[CW][MQ];
+#pragma unroll
+    for (int s = 0; s < CW; ++s) {
+      const int u = u0 + s > H ? H : u0 + s;
+#pragma unroll
+      for (int m = 0; m < MQ; ++m) {
+        const int q = lane + 64 * m;
+        if (q < N / 2) t[s][m] = *reinterpret_cast<const float4*>(Zf + (size_t)u * N + 2 * q);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < CW; ++s)
+#pragma unroll
+      for (int m = 0; m < MQ; ++m) {
+        const int q = lane + 64 * m;
+        if (q < N / 2) {
+          z[s * P::LINE + 2 * q] = {t[s][m].x, t[s][m].y};
+          z[s * P::LINE + 2 * q + 1] = {t[s][m].z, t[s][m].w};
+        }
+      }
+    wave_sync();
+    wave_fft<N>(z, CW, lane, tw, StoreNatural<N>{});
+  };
+
+  cf ap[CW][MV];  // column spectra of the previous frame (doubled): 2 B[v][u]
+  load_cols(zh_prev + (size_t)p0 * zh_stride);
+#pragma unroll
+  for (int s = 0; s < CW; ++s)
+#pragma unroll
+    for (int m = 0; m < MV; ++m) {
+      const int v = lane + 64 * m;
+      ap[s][m] = v < N ? lds_read(&z[s * P::LINE + v]) : cf{0.f, 0.f};
+    }
+  wave_sync();
+  for (int j = 0; j < np; ++j) {
+    load_cols(zh_cur + (size_t)(p0 + j) * zh_stride);
+    // normalised cross-power spectrum of bins (v, u), conjugated in place; the current spectra move into the registers
+#pragma unroll
+    for (int s = 0; s < CW; ++s) {
+      const int u = u0 + s > H ? H : u0 + s;
+      const bool u_edge = u == 0 || u == H;
+#pragma unroll
+      for (int m = 0; m < MV; ++m) {
+        const int v = lane + 64 * m;
+        const int vv = v < N ? v : N - 1;  // (lanes past the line repeat its last bin: the wave-uniform branch inside
+        const cf a = lds_read(&z[s * P::LINE + vv]);  //  cross_power_ab wants every lane to take part)
+        const cf C = cross_power_ab(a, ap[s][m], u_edge && (vv == 0 || vv == H));
+        ap[s][m] = a;
+        if (v < N) z[s * P::LINE + v] = {C.x, -C.y};
+      }
+    }
+    wave_sync();
+    wave_fft<N>(z, CW, lane, tw, StoreNatural<N>{});
+    cf* D = reinterpret_cast<cf*>(Dt) + (size_t)(p0 + j) * (H + 1) * N;
+#pragma unroll
+    for (int s = 0; s < CW; ++s) {
+      const int u = u0 + s;
+#pragma unroll
+      for (int m = 0; m < MQ; ++m) {
+        const int q = lane + 64 * m;
+        if (q < N / 2 && u <= H) {
+          const cf a0 = z[s * P::LINE + 2 * q], a1 = z[s * P::LINE + 2 * q + 1];
+          *reinterpret_cast<float4*>(D + (size_t)u * N + 2 * q) = make_float4(a0.x, a0.y, a1.x, a1.y);
+        }
+      }
+    }
+    wave_sync();
+  }
+}
+
+// what processImage returns for the very first frame of a sequence (scaleRotationEstimator.cpp:74): (1, 0), no pt
+__global__ void sr_identity_kernel(double* __restrict__ out) {
+  if (threadIdx.x < 4) out[threadIdx.x] = threadIdx.x == 0 ? 1.0 : 0.0;
+}
+
+template <int N>
+hipError_t launch_rows_real_n(const uint8_t* lp, size_t lp_stride, const float* tw, float* zh, size_t zh_stride, int n_frames,
+                              hipStream_t stream) {
+  using R = RowsReal<N>;
+  static_assert(N % R::ROWS == 0, "rows divide evenly over the workgroups");
+  constexpr size_t lds = sizeof(cf) * R::LINES * SrPlan<N>::LINE;
+  if (lds > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_rows_real_kernel<N>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(sr_rows_real_kernel<N>, dim3(N / R::ROWS, (unsigned)n_frames), dim3(R::T), lds, stream, lp, lp_stride, tw, zh,
+                     zh_stride);
+  return hipGetLastError();
+}
+
+template <int N>
+hipError_t launch_cols_seq_n(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* tw, float* Dt, int n_pairs,
+                             int run, hipStream_t stream) {
+  constexpr int H = N / 2;
+  const unsigned groups = (H + 1 + SEQ_CW - 1) / SEQ_CW, runs = (unsigned)((n_pairs + run - 1) / run);
+  hipLaunchKernelGGL(sr_cols_seq_kernel<N>, dim3(groups, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+size_t sr_zh_floats(int res) { return (size_t)(res / 2 + 1) * res * 2; }
+
+hipError_t launch_sr_identity(double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(sr_identity_kernel, dim3(1), dim3(64), 0, stream, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float* twiddles, float* zh, size_t zh_stride, int res,
+                               int n_frames, hipStream_t stream) {
+  if (n_frames <= 0) return hipSuccess;
+  switch (res) {
+    case 240: return launch_rows_real_n<240>(lp, lp_stride, twiddles, zh, zh_stride, n_frames, stream);
+    case 256: return launch_rows_real_n<256>(lp, lp_stride, twiddles, zh, zh_stride, n_frames, stream);
+    case 480: return launch_rows_real_n<480>(lp, lp_stride, twiddles, zh, zh_stride, n_frames, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* twiddles, float* Dt, int res,
+                              int n_pairs, int run, hipStream_t stream) {
+  if (n_pairs <= 0) return hipSuccess;
+  if (run < 1) run = 1;
+  // a run longer than one pair walks cur(p) as prev(p + 1): only valid for a contiguous sequence
+  if (run > 1 && zh_cur != zh_prev + zh_stride) return hipErrorInvalidValue;
+  switch (res) {
+    case 240: return launch_cols_seq_n<240>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
+    case 256: return launch_cols_seq_n<256>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
+    case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mof

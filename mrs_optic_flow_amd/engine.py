@@ -435,6 +435,25 @@ class ScaleRotationEstimator:
                                                     prev.stride(0), cur.stride(1), n, out.data_ptr(), _stream_ptr(s)))
         return out
 
+    def process_sequence_device(self, frames, resolve_gate: bool = True, stream=None):
+        """frames: torch uint8 [n, res, res] view of a video (any pitch / frame stride) -> float64 [n, 4] = what n consecutive
+        processImage calls return (scale, rot, pt.x, pt.y; the first frame of a fresh estimator: 1, 0, 0, 0), continuing
+        and updating the engine's stateful sequence. resolve_gate=True is synchronous and exact under the gate of
+        scaleRotationEstimator.cpp:119-121 (``self.last_gated`` = gated frames); False is asynchronous / capturable."""
+        import torch
+
+        _check_device_batch(frames, frames, (self.cfg.resolution, self.cfg.resolution), self.cfg.device)
+        n = frames.shape[0]
+        out = torch.empty((n, 4), dtype=torch.float64, device=frames.device)
+        s = stream if stream is not None else torch.cuda.current_stream(frames.device)
+        _pin_if_capturing(self, s)
+        gated = C.c_int(0)
+        check(self._lib.mof_sr_process_sequence_device(self._h, frames.data_ptr(), frames.stride(0), frames.stride(1), n,
+                                                       out.data_ptr(), _stream_ptr(s),
+                                                       C.byref(gated) if resolve_gate else None))
+        self.last_gated = gated.value if resolve_gate else None
+        return out
+
     def logpolar_batch_device(self, src, interpolation: int = INTER_LANCZOS4, dst=None, stream=None):
         """cv::logPolar of n res x res crops (torch uint8 [n, res, res], any pitch/stride) -> uint8 [n, res, res].
         Destination pixels whose source lies outside the image keep the content of ``dst`` (zeros when omitted)."""

@@ -177,3 +177,36 @@ def batch_torch(n_pairs: int, height: int, width: int, s: int, device, blur: boo
             shifts[i, 0], shifts[i, 1] = dx, dy
             kinds.append(kind)
     return cur, prev, shifts, kinds
+
+
+def video_torch(n_frames: int, height: int, width: int, device, k: int = 0, blur: bool = True, seed: int = SEED):
+    """A synthetic VIDEO on `device`: frame t is the height x width window of one canvas (texture index k) at an offset that
+    follows a closed Lissajous path inside the canvas margin, so consecutive frames are translated copies of each other
+    (what the sequence entry points -- K1 on frames[1:] / frames[:-1], the estimator's sequence mode -- are meant for).
+    Returns (frames uint8 [n_frames, height, width], offsets int32 [n_frames, 2] cpu (x, y))."""
+    import math
+
+    import torch
+
+    m = MARGIN
+    pad = 1 if blur else 0
+    hh, ww = height + 2 * m, width + 2 * m
+    y = torch.arange(hh + 2 * pad, dtype=torch.int64, device=device)[:, None]
+    x = torch.arange(ww + 2 * pad, dtype=torch.int64, device=device)[None, :]
+    t = _mix32_t(seed, k, y, x) >> 24
+    if blur:
+        acc = torch.zeros((hh, ww), dtype=torch.int64, device=device)
+        for oy in range(3):
+            for ox in range(3):
+                acc += t[oy:oy + hh, ox:ox + ww]
+        canvas = ((acc + 4) // 9).to(torch.uint8)
+    else:
+        canvas = t.to(torch.uint8)
+    frames = torch.empty((n_frames, height, width), dtype=torch.uint8, device=device)
+    offs = torch.zeros((n_frames, 2), dtype=torch.int32)
+    for f in range(n_frames):
+        ox = int(round((m - 1) * math.sin(2.0 * math.pi * f / 97.0)))
+        oy = int(round((m - 1) * math.sin(2.0 * math.pi * f / 61.0 + 0.5)))
+        frames[f] = canvas[m + oy:m + oy + height, m + ox:m + ox + width]
+        offs[f, 0], offs[f, 1] = ox, oy
+    return frames, offs
