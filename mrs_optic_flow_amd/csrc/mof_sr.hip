@@ -267,7 +267,7 @@ struct mof_sr_engine {
   uint8_t* h_stage = nullptr;
   double* h_out = nullptr;
   double* h_seq = nullptr;       // pinned [chunk][4]: a pass's results, read back when a sequence call resolves the gate
-  int seq_run = 8;               // pairs one wave of K6s walks in time (MOF_SR_SEQ_RUN overrides)
+  int seq_run = 16;              // pairs one wave of K6s walks in time (MOF_SR_SEQ_RUN overrides)
   int chunk = 0;                 // frame pairs per pipeline pass
   int scratch_pairs = 0;         // pairs per pass the scratch holds now (1 after create, `chunk` after the first batch)
   bool two_lanes = false;        // remap of pass k+1 beside the transforms of pass k (mof_sr_config.pipeline_lanes == 2)

@@ -110,6 +110,7 @@ def test_captured_graph_outlives_every_python_reference(gpu):
     with pytest.raises(MofError) as exc:
         sr.process_batch_device(big_c, big_c)
     assert exc.value.code == _capi.MOF_ERR_BUSY and "graph" in str(exc.value)
+    del exc  # (its traceback holds the frame of sr.process_batch_device, and with it the engine)
     # the C ABI's own protection, without Python's keep-alive set: destroying a pinned engine parks it
     from mrs_optic_flow_amd import engine as E
     E._CAPTURED.discard(fm)
