@@ -48,6 +48,9 @@ def binding_note(name: str, wl) -> str:
                 "0.10 ms per 1024 pairs, the one path here whose time is mostly frame fetch")
     if wl["kind"] == "fft+rt":
         return "K1 as in ref + the getRT tail (one wavefront per pair, fp64 recurrences: 0.35 ms per 1024 pairs); not HBM"
+    if wl["kind"] == "fftseq":
+        return ("K1 sequence kernel: one real forward transform + one Hermitian inverse per frame and patch (1.0 instead of 1.5 "
+                "complex-transform units), four barriers per frame; VALU issue / phase-chain latency as K1; not HBM")
     if wl["kind"] == "fft+srseq":
         return ("c5 on a video: one Lanczos4 remap and one real row transform per frame (K5s), column pass walking pairs in "
                 "time with the previous spectra in registers (K6s); DESIGN.md section 4 (sequence mode)")
@@ -109,6 +112,12 @@ WORKLOADS = {
                     "phase correlation), 752x480, batch=1024 frame pairs per GPU",
                # 2*W*H u8 in + flow vectors + (scale, rot)
                bytes_per_pair=2 * 752 * 480 + 64 * 8 + 8),
+    # c2 on a VIDEO (FftMethod.cpp:1872: every frame is cur once and prev once): B + 1 frames = B consecutive pairs through the
+    # sequence kernel (one real 2-D transform per frame and patch, the previous spectrum in registers)
+    "c2seq": dict(kind="fftseq", h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=1024, s=8,
+                  name="c2seq: c2 on a video -- FftMethod on 1024 consecutive frame pairs (1025 frames per GPU), sequence kernel",
+                  # one NEW frame's patch pixels per pair + flow vectors
+                  bytes_per_pair=64 * 64 * 64 + 64 * 8),
     # c5 on a VIDEO (the node's real workload, scaleRotationEstimator.cpp:34-148 steady state): B + 1 consecutive frames,
     # K1 on the B consecutive pairs, the estimator in sequence mode (every frame remapped and row-transformed once)
     "c5seq": dict(kind="fft+srseq", h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=1024, s=8,
@@ -187,7 +196,7 @@ def cpu_baseline(wl, budget_s: float = 12.0):
             flow, _ = O.fft_process(cur[k % n_gen], prev[k % n_gen], lay, 32)
             O.geom_get_rt(flow, ol, ocam, opar, 8)
         what = "f32 oracle (oracle/pc_ref.c) + fp64 getRT (oracle/geom_ref.c)"
-    elif wl["kind"] == "fft":
+    elif wl["kind"] in ("fft", "fftseq"):  # (the CPU path transforms both patches of every pair, as cv::phaseCorrelate does)
         lay = O.fft_layout(wl["w"], wl["h"], wl["n"], wl["grid"][0], wl["grid"][1], wl["origin"], wl["stride"])
         run = lambda k: O.fft_process(cur[k % n_gen], prev[k % n_gen], lay, 32)
         what = "f32 oracle (oracle/pc_ref.c)"
@@ -239,25 +248,29 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
 
     B = wl["batch"]
     state = {"out": None}
-    if wl["kind"] == "fft+srseq":
+    if wl["kind"] in ("fft+srseq", "fftseq"):
         # every rank owns its own video (texture index = rank): B + 1 frames = B consecutive pairs
         video, _ = synth.video_torch(B + 1, wl["h"], wl["w"], dev, k=rank)
         cur, prev = video[1:], video[:-1]  # a video needs no copy: cur = frames + 1, prev = frames
     else:
         # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
         cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
-    if wl["kind"] in ("fft", "fft+sr", "fft+srseq", "fft+rt", "fft+2dt"):
+    if wl["kind"] in ("fft", "fftseq", "fft+sr", "fft+srseq", "fft+rt", "fft+2dt"):
         eng = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"],
                         origin=wl["origin"], stride=wl["stride"], device=local_rank)
         state["out"] = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
-        if wl["kind"] == "fft+srseq":
+        if wl["kind"] == "fftseq":
+            def launch():
+                eng.process_sequence_device(video, out=state["out"])
+                return state["out"]
+        elif wl["kind"] == "fft+srseq":
             sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank)
             x0, r = wl["sr_x0"], wl["sr_res"]
             crop = video[:, :r, x0:x0 + r]
             sr.process_sequence_device(crop[:2])  # arm the steady state: every timed frame goes through INTER_LANCZOS4
 
             def launch():
-                eng.process_batch_device(cur, prev, out=state["out"])
+                eng.process_sequence_device(video, out=state["out"])
                 srout = sr.process_sequence_device(crop[1:], resolve_gate=False)  # B new frames = B pairs
                 return torch.cat([state["out"].reshape(B, -1), srout], dim=1)
         elif wl["kind"] == "fft+sr":
@@ -404,7 +417,7 @@ def roofline_block(tag: str, wl, B: int, kern_ms: float):
                               "not measured live") if traffic is not None else None,
            "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
            "binding": binding_note(tag, wl)}
-    if wl["kind"] == "fft":
+    if wl["kind"] in ("fft", "fftseq"):
         # the resource that actually binds K1: vector fp32. Informational, next to the HBM figure.
         fl = fft_flops_per_pair(wl["n"], wl["grid"][0] * wl["grid"][1]) * B
         blk["compute"] = {"unit": "TFLOP/s", "achieved": fl / (kern_ms * 1e-3) / 1e12, "peak": VALU_FP32_PEAK_TFLOPS,
@@ -549,7 +562,8 @@ def main() -> None:
     if rank == 0:
         pairs = B * world * args.steps
         line = {
-            "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fft+sr": "_fft_phase_corr_plus_scale_rotation",
+            "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fftseq": "_fft_phase_corr_sequence",
+                                             "fft+sr": "_fft_phase_corr_plus_scale_rotation",
                                              "fft+srseq": "_fft_phase_corr_plus_scale_rotation_sequence",
                                              "fft+rt": "_fft_phase_corr_plus_get_rt",
                                              "fft+2dt": "_long_range_plus_get_2dt",

@@ -149,6 +149,16 @@ int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_
  * the caller synchronises. The engine's stateful previous frame is not touched. */
 int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                  size_t prev_stride, size_t pitch, int n_pairs, double* d_out_xy, void* stream);
+/* A VIDEO on the device: frame i at d_frames + i*frame_stride; pair k = (cur: frame k + 1, prev: frame k), i.e. what
+ * n_frames - 1 consecutive processImage calls return after the first one (`imPrev = imCurr.clone()`, FftMethod.cpp:1872).
+ * d_out_xy receives (n_frames - 1) * grid_x * grid_y * 2 doubles. Same estimator as mof_fft_process_batch_device on
+ * (d_frames + frame_stride, d_frames): same arg-max, sub-pixel shifts equal within rounding. For 64 x 64 patches a
+ * workgroup owns one patch position and walks consecutive frames, keeping the previous frame's half spectrum in
+ * registers: one real 2-D transform forward and one Hermitian inverse per frame and patch -- 1.0 instead of the pair
+ * kernel's 1.5 complex-transform units (csrc/pc_seq_kernel.hip); other patch sizes run the pair kernel on the two
+ * views of the video. The engine's stateful previous frame is not touched. Asynchronous on `stream`. */
+int mof_fft_process_sequence_device(mof_fft_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch,
+                                    int n_frames, double* d_out_xy, void* stream);
 /* Front-end fusion: the frames are interleaved BGR8 as the node receives them
  * (cv_bridge::toCvCopy(msg, BGR8), optic_flow.cpp:1465) and cv::cvtColor(crop, gray, CV_RGB2GRAY) (:1622) -- applied to
  * BGR data, i.e. gray = (B*4899 + G*9617 + R*1868 + 8192) >> 14 -- happens inside the kernel's load. d_cur / d_prev

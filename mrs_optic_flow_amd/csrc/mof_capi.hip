@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -241,6 +242,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   CREATE_TRY(hipHostMalloc(&e->h_out, res * sizeof(double), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
   CREATE_TRY(mof::pc_configure(n));
+  if (mof::pc_sequence_supported(n)) CREATE_TRY(mof::pc_configure_sequence());
 #undef CREATE_TRY
   *out = e;
   return MOF_OK;
@@ -449,6 +451,32 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
   mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
   HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
+  return MOF_OK;
+}
+
+// A video: pair k = (frame k + 1, frame k). 64 x 64 patches run the sequence kernel (one real transform per frame and
+// patch, pc_seq_kernel.hip); the other sizes run the pair kernel on cur = frames + 1, prev = frames (no copy either).
+int mof_fft_process_sequence_device(mof_fft_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch, int n_frames,
+                                    double* d_out_xy, void* stream) {
+  if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_frames == 0 || n_frames == 1) return MOF_OK;  // no pair
+  if (!d_frames || !d_out_xy || n_frames < 0 || pitch < (size_t)e->cfg.frame_width)
+    return fail(MOF_ERR_BAD_ARG, "bad sequence arguments");
+  const int n_pairs = n_frames - 1;
+  if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
+    return fail(MOF_ERR_BAD_ARG, "sequence too long for one launch");
+  BusyGuard g(e->busy);
+  if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  mof::PcArgs a = fft_args(e, d_frames + frame_stride, frame_stride, d_frames, frame_stride, pitch, d_out_xy);
+  if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
+  static const int run = [] { const char* v = getenv("MOF_FFT_SEQ_RUN"); const int r = v ? atoi(v) : 0; return r >= 1 ? r : 16; }();
+  if (mof::pc_sequence_supported(e->cfg.patch_size) && !getenv("MOF_FFT_SEQ_PAIRS")) {
+    a.cur = d_frames;  // the sequence kernel indexes frames, not pairs
+    HIP_TRY(mof::launch_pc_sequence(a, n_pairs, run, (hipStream_t)stream));
+  } else {
+    HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
+  }
   return MOF_OK;
 }
 

@@ -34,6 +34,11 @@ bool pc_patch_size_supported(int n);
 const char* pc_kernel_variant(int patch_size);
 hipError_t pc_configure(int patch_size);  // once per device before the first launch
 hipError_t launch_pc_field(const PcArgs& a, int patch_size, int n_pairs, hipStream_t stream);
+// Frame sequences (pc_seq_kernel.hip; 64 x 64 patches): a.cur = frame 0, a.cur_stride = bytes between frames, pair k =
+// (frame k + 1, frame k) for k < n_pairs; one workgroup per patch position walks `run` consecutive pairs
+bool pc_sequence_supported(int patch_size);
+hipError_t pc_configure_sequence();
+hipError_t launch_pc_sequence(const PcArgs& a, int n_pairs, int run, hipStream_t stream);
 // N = 64, quad-per-line formulation (pc_kernel_quad.hip)
 hipError_t pc_configure_quad64();
 hipError_t launch_pc_field_quad64(const PcArgs& a, int n_pairs, hipStream_t stream);

@@ -34,351 +34,9 @@
 #include "mof_kernels.h"
 #include "pc_common.hpp"
 
-#ifndef MOF_FUSE_XPOW
-#define MOF_FUSE_XPOW 1  // 1: where it pays (PcTraits::FUSE_XPOW), the cross-power spectrum is formed inside the inverse row pass
-#endif
-#ifndef MOF_XPOW_SPLIT
-#define MOF_XPOW_SPLIT 1  // the inverse row pass of the waves that do not own row 0 carries no select for the packed row
-#endif
-#ifndef MOF_FUSED_TW
-#define MOF_FUSED_TW 1  // twiddles of the radix-8 second stage fused into its first layer (butterfly8_tw)
-#endif
+#include "pc_passes.hpp"
 
 namespace mof {
-
-namespace {
-
-template <int N>
-struct Cfg;
-template <>
-struct Cfg<32> {
-  static constexpr int R1 = 8, R2 = 4, SK = 3, PITCH = 36;
-};
-template <>
-struct Cfg<64> {
-  static constexpr int R1 = 8, R2 = 8, SK = 3, PITCH = 72;
-};
-#ifndef MOF_SK128
-#define MOF_SK128 4
-#endif
-#ifndef MOF_PITCH128
-#define MOF_PITCH128 136
-#endif
-template <>
-struct Cfg<128> {
-  static constexpr int R1 = 16, R2 = 8, SK = MOF_SK128, PITCH = MOF_PITCH128;
-};
-
-}  // namespace
-
-template <int N>
-struct PcTraits {
-#ifndef MOF_K1_T64
-#define MOF_K1_T64 256
-#endif
-  static constexpr int T = (N == 64) ? MOF_K1_T64 : N * N / 16;
-  static constexpr int WAVES = T / 64;
-  static constexpr int LPW = N / WAVES;  // lines (rows or columns) owned by a wave
-  static constexpr int R1 = Cfg<N>::R1, R2 = Cfg<N>::R2, SK = Cfg<N>::SK, PITCH = Cfg<N>::PITCH;
-  static constexpr int BMIN = R1 < R2 ? R1 : R2;
-  // inverse (half-size) passes: lines per active wave, active waves
-  static constexpr int LI = (LPW / 2 > 64 / BMIN) ? LPW / 2 : 64 / BMIN;
-  static constexpr int WI = (N / 2) / LI;
-  static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best);
-#ifndef MOF_PERSIST_MIN_N
-#define MOF_PERSIST_MIN_N 128
-#endif
-  static constexpr bool PERSIST = N >= MOF_PERSIST_MIN_N;  // see pc_field_kernel
-  // cross-power spectrum inside the inverse row pass (row_pass_xpow): one barrier and 1.5 tile passes fewer. Same-box
-  // A/B: +4.4 % at N = 64 (several workgroups per CU, latency-bound), -4.4 % at N = 128 (one workgroup per CU: the
-  // separate pass spreads the cross-power over all 16 waves, the fused one over the 8 that run the inverse)
-  static constexpr bool FUSE_XPOW = MOF_FUSE_XPOW && N <= 64;
-  static_assert(R1 * R2 == N && T % 64 == 0 && 64 % R1 == 0 && 64 % R2 == 0, "bad plan");
-};
-
-// z(r, c): skewed tile address in complex units
-template <int N>
-__device__ __forceinline__ int zaddr(int r, int c) {
-  return r * PcTraits<N>::PITCH + c + (c >> PcTraits<N>::SK);
-}
-
-// ---- row pass over LINES lines starting at line0 (wave-local) --------------------------------
-template <int N, int LINES>
-__device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane, const cf* tw_row) {
-  using P = PcTraits<N>;
-  constexpr int R1 = P::R1, R2 = P::R2;
-  {  // stage 1: radix R1, P = 1; R2 butterflies per line
-    constexpr int PER = LINES * R2 / 64;
-    static_assert(LINES * R2 % 64 == 0, "row stage 1 does not fill the wave");
-    cf v[PER][R1];
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int q = lane + 64 * b;
-      const int line = line0 + q / R2, x = q % R2;
-#pragma unroll
-      for (int k = 0; k < R1; ++k) v[b][k] = lds_read(&z[zaddr<N>(line, x + k * R2)]);
-      butterfly<R1>(v[b]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int q = lane + 64 * b;
-      const int line = line0 + q / R2, x = q % R2;
-#pragma unroll
-      for (int k = 0; k < R1; ++k) z[zaddr<N>(line, x * R1 + k)] = v[b][k];
-    }
-    wave_sync();
-  }
-  {  // stage 2: radix R2, P = R1; R1 butterflies per line, twiddle W_N^{k x}
-    constexpr int PER = LINES * R1 / 64;
-    static_assert(LINES * R1 % 64 == 0, "row stage 2 does not fill the wave");
-    cf v[PER][R2];
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int q = lane + 64 * b;
-      const int line = line0 + q / R1, x = q % R1;
-#pragma unroll
-      for (int k = 0; k < R2; ++k) {
-        cf a = lds_read(&z[zaddr<N>(line, x + k * R1)]);
-#ifdef MOF_ABLATE_NOBFLY
-        v[b][k] = a;
-#else
-        v[b][k] = (k == 0 || (R2 == 8 && MOF_FUSED_TW)) ? a : cmul(a, tw_row[k - 1]);
-#endif
-      }
-      if constexpr (R2 == 8 && MOF_FUSED_TW) butterfly8_tw(v[b], tw_row);
-      else butterfly<R2>(v[b]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int q = lane + 64 * b;
-      const int line = line0 + q / R1, x = q % R1;
-#pragma unroll
-      for (int k = 0; k < R2; ++k) z[zaddr<N>(line, x + k * R1)] = v[b][k];
-    }
-    wave_sync();
-  }
-}
-
-// ---- inverse row pass with the cross-power spectrum formed on the fly (MOF_FUSE_XPOW) ------------------------------
-// Rows 0..H-1 of the half spectrum D = conj(C): stage 1 reads bin (v, u) AND its Hermitian partner (N-v, N-u) from the
-// forward spectrum, forms conj(C[v][u]) in registers and goes straight into the first butterfly. The separate
-// cross-power pass (a tile read and half a tile write, one workgroup barrier) disappears. Partner rows are N-1..H+1,
-// which nobody writes in this phase; row 0 (packed with row H by the owning wave beforehand) is taken as it is.
-// HAS_ROW0: the wave that owns row 0 (wave 0); the others never meet the packed row and carry no per-element select for it.
-template <int N, int PK, bool HAS_ROW0>
-__device__ __forceinline__ void row_pass_xpow(cf* __restrict__ z, int line0, int lane, const cf* tw_row) {
-  using P = PcTraits<N>;
-  constexpr int R1 = P::R1, R2 = P::R2, LINES = P::LI;
-  {
-    constexpr int PER = LINES * R2 / 64;
-    static_assert(LINES * R2 % 64 == 0, "row stage 1 does not fill the wave");
-    cf v[PER][R1];
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int q = lane + 64 * b;
-      const int line = line0 + q / R2, x = q % R2;
-      const int pline = (N - line) % N;
-      const bool packed = HAS_ROW0 && line == 0;
-#pragma unroll
-      for (int k = 0; k < R1; ++k) {
-        const int u = x + k * R2, um = (N - u) % N;
-        const cf zk = lds_read(&z[zaddr<N>(line, u)]), zm = lds_read(&z[zaddr<N>(pline, um)]);
-        const cf C = cross_power<PK>(zk, zm, false);
-        v[b][k] = packed ? zk : cf{C.x, -C.y};
-      }
-      butterfly<R1>(v[b]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int q = lane + 64 * b;
-      const int line = line0 + q / R2, x = q % R2;
-#pragma unroll
-      for (int k = 0; k < R1; ++k) z[zaddr<N>(line, x * R1 + k)] = v[b][k];
-    }
-    wave_sync();
-  }
-  {  // stage 2: as row_pass
-    constexpr int PER = LINES * R1 / 64;
-    cf v[PER][R2];
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int q = lane + 64 * b;
-      const int line = line0 + q / R1, x = q % R1;
-#pragma unroll
-      for (int k = 0; k < R2; ++k) {
-        cf a = lds_read(&z[zaddr<N>(line, x + k * R1)]);
-        v[b][k] = (k == 0 || (R2 == 8 && MOF_FUSED_TW)) ? a : cmul(a, tw_row[k - 1]);
-      }
-      if constexpr (R2 == 8 && MOF_FUSED_TW) butterfly8_tw(v[b], tw_row);
-      else butterfly<R2>(v[b]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int q = lane + 64 * b;
-      const int line = line0 + q / R1, x = q % R1;
-#pragma unroll
-      for (int k = 0; k < R2; ++k) z[zaddr<N>(line, x + k * R1)] = v[b][k];
-    }
-    wave_sync();
-  }
-}
-
-// ---- forward column pass over the LPW columns starting at col0 (wave-local) --------------------
-template <int N>
-__device__ __forceinline__ void col_pass_fwd(cf* __restrict__ z, int col0, int lane, const cf* tw_col) {
-  using P = PcTraits<N>;
-  constexpr int R1 = P::R1, R2 = P::R2, LPW = P::LPW;
-  {  // stage 1: R2 butterflies per column
-    constexpr int PER = LPW * R2 / 64, CW = 64 / R2;
-    cf v[PER][R1];
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
-#pragma unroll
-      for (int k = 0; k < R1; ++k) v[b][k] = lds_read(&z[zaddr<N>(x + k * R2, col)]);
-      butterfly<R1>(v[b]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
-#pragma unroll
-      for (int k = 0; k < R1; ++k) z[zaddr<N>(x * R1 + k, col)] = v[b][k];
-    }
-    wave_sync();
-  }
-  {  // stage 2: R1 butterflies per column
-    constexpr int PER = LPW * R1 / 64, CW = 64 / R1;
-    cf v[PER][R2];
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
-#pragma unroll
-      for (int k = 0; k < R2; ++k) {
-        cf a = lds_read(&z[zaddr<N>(x + k * R1, col)]);
-#ifdef MOF_ABLATE_NOBFLY
-        v[b][k] = a;
-#else
-        v[b][k] = (k == 0 || (R2 == 8 && MOF_FUSED_TW)) ? a : cmul(a, tw_col[k - 1]);
-#endif
-      }
-      if constexpr (R2 == 8 && MOF_FUSED_TW) butterfly8_tw(v[b], tw_col);
-      else butterfly<R2>(v[b]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
-#pragma unroll
-      for (int k = 0; k < R2; ++k) z[zaddr<N>(x + k * R1, col)] = v[b][k];
-    }
-    wave_sync();
-  }
-}
-
-// ---- inverse column pass on LI column PAIRS (x1, x1 + N/2) starting at col0 (wave-local) -------
-// Input: rows 0..N/2-1 hold F1 = FFT_u(conj C) of the packed half spectrum: row 0 = F1[0] + i F1[N/2]
-// (both real), rows 1..N/2-1 = F1[v]; F1[N-v] = conj F1[v]. Column x of the result is real, so two
-// columns ride one complex transform: E[v] = F1[v][x1] + i F1[v][x2]; Re/Im of its transform are the
-// correlation surface at columns x1 / x2. Output: z(y, x1) = (c[y][x1], c[y][x1 + N/2]); returns the
-// lane's best (value, shifted index).
-template <int N, int PK>
-__device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int lane, const cf* tw_col, int search_radius) {
-  using P = PcTraits<N>;
-  constexpr int R1 = P::R1, R2 = P::R2, LI = P::LI, H = N / 2;
-  {  // stage 1
-    constexpr int PER = LI * R2 / 64, CW = 64 / R2;
-    static_assert(PER >= 1, "inverse column stage 1 does not fill the wave");
-    cf v[PER][R1];
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
-      // r = x + k R2 with x < R2: r < H exactly for k < R1/2, so the four Hermitian cases are decided at compile time
-      // per k, except for the lanes with x == 0 at k = 0 (r = 0) and k = R1/2 (r = H), which read the packed row 0
-      static_assert(R1 % 2 == 0 && 64 / CW == R2, "row classes below assume x < R2 and an even R1");
-      const bool x0 = x == 0;
-#pragma unroll
-      for (int k = 0; k < R1; ++k) {
-        const int r = x + k * R2;  // 0..N-1
-        const int rr = (k < R1 / 2) ? r : ((k == R1 / 2 && x0) ? 0 : N - r);
-        const cf a = lds_read(&z[zaddr<N>(rr, col)]), c = lds_read(&z[zaddr<N>(rr, col + H)]);
-        cf e;
-        if (k < R1 / 2) {
-          e = {a.x - c.y, a.y + c.x};
-          if (k == 0 && x0) e = {a.x, c.x};
-        } else {
-          e = {a.x + c.y, c.x - a.y};
-          if (k == R1 / 2 && x0) e = {a.y, c.y};
-        }
-        v[b][k] = e;
-      }
-      butterfly<R1>(v[b]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
-#pragma unroll
-      for (int k = 0; k < R1; ++k) z[zaddr<N>(x * R1 + k, col)] = v[b][k];
-    }
-    wave_sync();
-  }
-  Best best = {-__builtin_huge_valf(), 0x7fffffff};
-  {  // stage 2 + arg-max from registers (fftShift :1297-1305, minMaxLoc :1539)
-    constexpr int PER = LI * R1 / 64, CW = 64 / R1;
-    cf v[PER][R2];
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
-#pragma unroll
-      for (int k = 0; k < R2; ++k) {
-        cf a = lds_read(&z[zaddr<N>(x + k * R1, col)]);
-#ifdef MOF_ABLATE_NOBFLY
-        v[b][k] = a;
-#else
-        v[b][k] = (k == 0 || (R2 == 8 && MOF_FUSED_TW)) ? a : cmul(a, tw_col[k - 1]);
-#endif
-      }
-      if constexpr (R2 == 8 && MOF_FUSED_TW) butterfly8_tw(v[b], tw_col);
-      else butterfly<R2>(v[b]);
-      if constexpr (PK == 1) {  // OpenCL-kernel model: 1/N^2 scaling and the +-search_radius mask (cl:733, :737-746, :823-826)
-#pragma unroll
-        for (int k = 0; k < R2; ++k) {
-          const int y = x + k * R1;
-          v[b][k].x = ocl_scale_mask<N>(v[b][k].x, y, col, search_radius);
-          v[b][k].y = ocl_scale_mask<N>(v[b][k].y, y, col + H, search_radius);
-        }
-      }
-    }
-    wave_sync();
-    // lane-local first maximum in two steps (max value, then the smallest shifted index that attains it): half the
-    // instructions of a running (value, index) compare per candidate
-    float m = -__builtin_huge_valf();
-#pragma unroll
-    for (int b = 0; b < PER; ++b)
-#pragma unroll
-      for (int k = 0; k < R2; ++k) m = fmaxf(m, fmaxf(v[b][k].x, v[b][k].y));
-    int mi = 0x7fffffff;
-#pragma unroll
-    for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
-#pragma unroll
-      for (int k = 0; k < R2; ++k) {
-        const int y = x + k * R1;
-        z[zaddr<N>(y, col)] = v[b][k];
-        const int base = ((y + H) % N) * N + col;
-        mi = min(mi, v[b][k].x == m ? base + H : 0x7fffffff);  // column col      -> shifted col + H
-        mi = min(mi, v[b][k].y == m ? base : 0x7fffffff);      // column col + H  -> shifted col
-      }
-    }
-    best = Best{m, mi};
-  }
-  return best;
-}
 
 // DS = 1: patches are read from the frames as they are. DS = 4: long-range mode -- every patch pixel is the
 // quarter-resolution pixel cv::resize(.., 1/4, 1/4, INTER_LINEAR) would produce (FftMethod.cpp:1931-1932), i.e.

@@ -223,6 +223,24 @@ class FftMethod:
                                                      prev.stride(0), cur.stride(1), n, out.data_ptr(), _stream_ptr(s)))
         return out
 
+    def process_sequence_device(self, frames, out=None, stream=None):
+        """frames: torch uint8 [n, H, W] video on this engine's device -> float64 [n - 1, patches, 2]: pair k = (frame k + 1,
+        frame k), what consecutive processImage calls return after the first (FftMethod.cpp:1872). Asynchronous."""
+        import torch
+
+        _check_device_batch(frames, frames, (self.cfg.frame_height, self.cfg.frame_width), self.cfg.device)
+        n = frames.shape[0]
+        if out is None:
+            out = torch.empty((max(n - 1, 0), self.n_patches, 2), dtype=torch.float64, device=frames.device)
+        if not (out.is_cuda and out.device == frames.device and out.is_contiguous() and out.dtype == torch.float64
+                and out.numel() == max(n - 1, 0) * self.n_patches * 2):
+            raise ValueError("out must be a dense float64 tensor of (n - 1) * patches * 2 elements on the engine's device")
+        s = stream if stream is not None else torch.cuda.current_stream(frames.device)
+        _pin_if_capturing(self, s)
+        check(self._lib.mof_fft_process_sequence_device(self._h, frames.data_ptr(), frames.stride(0), frames.stride(1), n,
+                                                        out.data_ptr(), _stream_ptr(s)))
+        return out
+
     def process_batch_device_bgr(self, cur, prev, stream=None):
         """cur, prev: torch uint8 [n, H, W, 3] BGR8 views (crop of the camera frames; W-stride 3, any row pitch):
         CV_RGB2GRAY (as the node applies it to BGR data) is fused into the kernel's load."""

@@ -1,0 +1,118 @@
+"""GPU tests of FftMethod's SEQUENCE mode (mof_fft_process_sequence_device, csrc/pc_seq_kernel.hip): a video on the
+device, pair k = (frame k + 1, frame k) -- what consecutive processImage calls compute after `imPrev = imCurr.clone()`
+(/root/reference/src/FftMethod.cpp:1872). 64 x 64 patches run the sequence kernel (one real transform per frame, the
+previous spectrum in registers); the bar is the pair kernel's: 1e-4 px against the oracle on well-conditioned patches,
+the same validity (NaN) pattern, and agreement with the pair kernel on (frames[1:], frames[:-1]) within 1e-4 px."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from mrs_optic_flow_amd import FftMethod, synth
+from mrs_optic_flow_amd.engine import PEAK_OCL
+from test_gpu_fft import TOL, _compare, _compare_ocl
+
+pytestmark = pytest.mark.gpu
+
+
+def _video_np(n_frames, h, w, k=0):
+    frames, offs = synth.video_torch(n_frames, h, w, "cpu", k=k)
+    return frames.numpy(), offs.numpy()
+
+
+@pytest.mark.parametrize("shape,grid,origin,stride,n_frames", [
+    ((480, 752), (8, 8), (1, 1), (98, 59), 7),      # BASELINE c2 layout
+    ((448, 448), (7, 7), (0, 0), (64, 64), 5),      # the reference's own square tiling (sqNum = 7)
+    ((70, 200), (2, 1), (3, 5), (129, 1), 38),      # 37 pairs: the 16-pair runs of a workgroup end twice
+])
+def test_video_matches_oracle_and_pair_kernel(gpu, shape, grid, origin, stride, n_frames):
+    h, w = shape
+    frames, offs = _video_np(n_frames, h, w, k=3)
+    fm = FftMethod(sample_point_size=64, frame_shape=shape, grid=grid, origin=origin, stride=stride)
+    video = torch.from_numpy(frames).to(gpu)
+    got = fm.process_sequence_device(video)
+    pairs = fm.process_batch_device(video[1:], video[:-1])
+    torch.cuda.synchronize()
+    got, pairs = got.cpu().numpy(), pairs.cpu().numpy()
+    assert got.shape == (n_frames - 1, grid[0] * grid[1], 2)
+    assert np.array_equal(np.isnan(got), np.isnan(pairs))
+    assert np.allclose(got, pairs, rtol=0, atol=TOL, equal_nan=True)
+    lay = O.fft_layout(w, h, 64, grid[0], grid[1], origin, stride)
+    checked = 0
+    for k in list(range(min(n_frames - 1, 4))) + ([15, 16, 17, 31, 32, 36] if n_frames > 37 else []):
+        checked += _compare(got[k], frames[k + 1], frames[k], lay, f"pair{k}")
+        # the planted motion: the window moved by (dox, doy) over the canvas = content moved by the negative of it
+        d = -(offs[k + 1] - offs[k]).astype(float)
+        assert np.allclose(np.nanmedian(got[k], axis=0), d, rtol=0, atol=0.5), (k, d)
+    assert checked > 0.7 * min(n_frames - 1, 4) * grid[0] * grid[1]
+
+
+def test_frames_in_a_wider_allocation(gpu):
+    """Row pitch > width and frame stride > frame: the video is a view."""
+    h, w, n = 130, 150, 9
+    frames, _ = _video_np(n, h, w, k=1)
+    big = torch.zeros((n, h + 5, w + 24), dtype=torch.uint8, device=gpu)
+    big[:, 2:2 + h, 8:8 + w] = torch.from_numpy(frames).to(gpu)
+    view = big[:, 2:2 + h, 8:8 + w]
+    fm = FftMethod(sample_point_size=64, frame_shape=(h, w), grid=(2, 2), origin=(5, 1), stride=(81, 65))
+    got = fm.process_sequence_device(view).cpu().numpy()
+    dense = fm.process_sequence_device(torch.from_numpy(frames).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, dense, equal_nan=True)
+    lay = O.fft_layout(w, h, 64, 2, 2, (5, 1), (81, 65))
+    assert sum(_compare(got[k], frames[k + 1], frames[k], lay) for k in range(n - 1)) >= 24
+
+
+def test_known_answers_and_degenerate_frames(gpu):
+    """Circular shifts are exact; identical frames give 0; constant frames are invalid (NaN) as in the pair kernel;
+    a sequence of 0 or 1 frames has no pair."""
+    n = 64
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    base = torch.randint(0, 256, (n, n), dtype=torch.uint8, generator=gen)
+    moves = [(3, -2), (-5, 7), (0, 0), (11, 0), (0, -9), (1, 1)]
+    seq, pos = [base], (0, 0)
+    for dx, dy in moves:
+        pos = (pos[0] + dx, pos[1] + dy)
+        seq.append(torch.roll(base, (pos[1], pos[0]), dims=(0, 1)))
+    const = torch.full((n, n), 77, dtype=torch.uint8)
+    video = torch.stack(seq + [const, const, base]).to(gpu)
+    fm = FftMethod(n, n, 80.0)
+    got = fm.process_sequence_device(video).cpu().numpy()[:, 0]
+    assert np.allclose(got[:len(moves)], np.array(moves, float), rtol=0, atol=3e-5)
+    assert not np.isnan(got[:len(moves)]).any()
+    assert np.isnan(got[len(moves) + 1]).all()  # constant vs constant (FftMethod.cpp:1851-1853)
+    assert fm.process_sequence_device(video[:1]).shape[0] == 0 and fm.process_sequence_device(video[:0]).shape[0] == 0
+
+
+def test_ocl_peak_model_sequence(gpu):
+    h = w = 128
+    frames, _ = _video_np(5, h, w, k=5)
+    fm = FftMethod(128, 64, 80.0, peak_model=PEAK_OCL)
+    got = fm.process_sequence_device(torch.from_numpy(frames).to(gpu)).cpu().numpy()
+    lay = O.fft_layout(w, h, 64, 2, 2, (0, 0), (64, 64))
+    assert sum(_compare_ocl(got[k], frames[k + 1], frames[k], lay, 55, f"pair{k}") for k in range(4)) >= 12
+
+
+def test_other_patch_sizes_run_the_pair_kernel_on_the_video(gpu):
+    h, w, n = 270, 480, 128
+    frames, _ = _video_np(4, h, w, k=2)
+    video = torch.from_numpy(frames).to(gpu)
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(3, 2), origin=(0, 0), stride=(119, 63))
+    assert torch.equal(fm.process_sequence_device(video), fm.process_batch_device(video[1:], video[:-1]))
+
+
+def test_full_size_c2seq_properties(gpu):
+    """c2seq at BASELINE's size: 752 x 480, 8 x 8 patches of 64 x 64, 1025 frames. The video's window follows a closed
+    path, so every pair has a known integer motion; every valid patch of every pair must sit within half a pixel of
+    it, and the whole field must agree with the pair kernel."""
+    h, w, n = 480, 752, 1025
+    video, offs = synth.video_torch(n, h, w, gpu, k=0)
+    fm = FftMethod(sample_point_size=64, frame_shape=(h, w), grid=(8, 8), origin=(1, 1), stride=(98, 59))
+    got = fm.process_sequence_device(video)
+    pairs = fm.process_batch_device(video[1:], video[:-1])
+    torch.cuda.synchronize()
+    assert torch.equal(torch.isnan(got), torch.isnan(pairs))
+    assert torch.allclose(got, pairs, rtol=0, atol=TOL, equal_nan=True)
+    d = -(offs[1:] - offs[:-1]).to(torch.float64).to(gpu)[:, None, :]
+    ok = ~torch.isnan(got[..., 0])
+    assert ok.float().mean() > 0.99
+    assert ((got - d).abs().amax(dim=-1)[ok] < 0.5).all()
