@@ -63,8 +63,9 @@ def test_frames_in_a_wider_allocation(gpu):
 
 
 def test_known_answers_and_degenerate_frames(gpu):
-    """Circular shifts are exact; identical frames give 0; constant frames are invalid (NaN) as in the pair kernel;
-    a sequence of 0 or 1 frames has no pair."""
+    """Circular shifts are exact; identical frames give 0; constant frames give the CPU path's degenerate answer
+    (1 - N/2: a flat surface, first maximum at the corner -- tests/test_oracle_fft.py); a sequence of 0 or 1 frames has
+    no pair."""
     n = 64
     gen = torch.Generator(device="cpu").manual_seed(11)
     base = torch.randint(0, 256, (n, n), dtype=torch.uint8, generator=gen)
@@ -79,7 +80,8 @@ def test_known_answers_and_degenerate_frames(gpu):
     got = fm.process_sequence_device(video).cpu().numpy()[:, 0]
     assert np.allclose(got[:len(moves)], np.array(moves, float), rtol=0, atol=3e-5)
     assert not np.isnan(got[:len(moves)]).any()
-    assert np.isnan(got[len(moves) + 1]).all()  # constant vs constant (FftMethod.cpp:1851-1853)
+    want = O.fft_process(const.numpy(), const.numpy(), O.fft_layout(n, n, n, 1, 1), 32)[0][0]
+    assert np.allclose(got[len(moves) + 1], want, rtol=0, atol=TOL) and np.allclose(want, 1 - n / 2, atol=1e-4)
     assert fm.process_sequence_device(video[:1]).shape[0] == 0 and fm.process_sequence_device(video[:0]).shape[0] == 0
 
 
