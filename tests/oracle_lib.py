@@ -422,3 +422,31 @@ def geom_get_2dt(shifts, layout: GeomLayout, cam: GeomCamera, params: Geom2dtPar
     out = np.zeros(6)
     status = lib().oracle_get_2dt(_ptr(s), C.byref(layout), C.byref(cam), C.byref(params), _ptr(out))
     return status, out[:3].copy(), out[3:].copy()
+
+
+# ---- the TUNED CPU path (oracle/pc_fast.c): bench.py's cpu_baseline.tuned leg, NOT the parity oracle ----------------
+_fast = None
+
+
+def fast_lib(path: str | None = None):
+    """liboracle's sibling libpcfast.so (or a -march=native rebuild of it at `path`)."""
+    global _fast
+    if _fast is None or path is not None:
+        p = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libpcfast.so")
+        lib_ = C.CDLL(p)
+        lib_.pcfast_fft_process_u8.restype = C.c_int
+        lib_.pcfast_fft_process_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FftLayout), C.c_void_p]
+        _fast = lib_
+    return _fast
+
+
+def fft_process_fast(cur: np.ndarray, prev: np.ndarray, layout: FftLayout) -> np.ndarray:
+    """Same estimator as fft_process(.., 32), power-of-two patches only (the tuned implementation)."""
+    assert cur.dtype == np.uint8 and prev.dtype == np.uint8 and cur.shape == prev.shape
+    cur = np.ascontiguousarray(cur)
+    prev = np.ascontiguousarray(prev)
+    out = np.zeros((layout.grid_x * layout.grid_y, 2), np.float64)
+    rc = fast_lib().pcfast_fft_process_u8(cur.ctypes.data, prev.ctypes.data, cur.shape[1], C.byref(layout), out.ctypes.data)
+    if rc:
+        raise ValueError(f"pcfast_fft_process_u8 rc={rc}")
+    return out
