@@ -60,9 +60,10 @@ def binding_note(name: str, wl) -> str:
                 "K1 as in c2; DESIGN.md section 4 (K4-K8)")
     if wl["n"] >= 120:
         return ("one persistent workgroup per CU (the tile fills the LDS): latency of the per-patch phase chain, "
-                "VALU 77-79 % active, LDS pipe 35-59 %; not HBM")
-    return ("latency of the per-patch phase chain at 4 workgroups/CU (LDS-capacity limit); VALU 91 % active, "
-            "LDS pipe 57-66 %; not HBM -- see DESIGN.md section 4 (K1)")
+                "VALU issue ~37 %, LDS pipe 35-60 % busy (N = 128: 28 % of it bank conflicts); not HBM")
+    return ("latency of the per-patch phase chain at 4 workgroups/CU (LDS-capacity limit); VALU issue ~44 % "
+            "(334.9 M instructions x 2 cycles per launch, profiles/r02_c2_sq_pmc.csv), LDS pipe 57-66 % busy of which 16-19 % "
+            "bank conflicts, 21 % of wave-cycles waiting on LDS; not HBM -- see DESIGN.md section 4 (K1)")
 
 
 def fft_flops_per_pair(n: int, patches: int) -> float:
@@ -334,25 +335,9 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
             x0, r = wl["sr_x0"], wl["sr_res"]
             cur_c, prev_c = cur[:, :r, x0:x0 + r], prev[:, :r, x0:x0 + r]
 
-            side_mode = int(os.environ.get("MOF_C5_SIDE", "0"))  # experiment: K1 on a second stream beside the estimator
-            side = torch.cuda.Stream(priority=0 if side_mode < 2 else -1) if side_mode else None
-
             def launch():
-                if side is None:
-                    eng.process_batch_device(cur, prev, out=state["out"])
-                    srout = sr.process_batch_device(cur_c, prev_c)
-                else:
-                    main = torch.cuda.current_stream()
-                    side.wait_stream(main)
-                    if side_mode == 3:  # the estimator on the side stream, K1 on the main one
-                        with torch.cuda.stream(side):
-                            srout = sr.process_batch_device(cur_c, prev_c)
-                        eng.process_batch_device(cur, prev, out=state["out"])
-                    else:
-                        with torch.cuda.stream(side):
-                            eng.process_batch_device(cur, prev, out=state["out"])
-                        srout = sr.process_batch_device(cur_c, prev_c)
-                    main.wait_stream(side)
+                eng.process_batch_device(cur, prev, out=state["out"])
+                srout = sr.process_batch_device(cur_c, prev_c)
                 return torch.cat([state["out"].reshape(B, -1), srout], dim=1)
         elif wl["kind"] == "fft+2dt":
             import numpy as np

@@ -117,6 +117,14 @@ class FftMethod {
     return speeds;
   }
 
+  // A video on the DEVICE: pair k = (frame k + 1, frame k), i.e. the vectors the processImage calls of frames 1..n-1 return
+  // (`imPrev = imCurr.clone()`, FftMethod.cpp:1872). d_out_xy: (n_frames - 1) * sqNum^2 * 2 doubles. Asynchronous on `stream`.
+  void processSequenceDevice(const uint8_t* d_frames, size_t frame_stride, size_t pitch, int n_frames, double* d_out_xy,
+                             void* stream = nullptr) {
+    detail::check(mof_fft_process_sequence_device(engine_, d_frames, frame_stride, pitch, n_frames, d_out_xy, stream),
+                  "mof_fft_process_sequence_device");
+  }
+
   int sqNum() const { return cfg_.grid_x; }
   int invalidPatches() const { return last_invalid_; }
   const mof_fft_config& config() const { return cfg_; }
@@ -246,6 +254,18 @@ class scaleRotationEstimator {
     detail::check(mof_sr_process(engine_, imCurr.data, imCurr.step, out), "mof_sr_process");
     return Point2d{out[0], out[1]};
   }
+  // A video on the DEVICE: what n_frames consecutive processImage calls return (scale, rot, pt.x, pt.y per frame), continuing
+  // and updating this estimator's state (first frame INTER_CUBIC, the gate of :119-121 resolved). d_frames: top-left pixel of
+  // the res x res crop of frame 0, frame i at + i * frame_stride, `pitch` bytes per row; d_out4: n_frames * 4 doubles.
+  // Synchronous; returns the number of gated frames. mof_sr_process_sequence_device (include/mof.h).
+  int processSequenceDevice(const uint8_t* d_frames, size_t frame_stride, size_t pitch, int n_frames, double* d_out4,
+                            void* stream = nullptr) {
+    int gated = 0;
+    detail::check(mof_sr_process_sequence_device(engine_, d_frames, frame_stride, pitch, n_frames, d_out4, stream, &gated),
+                  "mof_sr_process_sequence_device");
+    return gated;
+  }
+  mof_sr_engine* handle() { return engine_; }
 
  private:
   mof_sr_engine* engine_ = nullptr;
