@@ -56,6 +56,9 @@ int main() {
   CHECK(mof_fft_process_batch_device_bgr(nullptr, px, 0, px, 0, 4, 1, d2, nullptr) == MOF_ERR_NOT_INIT);
   CHECK(mof_fft_process_long_range_batch_device(nullptr, px, 0, px, 0, 4, 1, d2, nullptr) == MOF_ERR_NOT_INIT);
   CHECK(mof_fft_process_batch_host(nullptr, px, 0, px, 0, 4, 1, d2) == MOF_ERR_NOT_INIT);
+  CHECK(mof_fft_process_sequence_device(nullptr, px, 0, 4, 3, d2, nullptr) == MOF_ERR_NOT_INIT);
+  CHECK(mof_fft_release_graphs(nullptr) == MOF_ERR_NOT_INIT && mof_fft_graph_pinned(nullptr) == 0);
+  CHECK(mof_purge_deferred() == 0 && mof_deferred_count() == 0);
   CHECK(std::strcmp(mof_fft_kernel_variant(nullptr), "") == 0);
   mof_fft_destroy(nullptr);
   // ---- block matching geometry (BlockMethod.cpp:11; FastSpacedBMMethod_OCL.cpp:82-90) ----
@@ -76,6 +79,7 @@ int main() {
   CHECK(mof_bm_process(nullptr, px, 4, i8, i8, i8) == MOF_ERR_NOT_INIT && mof_bm_refine(nullptr, 0, 0, 2, 1, d2) == MOF_ERR_NOT_INIT);
   CHECK(mof_bm_process_batch_device(nullptr, px, 0, px, 0, 4, 1, i8, i8, i8, nullptr) == MOF_ERR_NOT_INIT);
   CHECK(mof_bm_process_batch_host(nullptr, px, 0, px, 0, 4, 1, i8, i8, i8) == MOF_ERR_NOT_INIT && mof_bm_sync(nullptr) == MOF_ERR_NOT_INIT);
+  CHECK(mof_bm_release_graphs(nullptr) == MOF_ERR_NOT_INIT && mof_bm_graph_pinned(nullptr) == 0);
   mof_bm_destroy(nullptr);
   // ---- scale/rotation estimator: argument paths and the host-built tables against the oracle ----
   mof_sr_engine* se = nullptr;
@@ -90,6 +94,11 @@ int main() {
   CHECK(mof_sr_process(nullptr, px, 4, d2) == MOF_ERR_NOT_INIT && mof_sr_reset(nullptr) == MOF_ERR_NOT_INIT);
   CHECK(mof_sr_process_batch_device(nullptr, px, 0, px, 0, 4, 1, d2, nullptr) == MOF_ERR_NOT_INIT);
   CHECK(mof_sr_logpolar_batch_device(nullptr, px, 0, 4, 1, 2, px, nullptr) == MOF_ERR_NOT_INIT);
+  {
+    int gated = 7;
+    CHECK(mof_sr_process_sequence_device(nullptr, px, 0, 4, 3, d2, nullptr, &gated) == MOF_ERR_NOT_INIT);
+  }
+  CHECK(mof_sr_release_graphs(nullptr) == MOF_ERR_NOT_INIT && mof_sr_graph_pinned(nullptr) == 0 && mof_sr_reserve(nullptr, 1) == MOF_ERR_NOT_INIT);
   mof_sr_destroy(nullptr);
   for (int variant = 0; variant < 2; ++variant)
     for (int res : {240, 256, 480}) {

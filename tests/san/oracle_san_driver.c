@@ -9,6 +9,8 @@
 
 #include "oracle.h"
 
+int pcfast_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch, const oracle_fft_layout* L, double* out_xy);
+
 static uint32_t rng_state = 12345u;
 static uint32_t rnd(void) { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
 
@@ -30,8 +32,14 @@ int main(void) {
       CHECK(oracle_fft_process_u8(cur, prev, (size_t)pitch, &L, prec, out, &ninv, diag) == 0);
       CHECK(oracle_fft_process_ocl_u8(cur, prev, (size_t)pitch, &L, 55, prec, out, &ninv, diag) == 0);
     }
+    { /* the tuned bench-only path (oracle/pc_fast.c): power-of-two patches, must decline the rest */
+      double fast[4];
+      const int rc = pcfast_fft_process_u8(cur, prev, (size_t)pitch, &L, fast);
+      CHECK((n & (n - 1)) ? rc != 0 : rc == 0);
+    }
     L.grid_x = 3; /* leaves the frame: must be refused, not read */
     CHECK(oracle_fft_process_u8(cur, prev, (size_t)pitch, &L, 32, out, &ninv, NULL) != 0);
+    CHECK(pcfast_fft_process_u8(cur, prev, (size_t)pitch, &L, out) != 0);
     free(cur);
     free(prev);
   }
