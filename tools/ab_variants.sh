@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 SRC=$1; BENCH_ARGS=$2; shift 2
 cd $R/mrs_optic_flow_amd/csrc
 BASE="-O3 -std=c++17 -fPIC -fno-slp-vectorize -Wno-unused-parameter -Wno-unused-function"
-OTHERS=$(ls *.hip | grep -v "^$SRC$" | sed 's/\.hip$/.o/')
+OTHERS=$(ls *.hip | grep -v "^$SRC$" | grep -v "^pc_kernel_quad.hip$" | sed 's/\.hip$/.o/')
 for o in $OTHERS; do [ -f $o ] || { echo "missing $o: build the product library first"; exit 1; }; done
 EXTRA=""; [ "$SRC" == "mof_geom.hip" ] && EXTRA="-ffp-contract=off"
 i=0
