@@ -8,6 +8,7 @@ through the C ABI (mof_*_process_batch_device, ONE kernel launch per batch for t
   c3            FastSpacedBMMethod, 752x480, sps 16 / step 8 / radius 16, 1024 pairs per GPU
   c4            FftMethod, 1920x1080, 16x16 grid of 128x128 patches, 1024 pairs per GPU (8192 over 8 GPUs)
   c5            c2 + scaleRotationEstimator (log-polar + whole-frame phase correlation of the 480^2 centre crop)
+  c2seq / c5seq the same two on a VIDEO (1025 consecutive frames): the sequence entry points, every frame transformed once
 
 Multi-GPU (--gpus N under torch.distributed.run): frame pairs are independent, so every rank owns
 its own shard of the batch (weak scaling, no data-path collective); each step ends with the one
@@ -634,7 +635,8 @@ def main() -> None:
             torch.cuda.empty_cache()
             # driver-visible records of the other BASELINE configurations (same protocol, fewer steps)
             line["other_workloads"] = {tag: measure_other(tag, dev, st, 5)
-                                       for tag, st in (("c3", 50), ("c4", 10), ("c5", 20), ("ref", 50), ("bmref", 50), ("refrt", 50), ("reflr", 50))}
+                                       for tag, st in (("c3", 50), ("c4", 10), ("c5", 20), ("c2seq", 50), ("c5seq", 20), ("ref", 50),
+                                                       ("bmref", 50), ("refrt", 50), ("reflr", 50))}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

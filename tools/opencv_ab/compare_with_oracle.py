@@ -55,6 +55,14 @@ for c in man["cases"]:
                 if cv is not None:
                     n = int((cv != oracle(c["oracle"][f"i{interp}_v{v}"])).sum())
                     report(name, f"cv::remap on oracle maps i{interp} v{v}", n == 0, f"{n} bytes differ (remap fixed point only)")
+    elif k == "srseq":
+        o = oracle(c["oracle"])
+        cv = rd(name + "_cv", np.float64, o.shape)
+        if cv is not None:
+            e_pt = float(np.abs(cv[:, 2:] - o[:, 2:]).max())
+            e_sr = float(np.abs(cv[:, :2] - o[:, :2]).max())
+            report(name, "scaleRotationEstimator stream (logPolar + phaseCorrelate per frame)", e_pt <= 1e-4 and e_sr <= 1e-5,
+                   f"max |d pt| {e_pt:.2e} px (bar 1e-4), max |d (scale, rot)| {e_sr:.2e} (bar 1e-5)")
     elif k in ("resize_quarter", "resize_2x", "gray"):
         o = oracle(c["oracle"])
         cv = rd(name + "_cv", np.uint8, o.shape)

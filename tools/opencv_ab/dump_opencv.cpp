@@ -9,6 +9,7 @@
 //   cv::resize 1/4, x2                      src/FftMethod.cpp:1931-1932, src/BlockMethod.cpp:110-111
 //   cv::cvtColor(CV_RGB2GRAY)               src/optic_flow.cpp:1622
 //   cv::undistortPoints, cv::findHomography(RANSAC, 0.01), cv::decomposeHomographyMat   src/optic_flow.cpp:549-550, :559, :595
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -91,6 +92,37 @@ int main(int argc, char** argv) {
           save_mat_u8(name + "_cv_remap_i" + std::to_string(interp) + "_v" + std::to_string(variant), DR);
         }
       }
+    } else if (kind == "srseq") {
+      // scaleRotationEstimator::processImage as a stream (src/scaleRotationEstimator.cpp:34-148), call for call
+      int res, nf;
+      double M;
+      is >> res >> M >> nf;
+      auto video = load<unsigned char>(name + "_video", (size_t)nf * res * res);
+      const cv::Point2f center((float)(res / 2), (float)(res / 2));  // :25
+      cv::Mat tempIm = cv::Mat::zeros(res, res, CV_8UC1), tempF, prevF;  // :27
+      std::vector<double> out((size_t)nf * 4);
+      bool first = true;  // :31
+      for (int t = 0; t < nf; ++t) {
+        cv::Mat im(res, res, CV_8UC1, video.data() + (size_t)t * res * res);
+        double sc = 1.0, ro = 0.0, px = 0.0, py = 0.0;
+        if (first) {
+          cv::logPolar(im, tempIm, center, M, cv::INTER_CUBIC);  // :45
+          tempIm.convertTo(prevF, CV_32FC1);                      // :47-48
+          first = false;                                          // :73
+        } else {
+          cv::logPolar(im, tempIm, center, M, cv::INTER_LANCZOS4);  // :112
+          tempIm.convertTo(tempF, CV_32FC1);                        // :115
+          const cv::Point2d pt = cv::phaseCorrelate(tempF, prevF);  // :117
+          px = pt.x, py = pt.y;
+          if (!(std::fabs(pt.x) > res / 2)) {                       // :119-121
+            sc = std::exp(pt.x / M);                                 // :123
+            ro = (pt.y / ((double)res / 360.0)) * (3.14159265358979323846 / 180.0);  // :124
+            prevF = tempF.clone();                                   // :128
+          }
+        }
+        out[4 * (size_t)t] = sc, out[4 * (size_t)t + 1] = ro, out[4 * (size_t)t + 2] = px, out[4 * (size_t)t + 3] = py;
+      }
+      save(name + "_cv", out.data(), out.size());
     } else if (kind == "resize_quarter" || kind == "resize_2x" || kind == "gray") {
       int h, w;
       is >> h >> w;

@@ -68,6 +68,20 @@ for res, M in ((240, 40.0), (256, 45.0), (480, 49.9)):
     cases.append(entry)
     k += 1
 
+# ---- the estimator as a STREAM (scaleRotationEstimator.cpp:34-148): first frame INTER_CUBIC -> (1, 0); then INTER_LANCZOS4,
+#      cv::phaseCorrelate(tempIm_F32, prevIm_F32), the gate of :119-121, prev <- cur. What the sequence entry
+#      (mof_sr_process_sequence_device) and the stateful mof_sr_process reproduce.
+for k, (res, M, nf) in enumerate(((240, 40.0, 6), (480, 49.9, 4))):
+    base = sr_scenes.canvas(31 + res, res)
+    video = np.stack([sr_scenes.view(base, res, 1.0 + 0.015 * t, 1.7 * t) for t in range(nf)])
+    ref = O.ScaleRotationEstimator(res, M, 32)
+    want = []
+    for t in range(nf):
+        sc, ro = ref.processImage(video[t])
+        want.append([sc, ro, ref.pt[0] if t else 0.0, ref.pt[1] if t else 0.0])
+    cases.append({"kind": "srseq", "name": f"srseq_{k}", "res": res, "M": M, "frames": nf, "video": put(f"srseq_{k}_video", video),
+                  "oracle": put(f"srseq_{k}_oracle", np.array(want))})
+
 # ---- resize 1/4 and x2, RGB2GRAY
 img = synth.canvas_np(77, 128, 160, True)[:128, :160].copy()
 cases.append({"kind": "resize_quarter", "name": "rq_0", "src": put("rq_0_src", img), "oracle": put("rq_0_oracle", O.resize_quarter(img))})
@@ -109,5 +123,7 @@ with open(os.path.join(out, "manifest.txt"), "w") as f:
             f.write(f"undistort {c['name']} {c['pts']['shape'][0]} " + " ".join(repr(v) for v in c["camera"]) + f" {c['ul_corner_x']!r}\n")
         elif c["kind"] == "homography":
             f.write(f"homography {c['name']} {c['a']['shape'][0]}\n")
+        elif c["kind"] == "srseq":
+            f.write(f"srseq {c['name']} {c['res']} {c['M']!r} {c['frames']}\n")
 json.dump({"cases": cases, "oracle_version": O.lib().oracle_version().decode()}, open(os.path.join(out, "manifest.json"), "w"), indent=1)
 print(f"wrote {len(cases)} cases to {out}/")
