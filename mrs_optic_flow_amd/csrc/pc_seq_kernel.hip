@@ -24,6 +24,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mof_kernels.h"
 #include "pc_common.hpp"
@@ -278,12 +279,22 @@ __global__ void __launch_bounds__(256) pc_seq_kernel(PcArgs a, int n_pairs, int 
 
 bool pc_sequence_supported(int patch_size) { return patch_size == 64; }
 
+// Diagnostic knob (co-scheduling experiments): MOF_PC_EXTRA_LDS=<bytes> pads the dynamic LDS request, i.e. caps the
+// workgroups per CU (as for K1, pc_kernel.hip)
+static size_t seq_extra_lds() {
+  static const size_t v = [] {
+    const char* e = getenv("MOF_PC_EXTRA_LDS");
+    return e ? (size_t)atol(e) : (size_t)0;
+  }();
+  return v;
+}
+
+
 hipError_t pc_configure_sequence() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)PcTraits<64>::LDS_BYTES);
+  const int lds = (int)(PcTraits<64>::LDS_BYTES + seq_extra_lds());
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)PcTraits<64>::LDS_BYTES);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 // a.cur = frame 0, a.cur_stride = bytes between frames; pair k = (frame k + 1, frame k), k < n_pairs; a.prev unused.
@@ -293,10 +304,11 @@ hipError_t launch_pc_sequence(const PcArgs& a, int n_pairs, int run, hipStream_t
   const int runs = (n_pairs + run - 1) / run;
   if (runs > 65535 || a.channels != 1 || a.downscale != 1) return hipErrorInvalidValue;
   const dim3 g((unsigned)a.grid_x, (unsigned)a.grid_y, (unsigned)runs);
+  const size_t lds = PcTraits<64>::LDS_BYTES + seq_extra_lds();
   if (a.peak_model == 1)
-    hipLaunchKernelGGL(pc_seq_kernel<1>, g, dim3(256), PcTraits<64>::LDS_BYTES, stream, a, n_pairs, run);
+    hipLaunchKernelGGL(pc_seq_kernel<1>, g, dim3(256), lds, stream, a, n_pairs, run);
   else
-    hipLaunchKernelGGL(pc_seq_kernel<0>, g, dim3(256), PcTraits<64>::LDS_BYTES, stream, a, n_pairs, run);
+    hipLaunchKernelGGL(pc_seq_kernel<0>, g, dim3(256), lds, stream, a, n_pairs, run);
   return hipGetLastError();
 }
 
