@@ -120,6 +120,10 @@ WORKLOADS = {
                   name="c2seq: c2 on a video -- FftMethod on 1024 consecutive frame pairs (1025 frames per GPU), sequence kernel",
                   # one NEW frame's patch pixels per pair + flow vectors
                   bytes_per_pair=64 * 64 * 64 + 64 * 8),
+    # c4 on a video: 128 x 128 patches, the half-tile sequence kernel
+    "c4seq": dict(kind="fftseq", h=1080, w=1920, n=128, grid=(16, 16), origin=(0, 0), stride=(119, 63), batch=512, s=16,
+                  name="c4seq: c4 on a video -- FftMethod 1920x1080, 16x16 grid of 128x128 patches, 512 consecutive frame pairs",
+                  bytes_per_pair=1920 * 1080 + 256 * 8),
     # c5 on a VIDEO (the node's real workload, scaleRotationEstimator.cpp:34-148 steady state): B + 1 consecutive frames,
     # K1 on the B consecutive pairs, the estimator in sequence mode (every frame remapped and row-transformed once)
     "c5seq": dict(kind="fft+srseq", h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=1024, s=8,

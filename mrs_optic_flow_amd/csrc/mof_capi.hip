@@ -243,6 +243,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
   CREATE_TRY(mof::pc_configure(n));
   if (mof::pc_sequence_supported(n)) CREATE_TRY(mof::pc_configure_sequence());
+  if (mof::pc_sequence_half_supported(n)) CREATE_TRY(mof::pc_configure_sequence_half(n));
 #undef CREATE_TRY
   *out = e;
   return MOF_OK;
@@ -471,8 +472,13 @@ int mof_fft_process_sequence_device(mof_fft_engine* e, const uint8_t* d_frames, 
   mof::PcArgs a = fft_args(e, d_frames + frame_stride, frame_stride, d_frames, frame_stride, pitch, d_out_xy);
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
   static const int run = [] { const char* v = getenv("MOF_FFT_SEQ_RUN"); const int r = v ? atoi(v) : 0; return r >= 1 ? r : 16; }();
-  if (mof::pc_sequence_supported(e->cfg.patch_size) && !getenv("MOF_FFT_SEQ_PAIRS")) {
-    a.cur = d_frames;  // the sequence kernel indexes frames, not pairs
+  static const bool pairs_only = getenv("MOF_FFT_SEQ_PAIRS") != nullptr, half64 = getenv("MOF_FFT_SEQ_HALF64") != nullptr;
+  const int n = e->cfg.patch_size;
+  if (!pairs_only && mof::pc_sequence_half_supported(n) && (n != 64 || half64)) {
+    a.cur = d_frames;  // the sequence kernels index frames, not pairs
+    HIP_TRY(mof::launch_pc_sequence_half(a, n, n_pairs, run, (hipStream_t)stream));
+  } else if (!pairs_only && mof::pc_sequence_supported(n)) {
+    a.cur = d_frames;
     HIP_TRY(mof::launch_pc_sequence(a, n_pairs, run, (hipStream_t)stream));
   } else {
     HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));

@@ -39,6 +39,10 @@ hipError_t launch_pc_field(const PcArgs& a, int patch_size, int n_pairs, hipStre
 bool pc_sequence_supported(int patch_size);
 hipError_t pc_configure_sequence();
 hipError_t launch_pc_sequence(const PcArgs& a, int n_pairs, int run, hipStream_t stream);
+// The same on a half-size tile (pc_seq_half.hip): 128 x 128 patches (two workgroups per CU); 64 x 64 for A/B only
+bool pc_sequence_half_supported(int patch_size);
+hipError_t pc_configure_sequence_half(int patch_size);
+hipError_t launch_pc_sequence_half(const PcArgs& a, int patch_size, int n_pairs, int run, hipStream_t stream);
 // N = 64, quad-per-line formulation (pc_kernel_quad.hip)
 hipError_t pc_configure_quad64();
 hipError_t launch_pc_field_quad64(const PcArgs& a, int n_pairs, hipStream_t stream);

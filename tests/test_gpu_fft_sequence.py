@@ -94,12 +94,44 @@ def test_ocl_peak_model_sequence(gpu):
     assert sum(_compare_ocl(got[k], frames[k + 1], frames[k], lay, 55, f"pair{k}") for k in range(4)) >= 12
 
 
-def test_other_patch_sizes_run_the_pair_kernel_on_the_video(gpu):
-    h, w, n = 270, 480, 128
-    frames, _ = _video_np(4, h, w, k=2)
+def test_n128_video_matches_oracle_and_pair_kernel(gpu):
+    """128 x 128 patches run the half-tile sequence kernel (pc_seq_half.hip)."""
+    h, w, n, nf = 270, 480, 128, 21
+    frames, offs = _video_np(nf, h, w, k=2)
     video = torch.from_numpy(frames).to(gpu)
     fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(3, 2), origin=(0, 0), stride=(119, 63))
-    assert torch.equal(fm.process_sequence_device(video), fm.process_batch_device(video[1:], video[:-1]))
+    got = fm.process_sequence_device(video).cpu().numpy()
+    pairs = fm.process_batch_device(video[1:], video[:-1]).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(pairs))
+    assert np.allclose(got, pairs, rtol=0, atol=TOL, equal_nan=True)
+    lay = O.fft_layout(w, h, n, 3, 2, (0, 0), (119, 63))
+    checked = 0
+    for k in (0, 1, 15, 16, 17, 19):
+        checked += _compare(got[k], frames[k + 1], frames[k], lay, f"pair{k}")
+        d = -(offs[k + 1] - offs[k]).astype(float)
+        assert np.allclose(np.nanmedian(got[k], axis=0), d, rtol=0, atol=0.5), (k, d)
+    assert checked >= 30
+    # circular shifts are exact; a constant pair gives the CPU path's degenerate answer
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    base = torch.randint(0, 256, (n, n), dtype=torch.uint8, generator=gen)
+    moves = [(5, -3), (-9, 14), (0, 0), (21, 1)]
+    seq, pos = [base], (0, 0)
+    for dx, dy in moves:
+        pos = (pos[0] + dx, pos[1] + dy)
+        seq.append(torch.roll(base, (pos[1], pos[0]), dims=(0, 1)))
+    const = torch.full((n, n), 9, dtype=torch.uint8)
+    one = FftMethod(n, n, 200.0)
+    res = one.process_sequence_device(torch.stack(seq + [const, const]).to(gpu)).cpu().numpy()[:, 0]
+    assert np.allclose(res[:len(moves)], np.array(moves, float), rtol=0, atol=5e-5)
+    assert np.allclose(res[-1], 1 - n / 2, rtol=0, atol=1e-4)
+
+
+def test_other_patch_sizes_run_the_pair_kernel_on_the_video(gpu):
+    h, w, n = 250, 380, 120
+    frames, _ = _video_np(4, h, w, k=2)
+    video = torch.from_numpy(frames).to(gpu)
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(3, 2), origin=(3, 1), stride=(127, 129))
+    assert torch.equal(fm.process_sequence_device(video), fm.process_batch_device(video[1:], video[:-1]), )
 
 
 def test_full_size_c2seq_properties(gpu):
