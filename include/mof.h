@@ -152,11 +152,12 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
 /* A VIDEO on the device: frame i at d_frames + i*frame_stride; pair k = (cur: frame k + 1, prev: frame k), i.e. what
  * n_frames - 1 consecutive processImage calls return after the first one (`imPrev = imCurr.clone()`, FftMethod.cpp:1872).
  * d_out_xy receives (n_frames - 1) * grid_x * grid_y * 2 doubles. Same estimator as mof_fft_process_batch_device on
- * (d_frames + frame_stride, d_frames): same arg-max, sub-pixel shifts equal within rounding. For 64 x 64 patches a
- * workgroup owns one patch position and walks consecutive frames, keeping the previous frame's half spectrum in
- * registers: one real 2-D transform forward and one Hermitian inverse per frame and patch -- 1.0 instead of the pair
- * kernel's 1.5 complex-transform units (csrc/pc_seq_kernel.hip); other patch sizes run the pair kernel on the two
- * views of the video. The engine's stateful previous frame is not touched. Asynchronous on `stream`. */
+ * (d_frames + frame_stride, d_frames): same arg-max, sub-pixel shifts equal within rounding. For 64 x 64 and 128 x 128
+ * patches a workgroup owns one patch position and walks consecutive frames, keeping the previous frame's half spectrum
+ * in registers: one real 2-D transform forward and one Hermitian inverse per frame and patch -- 1.0 instead of the
+ * pair kernel's 1.5 complex-transform units (csrc/pc_seq_kernel.hip; csrc/pc_seq_half.hip for 128 x 128, on a half-size
+ * LDS tile); 32 x 32 and 120 x 120 run the pair kernel on the two views of the video. The engine's stateful previous
+ * frame is not touched. Asynchronous on `stream`. */
 int mof_fft_process_sequence_device(mof_fft_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch,
                                     int n_frames, double* d_out_xy, void* stream);
 /* Front-end fusion: the frames are interleaved BGR8 as the node receives them

@@ -80,4 +80,64 @@ for trial in range(n_sr):
                 sr_bad += 1
                 print("SR PT MISMATCH", trial, res, M, variant, k, pt[k], ref.pt)
 print(f"sr: {n_sr} settings, mismatches {sr_bad}")
-sys.exit(1 if bad or sr_bad else 0)
+
+# ---- sequence modes (r03): random videos through mof_fft_process_sequence_device (64 / 128: the sequence kernels, 32 / 120:
+#      the pair kernel on the two views) and mof_sr_process_sequence_device, against the oracle and the non-sequence entries
+seq_bad = seq_checked = 0
+for trial in range(max(4, n_fft // 4)):
+    n = int(rng.choice([32, 64, 64, 120, 128, 128]))
+    gx, gy = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    sx, sy = int(rng.integers(max(1, n // 3), n + 30)), int(rng.integers(max(1, n // 3), n + 30))
+    ox, oy = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+    w = ox + (gx - 1) * sx + n + int(rng.integers(0, 13))
+    h = oy + (gy - 1) * sy + n + int(rng.integers(0, 13))
+    nf = int(rng.choice([2, 3, 18, 35]))
+    video, _ = synth.video_torch(nf, h, w, "cpu", k=int(rng.integers(0, 1000)))
+    if rng.integers(0, 3) == 0:
+        video[int(rng.integers(0, nf))] = int(rng.integers(0, 256))  # a constant frame in the stream
+    frames = video.numpy()
+    pad = int(rng.choice([0, 8, 20]))
+    big = torch.zeros((nf, h + 1, w + pad), dtype=torch.uint8, device=dev)
+    big[:, :h, :w] = video.to(dev)
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(ox, oy), stride=(sx, sy))
+    got = fm.process_sequence_device(big[:, :h, :w]).cpu().numpy()
+    pairs = fm.process_batch_device(big[1:, :h, :w], big[:-1, :h, :w]).cpu().numpy()
+    lay = O.fft_layout(w, h, n, gx, gy, (ox, oy), (sx, sy))
+    for k in range(nf - 1):
+        if k > 2 and k not in (15, 16, 17, 31, 32, 33):
+            continue
+        want64, _, diags = O.fft_process(frames[k + 1], frames[k], lay, 64, want_diag=True)
+        want32, _ = O.fft_process(frames[k + 1], frames[k], lay, 32)
+        for p in range(want64.shape[0]):
+            stable = diags[p].second_value < 0.5 * diags[p].peak_value or (
+                np.array_equal(np.isnan(want64[p]), np.isnan(want32[p])) and np.allclose(want64[p], want32[p], rtol=0, atol=TOL, equal_nan=True))
+            if not stable:
+                continue
+            seq_checked += 1
+            if not (np.allclose(got[k, p], want64[p], rtol=0, atol=TOL, equal_nan=True)
+                    and np.allclose(got[k, p], pairs[k, p], rtol=0, atol=TOL, equal_nan=True)):
+                seq_bad += 1
+                print("SEQ FFT MISMATCH", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), nf, k, p, got[k, p], want64[p], pairs[k, p])
+for trial in range(max(2, n_sr // 3)):
+    res = int(rng.choice([240, 256, 480]))
+    M = float(rng.uniform(28.0, 90.0)) * res / 480.0
+    variant = int(rng.integers(0, 2))
+    nf = int(rng.choice([2, 5, 11]))
+    chunk = int(rng.choice([0, 2, 3]))
+    base = sr_scenes.canvas(int(rng.integers(0, 1000)), res)
+    frames = np.stack([sr_scenes.view(base, res, 1.0 + 0.01 * t * float(rng.uniform(-1, 1)), 1.5 * t) for t in range(nf)])
+    est = ScaleRotationEstimator(res, M, logpolar_variant=variant, batch_chunk=chunk)
+    got = est.process_sequence_device(torch.from_numpy(frames).to(dev)).cpu().numpy()
+    one, ref = ScaleRotationEstimator(res, M, logpolar_variant=variant), O.ScaleRotationEstimator(res, M, 64, variant=variant)
+    for t in range(nf):
+        s_, r_ = one.processImage(frames[t])
+        ws, wr = ref.processImage(frames[t])
+        seq_checked += 1
+        ok = (s_, r_) == (got[t, 0], got[t, 1]) and abs(got[t, 0] - ws) < 1e-5 and abs(got[t, 1] - wr) < 1e-5
+        if t > 0:
+            ok = ok and np.allclose(got[t, 2:], ref.pt, rtol=0, atol=TOL)
+        if not ok:
+            seq_bad += 1
+            print("SEQ SR MISMATCH", trial, res, M, variant, nf, chunk, t, got[t], (s_, r_), (ws, wr), ref.pt)
+print(f"sequence modes: {seq_checked} results checked, mismatches {seq_bad}")
+sys.exit(1 if bad or sr_bad or seq_bad else 0)
