@@ -310,6 +310,39 @@ __device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
   return cross_power_ab<PK>(A, B, real_only);
 }
 
+// ---- degenerate pairs: a CONSTANT patch ----------------------------------------------------------------------------
+// cv::phaseCorrelate transforms the two patches separately (FftMethod.cpp:1491-1493): a constant patch has an EXACTLY zero
+// AC spectrum, the cross-power spectrum keeps its DC bin (a real-only slot: C = P / (P^2 + eps)) and nothing else, and the
+// surface is flat = C_dc: first maximum at shifted (0, 0), centroid of the clamped 3 x 3 window of equal values =
+// (1, 1) 9c / (9c + DBL_EPSILON) -- or (0, 0) when C_dc = 0 (an all-zero patch). The pair kernels pack cur + i prev into one
+// complex transform, which leaks ~1e-7 of the textured patch's spectrum into those zeros; the normalisation blows that up
+// to unit magnitude and the result is noise (found by tools/fft_sr_fuzz.py, r03). So constant patches are detected where
+// the pixels are loaded (exact: integer compares) and the exact answer is substituted in the tail.
+// (1) per lane: `first` = its first pixel, `diff` != 0 iff one of its packed pixels differs from it
+__device__ __forceinline__ void const_track(const uint32_t* words, int n_words, bool reset, uint32_t& first, uint32_t& diff) {
+  if (reset) {
+    first = words[0] & 0xffu;
+    diff = 0u;
+  }
+  const uint32_t pat = first * 0x01010101u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < n_words) diff |= words[i] ^ pat;
+}
+// (2) per wave: the pixel value if every `on` lane holds nothing else, or 256 (lane 0 must be `on`)
+__device__ __forceinline__ int wave_const_code(bool on, uint32_t first, uint32_t diff) {
+  const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+  const bool bad = on && (diff != 0u || first != f0);
+  return __builtin_amdgcn_ballot_w64(bad) == 0ull ? (int)f0 : 256;
+}
+// (3) one wave over the per-wave codes of a patch (LDS): the patch's constant value, or -1
+template <int WAVES>
+__device__ __forceinline__ int patch_const_value(const int* codes, int lane) {
+  const int my = codes[lane < WAVES ? lane : 0];
+  const int c0 = __builtin_amdgcn_readfirstlane(my);
+  return (c0 < 256 && __builtin_amdgcn_ballot_w64(my != c0) == 0ull) ? c0 : -1;
+}
+
 // Weighted centroid in double + validity gate, executed by ONE wave in two steps so that the tile can be recycled in
 // between: (1) (2 RAD + 1)^2 lanes fetch one window element each (`surface(ys, xs)` returns the fft-shifted correlation
 // value; 0 outside the clamped window), (2) three fp64 sums are reduced by shuffles and lane 0 stores (x, y) or
@@ -337,8 +370,10 @@ __device__ __forceinline__ float centroid_window_value(Best best, int lane, Surf
   return 0.f;
 }
 
+// degenerate: one of the two patches is constant; c_dc = the DC bin of the cross-power spectrum (see above)
 template <int N, int PK = 0>
-__device__ __forceinline__ void centroid_gate_store(Best best, float wval, int lane, double max_px_speed_sq, double* out) {
+__device__ __forceinline__ void centroid_gate_store(Best best, float wval, int lane, double max_px_speed_sq, double* out,
+                                                    bool degenerate = false, float c_dc = 0.f) {
   constexpr int RAD = PeakModel<PK>::RAD, W = PeakModel<PK>::W;
   const int px = best.idx % N, py = best.idx / N;
   const int ys = py - RAD + lane / W, xs = px - RAD + lane % W;
@@ -355,10 +390,18 @@ __device__ __forceinline__ void centroid_gate_store(Best best, float wval, int l
     // shift = -(center - t) = t - N/2   (:1836); the OpenCL branch returns centroid - N/2 un-negated (cl:1370, :1833)
     double sx = cx / sum - (double)N / 2.0;
     double sy = cy / sum - (double)N / 2.0;
+    if (degenerate) {
+      if constexpr (PK == 1) {
+        sx = sy = __builtin_nan("");  // 1 / (a b) with b = 0 in the three other real-only slots (cl:1029): no finite surface
+      } else {
+        const double c9 = 9.0 * (double)c_dc;
+        sx = sy = (c9 > 0.0 ? c9 / (c9 + 2.220446049250313e-16) : 0.0) - (double)N / 2.0;
+      }
+    }
     // best.idx == 0x7fffffff: no value compared equal to the maximum, i.e. the whole surface is NaN (a patch whose
     // spectrum holds infinities, e.g. 1/0 in a real-only slot under the OpenCL model) -> invalid, as a NaN centroid is
     const bool bad = (sx * sx + sy * sy > max_px_speed_sq) || (fabs(sx) > (double)N / 2.0) ||
-                     (fabs(sy) > (double)N / 2.0) || (sx != sx) || (sy != sy) || best.idx == 0x7fffffff;
+                     (fabs(sy) > (double)N / 2.0) || (sx != sx) || (sy != sy) || (best.idx == 0x7fffffff && !degenerate);
     if (bad) sx = sy = __builtin_nan("");
     out[0] = sx;
     out[1] = sy;

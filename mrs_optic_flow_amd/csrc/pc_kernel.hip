@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* z = reinterpret_cast<cf*>(smem);
   Best* red = reinterpret_cast<Best*>(z + N * P::PITCH);
+  int* const_code = reinterpret_cast<int*>(red + 32);  // [2][16]: per-wave constant-patch codes of cur / prev (pc_common.hpp)
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
   const int patches = a.grid_x * a.grid_y;
@@ -136,8 +137,11 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   // ---- the wave's own LPW rows: u8 -> f32 (exact), z = cur + i*prev  (convertTo, :1805-1806)
   {
     const int row = wave * LPW + lane / CPR, col = (lane % CPR) * 16;
+    uint32_t fc = 0, dc = 0, fp = 0, dp = 0;  // constant-patch tracking
     if constexpr (DS == 1) {
       if (ld_on) {
+        const_track(cw, 4, true, fc, dc);
+        const_track(pw, 4, true, fp, dp);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -163,8 +167,19 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
         for (int b = 0; b < 4; ++b) {
           const uint32_t cs = ((ca[b] >> 8) & 0xffu) + ((ca[b] >> 16) & 0xffu) + ((cb[b] >> 8) & 0xffu) + ((cb[b] >> 16) & 0xffu);
           const uint32_t ps = ((pa[b] >> 8) & 0xffu) + ((pa[b] >> 16) & 0xffu) + ((pb[b] >> 8) & 0xffu) + ((pb[b] >> 16) & 0xffu);
-          z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cs + 2u) >> 2), (float)((ps + 2u) >> 2)};
+          const uint32_t cv = (cs + 2u) >> 2, pv = (ps + 2u) >> 2;
+          if (q == 0 && b == 0) fc = cv, fp = pv;
+          dc |= cv ^ fc;
+          dp |= pv ^ fp;
+          z[zaddr<N>(row, col + q * 4 + b)] = {(float)cv, (float)pv};
         }
+      }
+    }
+    {
+      const int cc = wave_const_code(ld_on, fc, dc), cp = wave_const_code(ld_on, fp, dp);
+      if (lane == 0) {
+        const_code[wave] = cc;
+        const_code[16 + wave] = cp;
       }
     }
     wave_sync();
@@ -177,6 +192,9 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   col_pass_fwd<N>(z, wave * LPW, lane, tw_col);
 #endif
   __syncthreads();
+  // (sum cur, sum prev): the DC bin, needed only when a patch turns out to be constant (wave 0 overwrites it below)
+  cf dc_bin = {0.f, 0.f};
+  if (wave == 0) dc_bin = z[zaddr<N>(0, 0)];
 
   // ---- untangle A = FFT(cur), B = FFT(prev); P = A conj(B); C = P|P| / (|P|^2 + eps)
   //      (mulSpectrums :1494, magSpectrums :70-168, divSpectrums :1086-1251, incl. the real-only-slot
@@ -266,6 +284,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   // ---- 5x5 weighted centroid in double + validity gate  (:1337-1383, :1838-1856), wave 0. The window is read
   //      before a second barrier releases the other waves to overwrite the tile with the next patch.
   float wval = 0.f;
+  bool degenerate = false;
 #ifdef MOF_ABLATE_NOTAIL
   if (wave == 0 && lane == 0) { a.out[2 * (size_t)p] = best.v; a.out[2 * (size_t)p + 1] = (double)best.idx; }
   continue;
@@ -277,9 +296,12 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       const cf s = z[zaddr<N>(y, x % H)];
       return x < H ? s.x : s.y;
     });
+    degenerate = patch_const_value<P::WAVES>(const_code, lane) >= 0 || patch_const_value<P::WAVES>(const_code + 16, lane) >= 0;
   }
   __syncthreads();  // (needed by the persistent form only; dropping it for one-workgroup-per-patch sizes measured -1 %)
-  if (wave == 0) centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p);
+  if (wave == 0)
+    centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p, degenerate,
+                               degenerate ? cross_power<0>(dc_bin, dc_bin, true).x : 0.f);
   }  // persistent loop
 }
 

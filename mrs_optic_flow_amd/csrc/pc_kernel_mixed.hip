@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* z = reinterpret_cast<cf*>(smem);
   Best* red = reinterpret_cast<Best*>(z + N * PITCH);
+  int* const_code = reinterpret_cast<int*>(red + 32);  // [2][16]: per-wave constant-patch codes of cur / prev
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
   const int patches = a.grid_x * a.grid_y;
@@ -257,6 +258,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   (void)cur; (void)prev;
 
   // ---- load: the wave's own 8 rows in 8-pixel chunks (15 per row), u8 -> f32, z = cur + i*prev (:1805-1806)
+  uint32_t fc = 0, dc = 0, fp = 0, dp = 0;  // constant-patch tracking (pc_common.hpp)
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int q = lane + 64 * b;
@@ -297,6 +299,8 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
           }
         }
       }
+      const_track(c, 2, b == 0, fc, dc);
+      const_track(pv, 2, b == 0, fp, dp);
       // The 8 pixels of a chunk are stored in a per-lane rotated order: straight order puts the 16 lanes of a
       // ds_write_b64 group on two banks (chunks are 8 elements apart), an 8-way conflict on every store.
       const int rot = ((q % (N / 8)) >> 1) & 7;
@@ -308,6 +312,13 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
     }
   }
   if (p + (int)gridDim.x < a.total) prefetch(p + (int)gridDim.x);
+  {
+    const int cc = wave_const_code(true, fc, dc), cp = wave_const_code(true, fp, dp);  // (every lane holds chunk b = 0)
+    if (lane == 0) {
+      const_code[wave] = cc;
+      const_code[16 + wave] = cp;
+    }
+  }
   wave_sync();
 
   // ---- forward 2-D transform: rows (wave-local), barrier, columns (wave-local)
@@ -315,6 +326,8 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   __syncthreads();
   col_pass_fwd(z, wave * LPW, lane, tw);
   __syncthreads();
+  cf dc_bin = {0.f, 0.f};  // (sum cur, sum prev): needed only when a patch turns out to be constant
+  if (wave == 0) dc_bin = z[za(0, 0)];
 
   // ---- normalised cross-power spectrum, half spectrum kept conjugated (see pc_kernel.hip)
   for (int g = tid; g < (H - 1) * N; g += T) {
@@ -348,6 +361,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
 
   // wave 0 reads the centroid window, then a barrier releases the others to overwrite the tile with the next patch
   float wval = 0.f;
+  bool degenerate = false;
   if (wave == 0) {
     for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
     wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
@@ -355,9 +369,12 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
       const cf s = z[za(y, x % H)];
       return x < H ? s.x : s.y;
     });
+    degenerate = patch_const_value<WAVES>(const_code, lane) >= 0 || patch_const_value<WAVES>(const_code + 16, lane) >= 0;
   }
   __syncthreads();
-  if (wave == 0) centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p);
+  if (wave == 0)
+    centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p, degenerate,
+                               degenerate ? cross_power<0>(dc_bin, dc_bin, true).x : 0.f);
   }  // persistent loop
 }
 

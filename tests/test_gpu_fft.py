@@ -133,6 +133,53 @@ def test_gating_constant_and_large_shift(gpu):
     assert np.isnan(fm128.process_batch_host(c128[None], c128[None])).all()  # (-63,-63) exceeds 80 px
 
 
+@pytest.mark.parametrize("n", [32, 64, 128, 120])
+def test_one_constant_patch_gives_the_reference_degenerate_answer(gpu, n):
+    """cv::phaseCorrelate transforms the two patches separately: a CONSTANT patch has an exactly zero AC spectrum, the
+    surface is flat and the answer is the first-index / 3 x 3-centroid artefact 9c / (9c + DBL_EPSILON) - N/2 (or -N/2 for
+    an all-zero patch) -- deterministic, and what the gate then sees. The packed two-for-one transform of K1 leaked rounding
+    noise into those zeros and answered with noise (found by tools/fft_sr_fuzz.py in round 3); constant patches are now
+    detected at the load. Checked against the oracle patch by patch (N = 120: the oracle's own radix-3/5 DFT of a constant
+    is not exactly zero, so there the closed form is the reference)."""
+    tex = synth.canvas_np(5, n, n, True)[:n, :n].copy()
+    tex2 = synth.canvas_np(6, n, n, True)[:n, :n].copy()
+    c77, zero = np.full((n, n), 77, np.uint8), np.zeros((n, n), np.uint8)
+    pairs = [(tex, c77), (c77, tex), (tex, zero), (zero, tex), (c77, c77), (zero, zero), (c77, zero), (tex, tex2)]
+    cur = np.stack([a for a, _ in pairs])
+    prev = np.stack([b for _, b in pairs])
+    fm = FftMethod(n, n, 1000.0)  # gate wide open: the values themselves are compared
+    got = fm.process_batch_device(torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)).cpu().numpy()[:, 0]
+    lay = O.fft_layout(n, n, n, 1, 1)
+    lay.max_px_speed = 1000.0
+    for k, (a, b) in enumerate(pairs[:-1]):
+        if n == 120:
+            sa, sb = float(a.astype(np.float64).sum()), float(b.astype(np.float64).sum())
+            pdc = sa * sb
+            c = pdc / (pdc * pdc + np.finfo(np.float32).eps) if pdc > 0 else 0.0
+            want = (9 * c / (9 * c + np.finfo(np.float64).eps) if c > 0 else 0.0) - n / 2
+            assert np.allclose(got[k], want, rtol=0, atol=1e-4), (n, k, got[k], want)
+        else:
+            want = O.fft_process(a, b, lay, 32)[0][0]
+            assert np.allclose(got[k], want, rtol=0, atol=TOL), (n, k, got[k], want)
+            assert np.allclose(want, O.fft_process(a, b, lay, 64)[0][0], rtol=0, atol=1e-9)
+    assert np.isfinite(got[-1]).all()  # an ordinary pair in the same batch is untouched
+    # through the gate of a real configuration (max_px_speed 80): (1 - N/2, 1 - N/2) is valid at N = 64, invalid at N = 128 / 120
+    gated = FftMethod(n, n, 80.0).process_batch_device(torch.from_numpy(cur[:2]).to(gpu), torch.from_numpy(prev[:2]).to(gpu)).cpu().numpy()[:, 0]
+    assert np.isnan(gated).all() == (2 * (n / 2 - 1) ** 2 > 80.0 ** 2)
+    # a frame with a constant rectangle: only the patches inside it are degenerate, in the stateful entry as well
+    if n == 64:
+        frame_a = synth.canvas_np(9, 192, 192, True)[:192, :192].copy()
+        frame_b = synth.canvas_np(10, 192, 192, True)[:192, :192].copy()
+        frame_b[:64, 64:128] = 200
+        f3 = FftMethod(192, 64, 1000.0)
+        lay3 = O.fft_layout(192, 192, 64, 3, 3)
+        lay3.max_px_speed = 1000.0
+        f3.processImage(frame_a)
+        res = f3.processImage(frame_b)
+        want = O.fft_process(frame_b, frame_a, lay3, 32)[0]
+        assert np.allclose(res[1], want[1], rtol=0, atol=TOL) and abs(res[1][0] + 31) < 1e-3
+
+
 def test_circular_shifts_are_exact(gpu):
     n = 64
     prev = synth.canvas_np(11, n, n, False)[:n, :n].copy()
