@@ -335,12 +335,16 @@ __device__ __forceinline__ int wave_const_code(bool on, uint32_t first, uint32_t
   const bool bad = on && (diff != 0u || first != f0);
   return __builtin_amdgcn_ballot_w64(bad) == 0ull ? (int)f0 : 256;
 }
-// (3) one wave over the per-wave codes of a patch (LDS): the patch's constant value, or -1
+// (3) the per-wave codes live in LDS as int codes[2][16] (cur, prev), 256 = "not constant", written by lane 0 of every wave
+// for every patch (a textured patch fails a two-compare pre-test and writes 256); one wave reads them in the tail
+// (the LDS read `my = codes[lane & 31]` is issued by the caller ahead of its other tail reads, so that its latency overlaps)
 template <int WAVES>
-__device__ __forceinline__ int patch_const_value(const int* codes, int lane) {
-  const int my = codes[lane < WAVES ? lane : 0];
-  const int c0 = __builtin_amdgcn_readfirstlane(my);
-  return (c0 < 256 && __builtin_amdgcn_ballot_w64(my != c0) == 0ull) ? c0 : -1;
+__device__ __forceinline__ bool const_codes_degenerate(int my, int lane) {
+  static_assert(WAVES <= 16, "two rows of 16 codes");
+  const int c0 = __builtin_amdgcn_readlane(my, 0), p0 = __builtin_amdgcn_readlane(my, 16);
+  const bool cur_const = c0 < 256 && __builtin_amdgcn_ballot_w64(lane < WAVES && my != c0) == 0ull;
+  const bool prev_const = p0 < 256 && __builtin_amdgcn_ballot_w64(lane >= 16 && lane < 16 + WAVES && my != p0) == 0ull;
+  return cur_const || prev_const;
 }
 
 // Weighted centroid in double + validity gate, executed by ONE wave in two steps so that the tile can be recycled in

@@ -137,11 +137,23 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   // ---- the wave's own LPW rows: u8 -> f32 (exact), z = cur + i*prev  (convertTo, :1805-1806)
   {
     const int row = wave * LPW + lane / CPR, col = (lane % CPR) * 16;
-    uint32_t fc = 0, dc = 0, fp = 0, dp = 0;  // constant-patch tracking
+    uint32_t fc = 0, dc = 1, fp = 0, dp = 1;  // constant-patch tracking (pc_common.hpp)
+    if constexpr (DS == 1) {
+      // pre-test: a textured patch has a lane whose first two dwords differ -- two compares and it is out
+      const bool maybe_c = __builtin_amdgcn_ballot_w64(ld_on && cw[0] != cw[1]) == 0ull;
+      const bool maybe_p = __builtin_amdgcn_ballot_w64(ld_on && pw[0] != pw[1]) == 0ull;
+      // (the empty asm keeps the compiler from if-converting the rare branch into 12 unconditional instructions per image)
+      if (__builtin_expect(maybe_c, 0)) {
+        asm volatile("");
+        const_track(cw, 4, true, fc, dc);
+      }
+      if (__builtin_expect(maybe_p, 0)) {
+        asm volatile("");
+        const_track(pw, 4, true, fp, dp);
+      }
+    }
     if constexpr (DS == 1) {
       if (ld_on) {
-        const_track(cw, 4, true, fc, dc);
-        const_track(pw, 4, true, fp, dp);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -168,7 +180,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
           const uint32_t cs = ((ca[b] >> 8) & 0xffu) + ((ca[b] >> 16) & 0xffu) + ((cb[b] >> 8) & 0xffu) + ((cb[b] >> 16) & 0xffu);
           const uint32_t ps = ((pa[b] >> 8) & 0xffu) + ((pa[b] >> 16) & 0xffu) + ((pb[b] >> 8) & 0xffu) + ((pb[b] >> 16) & 0xffu);
           const uint32_t cv = (cs + 2u) >> 2, pv = (ps + 2u) >> 2;
-          if (q == 0 && b == 0) fc = cv, fp = pv;
+          if (q == 0 && b == 0) fc = cv, fp = pv, dc = 0u, dp = 0u;
           dc |= cv ^ fc;
           dp |= pv ^ fp;
           z[zaddr<N>(row, col + q * 4 + b)] = {(float)cv, (float)pv};
@@ -176,7 +188,15 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       }
     }
     {
-      const int cc = wave_const_code(ld_on, fc, dc), cp = wave_const_code(ld_on, fp, dp);
+      int cc = 256, cp = 256;
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(ld_on && dc != 0u) == 0ull, 0)) {  // (rare)
+        asm volatile("");
+        cc = wave_const_code(ld_on, fc, dc);
+      }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(ld_on && dp != 0u) == 0ull, 0)) {
+        asm volatile("");
+        cp = wave_const_code(ld_on, fp, dp);
+      }
       if (lane == 0) {
         const_code[wave] = cc;
         const_code[16 + wave] = cp;
@@ -192,9 +212,6 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   col_pass_fwd<N>(z, wave * LPW, lane, tw_col);
 #endif
   __syncthreads();
-  // (sum cur, sum prev): the DC bin, needed only when a patch turns out to be constant (wave 0 overwrites it below)
-  cf dc_bin = {0.f, 0.f};
-  if (wave == 0) dc_bin = z[zaddr<N>(0, 0)];
 
   // ---- untangle A = FFT(cur), B = FFT(prev); P = A conj(B); C = P|P| / (|P|^2 + eps)
   //      (mulSpectrums :1494, magSpectrums :70-168, divSpectrums :1086-1251, incl. the real-only-slot
@@ -209,6 +226,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       const bool self = (u == um);
       const cf C0 = cross_power<PK>(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
       const cf Ch = cross_power<PK>(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
+      if (u == 0) *reinterpret_cast<float*>(const_code + 32) = C0.x;  // C_dc: all that is left of a degenerate pair's spectrum
       z[zaddr<N>(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
       if (!self) z[zaddr<N>(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
     }
@@ -253,6 +271,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       const bool self = (u == um);
       const cf C0 = cross_power<PK>(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
       const cf Ch = cross_power<PK>(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
+      if (u == 0) *reinterpret_cast<float*>(const_code + 32) = C0.x;  // C_dc (see the fused form above)
       z[zaddr<N>(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
       if (!self) z[zaddr<N>(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
     }
@@ -290,18 +309,19 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   continue;
 #endif
   if (wave == 0) {
+    const int my_code = const_code[lane & 31];
     for (int w = 1; w < P::WAVES; ++w) best = better(best, red[w]);
     wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
       const int y = (ys + H) % N, x = (xs + H) % N;  // un-shifted position
       const cf s = z[zaddr<N>(y, x % H)];
       return x < H ? s.x : s.y;
     });
-    degenerate = patch_const_value<P::WAVES>(const_code, lane) >= 0 || patch_const_value<P::WAVES>(const_code + 16, lane) >= 0;
+    degenerate = const_codes_degenerate<P::WAVES>(my_code, lane);
   }
   __syncthreads();  // (needed by the persistent form only; dropping it for one-workgroup-per-patch sizes measured -1 %)
   if (wave == 0)
     centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p, degenerate,
-                               degenerate ? cross_power<0>(dc_bin, dc_bin, true).x : 0.f);
+                               degenerate ? *reinterpret_cast<const float*>(const_code + 32) : 0.f);
   }  // persistent loop
 }
 

@@ -259,6 +259,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
 
   // ---- load: the wave's own 8 rows in 8-pixel chunks (15 per row), u8 -> f32, z = cur + i*prev (:1805-1806)
   uint32_t fc = 0, dc = 0, fp = 0, dp = 0;  // constant-patch tracking (pc_common.hpp)
+  bool maybe_c = true, maybe_p = true;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int q = lane + 64 * b;
@@ -299,8 +300,18 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
           }
         }
       }
-      const_track(c, 2, b == 0, fc, dc);
-      const_track(pv, 2, b == 0, fp, dp);
+      if (b == 0) {  // pre-test: a textured patch has a lane whose two dwords differ -- two compares and it is out
+        maybe_c = __builtin_amdgcn_ballot_w64(c[0] != c[1]) == 0ull;
+        maybe_p = __builtin_amdgcn_ballot_w64(pv[0] != pv[1]) == 0ull;
+      }
+      if (__builtin_expect(maybe_c, 0)) {  // (the empty asm keeps the rare branch from being if-converted)
+        asm volatile("");
+        const_track(c, 2, b == 0, fc, dc);
+      }
+      if (__builtin_expect(maybe_p, 0)) {
+        asm volatile("");
+        const_track(pv, 2, b == 0, fp, dp);
+      }
       // The 8 pixels of a chunk are stored in a per-lane rotated order: straight order puts the 16 lanes of a
       // ds_write_b64 group on two banks (chunks are 8 elements apart), an 8-way conflict on every store.
       const int rot = ((q % (N / 8)) >> 1) & 7;
@@ -313,7 +324,15 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   }
   if (p + (int)gridDim.x < a.total) prefetch(p + (int)gridDim.x);
   {
-    const int cc = wave_const_code(true, fc, dc), cp = wave_const_code(true, fp, dp);  // (every lane holds chunk b = 0)
+    int cc = 256, cp = 256;
+    if (__builtin_expect(maybe_c, 0)) {  // (every lane holds a chunk b = 0)
+      asm volatile("");
+      cc = wave_const_code(true, fc, dc);
+    }
+    if (__builtin_expect(maybe_p, 0)) {
+      asm volatile("");
+      cp = wave_const_code(true, fp, dp);
+    }
     if (lane == 0) {
       const_code[wave] = cc;
       const_code[16 + wave] = cp;
@@ -326,8 +345,6 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   __syncthreads();
   col_pass_fwd(z, wave * LPW, lane, tw);
   __syncthreads();
-  cf dc_bin = {0.f, 0.f};  // (sum cur, sum prev): needed only when a patch turns out to be constant
-  if (wave == 0) dc_bin = z[za(0, 0)];
 
   // ---- normalised cross-power spectrum, half spectrum kept conjugated (see pc_kernel.hip)
   for (int g = tid; g < (H - 1) * N; g += T) {
@@ -341,6 +358,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
     const bool self = (u == um);
     const cf C0 = cross_power<PK>(z[za(0, u)], z[za(0, um)], self);
     const cf Ch = cross_power<PK>(z[za(H, u)], z[za(H, um)], self);
+    if (u == 0) *reinterpret_cast<float*>(const_code + 32) = C0.x;  // C_dc: all that is left of a degenerate pair's spectrum
     z[za(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
     if (!self) z[za(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
   }
@@ -363,18 +381,19 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   float wval = 0.f;
   bool degenerate = false;
   if (wave == 0) {
+    const int my_code = const_code[lane & 31];
     for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
     wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
       const int y = (ys + H) % N, x = (xs + H) % N;
       const cf s = z[za(y, x % H)];
       return x < H ? s.x : s.y;
     });
-    degenerate = patch_const_value<WAVES>(const_code, lane) >= 0 || patch_const_value<WAVES>(const_code + 16, lane) >= 0;
+    degenerate = const_codes_degenerate<WAVES>(my_code, lane);
   }
   __syncthreads();
   if (wave == 0)
     centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p, degenerate,
-                               degenerate ? cross_power<0>(dc_bin, dc_bin, true).x : 0.f);
+                               degenerate ? *reinterpret_cast<const float*>(const_code + 32) : 0.f);
   }  // persistent loop
 }
 
