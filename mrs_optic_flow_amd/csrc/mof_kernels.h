@@ -113,6 +113,7 @@ struct SrPcArgs {
   int n_cand;
   double M;                // log-polar magnitude
   double* out;             // [pairs][4] = scale, rot, pt.x, pt.y
+  int* degen;              // pair pipeline only (else null): [pairs], K6 -> K8: one of the two log-polar images is all zero
 };
 
 // host-side tables of cv::logPolar / cv::remap (mof_sr.hip); exposed so that the CPU suite can compare them with the oracle

@@ -264,6 +264,7 @@ struct mof_sr_engine {
   float *d_Zt = nullptr, *d_Dt = nullptr;
   float2* d_cand = nullptr;
   double* d_out = nullptr;       // [kChunk][4]
+  int* d_degen = nullptr;        // [kChunk]: K6 -> K8 flag of the pair pipeline (an all-zero log-polar image)
   uint8_t* h_stage = nullptr;
   double* h_out = nullptr;
   double* h_seq = nullptr;       // pinned [chunk][4]: a pass's results, read back when a sequence call resolves the gate
@@ -326,7 +327,7 @@ hipError_t scratch_alloc(mof_sr_engine* e, int pairs) {
   mof::RelaxedCapture relaxed;  // allocation / release must not invalidate a capture on another thread
   const int res = e->cfg.resolution;
   const size_t nn = (size_t)res * res;
-  void** bufs[] = {(void**)&e->d_lp, (void**)&e->d_Zt, (void**)&e->d_Dt, (void**)&e->d_cand, (void**)&e->d_out};
+  void** bufs[] = {(void**)&e->d_lp, (void**)&e->d_Zt, (void**)&e->d_Dt, (void**)&e->d_cand, (void**)&e->d_out, (void**)&e->d_degen};
   for (void** b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
@@ -342,6 +343,7 @@ hipError_t scratch_alloc(mof_sr_engine* e, int pairs) {
   if ((err = hipMalloc(&e->d_Dt, (size_t)pairs * res * (res / 2 + 1) * 2 * sizeof(float))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_cand, (size_t)pairs * mof::sr_candidates(res) * sizeof(float2))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_out, (size_t)pairs * 4 * sizeof(double))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_degen, (size_t)pairs * sizeof(int))) != hipSuccess) return err;
   e->scratch_pairs = pairs;
   return hipSuccess;
 }
@@ -399,7 +401,7 @@ static void sr_destroy_now(void* p) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
   void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_sboxes[0], e->d_sboxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_wp[0], e->d_wp[1], e->d_twiddles, e->d_frame, e->d_temp_im, e->d_zh_prev,
-                 e->d_lp,  e->d_Zt,      e->d_Dt,        e->d_cand,     e->d_out};
+                 e->d_lp,  e->d_Zt,      e->d_Dt,        e->d_cand,     e->d_out, e->d_degen};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -789,6 +791,7 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
       SR_TRY(hipStreamWaitEvent(s, e->ev_lp[b], 0));  // also the join: every remap precedes a wait on the caller's stream
     }
     mof::SrPcArgs a = pc_args(e, lp_buf, lp_buf + nn, 2 * nn, d_out + 4 * (size_t)k0);
+    a.degen = e->d_degen;
     SR_TRY(mof::launch_sr_phase_correlate(a, res, n, s));
     if (two_lanes) SR_TRY(hipEventRecord(e->ev_fft[b], s));
   }

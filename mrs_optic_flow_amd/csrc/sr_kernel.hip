@@ -573,6 +573,10 @@ __global__ void __launch_bounds__(SR_T) sr_cols_kernel(SrPcArgs a) {
     if (u > H) u = H;
     const cf zk = z[s * P::LINE + v], zm = z[(CW + s) * P::LINE + (N - v) % N];
     const bool real_only = (v == 0 || v == H) && (u == 0 || u == H);
+    // The DC bin is exact in the packed transform: (sum cur, sum prev). A sum of zero = an all-zero (black) image, whose
+    // spectrum is exactly zero in the reference's separate transforms: P = 0 everywhere, flat zero surface, pt = (N/2, N/2).
+    // The packed form would leak rounding noise of the other image into it (see pc_common.hpp, degenerate pairs): tell K8.
+    if (u0 == 0 && i == 0 && a.degen) a.degen[pair] = (zk.x == 0.f || zk.y == 0.f) ? 1 : 0;
     const cf C = cross_power(zk, zm, real_only);
     z[s * P::LINE + v] = {C.x, -C.y};
   }
@@ -716,7 +720,8 @@ __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
   }
   if (lane == 0) {
     sum += 2.220446049250313e-16;
-    const double ptx = (double)N / 2.0 - cx / sum, pty = (double)N / 2.0 - cy / sum;
+    double ptx = (double)N / 2.0 - cx / sum, pty = (double)N / 2.0 - cy / sum;
+    if (a.degen && a.degen[pair]) ptx = pty = (double)N / 2.0;  // flat zero surface: first index, centroid 0 / (0 + eps)
     double scale = 1.0, rot = 0.0;
     if (!(fabs(ptx) > (double)(N / 2))) {
       scale = exp(ptx / a.M);

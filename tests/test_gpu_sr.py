@@ -78,3 +78,36 @@ def test_opencv3_logpolar_generation(gpu):
         fresh.processImage(seq[k])
         fresh.processImage(seq[k + 1])
         assert np.allclose(got[k, 2:], fresh.pt, rtol=0, atol=1e-4)
+
+
+def test_black_frames_give_the_reference_degenerate_answer(gpu):
+    """An all-zero frame has an all-zero log-polar image: in the reference's separate transforms its spectrum is exactly zero,
+    the surface is flat zero and pt = (res/2, res/2) -- scale = exp(res / 2M), rot = pi: nonsense, but deterministic, and not
+    gated (|pt.x| > res/2 is false). The pair pipeline packs cur + i prev into one transform and would leak rounding noise
+    into those zeros; K6 sees the exact DC bin (a sum of zero) and tells K8. The sequence / stateful kernels transform frames
+    separately and need nothing."""
+    res, M = 240, 40.0
+    base = sr_scenes.canvas(3, res)
+    v = sr_scenes.view(base, res, 1.02, 3.0)
+    black = np.zeros((res, res), np.uint8)
+    pairs = [(v, black), (black, v), (black, black), (v, v)]
+    cur = torch.from_numpy(np.stack([a for a, _ in pairs])).to(gpu)
+    prev = torch.from_numpy(np.stack([b for _, b in pairs])).to(gpu)
+    est = ScaleRotationEstimator(res, M)
+    got = est.process_batch_device(cur, prev).cpu().numpy()
+    for k, (a, b) in enumerate(pairs):
+        ref = O.ScaleRotationEstimator(res, M, 64)
+        ref.processImage(b)
+        s, r = ref.processImage(a)
+        assert np.allclose(got[k, 2:], ref.pt, rtol=0, atol=1e-4), (k, got[k], ref.pt)
+        assert abs(got[k, 0] - s) < 1e-5 * max(1.0, s) and abs(got[k, 1] - r) < 1e-5, (k, got[k], s, r)
+    assert np.allclose(got[0, 2:], res / 2) and np.allclose(got[2, 2:], res / 2)
+    # a black frame inside a stream: sequence entry == stateful calls == oracle
+    video = np.stack([v, black, v, sr_scenes.view(base, res, 1.0, 0.0)])
+    seq = ScaleRotationEstimator(res, M).process_sequence_device(torch.from_numpy(video).to(gpu)).cpu().numpy()
+    one, ref = ScaleRotationEstimator(res, M), O.ScaleRotationEstimator(res, M, 64)
+    for t in range(len(video)):
+        s1, r1 = one.processImage(video[t])
+        ws, wr = ref.processImage(video[t])
+        assert (s1, r1) == (seq[t, 0], seq[t, 1])
+        assert abs(seq[t, 0] - ws) < 1e-5 * max(1.0, ws) and abs(seq[t, 1] - wr) < 1e-5, (t, seq[t], ws, wr)
