@@ -166,6 +166,15 @@ def test_one_constant_patch_gives_the_reference_degenerate_answer(gpu, n):
     # through the gate of a real configuration (max_px_speed 80): (1 - N/2, 1 - N/2) is valid at N = 64, invalid at N = 128 / 120
     gated = FftMethod(n, n, 80.0).process_batch_device(torch.from_numpy(cur[:2]).to(gpu), torch.from_numpy(prev[:2]).to(gpu)).cpu().numpy()[:, 0]
     assert np.isnan(gated).all() == (2 * (n / 2 - 1) ** 2 > 80.0 ** 2)
+    if n == 120:  # long-range mode: constancy is judged on the quarter-resolution pixels the kernel forms on the fly
+        lr = FftMethod(480, 120, 1000.0)
+        big = synth.canvas_np(12, 480, 480, True)[:480, :480].copy()
+        lr.processImageLongRange(big)
+        res = lr.processImageLongRange(np.full((480, 480), 50, np.uint8))[0]
+        q = O.resize_quarter(big).astype(np.float64)
+        pdc = q.sum() * 50.0 * 120 * 120
+        c = pdc / (pdc * pdc + np.finfo(np.float32).eps)
+        assert np.allclose(res, 9 * c / (9 * c + np.finfo(np.float64).eps) - 60, rtol=0, atol=1e-4), res
     # a frame with a constant rectangle: only the patches inside it are degenerate, in the stateful entry as well
     if n == 64:
         frame_a = synth.canvas_np(9, 192, 192, True)[:192, :192].copy()
