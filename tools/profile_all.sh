@@ -5,7 +5,7 @@
 set -e
 TAG=$1
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for wl in ${MOF_PROFILE_WORKLOADS:-c2 cal c2seq c3 c4 c5 c5seq ref c1 bmref refrt reflr c3bgr}; do
+for wl in ${MOF_PROFILE_WORKLOADS:-c2 cal c2seq c3 c4 c4seq c5 c5seq ref c1 bmref refrt reflr c3bgr}; do
   bash $R/tools/profile.sh ${TAG}_$wl --workload $wl --no-others --sustain-s 0 > $R/gpurun_out/profile_${TAG}_$wl.log 2>&1 || { tail -5 $R/gpurun_out/profile_${TAG}_$wl.log; exit 1; }
   echo "$wl done: $(head -c 160 $R/gpurun_out/prof_${TAG}_$wl/bench.json)"
 done
