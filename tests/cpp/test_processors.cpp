@@ -5,10 +5,14 @@
 //          test_processors fftocl ...same...   (peak_model = MOF_PEAK_OCL)
 //          test_processors bm  <frameSize> <sps> <radius> <nframes> <file>
 //          test_processors fsbm <w> <h> <sps> <step> <radius> <nframes> <file>
+//          test_processors fftseq <frameSize> <sps> <max_px_speed> <nframes> <file>   (video on the device, sequence entry)
+//          test_processors srseq <res> <M> <nframes> <file>                          (estimator: sequence entry + stateful loop)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>  // only for the sequence modes below: device buffers for a video (the mirror itself needs no HIP)
 
 #include "mof/processors.hpp"
 
@@ -68,6 +72,53 @@ int main(int argc, char** argv) {
         for (size_t b = 0; b < proc.flowX().size(); ++b) std::printf(" %d %d", proc.flowX()[b], proc.flowY()[b]);
         std::printf("\n");
       }
+      return 0;
+    }
+    if (argc >= 7 && !std::strcmp(argv[1], "fftseq")) {
+      const int fs = std::atoi(argv[2]), sps = std::atoi(argv[3]), n = std::atoi(argv[5]);
+      const double mps = std::atof(argv[4]);
+      auto frames = read_all(argv[6], (size_t)fs * fs * n);
+      mof::FftMethod proc(fs, sps, mps);
+      const size_t per = (size_t)proc.sqNum() * proc.sqNum() * 2;
+      uint8_t* d_frames = nullptr;
+      double* d_out = nullptr;
+      if (hipMalloc((void**)&d_frames, frames.size()) != hipSuccess || hipMalloc((void**)&d_out, per * (n - 1) * sizeof(double)) != hipSuccess ||
+          hipMemcpy(d_frames, frames.data(), frames.size(), hipMemcpyHostToDevice) != hipSuccess)
+        throw std::runtime_error("device buffers");
+      proc.processSequenceDevice(d_frames, (size_t)fs * fs, (size_t)fs, n, d_out, nullptr);
+      std::vector<double> out(per * (n - 1));
+      if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out.data(), d_out, out.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        throw std::runtime_error("read-back");
+      for (int t = 0; t + 1 < n; ++t) {
+        std::printf("pair %d n %zu", t, per / 2);
+        for (size_t i = 0; i < per; ++i) std::printf(" %.17g", out[(size_t)t * per + i]);
+        std::printf("\n");
+      }
+      (void)hipFree(d_frames);
+      (void)hipFree(d_out);
+      return 0;
+    }
+    if (argc >= 6 && !std::strcmp(argv[1], "srseq")) {
+      const int res = std::atoi(argv[2]), n = std::atoi(argv[4]);
+      const double M = std::atof(argv[3]);
+      auto frames = read_all(argv[5], (size_t)res * res * n);
+      mof::scaleRotationEstimator seq(res, M), one(res, M);
+      uint8_t* d_frames = nullptr;
+      double* d_out = nullptr;
+      if (hipMalloc((void**)&d_frames, frames.size()) != hipSuccess || hipMalloc((void**)&d_out, (size_t)n * 4 * sizeof(double)) != hipSuccess ||
+          hipMemcpy(d_frames, frames.data(), frames.size(), hipMemcpyHostToDevice) != hipSuccess)
+        throw std::runtime_error("device buffers");
+      const int gated = seq.processSequenceDevice(d_frames, (size_t)res * res, (size_t)res, n, d_out, nullptr);
+      std::vector<double> out((size_t)n * 4);
+      if (hipMemcpy(out.data(), d_out, out.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("read-back");
+      std::printf("gated %d\n", gated);
+      for (int t = 0; t < n; ++t) {
+        const mof::Point2d p = one.processImage(mof::ImageView{frames.data() + (size_t)t * res * res, res, res, (size_t)res}, false, false);
+        std::printf("frame %d seq %.17g %.17g %.17g %.17g stateful %.17g %.17g\n", t, out[4 * (size_t)t], out[4 * (size_t)t + 1],
+                    out[4 * (size_t)t + 2], out[4 * (size_t)t + 3], p.x, p.y);
+      }
+      (void)hipFree(d_frames);
+      (void)hipFree(d_out);
       return 0;
     }
     std::fprintf(stderr, "bad usage\n");

@@ -106,3 +106,35 @@ def test_drop_in_adapter_against_the_reference_interface_header(gpu, tmp_path):
             want, _ = O.fft_process(frames[t], prev, lay, 64)
         got = np.array([float(v) for v in tok[5:]]).reshape(-1, 2)
         assert np.allclose(got, want, rtol=0, atol=1e-4, equal_nan=True), (t, tok[2])
+
+
+def test_cpp_mirror_sequence_entries(gpu, tmp_path):
+    """mof::FftMethod::processSequenceDevice and mof::scaleRotationEstimator::processSequenceDevice (a video on the device
+    through the C++ mirror): K1's sequence kernel against the oracle pair by pair, the estimator's sequence entry equal to
+    its own stateful loop bit for bit and to the oracle within the usual bars."""
+    import sr_scenes
+
+    fs, sps, n = 192, 64, 6
+    frames = np.stack([synth.pair_np(33, fs, fs, 2 * t, -3 * t)[0] for t in range(n)])
+    lines = _run(["fftseq", fs, sps, 80, n], frames, tmp_path)
+    lay = O.fft_layout(fs, fs, sps, 3, 3)
+    assert len(lines) == n - 1
+    for t, tok in enumerate(lines):
+        assert tok[0] == "pair" and int(tok[1]) == t and int(tok[3]) == 9
+        got = np.array([float(v) for v in tok[4:]]).reshape(9, 2)
+        want, _ = O.fft_process(frames[t + 1], frames[t], lay, 64)
+        assert np.allclose(got, want, rtol=0, atol=1e-4, equal_nan=True)
+    res, M, nf = 240, 40.0, 5
+    base = sr_scenes.canvas(8, res)
+    video = np.stack([sr_scenes.view(base, res, 1.0 + 0.012 * t, 1.4 * t) for t in range(nf)])
+    lines = _run(["srseq", res, M, nf], video, tmp_path)
+    assert lines[0] == ["gated", "0"]
+    ref = O.ScaleRotationEstimator(res, M, 64)
+    for t, tok in enumerate(lines[1:]):
+        seq = [float(v) for v in tok[3:7]]
+        stateful = [float(v) for v in tok[8:10]]
+        assert seq[:2] == stateful  # the same kernels behind both entries
+        ws, wr = ref.processImage(video[t])
+        assert abs(seq[0] - ws) < 1e-5 and abs(seq[1] - wr) < 1e-5
+        if t > 0:
+            assert np.allclose(seq[2:], ref.pt, rtol=0, atol=1e-4)
