@@ -90,7 +90,10 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint
 }
 
 // ---- K6s: column transforms + cross-power + inverse columns, one wave walking a run of pairs -------------------------
-constexpr int SEQ_CW = 4;  // columns per wave
+#ifndef MOF_SEQ_CW
+#define MOF_SEQ_CW 4
+#endif
+constexpr int SEQ_CW = MOF_SEQ_CW;  // columns per wave
 
 template <int N>
 __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur,

@@ -67,4 +67,31 @@ for lanes in (1, 2):
     torch.cuda.synchronize()
     assert torch.equal(out, want), (lanes, out, want)
     del g, est
+# reserve(small), capture, then a LARGER eager batch: growing would move the scratch under the captured graph, so it must be
+# refused (MOF_ERR_BUSY) while the engine is pinned, and the replay must still be right; release_captured() lifts the pin
+from mrs_optic_flow_amd import release_captured
+est = ScaleRotationEstimator(res, 45.0)
+est.reserve(n_pairs)
+want = est.process_batch_device(cur, prev).clone()
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    with torch.cuda.graph(g, stream=side):
+        out = est.process_batch_device(cur, prev)
+big_c, big_p = cur.repeat(16, 1, 1), prev.repeat(16, 1, 1)
+try:
+    est.process_batch_device(big_c, big_p)
+    raise SystemExit("a batch that grows the pinned scratch was accepted")
+except MofError as exc:
+    assert exc.code == -2 and "graph" in str(exc), exc
+out.zero_()
+g.replay()
+torch.cuda.synchronize()
+assert torch.equal(out, want)
+del g
+assert release_captured(est) == 1
+grown = est.process_batch_device(big_c, big_p)
+torch.cuda.synchronize()
+assert torch.equal(grown[:n_pairs], want)
 print("graph ok", res, n_pairs)
