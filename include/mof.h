@@ -160,6 +160,11 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
  * frame is not touched. Asynchronous on `stream`. */
 int mof_fft_process_sequence_device(mof_fft_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch,
                                     int n_frames, double* d_out_xy, void* stream);
+/* The same on interleaved BGR8 frames (the node's camera frames, optic_flow.cpp:1465): CV_RGB2GRAY as the node applies it
+ * (:1622) happens inside the kernels' loads, `pitch` in BYTES (3 per pixel), d_frames at the first byte of the crop.
+ * Identical bits to the gray entry on the converted frames. */
+int mof_fft_process_sequence_device_bgr(mof_fft_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch,
+                                        int n_frames, double* d_out_xy, void* stream);
 /* Front-end fusion: the frames are interleaved BGR8 as the node receives them
  * (cv_bridge::toCvCopy(msg, BGR8), optic_flow.cpp:1465) and cv::cvtColor(crop, gray, CV_RGB2GRAY) (:1622) -- applied to
  * BGR data, i.e. gray = (B*4899 + G*9617 + R*1868 + 8192) >> 14 -- happens inside the kernel's load. d_cur / d_prev

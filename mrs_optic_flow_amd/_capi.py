@@ -78,6 +78,7 @@ SYMBOLS = {
     "mof_fft_process_long_range_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_fft_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_fft_process_sequence_device": (_I, [_VP, _VP, _SZ, _SZ, _I, _VP, _VP]),
+    "mof_fft_process_sequence_device_bgr": (_I, [_VP, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_fft_process_batch_device_bgr": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_fft_process_batch_host": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP]),
     "mof_fft_sync": (_I, [_VP]),

@@ -457,11 +457,11 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
 
 // A video: pair k = (frame k + 1, frame k). 64 x 64 patches run the sequence kernel (one real transform per frame and
 // patch, pc_seq_kernel.hip); the other sizes run the pair kernel on cur = frames + 1, prev = frames (no copy either).
-int mof_fft_process_sequence_device(mof_fft_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch, int n_frames,
-                                    double* d_out_xy, void* stream) {
+static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch, int n_frames,
+                        double* d_out_xy, void* stream, int channels) {
   if (!e) return fail(MOF_ERR_NOT_INIT, "null engine");
   if (n_frames == 0 || n_frames == 1) return MOF_OK;  // no pair
-  if (!d_frames || !d_out_xy || n_frames < 0 || pitch < (size_t)e->cfg.frame_width)
+  if (!d_frames || !d_out_xy || n_frames < 0 || pitch < (size_t)channels * (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad sequence arguments");
   const int n_pairs = n_frames - 1;
   if ((unsigned long long)n_pairs * (unsigned long long)(e->cfg.grid_x * e->cfg.grid_y) > 0x7fffffffull)
@@ -470,6 +470,7 @@ int mof_fft_process_sequence_device(mof_fft_engine* e, const uint8_t* d_frames, 
   if (!g.owned) return fail(MOF_ERR_BUSY, "engine busy");
   HIP_TRY(hipSetDevice(e->cfg.device));
   mof::PcArgs a = fft_args(e, d_frames + frame_stride, frame_stride, d_frames, frame_stride, pitch, d_out_xy);
+  a.channels = channels;
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
   static const int run = [] { const char* v = getenv("MOF_FFT_SEQ_RUN"); const int r = v ? atoi(v) : 0; return r >= 1 ? r : 16; }();
   static const bool pairs_only = getenv("MOF_FFT_SEQ_PAIRS") != nullptr, half64 = getenv("MOF_FFT_SEQ_HALF64") != nullptr;
@@ -484,6 +485,16 @@ int mof_fft_process_sequence_device(mof_fft_engine* e, const uint8_t* d_frames, 
     HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
   }
   return MOF_OK;
+}
+
+int mof_fft_process_sequence_device(mof_fft_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch, int n_frames,
+                                    double* d_out_xy, void* stream) {
+  return fft_sequence(e, d_frames, frame_stride, pitch, n_frames, d_out_xy, stream, 1);
+}
+
+int mof_fft_process_sequence_device_bgr(mof_fft_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch, int n_frames,
+                                        double* d_out_xy, void* stream) {
+  return fft_sequence(e, d_frames, frame_stride, pitch, n_frames, d_out_xy, stream, 3);
 }
 
 int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,

@@ -258,6 +258,25 @@ __device__ __forceinline__ void gray16_from_bgr48(const uint8_t* p, uint32_t* g 
   }
 }
 
+// 8 gray pixels from 24 interleaved bytes (6 dwords, any alignment)
+__device__ __forceinline__ void gray8_from_bgr24(const uint8_t* p, uint32_t* g /*[2] packed u8x4*/) {
+  uint32_t w[6];
+  __builtin_memcpy(w, p, 24);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    uint32_t packed = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = 3 * (4 * q + b);
+      const uint32_t c0 = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+      const uint32_t c1 = (w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xffu;
+      const uint32_t c2 = (w[(i + 2) >> 2] >> (8 * ((i + 2) & 3))) & 0xffu;
+      packed |= rgb2gray_fixed(c0, c1, c2) << (8 * b);
+    }
+    g[q] = packed;
+  }
+}
+
 // One bin of the normalised cross-power spectrum from the packed transform Z = FFT(cur + i prev):
 //   A[k] = (Z[k] + conj(Z[-k]))/2 ; B[k] = (Z[k] - conj(Z[-k]))/(2i) ; P = A conj(B)        (mulSpectrums :1494)
 //   C = P |P| / (|P|^2 + eps)                                   (magSpectrums :70-168, divSpectrums :1086-1251)

@@ -353,7 +353,8 @@ __device__ __forceinline__ Best half_row_pairs(cf* __restrict__ z, int row0, int
   return Best{m, mi};
 }
 
-template <int N, int PK>
+// CH = 3: interleaved BGR8 frames, CV_RGB2GRAY in the load (as pc_seq_kernel.hip)
+template <int N, int PK, int CH>
 __global__ void __launch_bounds__(HalfTile<N>::T, (N == 64 ? 4 : 2)) pc_seq_half_kernel(PcArgs a, int n_pairs, int run) {
   using L = HalfTile<N>;
   constexpr int H = L::H, R1 = L::R1, W = HalfCfg<N>::WAVES, PPL = N / 8;  // pixels per lane and row
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(HalfTile<N>::T, (N == 64 ? 4 : 2)) pc_seq_half
   const int patches = a.grid_x * a.grid_y, patch = blockIdx.y * a.grid_x + blockIdx.x;
   const int px0 = a.origin_x + blockIdx.x * a.stride_x, py0 = a.origin_y + blockIdx.y * a.stride_y;
   // this lane's 2 x PPL pixels: patch rows 2j, 2j + 1 (j = 8 wave + lane / 8), columns PPL (lane % 8) .. + PPL - 1
-  const uint8_t* src = a.cur + (size_t)py0 * a.pitch + px0 + (size_t)(2 * (8 * wave0 + (lane0 >> 3))) * a.pitch + PPL * (lane0 & 7);
+  const uint8_t* src = a.cur + (size_t)py0 * a.pitch + CH * px0 + (size_t)(2 * (8 * wave0 + (lane0 >> 3))) * a.pitch + CH * PPL * (lane0 & 7);
   HalfTw<N> tw;
   tw.init(a.twiddles, lane0);
   constexpr int PER = 8 * R1 / 64, NC0 = (H + 64) / 64;
@@ -380,8 +381,16 @@ __global__ void __launch_bounds__(HalfTile<N>::T, (N == 64 ? 4 : 2)) pc_seq_half
   uint32_t ra[PPL / 4], rb[PPL / 4];
   auto fetch = [&](int f) {
     const uint8_t* s = src + (size_t)f * a.cur_stride;
-    __builtin_memcpy(ra, s, PPL);
-    __builtin_memcpy(rb, s + a.pitch, PPL);
+    if constexpr (CH == 1) {
+      __builtin_memcpy(ra, s, PPL);
+      __builtin_memcpy(rb, s + a.pitch, PPL);
+    } else if constexpr (PPL == 16) {
+      gray16_from_bgr48(s, ra);
+      gray16_from_bgr48(s + a.pitch, rb);
+    } else {
+      gray8_from_bgr24(s, ra);
+      gray8_from_bgr24(s + a.pitch, rb);
+    }
   };
   fetch(p0);
   for (int f = 0; f <= np; ++f) {
@@ -439,21 +448,27 @@ size_t half_extra_lds() {
 template <int N>
 hipError_t configure_half() {
   const int lds = (int)(HalfTile<N>::LDS_BYTES + half_extra_lds());
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_half_kernel<N, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_half_kernel<N, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_half_kernel<N, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_half_kernel<N, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_half_kernel<N, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_half_kernel<N, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 template <int N>
 hipError_t launch_half(const PcArgs& a, int n_pairs, int run, hipStream_t stream) {
   const int runs = (n_pairs + run - 1) / run;
-  if (runs > 65535 || a.channels != 1 || a.downscale != 1) return hipErrorInvalidValue;
+  if (runs > 65535 || (a.channels != 1 && a.channels != 3) || a.downscale != 1) return hipErrorInvalidValue;
   const dim3 g((unsigned)a.grid_x, (unsigned)a.grid_y, (unsigned)runs);
   const size_t lds = HalfTile<N>::LDS_BYTES + half_extra_lds();
-  if (a.peak_model == 1)
-    hipLaunchKernelGGL((pc_seq_half_kernel<N, 1>), g, dim3(HalfTile<N>::T), lds, stream, a, n_pairs, run);
-  else
-    hipLaunchKernelGGL((pc_seq_half_kernel<N, 0>), g, dim3(HalfTile<N>::T), lds, stream, a, n_pairs, run);
+  if (a.channels == 3) {
+    if (a.peak_model == 1) hipLaunchKernelGGL((pc_seq_half_kernel<N, 1, 3>), g, dim3(HalfTile<N>::T), lds, stream, a, n_pairs, run);
+    else hipLaunchKernelGGL((pc_seq_half_kernel<N, 0, 3>), g, dim3(HalfTile<N>::T), lds, stream, a, n_pairs, run);
+  } else if (a.peak_model == 1) {
+    hipLaunchKernelGGL((pc_seq_half_kernel<N, 1, 1>), g, dim3(HalfTile<N>::T), lds, stream, a, n_pairs, run);
+  } else {
+    hipLaunchKernelGGL((pc_seq_half_kernel<N, 0, 1>), g, dim3(HalfTile<N>::T), lds, stream, a, n_pairs, run);
+  }
   return hipGetLastError();
 }
 

@@ -168,7 +168,8 @@ __device__ __forceinline__ Best row_pass_inv64(cf* __restrict__ z, int row0, int
   return Best{m, mi};
 }
 
-template <int PK>
+// CH = 3: the frames are interleaved BGR8 and CV_RGB2GRAY (as the node applies it, optic_flow.cpp:1622) happens in the load
+template <int PK, int CH>
 __global__ void __launch_bounds__(256) pc_seq_kernel(PcArgs a, int n_pairs, int run) {
   constexpr int N = SQN, H = SQH;
   using P = PcTraits<N>;
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(256) pc_seq_kernel(PcArgs a, int n_pairs, int 
   const int patches = a.grid_x * a.grid_y, patch = blockIdx.y * a.grid_x + blockIdx.x;
   const int px0 = a.origin_x + blockIdx.x * a.stride_x, py0 = a.origin_y + blockIdx.y * a.stride_y;
   // this lane's 2 x 8 pixels: rows 2j, 2j + 1 of the patch (j = 8 wave + lane / 8), columns 8 (lane % 8) .. +7
-  const uint8_t* src = a.cur + (size_t)py0 * a.pitch + px0 + (size_t)(16 * wave0 + 2 * (lane0 >> 3)) * a.pitch + 8 * (lane0 & 7);
+  const uint8_t* src = a.cur + (size_t)py0 * a.pitch + CH * px0 + (size_t)(16 * wave0 + 2 * (lane0 >> 3)) * a.pitch + CH * 8 * (lane0 & 7);
   cf tw_row[7], tw_col[7];
   {
     const int xr = lane0 & 7, xc = lane0 >> 3;
@@ -197,8 +198,13 @@ __global__ void __launch_bounds__(256) pc_seq_kernel(PcArgs a, int n_pairs, int 
   uint32_t ra[2], rb[2];  // the next frame's pixels, requested one frame ahead
   auto fetch = [&](int f) {
     const uint8_t* s = src + (size_t)f * a.cur_stride;
-    __builtin_memcpy(ra, s, 8);
-    __builtin_memcpy(rb, s + a.pitch, 8);
+    if constexpr (CH == 1) {
+      __builtin_memcpy(ra, s, 8);
+      __builtin_memcpy(rb, s + a.pitch, 8);
+    } else {
+      gray8_from_bgr24(s, ra);
+      gray8_from_bgr24(s + a.pitch, rb);
+    }
   };
   fetch(p0);
   for (int f = 0; f <= np; ++f) {  // frame p0 + f; f = 0 primes the registers, f >= 1 closes pair p0 + f - 1
@@ -292,9 +298,11 @@ static size_t seq_extra_lds() {
 
 hipError_t pc_configure_sequence() {
   const int lds = (int)(PcTraits<64>::LDS_BYTES + seq_extra_lds());
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_seq_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 // a.cur = frame 0, a.cur_stride = bytes between frames; pair k = (frame k + 1, frame k), k < n_pairs; a.prev unused.
@@ -302,13 +310,17 @@ hipError_t launch_pc_sequence(const PcArgs& a, int n_pairs, int run, hipStream_t
   if (n_pairs <= 0) return hipSuccess;
   if (run < 1) run = 1;
   const int runs = (n_pairs + run - 1) / run;
-  if (runs > 65535 || a.channels != 1 || a.downscale != 1) return hipErrorInvalidValue;
+  if (runs > 65535 || (a.channels != 1 && a.channels != 3) || a.downscale != 1) return hipErrorInvalidValue;
   const dim3 g((unsigned)a.grid_x, (unsigned)a.grid_y, (unsigned)runs);
   const size_t lds = PcTraits<64>::LDS_BYTES + seq_extra_lds();
-  if (a.peak_model == 1)
-    hipLaunchKernelGGL(pc_seq_kernel<1>, g, dim3(256), lds, stream, a, n_pairs, run);
-  else
-    hipLaunchKernelGGL(pc_seq_kernel<0>, g, dim3(256), lds, stream, a, n_pairs, run);
+  if (a.channels == 3) {
+    if (a.peak_model == 1) hipLaunchKernelGGL((pc_seq_kernel<1, 3>), g, dim3(256), lds, stream, a, n_pairs, run);
+    else hipLaunchKernelGGL((pc_seq_kernel<0, 3>), g, dim3(256), lds, stream, a, n_pairs, run);
+  } else if (a.peak_model == 1) {
+    hipLaunchKernelGGL((pc_seq_kernel<1, 1>), g, dim3(256), lds, stream, a, n_pairs, run);
+  } else {
+    hipLaunchKernelGGL((pc_seq_kernel<0, 1>), g, dim3(256), lds, stream, a, n_pairs, run);
+  }
   return hipGetLastError();
 }
 

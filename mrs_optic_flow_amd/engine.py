@@ -241,6 +241,20 @@ class FftMethod:
                                                         out.data_ptr(), _stream_ptr(s)))
         return out
 
+    def process_sequence_device_bgr(self, frames, stream=None):
+        """frames: torch uint8 [n, H, W, 3] BGR8 video (W-stride 3, any row pitch) -> float64 [n - 1, patches, 2]; CV_RGB2GRAY
+        fused into the sequence kernels' loads, identical bits to process_sequence_device on the converted frames."""
+        import torch
+
+        _check_device_batch(frames, frames, (self.cfg.frame_height, self.cfg.frame_width), self.cfg.device, channels=3)
+        n = frames.shape[0]
+        out = torch.empty((max(n - 1, 0), self.n_patches, 2), dtype=torch.float64, device=frames.device)
+        s = stream if stream is not None else torch.cuda.current_stream(frames.device)
+        _pin_if_capturing(self, s)
+        check(self._lib.mof_fft_process_sequence_device_bgr(self._h, frames.data_ptr(), frames.stride(0), frames.stride(1), n,
+                                                            out.data_ptr(), _stream_ptr(s)))
+        return out
+
     def process_batch_device_bgr(self, cur, prev, stream=None):
         """cur, prev: torch uint8 [n, H, W, 3] BGR8 views (crop of the camera frames; W-stride 3, any row pitch):
         CV_RGB2GRAY (as the node applies it to BGR data) is fused into the kernel's load."""

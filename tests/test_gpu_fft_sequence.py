@@ -150,3 +150,22 @@ def test_full_size_c2seq_properties(gpu):
     ok = ~torch.isnan(got[..., 0])
     assert ok.float().mean() > 0.99
     assert ((got - d).abs().amax(dim=-1)[ok] < 0.5).all()
+
+
+@pytest.mark.parametrize("n,fs", [(64, 192), (128, 256), (120, 240)])
+def test_bgr_video_front_end(gpu, n, fs):
+    """SURVEY N2 on the sequence path: a BGR8 video, crop + CV_RGB2GRAY (optic_flow.cpp:1609-1622) fused into the sequence
+    kernels' loads (64 / 128) or the pair kernel's (120): identical bits to the gray entry on the converted crop, oracle bar."""
+    nf, H, W, xi, yi = 5, fs + 9, fs + 24, 11, 5
+    gray, _ = _video_np(nf, H, W, k=7)
+    rng = np.random.default_rng(5)
+    g = gray.astype(np.int32)
+    col = np.clip(np.stack([g, 255 - g // 2, g * 3 // 4 + 20], axis=-1) + rng.integers(-2, 3, g.shape + (3,)), 0, 255).astype(np.uint8)
+    fm = FftMethod(fs, n, 80.0)
+    tv = torch.from_numpy(col).to(gpu)
+    got = fm.process_sequence_device_bgr(tv[:, yi:yi + fs, xi:xi + fs]).cpu().numpy()
+    conv = np.stack([O.rgb2gray(col[t, yi:yi + fs, xi:xi + fs]) for t in range(nf)])
+    ref = fm.process_sequence_device(torch.from_numpy(conv).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, ref, equal_nan=True)
+    lay = O.fft_layout(fs, fs, n, fs // n, fs // n)
+    assert sum(_compare(got[k], conv[k + 1], conv[k], lay, f"bgr{k}") for k in range(nf - 1)) >= 0.7 * (nf - 1) * (fs // n) ** 2
