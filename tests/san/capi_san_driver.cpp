@@ -57,6 +57,7 @@ int main() {
   CHECK(mof_fft_process_long_range_batch_device(nullptr, px, 0, px, 0, 4, 1, d2, nullptr) == MOF_ERR_NOT_INIT);
   CHECK(mof_fft_process_batch_host(nullptr, px, 0, px, 0, 4, 1, d2) == MOF_ERR_NOT_INIT);
   CHECK(mof_fft_process_sequence_device(nullptr, px, 0, 4, 3, d2, nullptr) == MOF_ERR_NOT_INIT);
+  CHECK(mof_fft_process_sequence_device_bgr(nullptr, px, 0, 12, 3, d2, nullptr) == MOF_ERR_NOT_INIT);
   CHECK(mof_fft_release_graphs(nullptr) == MOF_ERR_NOT_INIT && mof_fft_graph_pinned(nullptr) == 0);
   CHECK(mof_purge_deferred() == 0 && mof_deferred_count() == 0);
   CHECK(std::strcmp(mof_fft_kernel_variant(nullptr), "") == 0);
