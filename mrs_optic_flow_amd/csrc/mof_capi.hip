@@ -475,14 +475,22 @@ static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame
   static const int run = [] { const char* v = getenv("MOF_FFT_SEQ_RUN"); const int r = v ? atoi(v) : 0; return r >= 1 ? r : 16; }();
   static const bool pairs_only = getenv("MOF_FFT_SEQ_PAIRS") != nullptr, half64 = getenv("MOF_FFT_SEQ_HALF64") != nullptr;
   const int n = e->cfg.patch_size;
-  if (!pairs_only && mof::pc_sequence_half_supported(n) && (n != 64 || half64)) {
-    a.cur = d_frames;  // the sequence kernels index frames, not pairs
-    HIP_TRY(mof::launch_pc_sequence_half(a, n, n_pairs, run, (hipStream_t)stream));
-  } else if (!pairs_only && mof::pc_sequence_supported(n)) {
-    a.cur = d_frames;
-    HIP_TRY(mof::launch_pc_sequence(a, n_pairs, run, (hipStream_t)stream));
-  } else {
+  const bool half = !pairs_only && mof::pc_sequence_half_supported(n) && (n != 64 || half64);
+  const bool full = !pairs_only && !half && mof::pc_sequence_supported(n);
+  if (!half && !full) {
     HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
+    return MOF_OK;
+  }
+  // the run index rides gridDim.z (at most 65535 per launch): a very long video goes out in several launches
+  const size_t per_pair = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
+  const int max_pairs = 65535 * run;
+  for (int k0 = 0; k0 < n_pairs; k0 += max_pairs) {
+    const int nk = n_pairs - k0 < max_pairs ? n_pairs - k0 : max_pairs;
+    mof::PcArgs c = a;
+    c.cur = d_frames + (size_t)k0 * frame_stride;  // the sequence kernels index frames, not pairs
+    c.out = d_out_xy + (size_t)k0 * per_pair;
+    if (half) HIP_TRY(mof::launch_pc_sequence_half(c, n, nk, run, (hipStream_t)stream));
+    else HIP_TRY(mof::launch_pc_sequence(c, nk, run, (hipStream_t)stream));
   }
   return MOF_OK;
 }

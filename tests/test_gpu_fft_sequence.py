@@ -169,3 +169,33 @@ def test_bgr_video_front_end(gpu, n, fs):
     assert np.array_equal(got, ref, equal_nan=True)
     lay = O.fft_layout(fs, fs, n, fs // n, fs // n)
     assert sum(_compare(got[k], conv[k + 1], conv[k], lay, f"bgr{k}") for k in range(nf - 1)) >= 0.7 * (nf - 1) * (fs // n) ** 2
+
+
+def test_more_pairs_than_one_grid_dimension_holds(gpu):
+    """The run index rides gridDim.z (65535 at most): with MOF_FFT_SEQ_RUN=1 a video of 65541 frames needs two launches.
+    Run in a child process (the run length is read once per process). Circular shifts: every pair has a known answer."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [%r, %r]
+from mrs_optic_flow_amd import FftMethod
+n, F = 64, 65535 + 6
+gen = torch.Generator(device="cpu").manual_seed(5)
+base = torch.randint(0, 256, (n, n), dtype=torch.uint8, generator=gen)
+moves = [(3, -2), (-5, 7), (0, 1), (11, 0)]
+pos, P = (0, 0), []
+for k in range(8):
+    P.append(pos)
+    pos = (pos[0] + moves[k %% 4][0], pos[1] + moves[k %% 4][1])
+protos = torch.stack([torch.roll(base, (p[1], p[0]), dims=(0, 1)) for p in P]).cuda()
+video = protos[torch.arange(F, device="cuda") %% 8]
+got = FftMethod(n, n, 80.0).process_sequence_device(video).cpu().numpy()[:, 0]
+step = np.array([(P[(k + 1) %% 8][0] - P[k][0], P[(k + 1) %% 8][1] - P[k][1]) for k in range(8)], float)
+want = step[np.arange(F - 1) %% 8]
+err = np.abs(got - want).max(axis=1)
+print("ok" if err.max() < 5e-5 else ("bad", err.max(), int(err.argmax())))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, MOF_FFT_SEQ_RUN="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
