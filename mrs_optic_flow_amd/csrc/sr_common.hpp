@@ -28,6 +28,46 @@ struct SrPlan<256> {
   static constexpr int R1 = 16, R2 = 16, Y2 = 17, LINE = 273;
 };
 
+// Zt / Zh / Dt (and the log-polar images) are STREAMS: written once by one kernel, read once by the next, hundreds of MB per
+// pass. Marking those accesses non-temporal keeps them from displacing each other's lines on their way through the caches:
+// same-box A/B (r03) c5seq 492 k -> 516 k pairs/s with K5s / K6s alone. MOF_SR_NT=0 builds the plain form.
+#ifndef MOF_SR_NT
+#define MOF_SR_NT 1
+#endif
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load(const float4* p) {
+#if MOF_SR_NT
+  const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void stream_store(float4* p, float4 v) {
+#if MOF_SR_NT
+  const v4f_t w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<v4f_t*>(p));
+#else
+  *p = v;
+#endif
+}
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store(cf* p, cf v) {
+#if MOF_SR_NT
+  const v2f_t w = {v.x, v.y};
+  __builtin_nontemporal_store(w, reinterpret_cast<v2f_t*>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ uint32_t stream_load(const uint32_t* p) {
+#if MOF_SR_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 template <int R>
 __device__ __forceinline__ void bfly(cf* v) {
   if constexpr (R == 15) butterfly15(v);

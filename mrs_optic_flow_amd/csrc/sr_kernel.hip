@@ -501,8 +501,8 @@ __global__ void __launch_bounds__(FWD_T) sr_rows_fwd_kernel(SrPcArgs a) {
     for (int k = 0; k < NL; ++k) {
       const int i = lane + 64 * k;
       if (i < N) {
-        c[k] = *reinterpret_cast<const uint32_t*>(cur + 4 * i);
-        p[k] = *reinterpret_cast<const uint32_t*>(prev + 4 * i);
+        c[k] = stream_load(reinterpret_cast<const uint32_t*>(cur + 4 * i));
+        p[k] = stream_load(reinterpret_cast<const uint32_t*>(prev + 4 * i));
       }
     }
 #pragma unroll
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(FWD_T) sr_rows_fwd_kernel(SrPcArgs a) {
   cf* Zt = reinterpret_cast<cf*>(a.Zt) + (size_t)pair * N * N + row0;
   for (int i = tid; i < FWD_ROWS * N; i += FWD_T) {
     const int u = i / FWD_ROWS, dv = i % FWD_ROWS;
-    Zt[(size_t)u * N + dv] = z[dv * P::LINE + u];
+    stream_store(&Zt[(size_t)u * N + dv], z[dv * P::LINE + u]);
   }
 }
 
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(SR_T) sr_cols_kernel(SrPcArgs a) {
         int u = u0 + s;
         if (u > H) u = H;  // tail group: clamp (results of clamped lines are never stored)
         const int col = wave == 0 ? u : (N - u) % N;
-        t[k] = *reinterpret_cast<const float4*>(Zt + (size_t)col * N + v);
+        t[k] = stream_load(reinterpret_cast<const float4*>(Zt + (size_t)col * N + v));
       }
     }
 #pragma unroll
@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(SR_T) sr_cols_kernel(SrPcArgs a) {
     const int s = (2 * i) / N, y = (2 * i) % N, u = u0 + s;
     if (u <= H) {
       const cf a0 = z[s * P::LINE + y], a1 = z[s * P::LINE + y + 1];
-      *reinterpret_cast<float4*>(Dt + (size_t)u * N + y) = make_float4(a0.x, a0.y, a1.x, a1.y);
+      stream_store(reinterpret_cast<float4*>(Dt + (size_t)u * N + y), make_float4(a0.x, a0.y, a1.x, a1.y));
     }
   }
 }
@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int i = tid + SR_T * k;
-      if (i < SR_LINES * (H + 1)) t[k] = *reinterpret_cast<const float4*>(Dt + (size_t)(i / SR_LINES) * N + 2 * (p0 + i % SR_LINES));
+      if (i < SR_LINES * (H + 1)) t[k] = stream_load(reinterpret_cast<const float4*>(Dt + (size_t)(i / SR_LINES) * N + 2 * (p0 + i % SR_LINES)));
     }
 #pragma unroll
     for (int k = 0; k < NL; ++k) {

@@ -60,8 +60,8 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint
       const int i = lane + 64 * k;
       if (i < 4 * ND) {
         const int l = i / ND, d = i % ND;
-        c[k] = *reinterpret_cast<const uint32_t*>(img + (size_t)(2 * l) * N + 4 * d);
-        p[k] = *reinterpret_cast<const uint32_t*>(img + (size_t)(2 * l + 1) * N + 4 * d);
+        c[k] = stream_load(reinterpret_cast<const uint32_t*>(img + (size_t)(2 * l) * N + 4 * d));
+        p[k] = stream_load(reinterpret_cast<const uint32_t*>(img + (size_t)(2 * l + 1) * N + 4 * d));
       }
     }
 #pragma unroll
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint
     const cf zk = z[j * P::LINE + u], zm = z[j * P::LINE + (N - u) % N];
     cf a2, b2;
     untangle2(zk, zm, &a2, &b2);  // 2 * DFT(row 2j)[u], 2 * DFT(row 2j + 1)[u]
-    *reinterpret_cast<float4*>(out + (size_t)u * N + 2 * j) = make_float4(a2.x, a2.y, b2.x, b2.y);
+    stream_store(reinterpret_cast<float4*>(out + (size_t)u * N + 2 * j), make_float4(a2.x, a2.y, b2.x, b2.y));
   }
 }
 
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
 #pragma unroll
       for (int m = 0; m < MQ; ++m) {
         const int q = lane + 64 * m;
-        if (q < N / 2) t[s][m] = *reinterpret_cast<const float4*>(Zf + (size_t)u * N + 2 * q);
+        if (q < N / 2) t[s][m] = stream_load(reinterpret_cast<const float4*>(Zf + (size_t)u * N + 2 * q));
       }
     }
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
         const int q = lane + 64 * m;
         if (q < N / 2 && u <= H) {
           const cf a0 = z[s * P::LINE + 2 * q], a1 = z[s * P::LINE + 2 * q + 1];
-          *reinterpret_cast<float4*>(D + (size_t)u * N + 2 * q) = make_float4(a0.x, a0.y, a1.x, a1.y);
+          stream_store(reinterpret_cast<float4*>(D + (size_t)u * N + 2 * q), make_float4(a0.x, a0.y, a1.x, a1.y));
         }
       }
     }
