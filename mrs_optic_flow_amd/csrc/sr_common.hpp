@@ -51,15 +51,6 @@ __device__ __forceinline__ void stream_store(float4* p, float4 v) {
   *p = v;
 #endif
 }
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void stream_store(cf* p, cf v) {
-#if MOF_SR_NT
-  const v2f_t w = {v.x, v.y};
-  __builtin_nontemporal_store(w, reinterpret_cast<v2f_t*>(p));
-#else
-  *p = v;
-#endif
-}
 __device__ __forceinline__ uint32_t stream_load(const uint32_t* p) {
 #if MOF_SR_NT
   return __builtin_nontemporal_load(p);

@@ -521,9 +521,12 @@ __global__ void __launch_bounds__(FWD_T) sr_rows_fwd_kernel(SrPcArgs a) {
   __syncthreads();
   // ... and the workgroup stores its rows transposed: Zt[u][row0 .. row0 + FWD_ROWS) is one contiguous segment per u
   cf* Zt = reinterpret_cast<cf*>(a.Zt) + (size_t)pair * N * N + row0;
-  for (int i = tid; i < FWD_ROWS * N; i += FWD_T) {
-    const int u = i / FWD_ROWS, dv = i % FWD_ROWS;
-    stream_store(&Zt[(size_t)u * N + dv], z[dv * P::LINE + u]);
+  // (two neighbouring rows per lane: 16-byte non-temporal stores, as K5s -- the 8-byte form cost 16 % more on this kernel)
+  static_assert(FWD_ROWS % 2 == 0, "row pairs");
+  for (int i = tid; i < FWD_ROWS / 2 * N; i += FWD_T) {
+    const int u = i / (FWD_ROWS / 2), dv = 2 * (i % (FWD_ROWS / 2));
+    const cf a0 = z[dv * P::LINE + u], a1 = z[(dv + 1) * P::LINE + u];
+    stream_store(reinterpret_cast<float4*>(&Zt[(size_t)u * N + dv]), make_float4(a0.x, a0.y, a1.x, a1.y));
   }
 }
 
