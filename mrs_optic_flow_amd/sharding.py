@@ -73,8 +73,9 @@ class Gathered:
         import torch
 
         if not self._done:
-            self._event = torch.cuda.Event()
-            self._event.record()
+            if self.tensor.is_cuda:  # (CPU tensors -- the gloo tests -- are consumed synchronously: nothing to wait for)
+                self._event = torch.cuda.Event()
+                self._event.record()
             self._done = True
 
 
@@ -117,8 +118,13 @@ class AsyncGather:
                 raise GatherBufferInUse(f"gathered buffer {k} (batch {self.i - self.depth}) is still held by its consumer: "
                                         "call done() on the handle submit() returned before this buffer comes round again")
             # the collective is ordered behind the current stream: make that stream wait for the consumer's last read
-            torch.cuda.current_stream().wait_event(prev._event)
-        self.work[k] = dist.all_gather_into_tensor(self.full[k], self.local[k], group=self.group, async_op=True)
+            if prev._event is not None:
+                torch.cuda.current_stream().wait_event(prev._event)
+        if self.full[k].is_cuda:
+            self.work[k] = dist.all_gather_into_tensor(self.full[k], self.local[k], group=self.group, async_op=True)
+        else:  # gloo on CPU tensors has no all_gather_into_tensor: gather into row views of the same buffer
+            parts = list(self.full[k].split(self.per, dim=0))
+            self.work[k] = dist.all_gather(parts, self.local[k], group=self.group, async_op=True)
         self.handed[k] = Gathered(self.full[k][: self.n_pairs], self.work[k])
         self.i += 1
         return self.handed[k]

@@ -85,3 +85,65 @@ def test_two_rank_gather_equals_single_rank(n_pairs):
     for r in range(2):
         assert got[r].shape == want.shape
         assert np.array_equal(got[r], want, equal_nan=True)  # bit-identical to the 1-rank result
+
+
+def _async_worker(rank, world, port, q):
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import torch.distributed as dist
+
+    from mrs_optic_flow_amd import sharding
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    per, steps = 3, 7
+    ag = sharding.AsyncGather((per, 2, 2), torch.float64, torch.device("cpu"), per * world)
+    seen = []
+    for i in range(steps):
+        buf = ag.slot()
+        buf.fill_(100.0 * i + rank)  # this rank's "flow vectors" of batch i
+        h = ag.submit()
+        if i >= 1:  # consume batch i - 1 one step late, as an overlapped pipeline does
+            prev_h.wait()
+            seen.append(prev_h.tensor[:, 0, 0].clone())
+            prev_h.done()
+        prev_h = h
+    prev_h.wait()
+    seen.append(prev_h.tensor[:, 0, 0].clone())
+    prev_h.done()
+    ag.drain()
+    # a consumer that never releases its buffer stops the pipeline loudly instead of being overwritten
+    blocked = False
+    try:
+        for i in range(3):
+            ag.slot().fill_(-1.0)
+            ag.submit()
+    except sharding.GatherBufferInUse:
+        blocked = True
+    q.put((rank, torch.stack(seen).numpy(), blocked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_gather_two_ranks_gloo():
+    """sharding.AsyncGather with world_size 2 (gloo, CPU tensors): every rank sees every rank's shard of every batch, in
+    order, while consuming one step late (double buffering); a buffer still held by its consumer is not re-used."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_async_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, seen, blocked in got:
+        assert blocked
+        assert seen.shape == (7, 6)
+        for i in range(7):
+            assert list(seen[i]) == [100.0 * i + 0] * 3 + [100.0 * i + 1] * 3, (rank, i, seen[i])
