@@ -354,15 +354,16 @@ __device__ __forceinline__ int wave_const_code(bool on, uint32_t first, uint32_t
   const bool bad = on && (diff != 0u || first != f0);
   return __builtin_amdgcn_ballot_w64(bad) == 0ull ? (int)f0 : 256;
 }
-// (3) the per-wave codes live in LDS as int codes[2][16] (cur, prev), 256 = "not constant", written by lane 0 of every wave
-// for every patch (a textured patch fails a two-compare pre-test and writes 256); one wave reads them in the tail
-// (the LDS read `my = codes[lane & 31]` is issued by the caller ahead of its other tail reads, so that its latency overlaps)
+// (3) the per-wave codes live in LDS as int codes[16]: cur code | prev code << 16, 256 = "not constant", written by lane 0
+// of every wave for every patch (a textured patch fails a two-compare pre-test and writes 256 | 256 << 16); one wave reads
+// them in the tail (the LDS read `my = codes[lane & 15]` is issued ahead of its other tail reads: the latencies overlap)
 template <int WAVES>
 __device__ __forceinline__ bool const_codes_degenerate(int my, int lane) {
-  static_assert(WAVES <= 16, "two rows of 16 codes");
-  const int c0 = __builtin_amdgcn_readlane(my, 0), p0 = __builtin_amdgcn_readlane(my, 16);
-  const bool cur_const = c0 < 256 && __builtin_amdgcn_ballot_w64(lane < WAVES && my != c0) == 0ull;
-  const bool prev_const = p0 < 256 && __builtin_amdgcn_ballot_w64(lane >= 16 && lane < 16 + WAVES && my != p0) == 0ull;
+  static_assert(WAVES <= 16, "16 codes");
+  const int c = my & 0xffff, p = (int)((unsigned)my >> 16);
+  const int c0 = __builtin_amdgcn_readfirstlane(c), p0 = __builtin_amdgcn_readfirstlane(p);
+  const bool cur_const = c0 < 256 && __builtin_amdgcn_ballot_w64(lane < WAVES && c != c0) == 0ull;
+  const bool prev_const = p0 < 256 && __builtin_amdgcn_ballot_w64(lane < WAVES && p != p0) == 0ull;
   return cur_const || prev_const;
 }
 

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* z = reinterpret_cast<cf*>(smem);
   Best* red = reinterpret_cast<Best*>(z + N * P::PITCH);
-  int* const_code = reinterpret_cast<int*>(red + 32);  // [2][16]: per-wave constant-patch codes of cur / prev (pc_common.hpp)
+  int* const_code = reinterpret_cast<int*>(red + 32);  // [16] per-wave constant-patch codes (cur | prev << 16), then C_dc (pc_common.hpp)
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
   const int patches = a.grid_x * a.grid_y;
@@ -137,21 +137,26 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   // ---- the wave's own LPW rows: u8 -> f32 (exact), z = cur + i*prev  (convertTo, :1805-1806)
   {
     const int row = wave * LPW + lane / CPR, col = (lane % CPR) * 16;
-    uint32_t fc = 0, dc = 1, fp = 0, dp = 1;  // constant-patch tracking (pc_common.hpp)
+    int cc = 256, cp = 256;  // constant-patch codes of this wave (pc_common.hpp)
     if constexpr (DS == 1) {
       // pre-test: a textured patch has a lane whose first two dwords differ -- two compares and it is out
       const bool maybe_c = __builtin_amdgcn_ballot_w64(ld_on && cw[0] != cw[1]) == 0ull;
       const bool maybe_p = __builtin_amdgcn_ballot_w64(ld_on && pw[0] != pw[1]) == 0ull;
-      // (the empty asm keeps the compiler from if-converting the rare branch into 12 unconditional instructions per image)
+      // (the empty asm keeps the compiler from if-converting the rare branch into unconditional instructions)
       if (__builtin_expect(maybe_c, 0)) {
         asm volatile("");
-        const_track(cw, 4, true, fc, dc);
+        uint32_t f, d;
+        const_track(cw, 4, true, f, d);
+        cc = wave_const_code(ld_on, f, d);
       }
       if (__builtin_expect(maybe_p, 0)) {
         asm volatile("");
-        const_track(pw, 4, true, fp, dp);
+        uint32_t f, d;
+        const_track(pw, 4, true, f, d);
+        cp = wave_const_code(ld_on, f, d);
       }
     }
+    uint32_t fc = 0, dc = 0, fp = 0, dp = 0;  // (long-range mode forms its pixels one by one: tracked in its loop)
     if constexpr (DS == 1) {
       if (ld_on) {
 #pragma unroll
@@ -187,21 +192,11 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
         }
       }
     }
-    {
-      int cc = 256, cp = 256;
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(ld_on && dc != 0u) == 0ull, 0)) {  // (rare)
-        asm volatile("");
-        cc = wave_const_code(ld_on, fc, dc);
-      }
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(ld_on && dp != 0u) == 0ull, 0)) {
-        asm volatile("");
-        cp = wave_const_code(ld_on, fp, dp);
-      }
-      if (lane == 0) {
-        const_code[wave] = cc;
-        const_code[16 + wave] = cp;
-      }
+    if constexpr (DS != 1) {
+      cc = wave_const_code(ld_on, fc, dc);
+      cp = wave_const_code(ld_on, fp, dp);
     }
+    if (lane == 0) const_code[wave] = cc | (cp << 16);
     wave_sync();
   }
 
@@ -226,7 +221,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       const bool self = (u == um);
       const cf C0 = cross_power<PK>(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
       const cf Ch = cross_power<PK>(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
-      if (u == 0) *reinterpret_cast<float*>(const_code + 32) = C0.x;  // C_dc: all that is left of a degenerate pair's spectrum
+      if (u == 0) *reinterpret_cast<float*>(const_code + 16) = C0.x;  // C_dc: all that is left of a degenerate pair's spectrum
       z[zaddr<N>(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
       if (!self) z[zaddr<N>(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
     }
@@ -271,7 +266,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       const bool self = (u == um);
       const cf C0 = cross_power<PK>(z[zaddr<N>(0, u)], z[zaddr<N>(0, um)], self);
       const cf Ch = cross_power<PK>(z[zaddr<N>(H, u)], z[zaddr<N>(H, um)], self);
-      if (u == 0) *reinterpret_cast<float*>(const_code + 32) = C0.x;  // C_dc (see the fused form above)
+      if (u == 0) *reinterpret_cast<float*>(const_code + 16) = C0.x;  // C_dc (see the fused form above)
       z[zaddr<N>(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
       if (!self) z[zaddr<N>(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
     }
@@ -309,7 +304,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   continue;
 #endif
   if (wave == 0) {
-    const int my_code = const_code[lane & 31];
+    const int my_code = const_code[lane & 15];
     for (int w = 1; w < P::WAVES; ++w) best = better(best, red[w]);
     wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
       const int y = (ys + H) % N, x = (xs + H) % N;  // un-shifted position
@@ -321,7 +316,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   __syncthreads();  // (needed by the persistent form only; dropping it for one-workgroup-per-patch sizes measured -1 %)
   if (wave == 0)
     centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p, degenerate,
-                               degenerate ? *reinterpret_cast<const float*>(const_code + 32) : 0.f);
+                               degenerate ? *reinterpret_cast<const float*>(const_code + 16) : 0.f);
   }  // persistent loop
 }
 

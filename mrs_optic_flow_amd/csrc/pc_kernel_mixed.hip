@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* z = reinterpret_cast<cf*>(smem);
   Best* red = reinterpret_cast<Best*>(z + N * PITCH);
-  int* const_code = reinterpret_cast<int*>(red + 32);  // [2][16]: per-wave constant-patch codes of cur / prev
+  int* const_code = reinterpret_cast<int*>(red + 32);  // [16] per-wave constant-patch codes (cur | prev << 16), then C_dc
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
   const int patches = a.grid_x * a.grid_y;
@@ -333,10 +333,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
       asm volatile("");
       cp = wave_const_code(true, fp, dp);
     }
-    if (lane == 0) {
-      const_code[wave] = cc;
-      const_code[16 + wave] = cp;
-    }
+    if (lane == 0) const_code[wave] = cc | (cp << 16);
   }
   wave_sync();
 
@@ -358,7 +355,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
     const bool self = (u == um);
     const cf C0 = cross_power<PK>(z[za(0, u)], z[za(0, um)], self);
     const cf Ch = cross_power<PK>(z[za(H, u)], z[za(H, um)], self);
-    if (u == 0) *reinterpret_cast<float*>(const_code + 32) = C0.x;  // C_dc: all that is left of a degenerate pair's spectrum
+    if (u == 0) *reinterpret_cast<float*>(const_code + 16) = C0.x;  // C_dc: all that is left of a degenerate pair's spectrum
     z[za(0, u)] = {C0.x + Ch.y, Ch.x - C0.y};
     if (!self) z[za(0, um)] = {C0.x - Ch.y, Ch.x + C0.y};
   }
@@ -381,7 +378,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   float wval = 0.f;
   bool degenerate = false;
   if (wave == 0) {
-    const int my_code = const_code[lane & 31];
+    const int my_code = const_code[lane & 15];
     for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
     wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
       const int y = (ys + H) % N, x = (xs + H) % N;
@@ -393,7 +390,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   __syncthreads();
   if (wave == 0)
     centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p, degenerate,
-                               degenerate ? *reinterpret_cast<const float*>(const_code + 32) : 0.f);
+                               degenerate ? *reinterpret_cast<const float*>(const_code + 16) : 0.f);
   }  // persistent loop
 }
 
