@@ -284,7 +284,8 @@ int mof_sr_graph_pinned(const mof_sr_engine* e);
  * scale = exp(pt.x / M), rot = (pt.y / (resolution/360)) * pi/180 (:123-124) and previous <- current (:128). */
 int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double* out_scale_rot);
 
-/* Batched mode on DEVICE pointers; each pair (prev, cur) is processed as the two-call sequence of a fresh estimator.
+/* Batched mode on DEVICE pointers; each pair (prev, cur) is processed as the two-call sequence of a fresh estimator --
+ * by the same kernels as mof_sr_process, so pair k's (scale, rot) are bit-identical to a fresh engine's stateful calls.
  * d_cur / d_prev point at the top-left pixel of the resolution^2 crop inside each frame (pitch bytes per row).
  * d_out receives n_pairs * 4 doubles: scale, rot, pt.x, pt.y. Asynchronous on `stream`.
  * The pipeline runs through scratch owned by the engine. Calls on the same stream are ordered by the stream; a call

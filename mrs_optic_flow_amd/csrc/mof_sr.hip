@@ -337,7 +337,9 @@ hipError_t scratch_alloc(mof_sr_engine* e, int pairs) {
   if ((err = hipMalloc(&e->d_lp, (size_t)2 * pairs * 2 * nn)) != hipSuccess) return err;  // two passes: remap of pass k+1 beside the transforms of pass k
   {
     // pair pipeline: packed row spectra Zt, nn complex per pair; sequence pipeline: (pairs + 1) frames of half spectra
-    const size_t zt = (size_t)pairs * nn * 2 * sizeof(float), zh = (size_t)(pairs + 1) * mof::sr_zh_floats(res) * sizeof(float);
+    // (or, pairs through the frame kernels: 2 * pairs frames of half spectra)
+    const size_t zt = (size_t)pairs * nn * 2 * sizeof(float), zh1 = (size_t)(pairs + 1) * mof::sr_zh_floats(res) * sizeof(float),
+                 zh2 = (size_t)2 * pairs * mof::sr_zh_floats(res) * sizeof(float), zh = zh1 > zh2 ? zh1 : zh2;
     if ((err = hipMalloc(&e->d_Zt, zt > zh ? zt : zh)) != hipSuccess) return err;
   }
   if ((err = hipMalloc(&e->d_Dt, (size_t)pairs * res * (res / 2 + 1) * 2 * sizeof(float))) != hipSuccess) return err;
@@ -791,8 +793,20 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
       SR_TRY(hipStreamWaitEvent(s, e->ev_lp[b], 0));  // also the join: every remap precedes a wait on the caller's stream
     }
     mof::SrPcArgs a = pc_args(e, lp_buf, lp_buf + nn, 2 * nn, d_out + 4 * (size_t)k0);
-    a.degen = e->d_degen;
-    SR_TRY(mof::launch_sr_phase_correlate(a, res, n, s));
+    // Independent pairs go through the FRAME kernels too (sr_seq_kernel.hip): each of the 2n log-polar images gets its own real
+    // row transform (image 2p = cur of pair p, 2p + 1 = prev), K6s correlates slot 2p against 2p + 1, one pair per wave-run.
+    // Same-box c5: 360 k pairs/s against 354 k for the packed pair kernels (K5 / K6 of sr_kernel.hip, MOF_SR_PAIR_SEQ=0), and
+    // the batch entry now computes exactly what the stateful entry computes for a fresh estimator fed (prev, cur): same bits.
+    static const bool via_frames = [] { const char* v = getenv("MOF_SR_PAIR_SEQ"); return !v || atoi(v) != 0; }();
+    if (via_frames) {
+      const size_t zhf = mof::sr_zh_floats(res);
+      SR_TRY(mof::launch_sr_rows_real(lp_buf, nn, e->d_twiddles, e->d_Zt, zhf, res, 2 * n, s));
+      SR_TRY(mof::launch_sr_cols_seq(e->d_Zt + zhf, e->d_Zt, 2 * zhf, e->d_twiddles, e->d_Dt, res, n, 1, s));
+      SR_TRY(mof::launch_sr_peak(a, res, n, s));
+    } else {
+      a.degen = e->d_degen;
+      SR_TRY(mof::launch_sr_phase_correlate(a, res, n, s));
+    }
     if (two_lanes) SR_TRY(hipEventRecord(e->ev_fft[b], s));
   }
   SR_TRY(scratch_release(e, s));
