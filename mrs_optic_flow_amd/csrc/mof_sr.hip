@@ -32,12 +32,15 @@ namespace {
 constexpr int kTab = 32;            // INTER_TAB_SIZE
 constexpr int kCoefScale = 1 << 15; // INTER_REMAP_COEF_SCALE
 #ifndef MOF_SR_CHUNK
-#define MOF_SR_CHUNK 512
+#define MOF_SR_CHUNK 1024
 #endif
 // frame pairs per pipeline pass: 512 pairs of 480^2 = 1.9 GB of scratch (log-polar images, Zt, Dt). Same-box sweeps at c5
 // (tools/sweep_c5.sh, profiles/r02_c5_sweep.txt): 64 / 128 / 256 pairs -> 240 / 277 / 308 k pairs/s on one lane, 512 ->
 // 326 k, 1024 -> 324 k; with the second lane 254 / 283 / 312 / 318 / 313 k -- once a pass is long enough to fill the
-// chip the two-lane overlap has nothing left to hide, so one lane is the default.
+// chip the two-lane overlap has nothing left to hide, so one lane is the default. r03 (frame kernels, non-temporal streams;
+// tools/ab_sr_chunk.sh): 256 / 512 / 1024 pairs -> 341 / 360 / 366 k (c5) and 424 / 518 / 535 k (c5seq); passes that fit the
+// 256 MB Infinity Cache (64 pairs: Zt 118 MB + Dt 59 MB) are no faster per byte and pay the launch gaps (248 k): the default
+// is now 1024 pairs = 3.8 GB of scratch.
 constexpr int kChunkDefault = MOF_SR_CHUNK;
 // mof_sr_config.batch_chunk / .pipeline_lanes; MOF_SR_CHUNK / MOF_SR_OVERLAP in the environment override both at
 // create() (sweeps)

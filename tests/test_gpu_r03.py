@@ -1,7 +1,7 @@
 """GPU tests added in round 3:
 
 * BASELINE c5's scale/rotation stage at its FULL size through the shipped configuration: 480^2, M = 49.9, the default
-  512-pair passes, 1100 pairs (two full passes + a ragged third), both lane settings;
+  1024-pair passes, 1100 pairs (a full pass + a ragged second), both lane settings, and 512-pair passes;
 * engine lifetime under HIP graphs: a captured batch survives the loss of every Python reference to its engines, a
   garbage collection inside and after the capture, and a later eager batch that would have grown the scratch;
 * the non-blocking RCCL gather (sharding.AsyncGather) in a fresh 1-rank child process, incl. its consumer guard;
@@ -34,10 +34,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_c5_scale_rotation_full_size_default_passes(gpu, lanes):
+@pytest.mark.parametrize("lanes,chunk", [(1, 0), (2, 0), (1, 512)])
+def test_c5_scale_rotation_full_size_default_passes(gpu, lanes, chunk):
     """scaleRotationEstimator.cpp:34-148 at BASELINE c5's size: 1100 pairs of 480 x 480 crops through the default
-    512-pair passes. Every sampled pair -- on both sides of both pass boundaries and in the ragged tail -- equals the
+    1024-pair passes (and through 512-pair ones). Every sampled pair -- on both sides of the pass boundaries and in the ragged tail -- equals the
     same pair processed alone, bit for bit; pairs that repeat a prototype repeat its bits; six samples match the oracle
     (pt within 1e-4 px, scale / rot within 1e-5); the log-polar bytes of a sample match the oracle's byte for byte."""
     res, M, B = 480, 49.9, 1100
@@ -53,7 +53,7 @@ def test_c5_scale_rotation_full_size_default_passes(gpu, lanes):
     wide[:, :, :, 136:136 + res] = torch.from_numpy(views).to(gpu)
     cur = wide[0][torch.from_numpy(idx).to(gpu)][:, :, 136:136 + res]
     prev = wide[1][torch.from_numpy(pidx).to(gpu)][:, :, 136:136 + res]
-    est = ScaleRotationEstimator(res, M, pipeline_lanes=lanes)  # batch_chunk = 0: the library's default pass
+    est = ScaleRotationEstimator(res, M, pipeline_lanes=lanes, batch_chunk=chunk)  # 0: the library's default pass
     got = est.process_batch_device(cur, prev)
     torch.cuda.synchronize()
     got = got.cpu().numpy()
