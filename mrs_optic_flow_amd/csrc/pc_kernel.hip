@@ -51,13 +51,13 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   constexpr int T = P::T, H = N / 2, R1 = P::R1, R2 = P::R2, LPW = P::LPW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* z = reinterpret_cast<cf*>(smem);
-  Best* red = reinterpret_cast<Best*>(z + N * P::PITCH);
+  Best* red = reinterpret_cast<Best*>(z + P::TILE);
   int* const_code = reinterpret_cast<int*>(red + 32);  // [16] per-wave constant-patch codes (cur | prev << 16), then C_dc (pc_common.hpp)
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
   const int patches = a.grid_x * a.grid_y;
   constexpr int CPR = N / 16;  // 16-pixel chunks per row
-  const int lrow = wave0 * LPW + lane0 / CPR, lcol = (lane0 % CPR) * 16;  // this lane's 16 pixels of the patch
+  const int lrow = wave0 * LPW + ord1<N>(lane0 / CPR), lcol = (lane0 % CPR) * 16;  // this lane's 16 pixels of the patch (ord1: pc_passes.hpp)
   const bool ld_on = lane0 < LPW * CPR;  // (all lanes unless the workgroup has more than N*N/16 threads)
 
   // N >= 128: persistent workgroups (one per CU) walking a linear patch index. Smaller tiles: one workgroup per
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
 #endif
   // ---- the wave's own LPW rows: u8 -> f32 (exact), z = cur + i*prev  (convertTo, :1805-1806)
   {
-    const int row = wave * LPW + lane / CPR, col = (lane % CPR) * 16;
+    const int row = wave * LPW + ord1<N>(lane / CPR), col = (lane % CPR) * 16;
     int cc = 256, cp = 256;  // constant-patch codes of this wave (pc_common.hpp)
     if constexpr (DS == 1) {
       // pre-test: a textured patch has a lane whose first two dwords differ -- two compares and it is out

@@ -35,13 +35,39 @@ struct Cfg<64> {
 #ifndef MOF_SK128
 #define MOF_SK128 4
 #endif
+#ifndef MOF_LAYOUT128
+#define MOF_LAYOUT128 1  // 1: pitch 140 + row skew + class-ordered lane maps (below); 0: the r01/r02 layout (pitch 136)
+#endif
 #ifndef MOF_PITCH128
-#define MOF_PITCH128 136
+#define MOF_PITCH128 (MOF_LAYOUT128 ? 140 : 136)
 #endif
 template <>
 struct Cfg<128> {
   static constexpr int R1 = 16, R2 = 8, SK = MOF_SK128, PITCH = MOF_PITCH128;
 };
+
+// ---- bank layout of the 128 x 128 tile (r03; model: tools/design/lds_conflicts_128.py, 1.44x -> 1.05x conflict-free) ----
+// ds_read_b64 serves 32 lanes per cycle over 64 dword banks (element indices distinct mod 32), ds_write_b64 16 lanes over
+// 32 banks (distinct mod 16). With pitch 140 = 12 (mod 32) row r starts at bank-pair 12 r mod 32: the eight rows of an
+// aligned block start at the eight multiples of 4 -- even rows at the multiples of 8, odd rows in between -- and
+//   * a 32-lane group of 4 lines x 8 consecutive elements is conflict-free when the lines are one parity CLASS
+//     ({0,2,4,6} or {1,3,5,7}; both closed under r -> -r, which the Hermitian reads of the inverse column pass need),
+//   * a 16-lane group of 2 lines x 8 elements when the lines are 2 apart (280 = 8 mod 16),
+//   * a 32-lane group of 2 lines x 16 elements when the lines are 4 apart (560 = 16 mod 32),
+//   * 4 columns x 8 (reads) or x 4 (writes) consecutive rows always (12 r mod 32 distinct, 12 r mod 16 distinct).
+// Which lines (or butterfly indices of a twiddle-free first stage) share a lane group is free -- the twiddle index of
+// every lane stays what it was -- so the passes below only re-order them: ord1 = class order, ord2 = bit reversal.
+// Rows 16 x + k of two lane-group neighbours x, x + 2 differ by 4480 = 0 (mod 16): the 8 (r >> 5) row skew separates them.
+template <int N>
+__device__ __forceinline__ int ord1(int j) {  // j = 0..7 -> 0 2 4 6 1 3 5 7
+  if constexpr (N == 128 && MOF_LAYOUT128) return 2 * (j & 3) + (j >> 2);
+  else return j;
+}
+template <int N>
+__device__ __forceinline__ int ord2(int j) {  // j = 0..7 -> 0 4 2 6 1 5 3 7
+  if constexpr (N == 128 && MOF_LAYOUT128) return ((j & 1) << 2) | (j & 2) | (j >> 2);
+  else return j;
+}
 
 }  // namespace
 
@@ -58,7 +84,8 @@ struct PcTraits {
   // inverse (half-size) passes: lines per active wave, active waves
   static constexpr int LI = (LPW / 2 > 64 / BMIN) ? LPW / 2 : 64 / BMIN;
   static constexpr int WI = (N / 2) / LI;
-  static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best);
+  static constexpr int TILE = N * PITCH + ((N == 128 && MOF_LAYOUT128) ? 24 : 0);  // complex elements (+ the row skew's 8 (r >> 5))
+  static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)TILE + 64 * sizeof(Best);
 #ifndef MOF_PERSIST_MIN_N
 #define MOF_PERSIST_MIN_N 128
 #endif
@@ -73,7 +100,8 @@ struct PcTraits {
 // z(r, c): skewed tile address in complex units
 template <int N>
 __device__ __forceinline__ int zaddr(int r, int c) {
-  return r * PcTraits<N>::PITCH + c + (c >> PcTraits<N>::SK);
+  if constexpr (N == 128 && MOF_LAYOUT128) return r * PcTraits<N>::PITCH + 8 * (r >> 5) + c + (c >> PcTraits<N>::SK);
+  else return r * PcTraits<N>::PITCH + c + (c >> PcTraits<N>::SK);
 }
 
 // ---- row pass over LINES lines starting at line0 (wave-local) --------------------------------
@@ -88,7 +116,7 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
-      const int line = line0 + q / R2, x = q % R2;
+      const int line = line0 + ord1<N>(q / R2), x = q % R2;
 #pragma unroll
       for (int k = 0; k < R1; ++k) v[b][k] = lds_read(&z[zaddr<N>(line, x + k * R2)]);
       butterfly<R1>(v[b]);
@@ -97,7 +125,7 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
-      const int line = line0 + q / R2, x = q % R2;
+      const int line = line0 + ord1<N>(q / R2), x = q % R2;
 #pragma unroll
       for (int k = 0; k < R1; ++k) z[zaddr<N>(line, x * R1 + k)] = v[b][k];
     }
@@ -110,7 +138,7 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
-      const int line = line0 + q / R1, x = q % R1;
+      const int line = line0 + ord2<N>(q / R1), x = q % R1;
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
         cf a = lds_read(&z[zaddr<N>(line, x + k * R1)]);
@@ -127,7 +155,7 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
-      const int line = line0 + q / R1, x = q % R1;
+      const int line = line0 + ord2<N>(q / R1), x = q % R1;
 #pragma unroll
       for (int k = 0; k < R2; ++k) z[zaddr<N>(line, x + k * R1)] = v[b][k];
     }
@@ -152,7 +180,7 @@ __device__ __forceinline__ void row_pass_xpow(cf* __restrict__ z, int line0, int
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
-      const int line = line0 + q / R2, x = q % R2;
+      const int line = line0 + ord1<N>(q / R2), x = q % R2;
       const int pline = (N - line) % N;
       const bool packed = HAS_ROW0 && line == 0;
 #pragma unroll
@@ -168,7 +196,7 @@ __device__ __forceinline__ void row_pass_xpow(cf* __restrict__ z, int line0, int
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
-      const int line = line0 + q / R2, x = q % R2;
+      const int line = line0 + ord1<N>(q / R2), x = q % R2;
 #pragma unroll
       for (int k = 0; k < R1; ++k) z[zaddr<N>(line, x * R1 + k)] = v[b][k];
     }
@@ -180,7 +208,7 @@ __device__ __forceinline__ void row_pass_xpow(cf* __restrict__ z, int line0, int
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
-      const int line = line0 + q / R1, x = q % R1;
+      const int line = line0 + ord2<N>(q / R1), x = q % R1;
 #pragma unroll
       for (int k = 0; k < R2; ++k) {
         cf a = lds_read(&z[zaddr<N>(line, x + k * R1)]);
@@ -193,7 +221,7 @@ __device__ __forceinline__ void row_pass_xpow(cf* __restrict__ z, int line0, int
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
-      const int line = line0 + q / R1, x = q % R1;
+      const int line = line0 + ord2<N>(q / R1), x = q % R1;
 #pragma unroll
       for (int k = 0; k < R2; ++k) z[zaddr<N>(line, x + k * R1)] = v[b][k];
     }
@@ -211,7 +239,7 @@ __device__ __forceinline__ void col_pass_fwd(cf* __restrict__ z, int col0, int l
     cf v[PER][R1];
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
+      const int col = col0 + lane % CW + CW * b, x = ord1<N>(lane / CW);
 #pragma unroll
       for (int k = 0; k < R1; ++k) v[b][k] = lds_read(&z[zaddr<N>(x + k * R2, col)]);
       butterfly<R1>(v[b]);
@@ -219,7 +247,7 @@ __device__ __forceinline__ void col_pass_fwd(cf* __restrict__ z, int col0, int l
     wave_sync();
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
+      const int col = col0 + lane % CW + CW * b, x = ord1<N>(lane / CW);
 #pragma unroll
       for (int k = 0; k < R1; ++k) z[zaddr<N>(x * R1 + k, col)] = v[b][k];
     }
@@ -270,7 +298,7 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
     cf v[PER][R1];
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
+      const int col = col0 + lane % CW + CW * b, x = ord1<N>(lane / CW);
       // r = x + k R2 with x < R2: r < H exactly for k < R1/2, so the four Hermitian cases are decided at compile time
       // per k, except for the lanes with x == 0 at k = 0 (r = 0) and k = R1/2 (r = H), which read the packed row 0
       static_assert(R1 % 2 == 0 && 64 / CW == R2, "row classes below assume x < R2 and an even R1");
@@ -295,7 +323,7 @@ __device__ __forceinline__ Best col_pass_inv(cf* __restrict__ z, int col0, int l
     wave_sync();
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
-      const int col = col0 + lane % CW + CW * b, x = lane / CW;
+      const int col = col0 + lane % CW + CW * b, x = ord1<N>(lane / CW);
 #pragma unroll
       for (int k = 0; k < R1; ++k) z[zaddr<N>(x * R1 + k, col)] = v[b][k];
     }
