@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   // than a static stride does, and the patch coordinates come from blockIdx without the integer divisions that
   // otherwise cost ~5 % of the kernel's VALU instructions.
   constexpr bool PERSIST = P::PERSIST;
+  constexpr bool RAW = MOF_RAW_STAGE && N == 128 && DS == 1 && MOF_LAYOUT128;  // raw pixel staging (pc_passes.hpp)
   (void)patches;
   // (x0, y0) of a patch are in the units of the correlated image: full-res pixels, or quarter-res when DS = 4
   auto patch_base = [&](int p, const uint8_t* frames, size_t frame_stride) -> const uint8_t* {
@@ -157,13 +158,24 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
       }
     }
     uint32_t fc = 0, dc = 0, fp = 0, dp = 0;  // (long-range mode forms its pixels one by one: tracked in its loop)
-    if constexpr (DS == 1) {
+    if constexpr (RAW) {
+      // raw bytes into the wave's staging area; the first row stage converts them (pc_passes.hpp, raw_store)
+      raw_store<N>(z, wave * LPW, lane, cw, pw);
+      if constexpr (PERSIST) {
+        const int pn = p + gridDim.x;
+        if (pn < a.total) fetch16(pn, cw, pw);
+      }
+    } else if constexpr (DS == 1) {
       if (ld_on) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
+          for (int b = 0; b < 4; ++b) {
+#ifdef MOF_ABLATE_NOLOADW  // diagnostic build: one tile store per lane instead of 16 (results wrong by design)
+            if (q + b) continue;
+#endif
             z[zaddr<N>(row, col + q * 4 + b)] = {(float)((cw[q] >> (8 * b)) & 0xffu), (float)((pw[q] >> (8 * b)) & 0xffu)};
+          }
         if constexpr (PERSIST) {
           const int pn = p + gridDim.x;
           if (pn < a.total) fetch16(pn, cw, pw);
@@ -202,7 +214,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
 
   // ---- forward 2-D transform of z: rows (wave-local), barrier, columns (wave-local)  (dft x2, :1491-1493)
 #ifndef MOF_ABLATE_NOFWD
-  row_pass<N, LPW>(z, wave * LPW, lane, tw_row);
+  row_pass<N, LPW, RAW>(z, wave * LPW, lane, tw_row);
   __syncthreads();
   col_pass_fwd<N>(z, wave * LPW, lane, tw_col);
 #endif

@@ -104,21 +104,71 @@ __device__ __forceinline__ int zaddr(int r, int c) {
   else return r * PcTraits<N>::PITCH + c + (c >> PcTraits<N>::SK);
 }
 
+// ---- raw pixel staging (MOF_RAW_STAGE, N = 128) -------------------------------------------------------------------
+// ds_write_b64 costs 6 cycles of the VGPR -> LDS path per wave-instruction (MI355X_MICROARCH.md, LDS table) and that path,
+// not the arithmetic, is what the 128 x 128 kernel waits for. Converting a lane's 16 + 16 pixels to 16 complex floats
+// BEFORE the tile store is 16 such stores; instead the lane interleaves the raw bytes (c0 p0 c1 p1 ..: 8 v_perm) and
+// stores 32 B with two ds_write_b128 into a per-wave raw area that overlays the wave's own (not yet written) tile rows,
+// and the first row stage reads its operands as 16 ds_read_u16 and converts them on the way into the butterfly.
+// Slot s = lane / 8 of the wave holds row line0 + ord1(s); RAW_PITCH = 272 B puts the four slots of a 32-lane read
+// group 16 B apart (mod 128): conflict-free like the writes (8 lanes x 16 B at a 32-B stride).
+#ifndef MOF_RAW_STAGE
+#define MOF_RAW_STAGE 1
+#endif
+constexpr int RAW_PITCH = 272;
+template <int N>
+__device__ __forceinline__ unsigned char* raw_area(cf* z, int line0) {
+  return reinterpret_cast<unsigned char*>(z + zaddr<N>(line0, 0));
+}
+__device__ __forceinline__ uint32_t lds_read_u16(const unsigned char* p) {
+  typedef const volatile uint16_t __attribute__((address_space(3))) * lds_u16_ptr;
+  return *(lds_u16_ptr)(p);
+}
+// this lane's 16 + 16 pixels (4 + 4 dwords) -> interleaved bytes -> raw area (slot = lane / 8, chunk = lane % 8)
+template <int N>
+__device__ __forceinline__ void raw_store(cf* z, int line0, int lane, const uint32_t* cw, const uint32_t* pw) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef u4 __attribute__((address_space(3))) * lds_u4_ptr;
+  unsigned char* dst = raw_area<N>(z, line0) + (lane >> 3) * RAW_PITCH + (lane & 7) * 32;
+  u4 lo, hi;
+  lo.x = __builtin_amdgcn_perm(pw[0], cw[0], 0x05010400u);
+  lo.y = __builtin_amdgcn_perm(pw[0], cw[0], 0x07030602u);
+  lo.z = __builtin_amdgcn_perm(pw[1], cw[1], 0x05010400u);
+  lo.w = __builtin_amdgcn_perm(pw[1], cw[1], 0x07030602u);
+  hi.x = __builtin_amdgcn_perm(pw[2], cw[2], 0x05010400u);
+  hi.y = __builtin_amdgcn_perm(pw[2], cw[2], 0x07030602u);
+  hi.z = __builtin_amdgcn_perm(pw[3], cw[3], 0x05010400u);
+  hi.w = __builtin_amdgcn_perm(pw[3], cw[3], 0x07030602u);
+  *(lds_u4_ptr)(dst) = lo;
+  *(lds_u4_ptr)(dst + 16) = hi;
+}
+
 // ---- row pass over LINES lines starting at line0 (wave-local) --------------------------------
-template <int N, int LINES>
+// RAW: stage 1 takes z = cur + i prev from the wave's raw area (raw_store above) instead of the tile
+template <int N, int LINES, bool RAW = false>
 __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane, const cf* tw_row) {
   using P = PcTraits<N>;
   constexpr int R1 = P::R1, R2 = P::R2;
   {  // stage 1: radix R1, P = 1; R2 butterflies per line
     constexpr int PER = LINES * R2 / 64;
     static_assert(LINES * R2 % 64 == 0, "row stage 1 does not fill the wave");
+    static_assert(!RAW || (PER == 1 && R2 == 8 && LINES == 8), "raw staging is laid out for 8 lines x 8 butterflies");
     cf v[PER][R1];
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
       const int line = line0 + ord1<N>(q / R2), x = q % R2;
+      if constexpr (RAW) {
+        const unsigned char* src = raw_area<N>(z, line0) + (q / R2) * RAW_PITCH + 2 * x;
 #pragma unroll
-      for (int k = 0; k < R1; ++k) v[b][k] = lds_read(&z[zaddr<N>(line, x + k * R2)]);
+        for (int k = 0; k < R1; ++k) {
+          const uint32_t cp = lds_read_u16(src + 2 * k * R2);
+          v[b][k] = {(float)(cp & 0xffu), (float)(cp >> 8)};
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < R1; ++k) v[b][k] = lds_read(&z[zaddr<N>(line, x + k * R2)]);
+      }
       butterfly<R1>(v[b]);
     }
     wave_sync();
