@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   // than a static stride does, and the patch coordinates come from blockIdx without the integer divisions that
   // otherwise cost ~5 % of the kernel's VALU instructions.
   constexpr bool PERSIST = P::PERSIST;
-  constexpr bool RAW = MOF_RAW_STAGE && N == 128 && DS == 1 && MOF_LAYOUT128;  // raw pixel staging (pc_passes.hpp)
+  constexpr bool RAW = MOF_RAW_STAGE && (N == 128 || N == 64) && DS == 1 && T == N * N / 16;  // raw pixel staging (pc_passes.hpp)  // raw pixel staging (pc_passes.hpp)
   (void)patches;
   // (x0, y0) of a patch are in the units of the correlated image: full-res pixels, or quarter-res when DS = 4
   auto patch_base = [&](int p, const uint8_t* frames, size_t frame_stride) -> const uint8_t* {

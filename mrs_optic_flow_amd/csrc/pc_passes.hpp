@@ -110,12 +110,16 @@ __device__ __forceinline__ int zaddr(int r, int c) {
 // BEFORE the tile store is 16 such stores; instead the lane interleaves the raw bytes (c0 p0 c1 p1 ..: 8 v_perm) and
 // stores 32 B with two ds_write_b128 into a per-wave raw area that overlays the wave's own (not yet written) tile rows,
 // and the first row stage reads its operands as 16 ds_read_u16 and converts them on the way into the butterfly.
-// Slot s = lane / 8 of the wave holds row line0 + ord1(s); RAW_PITCH = 272 B puts the four slots of a 32-lane read
-// group 16 B apart (mod 128): conflict-free like the writes (8 lanes x 16 B at a 32-B stride).
+// Slot s = lane / CPR of the wave holds row line0 + ord1(s); a slot pitch of 2 N + 16 B puts the four slots of a 32-lane read
+// group 16 B apart (mod 128): conflict-free like the writes (8 lanes x 16 B at a 32-B stride; N = 64: two slots interleave).
+// N = 64 (c2): same-box A/B in DESIGN.md.
 #ifndef MOF_RAW_STAGE
 #define MOF_RAW_STAGE 1
 #endif
-constexpr int RAW_PITCH = 272;
+template <int N>
+struct RawCfg {
+  static constexpr int PITCH = 2 * N + 16, CPR = N / 16;  // bytes per slot (272 / 144), 16-pixel chunks per row
+};
 template <int N>
 __device__ __forceinline__ unsigned char* raw_area(cf* z, int line0) {
   return reinterpret_cast<unsigned char*>(z + zaddr<N>(line0, 0));
@@ -124,12 +128,12 @@ __device__ __forceinline__ uint32_t lds_read_u16(const unsigned char* p) {
   typedef const volatile uint16_t __attribute__((address_space(3))) * lds_u16_ptr;
   return *(lds_u16_ptr)(p);
 }
-// this lane's 16 + 16 pixels (4 + 4 dwords) -> interleaved bytes -> raw area (slot = lane / 8, chunk = lane % 8)
+// this lane's 16 + 16 pixels (4 + 4 dwords) -> interleaved bytes -> raw area (slot = lane / CPR, chunk = lane % CPR)
 template <int N>
 __device__ __forceinline__ void raw_store(cf* z, int line0, int lane, const uint32_t* cw, const uint32_t* pw) {
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   typedef u4 __attribute__((address_space(3))) * lds_u4_ptr;
-  unsigned char* dst = raw_area<N>(z, line0) + (lane >> 3) * RAW_PITCH + (lane & 7) * 32;
+  unsigned char* dst = raw_area<N>(z, line0) + (lane / RawCfg<N>::CPR) * RawCfg<N>::PITCH + (lane % RawCfg<N>::CPR) * 32;
   u4 lo, hi;
   lo.x = __builtin_amdgcn_perm(pw[0], cw[0], 0x05010400u);
   lo.y = __builtin_amdgcn_perm(pw[0], cw[0], 0x07030602u);
@@ -152,14 +156,14 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
   {  // stage 1: radix R1, P = 1; R2 butterflies per line
     constexpr int PER = LINES * R2 / 64;
     static_assert(LINES * R2 % 64 == 0, "row stage 1 does not fill the wave");
-    static_assert(!RAW || (PER == 1 && R2 == 8 && LINES == 8), "raw staging is laid out for 8 lines x 8 butterflies");
+    static_assert(!RAW || (R2 == 8 && LINES == P::LPW && LINES * RawCfg<N>::CPR == 64), "raw staging: one slot per line, R2 = 8");
     cf v[PER][R1];
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
       const int q = lane + 64 * b;
       const int line = line0 + ord1<N>(q / R2), x = q % R2;
       if constexpr (RAW) {
-        const unsigned char* src = raw_area<N>(z, line0) + (q / R2) * RAW_PITCH + 2 * x;
+        const unsigned char* src = raw_area<N>(z, line0) + (q / R2) * RawCfg<N>::PITCH + 2 * x;
 #pragma unroll
         for (int k = 0; k < R1; ++k) {
           const uint32_t cp = lds_read_u16(src + 2 * k * R2);
