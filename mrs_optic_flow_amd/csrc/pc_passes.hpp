@@ -71,6 +71,9 @@ __device__ __forceinline__ int ord2(int j) {  // j = 0..7 -> 0 4 2 6 1 5 3 7
 
 }  // namespace
 
+#ifndef MOF_SKEW64
+#define MOF_SKEW64 1  // 64 x 64 tile: rows 8 x + k of lane-group neighbours x, x + 1 are 576 = 0 (mod 16) apart -> 8 (r >> 3) row skew
+#endif
 template <int N>
 struct PcTraits {
 #ifndef MOF_K1_T64
@@ -84,7 +87,8 @@ struct PcTraits {
   // inverse (half-size) passes: lines per active wave, active waves
   static constexpr int LI = (LPW / 2 > 64 / BMIN) ? LPW / 2 : 64 / BMIN;
   static constexpr int WI = (N / 2) / LI;
-  static constexpr int TILE = N * PITCH + ((N == 128 && MOF_LAYOUT128) ? 24 : 0);  // complex elements (+ the row skew's 8 (r >> 5))
+  // complex elements of the tile, incl. the row skew (zaddr): 8 (r >> 5) at N = 128, 8 (r >> 3) at N = 64
+  static constexpr int TILE = N * PITCH + ((N == 128 && MOF_LAYOUT128) ? 24 : 0) + ((N == 64 && MOF_SKEW64) ? 56 : 0);
   static constexpr size_t LDS_BYTES = sizeof(float) * 2 * (size_t)TILE + 64 * sizeof(Best);
 #ifndef MOF_PERSIST_MIN_N
 #define MOF_PERSIST_MIN_N 128
@@ -101,6 +105,7 @@ struct PcTraits {
 template <int N>
 __device__ __forceinline__ int zaddr(int r, int c) {
   if constexpr (N == 128 && MOF_LAYOUT128) return r * PcTraits<N>::PITCH + 8 * (r >> 5) + c + (c >> PcTraits<N>::SK);
+  else if constexpr (N == 64 && MOF_SKEW64) return r * PcTraits<N>::PITCH + 8 * (r >> 3) + c + (c >> PcTraits<N>::SK);
   else return r * PcTraits<N>::PITCH + c + (c >> PcTraits<N>::SK);
 }
 

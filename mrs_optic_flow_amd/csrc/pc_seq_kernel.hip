@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) pc_seq_kernel(PcArgs a, int n_pairs, int 
   using P = PcTraits<N>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* z = reinterpret_cast<cf*>(smem);
-  Best* red = reinterpret_cast<Best*>(z + N * P::PITCH);
+  Best* red = reinterpret_cast<Best*>(z + P::TILE);
   const int lane0 = threadIdx.x & 63, wave0 = threadIdx.x >> 6;
   const int p0 = blockIdx.z * run;                          // first pair of this run: frames p0 .. p0 + np
   const int np = n_pairs - p0 < run ? n_pairs - p0 : run;
