@@ -41,15 +41,47 @@ __device__ __forceinline__ cf twiddle(const float* __restrict__ table, int idx) 
   return {t.x, t.y};
 }
 
+// ---- raw pixel staging (as pc_passes.hpp, raw_store): a chunk's 8 + 8 pixels leave as ONE ds_write_b128 of interleaved
+// bytes (c0 p0 c1 p1 ..) into a per-wave area that overlays the wave's own tile rows, and the first row stage reads its
+// operands with ds_read_u16 and converts them on the way into the butterfly -- 8 ds_write_b64 (48 cycles of the
+// VGPR -> LDS path) per chunk less. Slot = line within the wave, 272 B apart (four lines of a 32-lane group 16 B apart).
+#ifndef MOF_RAW_STAGE
+#define MOF_RAW_STAGE 1
+#endif
+constexpr int RAW_PITCH = 272;
+__device__ __forceinline__ unsigned char* raw_area(cf* z, int line0) { return reinterpret_cast<unsigned char*>(z + za(line0, 0)); }
+__device__ __forceinline__ void raw_store8(cf* z, int line0, int slot, int chunk, const uint32_t* c, const uint32_t* pv) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef u4 __attribute__((address_space(3))) * lds_u4_ptr;
+  u4 d;
+  d.x = __builtin_amdgcn_perm(pv[0], c[0], 0x05010400u);
+  d.y = __builtin_amdgcn_perm(pv[0], c[0], 0x07030602u);
+  d.z = __builtin_amdgcn_perm(pv[1], c[1], 0x05010400u);
+  d.w = __builtin_amdgcn_perm(pv[1], c[1], 0x07030602u);
+  *(lds_u4_ptr)(raw_area(z, line0) + slot * RAW_PITCH + chunk * 16) = d;
+}
+
 // ---- row pass over lines [line0, line0 + 8) that are < nlines (wave-local) ----------------------------
+// RAW: stage 1 takes z = cur + i prev from the wave's raw area
+template <bool RAW = false>
 __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int nlines, int lane, const float* tw) {
   {  // stage 1: radix 15; 8 butterflies per line -> one per lane
     const int line = line0 + lane / R2, x = lane % R2;
     const bool on = line < nlines;
     cf v[R1];
     if (on) {
+      if constexpr (RAW) {
+        typedef const volatile uint16_t __attribute__((address_space(3))) * lds_u16_ptr;
+        const unsigned char* src = raw_area(z, line0) + (lane / R2) * RAW_PITCH + 2 * x;
 #pragma unroll
-      for (int k = 0; k < R1; ++k) v[k] = lds_read(&z[za(line, x + k * R2)]);
+        for (int k = 0; k < R1; ++k) {
+          const uint32_t cp = *(lds_u16_ptr)(src + 2 * k * R2);
+          v[k] = {(float)(cp & 0xffu), (float)(cp >> 8)};
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < R1; ++k) v[k] = lds_read(&z[za(line, x + k * R2)]);
+      }
       butterfly15(v);
     }
     wave_sync();
@@ -312,6 +344,10 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
         asm volatile("");
         const_track(pv, 2, b == 0, fp, dp);
       }
+      if constexpr (MOF_RAW_STAGE) {
+        raw_store8(z, wave * LPW, q / (N / 8), q % (N / 8), c, pv);
+        continue;
+      }
       // The 8 pixels of a chunk are stored in a per-lane rotated order: straight order puts the 16 lanes of a
       // ds_write_b64 group on two banks (chunks are 8 elements apart), an 8-way conflict on every store.
       const int rot = ((q % (N / 8)) >> 1) & 7;
@@ -338,7 +374,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   wave_sync();
 
   // ---- forward 2-D transform: rows (wave-local), barrier, columns (wave-local)
-  row_pass(z, wave * LPW, N, lane, tw);
+  row_pass<MOF_RAW_STAGE != 0>(z, wave * LPW, N, lane, tw);
   __syncthreads();
   col_pass_fwd(z, wave * LPW, lane, tw);
   __syncthreads();
@@ -362,7 +398,7 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
   __syncthreads();
 
   // ---- Hermitian inverse: rows 0..H-1, then column pairs (idft :1497)
-  if (wave * LPW < H) row_pass(z, wave * LPW, H, lane, tw);
+  if (wave * LPW < H) row_pass<false>(z, wave * LPW, H, lane, tw);
   __syncthreads();
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
   if (wave * LPW < H) best = col_pass_inv<PK>(z, wave * LPW, lane, tw, a.search_radius);
