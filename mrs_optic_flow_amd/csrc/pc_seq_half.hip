@@ -85,16 +85,54 @@ struct HalfTw {
   }
 };
 
-// ---- transforms along x of the wave's 8 lines, then the wave-local untangle into the two half-spectrum rows per line ----
+// ---- raw pixel staging (N = 128; as pc_passes.hpp, raw_store): the lane's 16 + 16 pixels (patch rows 2j, 2j + 1) leave as
+// two ds_write_b128 of interleaved bytes into a per-wave area over the wave's own lines; the first row stage converts.
+#ifndef MOF_RAW_STAGE
+#define MOF_RAW_STAGE 1
+#endif
+constexpr int HALF_RAW_PITCH = 272;
 template <int N>
+__device__ __forceinline__ unsigned char* half_raw_area(cf* z, int line0) {
+  return reinterpret_cast<unsigned char*>(z + HalfTile<N>::line(line0, 0));
+}
+template <int N>
+__device__ __forceinline__ void half_raw_store(cf* z, int line0, int lane, const uint32_t* ra, const uint32_t* rb) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef u4 __attribute__((address_space(3))) * lds_u4_ptr;
+  unsigned char* dst = half_raw_area<N>(z, line0) + (lane >> 3) * HALF_RAW_PITCH + (lane & 7) * 32;
+  u4 lo, hi;
+  lo.x = __builtin_amdgcn_perm(rb[0], ra[0], 0x05010400u);
+  lo.y = __builtin_amdgcn_perm(rb[0], ra[0], 0x07030602u);
+  lo.z = __builtin_amdgcn_perm(rb[1], ra[1], 0x05010400u);
+  lo.w = __builtin_amdgcn_perm(rb[1], ra[1], 0x07030602u);
+  hi.x = __builtin_amdgcn_perm(rb[2], ra[2], 0x05010400u);
+  hi.y = __builtin_amdgcn_perm(rb[2], ra[2], 0x07030602u);
+  hi.z = __builtin_amdgcn_perm(rb[3], ra[3], 0x05010400u);
+  hi.w = __builtin_amdgcn_perm(rb[3], ra[3], 0x07030602u);
+  *(lds_u4_ptr)(dst) = lo;
+  *(lds_u4_ptr)(dst + 16) = hi;
+}
+
+// ---- transforms along x of the wave's 8 lines, then the wave-local untangle into the two half-spectrum rows per line ----
+template <int N, bool RAW = false>
 __device__ __forceinline__ void half_rows(cf* __restrict__ z, int line0, int lane, const HalfTw<N>& tw) {
   using L = HalfTile<N>;
   constexpr int R1 = L::R1, R2 = L::R2, H = L::H;
   {
     const int ln = line0 + (lane >> 3), x = lane & 7;
     cf v[R1];
+    if constexpr (RAW) {
+      typedef const volatile uint16_t __attribute__((address_space(3))) * lds_u16_ptr;
+      const unsigned char* src = half_raw_area<N>(z, line0) + (lane >> 3) * HALF_RAW_PITCH + 2 * x;
 #pragma unroll
-    for (int k = 0; k < R1; ++k) v[k] = lds_read(&z[L::line(ln, x + k * R2)]);
+      for (int k = 0; k < R1; ++k) {
+        const uint32_t ab = *(lds_u16_ptr)(src + 2 * k * R2);
+        v[k] = {(float)(ab & 0xffu), (float)(ab >> 8)};
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < R1; ++k) v[k] = lds_read(&z[L::line(ln, x + k * R2)]);
+    }
     butterfly<R1>(v);
     wave_sync();
 #pragma unroll
@@ -399,13 +437,18 @@ __global__ void __launch_bounds__(HalfTile<N>::T, (N == 64 ? 4 : 2)) pc_seq_half
     lane &= 63;
     wave &= W - 1;
     {
-      const int lr = 8 * wave + (lane >> 3), c0 = PPL * (lane & 7);
+      constexpr bool RAW = MOF_RAW_STAGE && PPL == 16;
+      if constexpr (RAW) {
+        half_raw_store<N>(z, 8 * wave, lane, ra, rb);
+      } else {
+        const int lr = 8 * wave + (lane >> 3), c0 = PPL * (lane & 7);
 #pragma unroll
-      for (int i = 0; i < PPL; ++i)
-        z[L::line(lr, c0 + i)] = {(float)((ra[i >> 2] >> (8 * (i & 3))) & 0xffu), (float)((rb[i >> 2] >> (8 * (i & 3))) & 0xffu)};
+        for (int i = 0; i < PPL; ++i)
+          z[L::line(lr, c0 + i)] = {(float)((ra[i >> 2] >> (8 * (i & 3))) & 0xffu), (float)((rb[i >> 2] >> (8 * (i & 3))) & 0xffu)};
+      }
       if (f < np) fetch(p0 + f + 1);
       wave_sync();
-      half_rows<N>(z, 8 * wave, lane, tw);
+      half_rows<N, RAW>(z, 8 * wave, lane, tw);
     }
     __syncthreads();
     half_cols<N, PK>(z, 8 * wave, lane, tw, prev, prev0, prevH, f == 0, wave == 0);
