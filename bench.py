@@ -56,12 +56,14 @@ def binding_note(name: str, wl) -> str:
         return ("c5 on a video: one Lanczos4 remap and one real row transform per frame (K5s), column pass walking pairs in "
                 "time with the previous spectra in registers (K6s); DESIGN.md section 4 (sequence mode)")
     if wl["kind"] == "fft+sr":
-        return ("scale/rotation pipeline K4-K8 takes 79 % of the step: log-polar gathers (v_dot4c taps on LDS-staged source "
-                "boxes; VALU + L1 look-ups) 34 %, whole-frame transforms through Zt / Dt (2.2-2.8 TB/s of HBM traffic) 43 %; "
+        return ("scale/rotation pipeline K4-K8 takes 78 % of the step: log-polar gathers (v_dot4c taps on LDS-staged source "
+                "boxes: LDS reads + VALU) 34 %, whole-frame transforms through Zt / Dt (per-frame real row transforms K5s, column "
+                "pass K6s, inverse rows K7: 4.5-4.9 TB/s of HBM traffic each, 70-80 % of the achievable rate) 43 %; "
                 "K1 as in c2; DESIGN.md section 4 (K4-K8)")
     if wl["n"] >= 120:
-        return ("one persistent workgroup per CU (the tile fills the LDS): latency of the per-patch phase chain, "
-                "VALU issue ~37 %, LDS pipe 35-60 % busy (N = 128: 28 % of it bank conflicts); not HBM")
+        return ("one persistent workgroup per CU (the tile fills the LDS): the LDS store path (ds_write_b64 = 6 cycles per "
+                "wave-instruction, 7.5 tile stores per patch pair) and the 8-wave inverse passes; N = 128: VALU issue ~42 %, "
+                "LDS 46 % busy, 6 % of it bank conflicts (profiles/r03_c4_sq_pmc.csv); not HBM -- DESIGN.md section 4 (K1 at N = 128)")
     return ("latency of the per-patch phase chain at 4 workgroups/CU (LDS-capacity limit); VALU issue ~44 % "
             "(334.9 M instructions x 2 cycles per launch, profiles/r02_c2_sq_pmc.csv), LDS pipe 57-66 % busy of which 16-19 % "
             "bank conflicts, 21 % of wave-cycles waiting on LDS; not HBM -- see DESIGN.md section 4 (K1)")
