@@ -228,10 +228,10 @@ def test_full_size_c2_batch_properties(gpu):
         _compare(res[k], cur[k].cpu().numpy(), prev[k].cpu().numpy(), lay, f"full{k}")
 
 
-def test_long_range_mode(gpu):
+@pytest.mark.parametrize("fs,n", [(512, 64), (1024, 128), (256, 32), (960, 120)])
+def test_long_range_mode(gpu, fs, n):
     """processImageLongRange: quarter-resolution patches formed inside the kernel; shares `first`/prev with
-    processImage (FftMethod.cpp:1920-1922, :1992, :2004)."""
-    fs, n = 512, 64  # sqNum = 8 -> sqNum_lr = 2
+    processImage (FftMethod.cpp:1920-1922, :1992, :2004). Every patch size has its own load path (sqNum = 8 -> sqNum_lr = 2)."""
     seq = [synth.pair_np(41, fs, fs, 8 * t, -4 * t)[0] for t in range(3)]
     lay = O.fft_layout(fs, fs, n, 8, 8)
     fm = FftMethod(fs, n, 80.0)
@@ -240,7 +240,8 @@ def test_long_range_mode(gpu):
     assert np.allclose(out0, O.fft_process_long_range(seq[0], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
     out1 = fm.processImageLongRange(seq[1])
     assert np.allclose(out1, O.fft_process_long_range(seq[1], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
-    assert np.allclose(out1, [2.0, -1.0], rtol=0, atol=0.3)
+    if n >= 64:  # (a quarter-resolution 32-px patch of this texture is too coarse for the planted motion; parity above holds)
+        assert np.allclose(out1, [2.0, -1.0], rtol=0, atol=0.3)
     out2 = fm.processImage(seq[2])  # the ordinary path continues from the same previous frame
     assert np.allclose(out2, O.fft_process(seq[2], seq[1], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
     cur = torch.from_numpy(np.stack(seq[1:])).to(gpu)
@@ -277,7 +278,7 @@ def test_reference_default_geometry_480_120(gpu):
     assert np.allclose(got, np.array(shifts, float), rtol=0, atol=3e-5)
 
 
-@pytest.mark.parametrize("n,fs", [(64, 256), (120, 240)])
+@pytest.mark.parametrize("n,fs", [(64, 256), (120, 240), (128, 256), (32, 96)])
 def test_bgr_front_end_fused_into_the_load(gpu, n, fs):
     """BGR8 camera frames, crop at (xi, yi) and CV_RGB2GRAY (optic_flow.cpp:1609-1622) fused into K1."""
     B, H, W, xi, yi = 3, fs + 17, fs + 40, 23, 9
