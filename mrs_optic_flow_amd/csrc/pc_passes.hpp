@@ -152,6 +152,19 @@ __device__ __forceinline__ void raw_store(cf* z, int line0, int lane, const uint
   *(lds_u4_ptr)(dst + 16) = hi;
 }
 
+// 8 lines x 8 chunks of 8 + 8 pixels per wave (the sequence kernel's lines = patch rows 2j | 2j + 1): one ds_write_b128 per lane
+template <int N>
+__device__ __forceinline__ void raw_store8(cf* z, int line0, int lane, const uint32_t* a, const uint32_t* b) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef u4 __attribute__((address_space(3))) * lds_u4_ptr;
+  u4 d;
+  d.x = __builtin_amdgcn_perm(b[0], a[0], 0x05010400u);
+  d.y = __builtin_amdgcn_perm(b[0], a[0], 0x07030602u);
+  d.z = __builtin_amdgcn_perm(b[1], a[1], 0x05010400u);
+  d.w = __builtin_amdgcn_perm(b[1], a[1], 0x07030602u);
+  *(lds_u4_ptr)(raw_area<N>(z, line0) + (lane >> 3) * RawCfg<N>::PITCH + (lane & 7) * 16) = d;
+}
+
 // ---- row pass over LINES lines starting at line0 (wave-local) --------------------------------
 // RAW: stage 1 takes z = cur + i prev from the wave's raw area (raw_store above) instead of the tile
 template <int N, int LINES, bool RAW = false>
@@ -161,7 +174,7 @@ __device__ __forceinline__ void row_pass(cf* __restrict__ z, int line0, int lane
   {  // stage 1: radix R1, P = 1; R2 butterflies per line
     constexpr int PER = LINES * R2 / 64;
     static_assert(LINES * R2 % 64 == 0, "row stage 1 does not fill the wave");
-    static_assert(!RAW || (R2 == 8 && LINES == P::LPW && LINES * RawCfg<N>::CPR == 64), "raw staging: one slot per line, R2 = 8");
+    static_assert(!RAW || R2 == 8, "raw staging: one slot per line, 8 butterflies per line");
     cf v[PER][R1];
 #pragma unroll
     for (int b = 0; b < PER; ++b) {

@@ -215,13 +215,18 @@ __global__ void __launch_bounds__(256) pc_seq_kernel(PcArgs a, int n_pairs, int 
     wave &= 3;
     // ---- 1. the wave's 8 complex lines (tile rows 16 wave .. +7): u8 -> f32 (convertTo, :1805-1806), row transforms
     {
-      const int lr = 16 * wave + (lane >> 3), c0 = 8 * (lane & 7);
+      const int lr = 16 * wave + (lane >> 3);
+#if MOF_RAW_STAGE  // raw pixel staging (pc_passes.hpp): one ds_write_b128 instead of eight ds_write_b64 of converted pixels
+      raw_store8<N>(z, 16 * wave, lane, ra, rb);
+#else
+      const int c0 = 8 * (lane & 7);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         z[zaddr<N>(lr, c0 + i)] = {(float)((ra[i >> 2] >> (8 * (i & 3))) & 0xffu), (float)((rb[i >> 2] >> (8 * (i & 3))) & 0xffu)};
+#endif
       if (f < np) fetch(p0 + f + 1);
       wave_sync();
-      row_pass<N, 8>(z, 16 * wave, lane, tw_row);
+      row_pass<N, 8, MOF_RAW_STAGE != 0>(z, 16 * wave, lane, tw_row);
       // untangle line j into rows 2j, 2j + 1 (doubled): lane = (line, u mod 8), u = ug + 8 m
       const int ug = lane & 7;
       cf zk[4], zm[4], z32 = {0.f, 0.f};
