@@ -43,6 +43,8 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{tag}_*"))):
             shutil.copy(st, os.path.join(dst, f"{tag}_mfma_rowdft_kernel_stats.csv"))
         continue
     bench = None
+    if not os.path.exists(os.path.join(d, "bench.json")):
+        continue  # (a counter-only directory of tools/pmc.sh, e.g. prof_<round>_c4_sq: condensed by tools/pmc_table.py)
     if os.path.exists(os.path.join(d, "bench.json")):
         bench = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
         json.dump(bench, open(os.path.join(dst, f"{tag}_{wl}_bench.json"), "w"), indent=1)
