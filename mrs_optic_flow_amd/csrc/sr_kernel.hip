@@ -196,8 +196,15 @@ __host__ __device__ inline int lp_box_capacity(int box_dwords_max) {
 // every box row is a cache line of its own), and one shared box has 2.2-2.5x fewer rows than four separate ones. The
 // lanes of all four waves stage it together (slot = thread + 256 t) and meet at a raw s_barrier (a __syncthreads would
 // drain the ring's loads in flight).
+// SUPER runs four workgroups per CU (r03): 16 waves instead of 12 shorten nothing in a wave's own chain (≈60 VALU instructions
+// at one issue per ≈4 clocks + 24 LDS reads and their round trip per image) but put a third more of them side by side:
+// c5seq +3.4 % same-box even with 7 spilled dwords; with a 12-deep staging ring where the map's boxes allow it (NR = 12:
+// 8 VGPRs less) the Lanczos4 form fits 128 VGPRs.
+#ifndef MOF_LP_SUPER_WPE
+#define MOF_LP_SUPER_WPE 4
+#endif
 template <int K, int NR, bool SUPER>
-__global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave, int xcd_groups) {
+__global__ void __launch_bounds__(256, (SUPER ? MOF_LP_SUPER_WPE : 1)) MOF_LP_ATTR sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave, int xcd_groups) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lp_lds[];
   const int res = a.res, tiles = (res + 7) / 8, n_tiles = SUPER ? (tiles / 2) * (tiles / 2) : tiles * tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -463,15 +470,15 @@ __global__ void __launch_bounds__(256) MOF_LP_ATTR sr_logpolar_staged_kernel(SrL
   };
   // ring classes: 60 % of the 480^2 map's tiles have a box of at most 64 dwords (T = 1), the mean is 2.2 -- rounding T
   // up to {4, 8, 16} issued 2.2x the loads and made the texture addresser the limit (TA_BUSY 85 %)
-  static_assert(NR == 16, "ring classes are written for 16 staging registers");
+  static_assert(NR == 16 || NR == 12, "ring classes are written for 12 or 16 staging registers");
   if (T <= 1) pipeline(std::integral_constant<int, 1>{});
   else if (T <= 2) pipeline(std::integral_constant<int, 2>{});
   else if (T <= 3) pipeline(std::integral_constant<int, 3>{});
   else if (T <= 4) pipeline(std::integral_constant<int, 4>{});
   else if (T <= 6) pipeline(std::integral_constant<int, 6>{});
   else if (T <= 8) pipeline(std::integral_constant<int, 8>{});
-  else if (T <= 12) pipeline(std::integral_constant<int, 12>{});
-  else pipeline(std::integral_constant<int, 16>{});
+  else if (NR < 16 || T <= 12) pipeline(std::integral_constant<int, 12>{});
+  else if constexpr (NR >= 16) pipeline(std::integral_constant<int, 16>{});
 }
 
 // ---- K5: forward row transforms of z = cur_lp + i prev_lp, written transposed -----------------------------
@@ -784,8 +791,12 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
       const int n_super = (tiles / 2) * (tiles / 2);
       const unsigned sblocks = xcd_groups ? (unsigned)(8 * ((groups + 7) / 8) * n_super) : (unsigned)((long)n_super * groups);
       const size_t slds = sizeof(uint32_t) * (size_t)2 * 4 * lp_box_capacity((a.sbox_dwords_max + 3) / 4) + 512;  // two boxes + two output tiles
+      constexpr int NRS = 12;  // the shorter ring where every box of the map fits it (480^2, M = 49.9: 2472 dwords of 3072)
+      const bool short_ring = a.sbox_dwords_max <= 256 * NRS;
       if (interp == 2)
         hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
+      else if (short_ring)
+        hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NRS, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
       else
         hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
       return hipGetLastError();
