@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(1024) sr_logpolar_lds_kernel(SrLpArgs a, int n
 // largest box of the map
 __host__ __device__ inline int lp_box_capacity(int box_dwords_max) {
   const int t = (box_dwords_max + 63) / 64;
-  return 64 * (t <= 4 ? 4 : (t <= 8 ? 8 : 16));
+  return 64 * (t <= 4 ? 4 : (t <= 8 ? 8 : (t <= 12 ? 12 : 16)));
 }
 
 #ifdef MOF_LP_WPE
@@ -203,8 +203,11 @@ __host__ __device__ inline int lp_box_capacity(int box_dwords_max) {
 #ifndef MOF_LP_SUPER_WPE
 #define MOF_LP_SUPER_WPE 4
 #endif
+#ifndef MOF_LP_SUPER_WPE4
+#define MOF_LP_SUPER_WPE4 4  // the cubic form
+#endif
 template <int K, int NR, bool SUPER>
-__global__ void __launch_bounds__(256, (SUPER ? MOF_LP_SUPER_WPE : 1)) MOF_LP_ATTR sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave, int xcd_groups) {
+__global__ void __launch_bounds__(256, (SUPER ? (K == 4 ? MOF_LP_SUPER_WPE4 : MOF_LP_SUPER_WPE) : 1)) MOF_LP_ATTR sr_logpolar_staged_kernel(SrLpArgs a, int n_images, int img_per_wave, int xcd_groups) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lp_lds[];
   const int res = a.res, tiles = (res + 7) / 8, n_tiles = SUPER ? (tiles / 2) * (tiles / 2) : tiles * tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -793,7 +796,9 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
       const size_t slds = sizeof(uint32_t) * (size_t)2 * 4 * lp_box_capacity((a.sbox_dwords_max + 3) / 4) + 512;  // two boxes + two output tiles
       constexpr int NRS = 12;  // the shorter ring where every box of the map fits it (480^2, M = 49.9: 2472 dwords of 3072)
       const bool short_ring = a.sbox_dwords_max <= 256 * NRS;
-      if (interp == 2)
+      if (interp == 2 && short_ring)
+        hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NRS, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
+      else if (interp == 2)
         hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
       else if (short_ring)
         hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NRS, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
