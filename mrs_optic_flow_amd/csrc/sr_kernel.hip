@@ -795,7 +795,9 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
       const unsigned sblocks = xcd_groups ? (unsigned)(8 * ((groups + 7) / 8) * n_super) : (unsigned)((long)n_super * groups);
       const size_t slds = sizeof(uint32_t) * (size_t)2 * 4 * lp_box_capacity((a.sbox_dwords_max + 3) / 4) + 512;  // two boxes + two output tiles
       constexpr int NRS = 12;  // the shorter ring where every box of the map fits it (480^2, M = 49.9: 2472 dwords of 3072)
-      const bool short_ring = a.sbox_dwords_max <= 256 * NRS;
+      // (MOF_SR_LP_RING=16 keeps the 16-deep form for maps that fit the short one: A/B runs and the tests of that form)
+      static const bool long_ring = [] { const char* e = getenv("MOF_SR_LP_RING"); return e && atoi(e) == 16; }();
+      const bool short_ring = !long_ring && a.sbox_dwords_max <= 256 * NRS;
       if (interp == 2 && short_ring)
         hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NRS, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
       else if (interp == 2)

@@ -5,7 +5,9 @@
 * engine lifetime under HIP graphs: a captured batch survives the loss of every Python reference to its engines, a
   garbage collection inside and after the capture, and a later eager batch that would have grown the scratch;
 * the non-blocking RCCL gather (sharding.AsyncGather) in a fresh 1-rank child process, incl. its consumer guard;
-* bench.py's N > 1 path rehearsed as two fresh gloo ranks sharing the one GPU.
+* bench.py's N > 1 path rehearsed as two fresh gloo ranks sharing the one GPU;
+* the remap kernel's OTHER forms (16-deep staging ring, one box per wave instead of per super-tile), which the shipped maps no
+  longer select by themselves, byte for byte -- in child processes, because the selecting knobs are read once per process.
 """
 import gc
 import json
@@ -212,3 +214,38 @@ def test_bench_two_rank_rehearsal(gpu):
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
     assert "gloo" in line["config"]["gather"] and line["config"]["batch_per_gpu"] == 8
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]  # only rank 0 prints
+
+
+_REMAP_SCRIPT = r"""
+import sys
+sys.path[:0] = [{root!r}, {tests!r}]
+import numpy as np, torch
+import oracle_lib as O, sr_scenes
+from mrs_optic_flow_amd import ScaleRotationEstimator
+from mrs_optic_flow_amd.engine import INTER_CUBIC, INTER_LANCZOS4
+dev = torch.device("cuda", 0)
+checked = 0
+for res, M in ((480, 49.9), (256, 45.0)):
+    base = sr_scenes.canvas(900 + res, res)
+    frames = np.stack([sr_scenes.view(base, res, 1.0 + 0.02 * k, 3.0 * k - 9.0) for k in range(9)])
+    frames[4, :7, :] = 255
+    est = ScaleRotationEstimator(res, M)
+    t = torch.from_numpy(frames).to(dev)
+    for interp in (INTER_CUBIC, INTER_LANCZOS4):
+        got = est.logpolar_batch_device(t, interp).cpu().numpy()
+        for k in range(9):
+            want = O.logpolar(frames[k], M, interp)
+            assert np.array_equal(got[k], want), (res, interp, k, int((got[k] != want).sum()))
+            checked += 1
+print("remap ok", checked)
+"""
+
+
+@pytest.mark.parametrize("env", [{"MOF_SR_LP_RING": "16"}, {"MOF_SR_LP_SUPER": "0"}, {"MOF_SR_LP_STAGED": "0"}])
+def test_remap_other_kernel_forms_are_byte_exact(gpu, env):
+    """K4's 16-deep ring (maps whose largest super-tile box exceeds 3072 dwords), its one-box-per-wave form (resolutions that
+    are not a multiple of 16, boxes beyond 4096 dwords) and the table-in-LDS kernel (unaligned layouts), forced by their
+    knobs on maps that would take the 12-deep super-tile form: every byte against the oracle."""
+    script = _REMAP_SCRIPT.format(root=ROOT, tests=os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "remap ok 36" in r.stdout, (env, r.stdout[-1500:], r.stderr[-1500:])
