@@ -249,3 +249,17 @@ def test_remap_other_kernel_forms_are_byte_exact(gpu, env):
     script = _REMAP_SCRIPT.format(root=ROOT, tests=os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
     assert r.returncode == 0 and "remap ok 36" in r.stdout, (env, r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("env,target,select", [
+    ({"MOF_SR_PAIR_SEQ": "0"}, "tests/test_gpu_sr.py", "batch_pairs or black_frames or opencv3"),
+    ({"MOF_FFT_SEQ_HALF64": "1"}, "tests/test_gpu_fft_sequence.py", "video_matches or known_answers or wider_allocation"),
+])
+def test_knob_selected_kernel_forms_pass_their_parity_tests(gpu, env, target, select):
+    """The packed pair kernels of the estimator (K5 / K6, `MOF_SR_PAIR_SEQ=0`) and the half-tile form of the 64 x 64 sequence
+    kernel (`MOF_FFT_SEQ_HALF64=1`) stay in the library as A/B forms: the parity tests of the shipped forms, run once more in a
+    child process with the knob set (the knobs are read once per process)."""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, target), "-m", "gpu", "-x", "-q", "-k", select,
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, **env))
+    assert r.returncode == 0 and " passed" in r.stdout, (env, r.stdout[-2000:], r.stderr[-1000:])
