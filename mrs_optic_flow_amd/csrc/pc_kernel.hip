@@ -35,6 +35,7 @@
 #include "pc_common.hpp"
 
 #include "pc_passes.hpp"
+#include "pc_passes3.hpp"
 
 namespace mof {
 
@@ -44,6 +45,9 @@ namespace mof {
 // CH = 3: the frames are interleaved BGR8 and the CV_RGB2GRAY conversion of the node's front end
 // (optic_flow.cpp:1622) is fused into the load, so raw camera frames are read from HBM exactly once.
 // PK = 1: the peak model of the reference's useOCL=true branch (cl/FftMethod.cl) instead of cv::phaseCorrelate's.
+#ifndef MOF_K1_FWD3
+#define MOF_K1_FWD3 1
+#endif
 template <int N, int DS, int CH, int PK>
 __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   static_assert(CH == 1 || (CH == 3 && DS == 1), "BGR front end only for the full-resolution path");
@@ -65,6 +69,7 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
   // than a static stride does, and the patch coordinates come from blockIdx without the integer divisions that
   // otherwise cost ~5 % of the kernel's VALU instructions.
   constexpr bool PERSIST = P::PERSIST;
+  constexpr bool FWD3 = MOF_K1_FWD3 && N == 64 && DS == 1 && !P::PERSIST && MOF_RAW_STAGE && T == 256;  // pc_passes3.hpp
   constexpr bool RAW = MOF_RAW_STAGE && (N == 128 || N == 64) && DS == 1 && T == N * N / 16;  // raw pixel staging (pc_passes.hpp)  // raw pixel staging (pc_passes.hpp)
   (void)patches;
   // (x0, y0) of a patch are in the units of the correlated image: full-res pixels, or quarter-res when DS = 4
@@ -95,6 +100,8 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
     }
   }
 
+  Fwd3Tw tw3;
+  if constexpr (FWD3) tw3.load(a.twiddles, wave0, lane0);
   // ---- persistent workgroup: patches p = blockIdx.x, + gridDim.x, ...; the 2 x 16 B of the NEXT patch are
   //      requested from HBM before the current one is transformed, so the ~2 us load latency is off the critical path
   uint32_t cw[4] = {0u, 0u, 0u, 0u}, pw[4] = {0u, 0u, 0u, 0u};
@@ -214,9 +221,17 @@ __global__ void __launch_bounds__(PcTraits<N>::T) pc_field_kernel(PcArgs a) {
 
   // ---- forward 2-D transform of z: rows (wave-local), barrier, columns (wave-local)  (dft x2, :1491-1493)
 #ifndef MOF_ABLATE_NOFWD
-  row_pass<N, LPW, RAW>(z, wave * LPW, lane, tw_row);
-  __syncthreads();
-  col_pass_fwd<N>(z, wave * LPW, lane, tw_col);
+  if constexpr (FWD3) {
+    fwd3_rows(z, wave, lane);
+    __syncthreads();
+    fwd3_mid(z, wave, lane, tw3);
+    wave_sync();
+    fwd3_cols(z, wave, lane);
+  } else {
+    row_pass<N, LPW, RAW>(z, wave * LPW, lane, tw_row);
+    __syncthreads();
+    col_pass_fwd<N>(z, wave * LPW, lane, tw_col);
+  }
 #endif
   __syncthreads();
 

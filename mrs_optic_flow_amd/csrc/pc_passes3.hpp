@@ -1,0 +1,96 @@
+// pc_passes3.hpp -- the forward 2-D transform of a 64 x 64 tile in THREE register stages instead of four (r03).
+//
+// row_pass + col_pass_fwd (pc_passes.hpp) split each 1-D transform 8 x 8: four stages, four tile stores, three tile reads.
+// 16 elements per lane also hold 4 + 4 + 4 of the transform's 12 radix-2 levels:
+//   S1  rows, radix 16 over x = 4 n1 + n2 (n1 = 0..15), lane = (row y, n2):            A[y][n2][k1]
+//   S2  a 4 x 4 block per lane = (k1, m2): the rows' last radix 4 over n2 (twiddle W64^{n2 k1}) and the columns' first
+//       radix 4 over m1, y = m2 + 16 m1, then the column twiddle W64^{m2 l1}:          B[m2][l1][u = k1 + 16 k2]
+//   S3  columns, radix 16 over m2, lane = (l1, u):                                      Z[v = l1 + 4 l2][u]
+// (x u = 4 n1 k1 + n2 k1 + 16 n2 k2 (mod 64) and y v = m2 l1 + 4 m2 l2 + 16 m1 l1 (mod 64).) One LDS round trip less per
+// patch pair; S2 is in place and S2 -> S3 is wave-local (wave w owns k1 = 4w..4w+3, i.e. the columns u = k1 + 16 k2).
+// Intermediate layout: element (y, b, k1) at 68 y + 4 (y >> 4) + 17 b + k1 -- S1's stores (4 rows x 4 b per 16 lanes), S2's
+// loads (8 m2 x 4 k1 per 32 lanes) and stores are conflict-free, S3's loads 2-way (tools/design: no member of this family
+// clears all four). S3 leaves Z in the standard tile layout (zaddr) for the cross-power / inverse passes; the two layouts
+// overlap in memory, so every wave reads its S3 operands before any wave stores its results (one more barrier).
+#pragma once
+
+#include "pc_passes.hpp"
+
+namespace mof {
+
+struct Fwd3Tw {
+  cf wr[3], wc[3];  // W64^{n2 k1}, n2 = 1..3 (k1 = 4 wave + lane % 4);  W64^{m2 l1}, l1 = 1..3 (m2 = lane / 4)
+  __device__ __forceinline__ void load(const float* __restrict__ table, int wave, int lane) {
+    const int k1 = 4 * wave + (lane & 3), m2 = lane >> 2;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      wr[i - 1] = {table[2 * (i * k1)], table[2 * (i * k1) + 1]};
+      wc[i - 1] = {table[2 * (i * m2)], table[2 * (i * m2) + 1]};
+    }
+  }
+};
+
+__device__ __forceinline__ int t3addr(int y, int b, int k1) { return 68 * y + 4 * (y >> 4) + 17 * b + k1; }
+
+// S1: the wave's 16 rows from its raw area (raw_store, pc_passes.hpp); wave-local
+__device__ __forceinline__ void fwd3_rows(cf* __restrict__ z, int wave, int lane) {
+  constexpr int N = 64;
+  const int slot = lane >> 2, n2 = lane & 3, y = 16 * wave + slot;
+  const unsigned char* src = raw_area<N>(z, 16 * wave) + slot * RawCfg<N>::PITCH + 2 * n2;
+  cf v[16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const uint32_t cp = lds_read_u16(src + 8 * n1);
+    v[n1] = {(float)(cp & 0xffu), (float)(cp >> 8)};
+  }
+  butterfly<16>(v);
+  wave_sync();  // the raw area lies inside the wave's own part of the intermediate layout: all of it is read by now
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) z[t3addr(y, n2, k1)] = v[k1];
+}
+
+// S2: in place
+__device__ __forceinline__ void fwd3_mid(cf* __restrict__ z, int wave, int lane, const Fwd3Tw& tw) {
+  const int k1 = 4 * wave + (lane & 3), m2 = lane >> 2;
+  cf e[4][4];  // [m1][n2] -> [m1][k2] -> [l1][k2]
+#pragma unroll
+  for (int m1 = 0; m1 < 4; ++m1)
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) e[m1][n2] = lds_read(&z[t3addr(m2 + 16 * m1, n2, k1)]);
+#pragma unroll
+  for (int m1 = 0; m1 < 4; ++m1) {
+    cf t[4] = {e[m1][0], cmul(e[m1][1], tw.wr[0]), cmul(e[m1][2], tw.wr[1]), cmul(e[m1][3], tw.wr[2])};
+    butterfly<4>(t);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) e[m1][k2] = t[k2];
+  }
+#pragma unroll
+  for (int k2 = 0; k2 < 4; ++k2) {
+    cf c[4] = {e[0][k2], e[1][k2], e[2][k2], e[3][k2]};
+    butterfly<4>(c);
+    e[0][k2] = c[0];
+#pragma unroll
+    for (int l1 = 1; l1 < 4; ++l1) e[l1][k2] = cmul(c[l1], tw.wc[l1 - 1]);
+  }
+#pragma unroll
+  for (int l1 = 0; l1 < 4; ++l1)
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) z[t3addr(m2 + 16 * l1, k2, k1)] = e[l1][k2];
+}
+
+// S3: loads (wave-local after S2), workgroup barrier, stores in the standard layout. Lane map: 16-lane store groups hold
+// four j, two k2 of one parity and two neighbouring l1 -- distinct banks under zaddr<64>.
+__device__ __forceinline__ void fwd3_cols(cf* __restrict__ z, int wave, int lane) {
+  constexpr int N = 64;
+  const int j = lane & 3, k2 = 2 * ((lane >> 2) & 1) + ((lane >> 4) & 1), l1 = ((lane >> 3) & 1) + 2 * (lane >> 5);
+  const int u = 4 * wave + j + 16 * k2;
+  cf v[16];
+#pragma unroll
+  for (int m2 = 0; m2 < 16; ++m2) v[m2] = lds_read(&z[t3addr(m2 + 16 * l1, k2, 4 * wave + j)]);
+  butterfly<16>(v);
+  __syncthreads();
+#pragma unroll
+  for (int l2 = 0; l2 < 16; ++l2) z[zaddr<N>(l1 + 4 * l2, u)] = v[l2];
+}
+
+}  // namespace mof
