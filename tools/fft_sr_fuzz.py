@@ -22,7 +22,7 @@ n_fft = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 n_sr = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda")
-bad = checked = total = 0
+bad = checked = total = soft = 0
 for trial in range(n_fft):
     n = int(rng.choice([32, 64, 64, 120, 128]))
     gx, gy = int(rng.integers(1, 6)), int(rng.integers(1, 5))
@@ -40,15 +40,26 @@ for trial in range(n_fft):
         want32, _ = O.fft_process(cur[k], prev[k], lay, 32)
         for p in range(want64.shape[0]):
             total += 1
-            stable = diags[p].second_value < 0.5 * diags[p].peak_value or (
-                np.array_equal(np.isnan(want64[p]), np.isnan(want32[p])) and np.allclose(want64[p], want32[p], rtol=0, atol=TOL, equal_nan=True))
+            agree = np.array_equal(np.isnan(want64[p]), np.isnan(want32[p])) and np.allclose(want64[p], want32[p], rtol=0, atol=TOL, equal_nan=True)
+            stable = diags[p].second_value < 0.5 * diags[p].peak_value or agree
             if not stable:
+                continue
+            if not agree:
+                # a clear peak, but the reference's own arithmetic (f32) does not pin it to 1e-4 px against the f64 restatement
+                # (smooth patches: many cross-power bins sit at the f32 rounding floor and are normalised to unit magnitude):
+                # the GPU must stay as close to the f32 oracle as that one is to the f64 one
+                soft += 1
+                lim = TOL + float(np.nanmax(np.abs(want32[p] - want64[p])))
+                if not np.allclose(got[k, p], want32[p], rtol=0, atol=lim, equal_nan=True):
+                    bad += 1
+                    print("FFT MISMATCH (f32-limited patch)", trial, n, k, p, got[k, p], want64[p], want32[p])
                 continue
             checked += 1
             if not np.allclose(got[k, p], want64[p], rtol=0, atol=TOL, equal_nan=True):
                 bad += 1
-                print("FFT MISMATCH", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), k, p, got[k, p], want64[p])
-print(f"fft: {checked}/{total} patches with a stable arg-max checked, mismatches {bad}")
+                print("FFT MISMATCH", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), k, p, got[k, p], want64[p],
+                      "f32 oracle", want32[p], "peak", diags[p].peak_value, "second", diags[p].second_value)
+print(f"fft: {checked}/{total} patches with a stable arg-max checked at 1e-4 px (+ {soft} where f32 and f64 oracle differ by more: checked against the f32 oracle), mismatches {bad}")
 sr_bad = 0
 for trial in range(n_sr):
     res = int(rng.choice([240, 256, 480]))
@@ -109,9 +120,19 @@ for trial in range(max(4, n_fft // 4)):
         want64, _, diags = O.fft_process(frames[k + 1], frames[k], lay, 64, want_diag=True)
         want32, _ = O.fft_process(frames[k + 1], frames[k], lay, 32)
         for p in range(want64.shape[0]):
-            stable = diags[p].second_value < 0.5 * diags[p].peak_value or (
-                np.array_equal(np.isnan(want64[p]), np.isnan(want32[p])) and np.allclose(want64[p], want32[p], rtol=0, atol=TOL, equal_nan=True))
+            agree = np.array_equal(np.isnan(want64[p]), np.isnan(want32[p])) and np.allclose(want64[p], want32[p], rtol=0, atol=TOL, equal_nan=True)
+            stable = diags[p].second_value < 0.5 * diags[p].peak_value or agree
             if not stable:
+                continue
+            if not agree:
+                # a clear peak, but the reference's own arithmetic (f32) does not pin it to 1e-4 px against the f64 restatement
+                # (smooth patches: many cross-power bins sit at the f32 rounding floor and are normalised to unit magnitude):
+                # the GPU must stay as close to the f32 oracle as that one is to the f64 one
+                soft += 1
+                lim = TOL + float(np.nanmax(np.abs(want32[p] - want64[p])))
+                if not np.allclose(got[k, p], want32[p], rtol=0, atol=lim, equal_nan=True):
+                    seq_bad += 1
+                    print("SEQ FFT MISMATCH (f32-limited patch)", trial, n, k, p, got[k, p], want64[p], want32[p])
                 continue
             seq_checked += 1
             if not (np.allclose(got[k, p], want64[p], rtol=0, atol=TOL, equal_nan=True)
