@@ -11,6 +11,9 @@
 #ifndef MOF_FUSE_XPOW
 #define MOF_FUSE_XPOW 1  // 1: where it pays (PcTraits::FUSE_XPOW), the cross-power spectrum is formed inside the inverse row pass
 #endif
+#ifndef MOF_FUSE_XPOW_MAXN
+#define MOF_FUSE_XPOW_MAXN 64  // (128: measured again under the r03 layout)
+#endif
 #ifndef MOF_XPOW_SPLIT
 #define MOF_XPOW_SPLIT 1  // the inverse row pass of the waves that do not own row 0 carries no select for the packed row
 #endif
@@ -97,7 +100,7 @@ struct PcTraits {
   // cross-power spectrum inside the inverse row pass (row_pass_xpow): one barrier and 1.5 tile passes fewer. Same-box
   // A/B: +4.4 % at N = 64 (several workgroups per CU, latency-bound), -4.4 % at N = 128 (one workgroup per CU: the
   // separate pass spreads the cross-power over all 16 waves, the fused one over the 8 that run the inverse)
-  static constexpr bool FUSE_XPOW = MOF_FUSE_XPOW && N <= 64;
+  static constexpr bool FUSE_XPOW = MOF_FUSE_XPOW && N <= MOF_FUSE_XPOW_MAXN;
   static_assert(R1 * R2 == N && T % 64 == 0 && 64 % R1 == 0 && 64 % R2 == 0, "bad plan");
 };
 
