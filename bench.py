@@ -328,7 +328,7 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
                 eng.process_sequence_device(video, out=state["out"])
                 return state["out"]
         elif wl["kind"] == "fft+srseq":
-            sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank)
+            sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank, batch_chunk=1024)  # 1024-pair passes: +1.7 % for 3.8 GB of scratch (the library default is 512)
             x0, r = wl["sr_x0"], wl["sr_res"]
             crop = video[:, :r, x0:x0 + r]
             sr.process_sequence_device(crop[:2])  # arm the steady state: every timed frame goes through INTER_LANCZOS4
@@ -338,7 +338,7 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
                 srout = sr.process_sequence_device(crop[1:], resolve_gate=False)  # B new frames = B pairs
                 return torch.cat([state["out"].reshape(B, -1), srout], dim=1)
         elif wl["kind"] == "fft+sr":
-            sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank)
+            sr = ScaleRotationEstimator(wl["sr_res"], wl["sr_m"], device=local_rank, batch_chunk=1024)  # 1024-pair passes: +1.7 % for 3.8 GB of scratch (the library default is 512)
             x0, r = wl["sr_x0"], wl["sr_res"]
             cur_c, prev_c = cur[:, :r, x0:x0 + r], prev[:, :r, x0:x0 + r]
 

@@ -249,10 +249,11 @@ typedef struct mof_sr_config {
   int device;
   int logpolar_variant; /* MOF_LOGPOLAR_CV4 (0, default) or MOF_LOGPOLAR_CV3: see below              */
   /* Batched mode only (no reference counterpart; zero-initialise for the defaults):                 */
-  int batch_chunk;      /* frame pairs per pipeline pass, 0 = default (1024; 1..4096). From its first      */
+  int batch_chunk;      /* frame pairs per pipeline pass, 0 = default (512; 1..4096). From its first       */
                         /* batch on the engine owns scratch for min(batch size rounded up to a power of   */
                         /* two, batch_chunk) pairs at 4 res^2 + 8 res^2 + 8 res (res/2+1) bytes each      */
-                        /* (3.8 GB at 480^2 and 1024 pairs); until then one pair's worth                   */
+                        /* (1.9 GB at 480^2 and 512 pairs; 1024-pair passes measure +1.7 % at c5 for 3.8   */
+                        /* GB); until then one pair's worth                                                */
   int pipeline_lanes;   /* 0 = default (1), 1 = every pass on the caller's stream, 2 = the remap of pass  */
                         /* k+1 runs beside the transforms of pass k on a second stream of the engine      */
 } mof_sr_config;
@@ -293,7 +294,7 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
  * call's last kernel, so back-to-back batches on different streams are safe but do not overlap. While `stream` is
  * being captured into a HIP graph no cross-stream dependency is taken or left: replays of graphs that contain calls
  * on one engine must be ordered by the caller.
- * A batch runs in pipeline passes of batch_chunk pairs (default 1024) on `stream`. With pipeline_lanes = 2 (not the
+ * A batch runs in pipeline passes of batch_chunk pairs (default 512) on `stream`. With pipeline_lanes = 2 (not the
  * default) the log-polar remaps of pass k+1 run on a stream of the engine's own beside the transforms of pass k, handed
  * over with events; everything is complete when `stream` is. Under graph capture the engine's stream joins the capture
  * (fork / join by events) and the graph replays with the same lanes. A captured call pins the engine ("HIP graphs" at
@@ -312,9 +313,12 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
  * the next frame is correlated with an older one -- a serial dependency through a result.
  *   n_gated != NULL: the call resolves it (per pipeline pass it reads the pass's results back, re-runs the pairs that
  *     sit behind a gated frame against the right partner) and is SYNCHRONOUS; *n_gated = number of gated frames.
- *   n_gated == NULL: asynchronous on `stream` and capturable into a HIP graph; every frame is correlated with its
- *     immediate predecessor. Identical unless some frame is gated, which the caller can see in d_out (|pt.x| >
+ *   n_gated == NULL: asynchronous on `stream` and capturable into a HIP graph (on an ARMED engine only: the first frame
+ *     of a fresh estimator takes a one-off branch that a replay must not repeat -- MOF_ERR_BAD_ARG); every frame is
+ *     correlated with its immediate predecessor. Identical unless some frame is gated, which the caller can see in d_out (|pt.x| >
  *     resolution/2 with scale == 1, rot == 0) -- a degenerate case (constant or wrapped images).
+ * A call that fails half-way (a HIP error from a launch) leaves the estimator's state -- `first`, the previous image --
+ * exactly as it was before the call.
  * Each frame is remapped and row-transformed once (K5s), the column pass walks consecutive pairs in time (K6s,
  * csrc/sr_seq_kernel.hip): about half the remap work and a third less spectrum traffic than n_frames - 1 independent
  * pairs through mof_sr_process_batch_device. Uses the engine's scratch like the batch entry. */

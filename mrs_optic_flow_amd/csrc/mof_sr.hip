@@ -32,15 +32,17 @@ namespace {
 constexpr int kTab = 32;            // INTER_TAB_SIZE
 constexpr int kCoefScale = 1 << 15; // INTER_REMAP_COEF_SCALE
 #ifndef MOF_SR_CHUNK
-#define MOF_SR_CHUNK 1024
+#define MOF_SR_CHUNK 512
 #endif
 // frame pairs per pipeline pass: 512 pairs of 480^2 = 1.9 GB of scratch (log-polar images, Zt, Dt). Same-box sweeps at c5
 // (tools/sweep_c5.sh, profiles/r02_c5_sweep.txt): 64 / 128 / 256 pairs -> 240 / 277 / 308 k pairs/s on one lane, 512 ->
 // 326 k, 1024 -> 324 k; with the second lane 254 / 283 / 312 / 318 / 313 k -- once a pass is long enough to fill the
 // chip the two-lane overlap has nothing left to hide, so one lane is the default. r03 (frame kernels, non-temporal streams;
 // tools/ab_sr_chunk.sh): 256 / 512 / 1024 pairs -> 341 / 360 / 366 k (c5) and 424 / 518 / 535 k (c5seq); passes that fit the
-// 256 MB Infinity Cache (64 pairs: Zt 118 MB + Dt 59 MB) are no faster per byte and pay the launch gaps (248 k): the default
-// is now 1024 pairs = 3.8 GB of scratch.
+// 256 MB Infinity Cache (64 pairs: Zt 118 MB + Dt 59 MB) are no faster per byte and pay the launch gaps (248 k). 1024-pair
+// passes are worth +1.7 % at c5 and cost 3.8 GB of scratch that stays allocated (and pinned once a graph captured the engine),
+// so the DEFAULT stays 512 pairs = 1.9 GB (r04, advisor); a caller that has the memory opts in through
+// mof_sr_config.batch_chunk (bench.py does for c5 / c5seq).
 constexpr int kChunkDefault = MOF_SR_CHUNK;
 // mof_sr_config.batch_chunk / .pipeline_lanes; MOF_SR_CHUNK / MOF_SR_OVERLAP in the environment override both at
 // create() (sweeps)
@@ -666,72 +668,90 @@ int mof_sr_process_sequence_device(mof_sr_engine* e, const uint8_t* d_frames, si
     const int rc = scratch_reserve(e, scratch_want(e, n_frames), s);
     if (rc != MOF_OK) return rc;
   }
+  // A fresh estimator's first frame takes the INTER_CUBIC branch (:45) ONCE; captured, that branch would be baked into the
+  // graph and every replay would redo it while the engine believes it is in its steady state. Capture on an armed engine.
+  if (capturing && e->first)
+    return mof::capi_fail(MOF_ERR_BAD_ARG, "capturing a sequence on a fresh estimator would bake its one-off first-frame branch "
+                                            "(INTER_CUBIC, scaleRotationEstimator.cpp:45) into the graph: process one frame first");
   SR_TRY(scratch_acquire(e, s));
   if (capturing) e->graph_pinned.store(true);
   const int C = e->scratch_pairs < e->chunk ? e->scratch_pairs : e->chunk;  // new frames per pass
   float* zh = e->d_Zt;
-  mof::SrLpArgs lp{};
-  lp.zero_invalid = 1;  // tempIm starts as zeros (:27) and transparent pixels never change: write the zeros here
-  lp.pitch = pitch;
-  lp.map = e->d_map;
-  lp.res = res;
-  lp.src_stride = frame_stride;
-  lp.dst_stride = nn;
-  int done = 0, gated_total = 0;
-  int carry = -1;  // slot of the previous pass whose spectra are `prev` for the next frame (-1: the engine's state)
-  while (done < n_frames) {
-    if (e->first) {  // the very first frame: INTER_CUBIC (:45), becomes prev (:48), returns (1, 0) (:74)
-      lp.src = d_frames + (size_t)done * frame_stride;
-      lp.dst = e->d_lp;
-      lp_tables(e, 2, &lp);
-      SR_TRY(mof::launch_sr_logpolar(lp, 2, 1, s));
-      SR_TRY(mof::launch_sr_rows_real(e->d_lp, nn, e->d_twiddles, zh, zhf, res, 1, s));
-      SR_TRY(mof::launch_sr_identity(d_out + 4 * (size_t)done, s));
-      e->first = false;  // :73
-      ++done;
-    } else if (carry < 0) {
-      SR_TRY(hipMemcpyAsync(zh, e->d_zh_prev, zh_bytes, hipMemcpyDeviceToDevice, s));
-    } else if (carry > 0) {
-      SR_TRY(hipMemcpyAsync(zh, zh + (size_t)carry * zhf, zh_bytes, hipMemcpyDeviceToDevice, s));
-    }
-    const int m = n_frames - done < C ? n_frames - done : C;
-    carry = 0;
-    if (m > 0) {
-      lp.src = d_frames + (size_t)done * frame_stride;
-      lp.dst = e->d_lp + nn;
-      lp_tables(e, 4, &lp);
-      SR_TRY(mof::launch_sr_logpolar(lp, 4, m, s));  // INTER_LANCZOS4, :112 -- every frame once
-      SR_TRY(mof::launch_sr_rows_real(e->d_lp + nn, nn, e->d_twiddles, zh + zhf, zhf, res, m, s));
-      SR_TRY(mof::launch_sr_cols_seq(zh, zh + zhf, zhf, e->d_twiddles, e->d_Dt, res, m, e->seq_run, s));
-      mof::SrPcArgs a = pc_args(e, nullptr, nullptr, 0, d_out + 4 * (size_t)done);
-      SR_TRY(mof::launch_sr_peak(a, res, m, s));
-      carry = m;
-      if (n_gated) {
-        // The gate (:119-121): a frame whose |pt.x| > res/2 returns (1, 0) and does NOT become prev. The pass above
-        // correlated every frame with its immediate predecessor; behind a gated frame that is the wrong partner, so
-        // walk the results in order and redo the (rare) pairs whose reference partner is an older frame.
-        SR_TRY(hipMemcpyAsync(e->h_seq, d_out + 4 * (size_t)done, (size_t)m * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
-        SR_TRY(hipStreamSynchronize(s));
-        int prev_slot = 0;
-        for (int i = 1; i <= m; ++i) {
-          double ptx = e->h_seq[4 * (size_t)(i - 1) + 2];
-          if (prev_slot != i - 1) {
-            double* o = d_out + 4 * (size_t)(done + i - 1);
-            SR_TRY(seq_one_pair(e, zh + (size_t)prev_slot * zhf, zh + (size_t)i * zhf, o, s));
-            SR_TRY(hipMemcpyAsync(e->h_out, o, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
-            SR_TRY(hipStreamSynchronize(s));
-            ptx = e->h_out[2];
-          }
-          if (std::fabs(ptx) > (double)(res / 2)) ++gated_total;
-          else prev_slot = i;
-        }
-        carry = prev_slot;
+  // The host-side state (`first`, and the device-side prevIm_F32 = d_zh_prev, whose update is the LAST thing enqueued) is
+  // committed only when every launch of the call went out: a call that fails half-way leaves the estimator exactly as it was,
+  // and the scratch is released on that path too.
+  bool first = e->first;
+  int gated_total = 0;
+  const int rc = [&]() -> int {
+    mof::SrLpArgs lp{};
+    lp.zero_invalid = 1;  // tempIm starts as zeros (:27) and transparent pixels never change: write the zeros here
+    lp.pitch = pitch;
+    lp.map = e->d_map;
+    lp.res = res;
+    lp.src_stride = frame_stride;
+    lp.dst_stride = nn;
+    int done = 0;
+    int carry = -1;  // slot of the previous pass whose spectra are `prev` for the next frame (-1: the engine's state)
+    while (done < n_frames) {
+      if (first) {  // the very first frame: INTER_CUBIC (:45), becomes prev (:48), returns (1, 0) (:74)
+        lp.src = d_frames + (size_t)done * frame_stride;
+        lp.dst = e->d_lp;
+        lp_tables(e, 2, &lp);
+        SR_TRY(mof::launch_sr_logpolar(lp, 2, 1, s));
+        SR_TRY(mof::launch_sr_rows_real(e->d_lp, nn, e->d_twiddles, zh, zhf, res, 1, s));
+        SR_TRY(mof::launch_sr_identity(d_out + 4 * (size_t)done, s));
+        first = false;  // :73
+        ++done;
+      } else if (carry < 0) {
+        SR_TRY(hipMemcpyAsync(zh, e->d_zh_prev, zh_bytes, hipMemcpyDeviceToDevice, s));
+      } else if (carry > 0) {
+        SR_TRY(hipMemcpyAsync(zh, zh + (size_t)carry * zhf, zh_bytes, hipMemcpyDeviceToDevice, s));
       }
-      done += m;
+      const int m = n_frames - done < C ? n_frames - done : C;
+      carry = 0;
+      if (m > 0) {
+        lp.src = d_frames + (size_t)done * frame_stride;
+        lp.dst = e->d_lp + nn;
+        lp_tables(e, 4, &lp);
+        SR_TRY(mof::launch_sr_logpolar(lp, 4, m, s));  // INTER_LANCZOS4, :112 -- every frame once
+        SR_TRY(mof::launch_sr_rows_real(e->d_lp + nn, nn, e->d_twiddles, zh + zhf, zhf, res, m, s));
+        SR_TRY(mof::launch_sr_cols_seq(zh, zh + zhf, zhf, e->d_twiddles, e->d_Dt, res, m, e->seq_run, s));
+        mof::SrPcArgs a = pc_args(e, nullptr, nullptr, 0, d_out + 4 * (size_t)done);
+        SR_TRY(mof::launch_sr_peak(a, res, m, s));
+        carry = m;
+        if (n_gated) {
+          // The gate (:119-121): a frame whose |pt.x| > res/2 returns (1, 0) and does NOT become prev. The pass above
+          // correlated every frame with its immediate predecessor; behind a gated frame that is the wrong partner, so
+          // walk the results in order and redo the (rare) pairs whose reference partner is an older frame.
+          SR_TRY(hipMemcpyAsync(e->h_seq, d_out + 4 * (size_t)done, (size_t)m * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+          SR_TRY(hipStreamSynchronize(s));
+          int prev_slot = 0;
+          for (int i = 1; i <= m; ++i) {
+            double ptx = e->h_seq[4 * (size_t)(i - 1) + 2];
+            if (prev_slot != i - 1) {
+              double* o = d_out + 4 * (size_t)(done + i - 1);
+              SR_TRY(seq_one_pair(e, zh + (size_t)prev_slot * zhf, zh + (size_t)i * zhf, o, s));
+              SR_TRY(hipMemcpyAsync(e->h_out, o, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+              SR_TRY(hipStreamSynchronize(s));
+              ptx = e->h_out[2];
+            }
+            if (std::fabs(ptx) > (double)(res / 2)) ++gated_total;
+            else prev_slot = i;
+          }
+          carry = prev_slot;
+        }
+        done += m;
+      }
     }
+    // prevIm_F32 <- the last frame that passed the gate (:128)
+    if (carry >= 0) SR_TRY(hipMemcpyAsync(e->d_zh_prev, zh + (size_t)carry * zhf, zh_bytes, hipMemcpyDeviceToDevice, s));
+    return MOF_OK;
+  }();
+  if (rc != MOF_OK) {
+    (void)scratch_release(e, s);  // (the error text of the failing launch stays the thread's last error)
+    return rc;
   }
-  // prevIm_F32 <- the last frame that passed the gate (:128)
-  if (carry >= 0) SR_TRY(hipMemcpyAsync(e->d_zh_prev, zh + (size_t)carry * zhf, zh_bytes, hipMemcpyDeviceToDevice, s));
+  e->first = first;
   SR_TRY(scratch_release(e, s));
   if (n_gated) {
     SR_TRY(hipStreamSynchronize(s));

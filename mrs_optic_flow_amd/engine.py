@@ -50,13 +50,18 @@ def _pin_if_capturing(engine, stream) -> None:
 
 def release_captured(engine=None) -> int:
     """The caller states that the graphs which captured ``engine`` (default: every captured engine) are gone: the
-    engines may be collected, and the estimator's scratch may grow, again. Returns how many engines were released."""
+    engines may be collected, and the estimator's scratch may grow, again. Returns how many engines were released.
+    Only ``release_captured()`` without an argument -- "no graph of this process will replay any more" -- also frees the
+    engines that were destroyed while pinned (the library's parked list is process-wide)."""
     todo = list(_CAPTURED) if engine is None else [e for e in (engine,) if e in _CAPTURED]
     for e in todo:
         _CAPTURED.discard(e)
         e._release_graphs()
-    lib = _capi.load()
-    lib.mof_purge_deferred()
+    # mof_purge_deferred() frees EVERY parked engine of the process -- also engines that were closed while a graph other than
+    # the caller's still replays through them (include/mof.h: purge when the graphs are destroyed). Releasing ONE engine says
+    # nothing about those, so only the all-engines form ("every graph is gone") purges.
+    if engine is None:
+        _capi.load().mof_purge_deferred()
     return len(todo)
 
 

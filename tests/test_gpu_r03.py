@@ -36,7 +36,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("lanes,chunk", [(1, 0), (2, 0), (1, 512)])
+@pytest.mark.parametrize("lanes,chunk", [(1, 0), (2, 0), (1, 1024)])
 def test_c5_scale_rotation_full_size_default_passes(gpu, lanes, chunk):
     """scaleRotationEstimator.cpp:34-148 at BASELINE c5's size: 1100 pairs of 480 x 480 crops through the default
     1024-pair passes (and through 512-pair ones). Every sampled pair -- on both sides of the pass boundaries and in the ragged tail -- equals the
