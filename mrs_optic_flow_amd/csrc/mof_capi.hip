@@ -117,9 +117,16 @@ struct mof_fft_engine {
   double* h_out = nullptr;       // pinned
   uint8_t* h_stage = nullptr;    // pinned upload staging (tightly packed frame)
   bool first = true;             // FftMethod.cpp:1761
+  bool generic = false;          // patch sizes without a hand-tuned instantiation run the planned kernel (pc_kernel_generic.hip)
+  mof::PcPlan plan{};
   std::atomic<bool> busy{false};
   std::atomic<bool> graph_pinned{false};  // a batch call was captured into a HIP graph (capi_graph.hpp)
 };
+
+// every K1 launch of an engine: the hand-tuned instantiation of its patch size, or the planned general kernel
+static hipError_t launch_field(const mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hipStream_t stream) {
+  return e->generic ? mof::launch_pc_generic(a, e->plan, n_pairs, stream) : mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, stream);
+}
 
 struct mof_bm_engine {
   mof_bm_config cfg{};
@@ -182,8 +189,21 @@ static int validate_fft(const mof_fft_config* c) {
   if (c->frame_width < 1 || c->frame_height < 1 || c->grid_x < 1 || c->grid_y < 1 || c->origin_x < 0 ||
       c->origin_y < 0 || c->stride_x < 0 || c->stride_y < 0)
     return fail(MOF_ERR_BAD_ARG, "bad FFT geometry");
-  if (!mof::pc_patch_size_supported(c->patch_size))
-    return fail(MOF_ERR_UNSUPPORTED, "patch_size %d not supported by the HIP kernel (32, 64, 120, 128)", c->patch_size);
+  if (c->patch_size < 2) return fail(MOF_ERR_BAD_ARG, "patch_size %d: a patch needs at least 2 x 2 pixels", c->patch_size);
+  if (!mof::pc_patch_size_supported(c->patch_size)) {
+    // any other samplePointSize (FftMethod.cpp:1680-1720 takes it from a ROS parameter): the planned kernel on the size
+    // cv::phaseCorrelate pads to, M = getOptimalDFTSize(N)
+    mof::PcPlan plan;
+    if (!mof::pc_build_plan(c->patch_size, &plan))
+      return fail(MOF_ERR_UNSUPPORTED, "patch_size %d pads to %d: a %d x %d complex tile does not fit one CU's LDS (limit 135)",
+                  c->patch_size, mof::pc_optimal_dft_size(c->patch_size), mof::pc_optimal_dft_size(c->patch_size),
+                  mof::pc_optimal_dft_size(c->patch_size));
+    // useOCL=true plans radix-{2,3,4,5,8} passes for the patch size itself and never pads (FftMethod.cpp:481-539, :787-816):
+    // sizes with another prime factor have no OpenCL plan in the reference either; its CCS packing assumes an even size
+    if (c->peak_model == MOF_PEAK_OCL && (plan.m != plan.n || (plan.n & 1)))
+      return fail(MOF_ERR_UNSUPPORTED, "peak_model MOF_PEAK_OCL needs an even patch_size of the form 2^a 3^b 5^c (the reference's "
+                  "OpenCL branch cannot plan %d either)", c->patch_size);
+  }
   if (c->origin_x + (long)(c->grid_x - 1) * c->stride_x + c->patch_size > c->frame_width ||
       c->origin_y + (long)(c->grid_y - 1) * c->stride_y + c->patch_size > c->frame_height)
     return fail(MOF_ERR_BAD_ARG, "patch grid leaves the frame");
@@ -203,14 +223,19 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   rc = select_device(cfg->device);
   if (rc) return rc;
   mof::RelaxedCapture relaxed;  // allocating an engine must not invalidate a capture on another thread
-  const int n = cfg->patch_size;
   const size_t res = (size_t)cfg->grid_x * cfg->grid_y * 2;
-  // twiddles W_N^k = exp(-2 pi i k / N), double -> float, axis values exact
-  std::vector<float> tw(2 * (size_t)n);
   mof_fft_engine* e = new (std::nothrow) mof_fft_engine();
   if (!e) return fail(MOF_ERR_NO_MEMORY, "out of host memory");
   e->cfg = *cfg;
   e->frame_bytes = (size_t)cfg->frame_width * cfg->frame_height;
+  e->generic = !mof::pc_patch_size_supported(cfg->patch_size);
+  if (e->generic && !mof::pc_build_plan(cfg->patch_size, &e->plan)) {  // (validate_fft has checked it)
+    delete e;
+    return fail(MOF_ERR_UNSUPPORTED, "no plan for patch_size %d", cfg->patch_size);
+  }
+  const int n = e->generic ? e->plan.m : cfg->patch_size;  // transform size: the planned kernel works on the padded patch
+  // twiddles W_n^k = exp(-2 pi i k / n), double -> float, axis values exact
+  std::vector<float> tw(2 * (size_t)n);
   for (int k = 0; k < n; ++k) {
     double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)n;
     double c = std::cos(ang), s = std::sin(ang);
@@ -241,9 +266,13 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   CREATE_TRY(hipMalloc(&e->d_out, res * sizeof(double)));
   CREATE_TRY(hipHostMalloc(&e->h_out, res * sizeof(double), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
-  CREATE_TRY(mof::pc_configure(n));
-  if (mof::pc_sequence_supported(n)) CREATE_TRY(mof::pc_configure_sequence());
-  if (mof::pc_sequence_half_supported(n)) CREATE_TRY(mof::pc_configure_sequence_half(n));
+  if (e->generic) {
+    CREATE_TRY(mof::pc_configure_generic());
+  } else {
+    CREATE_TRY(mof::pc_configure(n));
+    if (mof::pc_sequence_supported(n)) CREATE_TRY(mof::pc_configure_sequence());
+    if (mof::pc_sequence_half_supported(n)) CREATE_TRY(mof::pc_configure_sequence_half(n));
+  }
 #undef CREATE_TRY
   *out = e;
   return MOF_OK;
@@ -251,7 +280,9 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   return fail(MOF_ERR_NO_MEMORY, "mof_fft_create: out of host memory");
 }
 
-const char* mof_fft_kernel_variant(const mof_fft_engine* e) { return e ? mof::pc_kernel_variant(e->cfg.patch_size) : ""; }
+const char* mof_fft_kernel_variant(const mof_fft_engine* e) {
+  return !e ? "" : (e->generic ? "planned" : mof::pc_kernel_variant(e->cfg.patch_size));
+}
 
 static void fft_destroy_now(void* p) {
   mof_fft_engine* e = static_cast<mof_fft_engine*>(p);
@@ -348,7 +379,7 @@ int mof_fft_process(mof_fft_engine* e, const uint8_t* frame, size_t pitch, doubl
   // `first`: the frame is correlated with itself (FftMethod.cpp:1791-1793)
   const uint8_t* prev = e->first ? e->d_frames[cur_slot] : e->d_frames[e->prev_slot];
   mof::PcArgs a = fft_args(e, e->d_frames[cur_slot], 0, prev, 0, (size_t)e->cfg.frame_width, e->d_out);
-  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, 1, e->stream));
+  HIP_TRY(launch_field(e, a, 1, e->stream));
   const size_t res = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
   HIP_TRY(hipMemcpyAsync(e->h_out, e->d_out, res * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -402,7 +433,7 @@ int mof_fft_process_long_range(mof_fft_engine* e, const uint8_t* frame, size_t p
   mof::PcArgs a = fft_args(e, e->d_frames[cur_slot], 0, prev, 0, (size_t)e->cfg.frame_width, e->d_out);
   int rc = long_range_args(e, &a);
   if (rc) return rc;
-  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, 1, e->stream));
+  HIP_TRY(launch_field(e, a, 1, e->stream));
   const size_t res = (size_t)a.grid_x * a.grid_y * 2;
   HIP_TRY(hipMemcpyAsync(e->h_out, e->d_out, res * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -434,7 +465,7 @@ int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_
   int rc = long_range_args(e, &a);
   if (rc) return rc;
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
-  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
+  HIP_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
 
@@ -451,7 +482,7 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
   HIP_TRY(hipSetDevice(e->cfg.device));
   mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
-  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
+  HIP_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
 
@@ -475,10 +506,10 @@ static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame
   static const int run = [] { const char* v = getenv("MOF_FFT_SEQ_RUN"); const int r = v ? atoi(v) : 0; return r >= 1 ? r : 16; }();
   static const bool pairs_only = getenv("MOF_FFT_SEQ_PAIRS") != nullptr, half64 = getenv("MOF_FFT_SEQ_HALF64") != nullptr;
   const int n = e->cfg.patch_size;
-  const bool half = !pairs_only && mof::pc_sequence_half_supported(n) && (n != 64 || half64);
-  const bool full = !pairs_only && !half && mof::pc_sequence_supported(n);
+  const bool half = !e->generic && !pairs_only && mof::pc_sequence_half_supported(n) && (n != 64 || half64);
+  const bool full = !e->generic && !pairs_only && !half && mof::pc_sequence_supported(n);
   if (!half && !full) {
-    HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
+    HIP_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
     return MOF_OK;
   }
   // the run index rides gridDim.z (at most 65535 per launch): a very long video goes out in several launches
@@ -519,7 +550,7 @@ int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, si
   mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
   a.channels = 3;
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
-  HIP_TRY(mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, (hipStream_t)stream));
+  HIP_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
 

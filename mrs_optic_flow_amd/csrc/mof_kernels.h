@@ -30,7 +30,26 @@ struct PcArgs {
   double* out;            // device, [pair][patch] (x, y)
 };
 
-bool pc_patch_size_supported(int n);
+// Run-time plan of the general K1 (pc_kernel_generic.hip): any samplePointSize n whose padded transform size
+// m = cv::getOptimalDFTSize(n) gives an m x m complex tile that fits one CU's LDS (m <= 135)
+struct PcPlan {
+  int n, m;          // patch size; padded transform size (smallest 2^a 3^b 5^c >= n)
+  int pitch;         // complex elements per tile row
+  int skew_mask;     // ~0: tile column c sits at c + (c >> 3); 0: no skew
+  int threads;       // workgroup size (multiple of 64)
+  int n_stages;      // Stockham stages of a 1-D transform
+  int radix[8];      // their radices, each of {2, 3, 4, 5, 8}, product m
+  uint32_t radix_packed;  // the same, four bits per stage (what the kernel reads)
+  int hermitian;     // 1: m even, the inverse runs on the half spectrum; 0: m odd, full complex inverse
+  int lds_bytes;     // dynamic LDS of a workgroup
+};
+int pc_optimal_dft_size(int n);                          // cv::getOptimalDFTSize
+int pc_radix_chain(int m, int* radix, int max_stages);   // number of stages, -1 if m is not 5-smooth
+bool pc_build_plan(int n, PcPlan* out);                  // false: n needs the large-patch pipeline (or is < 2)
+hipError_t pc_configure_generic();
+hipError_t launch_pc_generic(const PcArgs& a, const PcPlan& plan, int n_pairs, hipStream_t stream);
+
+bool pc_patch_size_supported(int n);  // the hand-tuned instantiations: 32, 64, 120, 128
 const char* pc_kernel_variant(int patch_size);
 hipError_t pc_configure(int patch_size);  // once per device before the first launch
 hipError_t launch_pc_field(const PcArgs& a, int patch_size, int n_pairs, hipStream_t stream);

@@ -1,0 +1,485 @@
+// pc_kernel_generic.hip -- K1g: the fused per-patch phase correlation for ANY samplePointSize, from a run-time plan.
+//
+// The reference takes samplePointSize from a ROS parameter (/root/reference/src/FftMethod.cpp:1680-1720,
+// config/default.yaml:31-32) and hands every patch to cv::phaseCorrelate (:1836), which zero-pads it to
+// M = cv::getOptimalDFTSize(N) -- the smallest 2^a 3^b 5^c >= N -- before it transforms (published OpenCV algorithm); its
+// OpenCL branch plans radix-{2,3,4,5,8} passes per size (`ocl_getRadixes`, :481-539). pc_kernel.hip / pc_kernel_mixed.hip
+// hold the hand-tuned instantiations (N = 32, 64, 120, 128); this kernel serves every other size whose padded M x M complex
+// tile fits one CU's LDS (M <= 135), with the SAME algorithm:
+//   z = cur + i prev packed into ONE complex M x M tile (zero rows / columns beyond N), forward 2-D transform in LDS,
+//   untangle + normalised cross-power spectrum with the real-only-slot rule (pc_common.hpp), inverse transform --
+//   Hermitian (half the lines) when M is even, a full complex one when M is odd (no Nyquist row to pack) --, first maximum
+//   of the fft-shifted surface, 5 x 5 (7 x 7) centroid in fp64 around it, centre M / 2.0, gate against N / 2.
+// A 1-D transform is a chain of Stockham auto-sort stages with the plan's radices; wave w owns a contiguous block of lines
+// through a whole pass (stages ordered by the wave's in-order LDS queue, no workgroup barrier inside a pass); a lane carries up
+// to 16 complex values = floor(16 / R) butterflies per stage, lines are packed into the wave's 64 lanes (division by the
+// run-time butterfly count through a host-computed float reciprocal + one correction step, exact for every index that occurs).
+// Twiddles: the M-entry table (cos, -sin computed in double on the host) is copied to LDS once per workgroup.
+// This is the general path: correctness and a sane mapping first; the tuned sizes above stay the fast path.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "mof_kernels.h"
+#include "pc_common.hpp"
+
+namespace mof {
+
+namespace {
+
+// q / d and q % d for 0 <= q < 2^22, 1 <= d < 2^12, inv = 1.0f / d: the float quotient is within one of the true one,
+// one correction step makes it exact
+__device__ __forceinline__ int fdiv(int q, int d, float inv, int* rem) {
+  int li = (int)(((float)q + 0.5f) * inv);
+  int r = q - li * d;
+  if (r < 0) { --li; r += d; }
+  else if (r >= d) { ++li; r -= d; }
+  *rem = r;
+  return li;
+}
+
+// Where a pass finds element e of line l in the tile: row passes walk along a tile row, column passes down a tile column;
+// the column coordinate c of the tile is stored at c + (c >> 3) when the plan skews (stride-8 stage writes then spread
+// over the banks).
+struct Walk {
+  int ls, es;        // strides (complex elements) of the line index / the element index before the skew
+  int lmask, emask;  // ~0 where the skew applies to that coordinate
+  __device__ __forceinline__ int at(int l, int e) const { return l * ls + ((l >> 3) & lmask) + e * es + ((e >> 3) & emask); }
+};
+
+template <int R>
+__device__ __forceinline__ void bfly_r(cf* v) {
+  if constexpr (R == 3) butterfly3(v);
+  else if constexpr (R == 5) butterfly5(v);
+  else butterfly<R>(v);
+}
+
+// One Stockham stage (radix R, `np` = product of the earlier radices) on lines [line0, line0 + nlines) owned by ONE wave,
+// in place. Butterfly x of a line reads elements x + j (m / R), multiplies them by W_{np R}^{j (x mod np)} and writes the
+// R outputs to (x - x mod np) R + x mod np + p np. HERM: the first stage of the Hermitian inverse column pass -- "line" c is
+// the column PAIR (c, c + m/2), element v is E[v] = F1[v][c] + i F1[v][c + m/2] built from rows 0 .. m/2 - 1 of the tile
+// (row 0 = F1[0] + i F1[m/2], both real; F1[m - v] = conj F1[v]) -- see col_pass_inv in pc_passes.hpp.
+template <int R, bool HERM>
+__device__ __attribute__((noinline)) void stage(cf* __restrict__ z, const cf* __restrict__ tw, const Walk w, int m, int np, float inv_np,
+                                                int tstep, int line0, int nlines, int lane) {
+  constexpr int NB = 16 / R;  // butterflies per lane and group
+  const int bpl = m / R;      // butterflies per line
+  const float inv_bpl = 1.0f / (float)bpl;  // (one v_rcp per stage; fdiv corrects the last bit)
+  int G = (64 * NB) / bpl;    // lines per group
+  if (G < 1) G = 1;           // (the plan guarantees bpl <= 64 NB)
+  const int H = m >> 1;
+  for (int g0 = 0; g0 < nlines; g0 += G) {
+    const int gl = nlines - g0 < G ? nlines - g0 : G;
+    const int nbf = gl * bpl;
+    cf v[NB][R];
+    int li[NB], xx[NB], kk[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int q = lane + 64 * b;
+      li[b] = xx[b] = kk[b] = 0;
+      if (q < nbf) {
+        int x;
+        const int l = line0 + g0 + fdiv(q, bpl, inv_bpl, &x);
+        int k = 0;
+        if (np > 1) (void)fdiv(x, np, inv_np, &k);
+        li[b] = l;
+        xx[b] = x;
+        kk[b] = k;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int e = x + j * bpl;
+          cf a;
+          if constexpr (HERM) {
+            const int r = e < H ? e : (e == H ? 0 : m - e);
+            const cf p = lds_read(&z[w.at(l, r)]), c = lds_read(&z[w.at(l + H, r)]);  // tile (row r, col l) and (row r, col l + H)
+            if (e == 0) a = {p.x, c.x};
+            else if (e == H) a = {p.y, c.y};
+            else if (e < H) a = {p.x - c.y, p.y + c.x};
+            else a = {p.x + c.y, c.x - p.y};
+          } else {
+            a = lds_read(&z[w.at(l, e)]);
+          }
+          if (j > 0 && np > 1) a = cmul(a, lds_read(&tw[j * k * tstep]));
+          v[b][j] = a;
+        }
+        bfly_r<R>(v[b]);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int q = lane + 64 * b;
+      if (q < nbf) {
+        const int base = (xx[b] - kk[b]) * R + kk[b];
+#pragma unroll
+        for (int p = 0; p < R; ++p) z[w.at(li[b], base + p * np)] = v[b][p];
+      }
+    }
+    wave_sync();
+  }
+}
+
+// all stages of one 1-D pass over the wave's lines
+template <bool HERM>
+__device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl, const Walk& w, int line0, int nlines, int lane) {
+  int np = 1;
+  for (int s = 0; s < pl.n_stages; ++s) {
+    const int R = (int)((pl.radix_packed >> (4 * s)) & 15u);  // (a dynamic index into the kernel argument would go through scratch)
+    const int tstep = pl.m / (np * R);
+    const float inv_np = 1.0f / (float)np;
+    if (HERM && s == 0) {
+      switch (R) {
+        case 8: stage<8, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+        case 5: stage<5, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+        case 4: stage<4, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+        case 3: stage<3, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+        default: stage<2, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+      }
+    } else {
+      switch (R) {
+        case 8: stage<8, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+        case 5: stage<5, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+        case 4: stage<4, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+        case 3: stage<3, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+        default: stage<2, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
+      }
+    }
+    np *= R;
+  }
+}
+
+// one pixel of the correlated image (row y, column x of the patch whose top-left pixel is `base`): as it is, through the
+// node's CV_RGB2GRAY on BGR8 data (CH = 3), or as the quarter-resolution pixel of the long-range mode (DS = 4) -- the same
+// three front ends as pc_field_kernel (pc_kernel.hip)
+template <int DS, int CH>
+__device__ __forceinline__ uint32_t fetch_px(const uint8_t* __restrict__ base, size_t pitch, int y, int x) {
+  if constexpr (DS == 4) {
+    const uint8_t* r1 = base + (size_t)(4 * y + 1) * pitch + 4 * x;
+    const uint8_t* r2 = r1 + pitch;
+    return ((uint32_t)r1[1] + r1[2] + r2[1] + r2[2] + 2u) >> 2;
+  } else if constexpr (CH == 3) {
+    const uint8_t* p = base + (size_t)y * pitch + 3 * x;
+    return rgb2gray_fixed(p[0], p[1], p[2]);
+  } else {
+    return base[(size_t)y * pitch + x];
+  }
+}
+
+}  // namespace
+
+template <int DS, int CH, int PK>
+__global__ void __launch_bounds__(1024) pc_generic_kernel(PcArgs a, PcPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+  const int m = pl.m, n = pl.n, H = m >> 1, T = (int)blockDim.x, WAVES = T >> 6;
+  cf* z = reinterpret_cast<cf*>(smem_g);
+  cf* tw = z + (size_t)m * pl.pitch;
+  Best* red = reinterpret_cast<Best*>(tw + m);
+  int* flags = reinterpret_cast<int*>(red + 16);  // [0] cur differs from its first pixel, [1] prev does, [2] C_dc bits
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float inv_m = 1.0f / (float)m;
+  const bool herm = pl.hermitian != 0;
+
+  // ---- patch origin (one workgroup per patch on a 3-D grid: column, row, pair)
+  const int px0 = a.origin_x + (int)blockIdx.x * a.stride_x, py0 = a.origin_y + (int)blockIdx.y * a.stride_y;
+  const size_t poff = (size_t)(DS * py0) * a.pitch + (size_t)(CH * DS * px0);
+  const uint8_t* cur = a.cur + (size_t)blockIdx.z * a.cur_stride + poff;
+  const uint8_t* prev = a.prev + (size_t)blockIdx.z * a.prev_stride + poff;
+  const size_t p = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+
+  if (tid < 2) flags[tid] = 0;
+  for (int k = tid; k < m; k += T) tw[k] = {a.twiddles[2 * k], a.twiddles[2 * k + 1]};
+
+  // ---- load: u8 -> f32 (convertTo, :1805-1806), z = cur + i prev, zero rows / columns beyond N (copyMakeBorder of
+  //      cv::phaseCorrelate); constant patches are detected here with integer compares (pc_common.hpp, degenerate pairs)
+  {
+    const uint32_t c00 = fetch_px<DS, CH>(cur, a.pitch, 0, 0), p00 = fetch_px<DS, CH>(prev, a.pitch, 0, 0);
+    uint32_t dc = 0u, dp = 0u;
+    for (int i = tid; i < m * m; i += T) {
+      int x;
+      const int y = fdiv(i, m, inv_m, &x);
+      cf v = {0.f, 0.f};
+      if (y < n && x < n) {
+        const uint32_t c = fetch_px<DS, CH>(cur, a.pitch, y, x), q = fetch_px<DS, CH>(prev, a.pitch, y, x);
+        dc |= c ^ c00;
+        dp |= q ^ p00;
+        v = {(float)c, (float)q};
+      }
+      z[y * pl.pitch + x + ((x >> 3) & pl.skew_mask)] = v;
+    }
+    __syncthreads();  // flags[] zeroed, twiddles in place
+    if (__builtin_amdgcn_ballot_w64(dc != 0u) != 0ull && lane == 0) flags[0] = 1;
+    if (__builtin_amdgcn_ballot_w64(dp != 0u) != 0ull && lane == 0) flags[1] = 1;
+  }
+  __syncthreads();
+
+  const Walk rows = {pl.pitch, 1, 0, pl.skew_mask}, cols = {1, pl.pitch, pl.skew_mask, 0};
+  auto zat = [&](int r, int c) -> cf& { return z[r * pl.pitch + c + ((c >> 3) & pl.skew_mask)]; };
+  // wave w owns lines [w lpw, min((w + 1) lpw, L))
+  auto my_lines = [&](int L, int* l0, int* nl) {
+    const int lpw = (L + WAVES - 1) / WAVES;
+    *l0 = wave * lpw;
+    int cnt = L - *l0;
+    cnt = cnt < 0 ? 0 : (cnt > lpw ? lpw : cnt);
+    *nl = cnt;
+  };
+
+  // ---- forward 2-D transform (dft x2, :1491-1493)
+  {
+    int l0, nl;
+    my_lines(m, &l0, &nl);
+    if (nl > 0) pass_lines<false>(z, tw, pl, rows, l0, nl, lane);
+    __syncthreads();
+    if (nl > 0) pass_lines<false>(z, tw, pl, cols, l0, nl, lane);
+    __syncthreads();
+  }
+
+  // ---- untangle, P = A conj(B), C = P |P| / (|P|^2 + eps) with the real-only-slot rule (mulSpectrums :1494, magSpectrums
+  //      :70-168, divSpectrums :1086-1251), stored conjugated for the inverse (a forward transform of conj C)
+  if (herm) {
+    // rows 1 .. H-1, every u: the partner (m - v, m - u) lies in the untouched lower half
+    for (int i = tid; i < (H - 1) * m; i += T) {
+      int u;
+      const int v = 1 + fdiv(i, m, inv_m, &u);
+      const int um = u == 0 ? 0 : m - u;
+      const cf C = cross_power<PK>(zat(v, u), zat(m - v, um), false);
+      zat(v, u) = {C.x, -C.y};
+    }
+    // rows 0 and H share row 0: G[u] = conj C[0][u] + i conj C[H][u]; the partner of u is m - u in the same rows
+    for (int u = tid; u <= H; u += T) {
+      const int um = u == 0 ? 0 : m - u;
+      const bool self = u == um;
+      const cf C0 = cross_power<PK>(zat(0, u), zat(0, um), self);
+      const cf Ch = cross_power<PK>(zat(H, u), zat(H, um), self);
+      if (u == 0) flags[2] = __float_as_int(C0.x);  // C_dc: all that is left of a degenerate pair's spectrum
+      zat(0, u) = {C0.x + Ch.y, Ch.x - C0.y};
+      if (!self) zat(0, um) = {C0.x - Ch.y, Ch.x + C0.y};
+    }
+  } else {
+    // odd M: no Nyquist row to pack, the only real-only slot is DC; every bin pair (k, -k) is formed once
+    for (int i = tid; i < m * m; i += T) {
+      int u;
+      const int v = fdiv(i, m, inv_m, &u);
+      const int vm = v == 0 ? 0 : m - v, um = u == 0 ? 0 : m - u;
+      const int ip = vm * m + um;
+      if (i > ip) continue;
+      const cf C = cross_power<PK>(zat(v, u), zat(vm, um), i == 0);
+      if (i == 0) flags[2] = __float_as_int(C.x);
+      zat(v, u) = {C.x, -C.y};
+      if (i != ip) zat(vm, um) = {C.x, C.y};  // C[-k] = conj C[k]
+    }
+  }
+  __syncthreads();
+
+  // ---- inverse (unscaled, idft :1497) as forward transforms of conj C
+  {
+    int l0, nl;
+    my_lines(herm ? H : m, &l0, &nl);
+    if (nl > 0) pass_lines<false>(z, tw, pl, rows, l0, nl, lane);
+    __syncthreads();
+    if (nl > 0) {
+      if (herm) pass_lines<true>(z, tw, pl, cols, l0, nl, lane);   // column pairs (c, c + H): z(y, c) = (S[y][c], S[y][c + H])
+      else pass_lines<false>(z, tw, pl, cols, l0, nl, lane);       // z(y, x).x = S[y][x]
+    }
+    __syncthreads();
+  }
+
+  // ---- surface value at UN-shifted (y, x), incl. the OpenCL model's scaling and +-search_radius mask (cl:733, :737-746)
+  const float ocl_scale = 1.0f / (float)(m * m);
+  auto surf = [&](int y, int x) -> float {
+    float s;
+    if (herm) {
+      const cf t = zat(y, x < H ? x : x - H);
+      s = x < H ? t.x : t.y;
+    } else {
+      s = zat(y, x).x;
+    }
+    if constexpr (PK == 1) {
+      const int sr = a.search_radius;
+      const bool masked = (y > sr && y < m - sr) || (x > sr && x < m - sr);
+      s = masked ? 0.f : s * ocl_scale;
+    }
+    return s;
+  };
+
+  // ---- first maximum of the fft-shifted surface in row-major order (fftShift :1257-1323: index i -> (i + (m >> 1)) mod m for
+  //      even and odd m alike; minMaxLoc :1539)
+  Best best = {-__builtin_huge_valf(), 0x7fffffff};
+  for (int y = wave; y < m; y += WAVES) {
+    const int ys = y + H >= m ? y + H - m : y + H;
+    for (int x = lane; x < m; x += 64) {
+      const int xs = x + H >= m ? x + H - m : x + H;
+      best = better(best, Best{surf(y, x), ys * m + xs});
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o = {__shfl_xor(best.v, off, 64), __shfl_xor(best.idx, off, 64)};
+    best = better(best, o);
+  }
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+
+  // ---- weighted centroid in double + validity gate (:1337-1383, :1838-1856), wave 0
+  if (wave == 0) {
+    for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
+    constexpr int RAD = PeakModel<PK>::RAD, W = PeakModel<PK>::W;
+    const bool have = best.idx != 0x7fffffff;
+    const int py = have ? best.idx / m : 0, pxk = have ? best.idx - py * m : 0;
+    const int ys = py - RAD + lane / W, xs = pxk - RAD + lane % W;
+    double val = 0.0;
+    if (have && lane < W * W && ys >= 0 && ys <= m - 1 && xs >= 0 && xs <= m - 1) {  // window clamped to the (padded) patch
+      const int y = ys - H < 0 ? ys - H + m : ys - H, x = xs - H < 0 ? xs - H + m : xs - H;  // un-shifted position
+      const float v = surf(y, x);
+      val = (double)((PK == 1 && !(v > 0.f)) ? 0.f : v);
+    }
+    double cx = (double)xs * val, cy = (double)ys * val, sum = val;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      cx += __shfl_xor(cx, off, 64);
+      cy += __shfl_xor(cy, off, 64);
+      sum += __shfl_xor(sum, off, 64);
+    }
+    if (lane == 0) {
+      sum += PK == 1 ? 1.1920928955078125e-07 : 2.220446049250313e-16;  // FLT_EPSILON cl:1342 / DBL_EPSILON :1378
+      // shift = -(center - t) = t - M / 2.0 (:1836): cv::phaseCorrelate's centre is that of the PADDED image
+      const double half_m = (double)m / 2.0, half_n = (double)n / 2.0;
+      double sx = cx / sum - half_m, sy = cy / sum - half_m;
+      // a constant patch: its separate transform is exactly zero off DC, the surface is flat = C_dc (pc_common.hpp). With
+      // padding (m > n) only the all-zero patch stays constant on the padded image.
+      const bool cconst = flags[0] == 0, pconst = flags[1] == 0;
+      const bool degenerate = m == n ? (cconst || pconst)
+                                     : ((cconst && fetch_px<DS, CH>(cur, a.pitch, 0, 0) == 0u) || (pconst && fetch_px<DS, CH>(prev, a.pitch, 0, 0) == 0u));
+      if (degenerate) {
+        if constexpr (PK == 1) {
+          sx = sy = __builtin_nan("");
+        } else {
+          const double c9 = 9.0 * (double)__int_as_float(flags[2]);
+          sx = sy = (c9 > 0.0 ? c9 / (c9 + 2.220446049250313e-16) : 0.0) - half_m;
+        }
+      }
+      // the gate compares with samplePointSize / 2 -- the UNPADDED size (:1841-1842)
+      const bool bad = (sx * sx + sy * sy > a.max_px_speed_sq) || (fabs(sx) > half_n) || (fabs(sy) > half_n) || (sx != sx) ||
+                       (sy != sy) || (!have && !degenerate);
+      if (bad) sx = sy = __builtin_nan("");
+      a.out[2 * p] = sx;
+      a.out[2 * p + 1] = sy;
+    }
+  }
+}
+
+// ---- host: the plan ------------------------------------------------------------------------------------------------------
+
+int pc_optimal_dft_size(int n) {
+  if (n < 1) return -1;
+  for (int m = n; m < (1 << 30); ++m) {
+    int r = m;
+    while (r % 2 == 0) r /= 2;
+    while (r % 3 == 0) r /= 3;
+    while (r % 5 == 0) r /= 5;
+    if (r == 1) return m;
+  }
+  return -1;
+}
+
+// radix chain of a 5-smooth m: the 5s and the 3s first, then 8s and one 4 or 2 for what is left of the power of two (the
+// radix set of ocl_getRadixes, FftMethod.cpp:494-520). The LAST radix is even whenever m is: bin m/2 of a Stockham chain is
+// then output R/2 of a twiddle-free last butterfly whose inputs are the p = 0 outputs of twiddle-free butterflies all the way
+// down -- sums and differences only, like bin 0. On u8 pixels those are exact in f32 (|sum| < 2^24), so the four real-only CCS
+// slots (0 | m/2, 0 | m/2) come out of the PACKED transform exactly as the reference's separate transforms produce them. It
+// matters: there C = P / (P^2 + eps), which is 0 for P = 0 but up to 1 / (2 sqrt(eps)) = 1448 for a P of rounding
+// noise -- a checkerboard higher than the peak. (Found on 30 x 30 patches: alternating pixel sums cancel exactly in about one
+// patch per 480 x 480 frame; with the odd radix last the result was off by 0.1 .. 0.9 px there.)
+int pc_radix_chain(int m, int* radix, int max_stages) {
+  int ns = 0, r = m, p2 = 0, p3 = 0, p5 = 0;
+  while (r % 2 == 0) { r /= 2; ++p2; }
+  while (r % 3 == 0) { r /= 3; ++p3; }
+  while (r % 5 == 0) { r /= 5; ++p5; }
+  if (r != 1) return -1;
+  auto push = [&](int R) { if (ns < max_stages) radix[ns] = R; ++ns; };
+  while (p5-- > 0) push(5);
+  while (p3-- > 0) push(3);
+  const int rest = p2 % 3;  // 8s, then the 4 or 2 (an even radix last either way)
+  for (int i = 0; i < p2 / 3; ++i) push(8);
+  if (rest == 2) push(4);
+  if (rest == 1) push(2);
+  return ns <= max_stages ? ns : -1;
+}
+
+bool pc_build_plan(int n, PcPlan* out) {
+  if (n < 2) return false;
+  PcPlan pl{};
+  pl.n = n;
+  pl.m = pc_optimal_dft_size(n);
+  if (pl.m < 2) return false;
+  pl.n_stages = pc_radix_chain(pl.m, pl.radix, 8);
+  if (pl.n_stages < 1) return false;
+  for (int s = 0; s < pl.n_stages; ++s)
+    if (pl.m / pl.radix[s] > 64 * (16 / pl.radix[s])) return false;  // a line's butterflies must fit one group (m <= 960)
+  for (int s = 0; s < pl.n_stages; ++s) pl.radix_packed |= (uint32_t)pl.radix[s] << (4 * s);
+  pl.hermitian = pl.m % 2 == 0 ? 1 : 0;
+  const size_t extra = sizeof(float) * 2 * (size_t)pl.m + 16 * sizeof(Best) + 64, cap = 160u * 1024u;
+  auto pitch_for = [](int row) { int p = row; while (p % 16 != 8) ++p; return p; };  // = 8 (mod 16): column walks spread over the banks
+  const int skew_row = pl.m + ((pl.m - 1) >> 3);
+  if ((size_t)pl.m * pitch_for(skew_row) * 8 + extra <= cap) {
+    pl.skew_mask = ~0;
+    pl.pitch = pitch_for(skew_row);
+  } else if ((size_t)pl.m * pitch_for(pl.m) * 8 + extra <= cap) {
+    pl.skew_mask = 0;
+    pl.pitch = pitch_for(pl.m);
+  } else if ((size_t)pl.m * pl.m * 8 + extra <= cap) {
+    pl.skew_mask = 0;
+    pl.pitch = pl.m;
+  } else {
+    return false;  // the tile does not fit one CU's LDS
+  }
+  pl.lds_bytes = (int)((size_t)pl.m * pl.pitch * 8 + extra);
+  int t = (pl.m * pl.m / 16 + 63) / 64 * 64;  // ~16 complex elements per lane
+  pl.threads = t < 64 ? 64 : (t > 1024 ? 1024 : t);
+  *out = pl;
+  return true;
+}
+
+template <int DS, int CH, int PK>
+static hipError_t configure_generic_one() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_generic_kernel<DS, CH, PK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             160 * 1024);
+}
+
+hipError_t pc_configure_generic() {
+  hipError_t e;
+  if ((e = configure_generic_one<1, 1, 0>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<1, 3, 0>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<4, 1, 0>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<1, 1, 1>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<1, 3, 1>()) != hipSuccess) return e;
+  return configure_generic_one<4, 1, 1>();
+}
+
+hipError_t launch_pc_generic(const PcArgs& a_in, const PcPlan& pl, int n_pairs, hipStream_t stream) {
+  if (a_in.downscale == 4 && a_in.channels == 3) return hipErrorInvalidValue;
+  if (pl.threads < 64 || pl.threads > 1024 || pl.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  const int patches = a_in.grid_x * a_in.grid_y;
+  const dim3 b((unsigned)pl.threads);
+  for (int k0 = 0; k0 < n_pairs; k0 += 65535) {  // the pair index rides gridDim.z
+    const int nk = n_pairs - k0 < 65535 ? n_pairs - k0 : 65535;
+    PcArgs c = a_in;
+    c.cur = a_in.cur + (size_t)k0 * a_in.cur_stride;
+    c.prev = a_in.prev + (size_t)k0 * a_in.prev_stride;
+    c.out = a_in.out + (size_t)k0 * patches * 2;
+    c.total = nk * patches;
+    const dim3 g((unsigned)c.grid_x, (unsigned)c.grid_y, (unsigned)nk);
+    if (c.peak_model == 1) {
+      if (c.downscale == 4) hipLaunchKernelGGL((pc_generic_kernel<4, 1, 1>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      else if (c.channels == 3) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 1>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 1>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+    } else {
+      if (c.downscale == 4) hipLaunchKernelGGL((pc_generic_kernel<4, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      else if (c.channels == 3) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+    }
+  }
+  return hipGetLastError();
+}
+
+}  // namespace mof

@@ -31,7 +31,7 @@ extern "C" {
  * case origin=0, stride=patch, grid=sqNum. */
 typedef struct oracle_fft_layout {
   int width, height;      /* frame size in pixels                       */
-  int patch;              /* samplePointSize N (even)                   */
+  int patch;              /* samplePointSize N (any >= 2; padded inside)*/
   int grid_x, grid_y;     /* patches per row / column                   */
   int origin_x, origin_y; /* top-left of patch (0,0)                    */
   int stride_x, stride_y; /* distance between patch origins             */
@@ -46,11 +46,17 @@ typedef struct oracle_pc_diag {
   double response;        /* sum over the 5x5 window / (N*N)            */
 } oracle_pc_diag;
 
+/* cv::getOptimalDFTSize: smallest 2^a 3^b 5^c >= n [published OpenCV algorithm, unpinned]. */
+int oracle_optimal_dft_size(int n);
+
 /* cv::phaseCorrelate(a, b) restated (src/FftMethod.cpp:1487-1498 stage order;
  * :70-168 magSpectrums; :1086-1251 divSpectrums; :1257-1323 fftShift;
- * :1329-1385 weightedCentroid). a,b: n x n, row strides in ELEMENTS.
- * Returns (center - t) in out_xy[0..1]. surface (optional, n*n) receives the
- * fft-shifted correlation surface. Return 0 ok, <0 bad argument. */
+ * :1329-1385 weightedCentroid). a,b: n x n (any n >= 2), row strides in ELEMENTS.
+ * As cv::phaseCorrelate does, both are zero-padded (bottom / right) to m x m,
+ * m = oracle_optimal_dft_size(n), which may be odd; peak, centroid and centre
+ * (m / 2.0) live on the padded image. Returns (center - t) in out_xy[0..1].
+ * surface (optional, m*m) receives the fft-shifted correlation surface; diag's
+ * peak is in its coordinates. Return 0 ok, <0 bad argument. */
 int oracle_phase_correlate_f32(const float* a, size_t a_stride, const float* b, size_t b_stride, int n,
                                double* out_xy, oracle_pc_diag* diag, float* surface);
 /* Same arithmetic carried in double everywhere ("truth" variant; eps stays FLT_EPSILON). */

@@ -21,6 +21,20 @@ static int largest_prime_factor(int n) {
   return best;
 }
 
+/* cv::getOptimalDFTSize(n): the smallest m >= n of the form 2^a 3^b 5^c (OpenCV looks it up in a table of exactly those
+ * numbers, optimalDFTSizeTab) [published OpenCV algorithm, unpinned]. */
+int oracle_optimal_dft_size(int n) {
+  if (n < 1) return -1;
+  for (int m = n;; ++m) {
+    int r = m;
+    while (r % 2 == 0) r /= 2;
+    while (r % 3 == 0) r /= 3;
+    while (r % 5 == 0) r /= 5;
+    if (r == 1) return m;
+    if (m == 2147483647) return -1;
+  }
+}
+
 #define R float
 #define SUFFIX _f32
 #define FMA_R fmaf
@@ -45,7 +59,7 @@ int oracle_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch,
                           int precision, double* out_xy, int* n_invalid, oracle_pc_diag* diag) {
   if (!cur || !prev || !L || !out_xy) return -1;
   const int n = L->patch;
-  if (n < 2 || (n & 1) || largest_prime_factor(n) > 61) return -1;
+  if (n < 2) return -1; /* any patch size: cv::phaseCorrelate pads to getOptimalDFTSize(n) itself */
   if (L->grid_x < 1 || L->grid_y < 1 || L->origin_x < 0 || L->origin_y < 0) return -1;
   if (L->origin_x + (L->grid_x - 1) * L->stride_x + n > L->width) return -1;
   if (L->origin_y + (L->grid_y - 1) * L->stride_y + n > L->height) return -1;
@@ -79,7 +93,7 @@ int oracle_fft_process_u8(const uint8_t* cur, const uint8_t* prev, size_t pitch,
       if (rc) { free(af); free(ad); return rc; }
       /* shift = -cv::phaseCorrelate(cur, prev)  (ref :1836) */
       double sx = -pc[0], sy = -pc[1];
-      /* gate (ref :1840-1856) */
+      /* gate (ref :1840-1856): against samplePointSize / 2 -- the UNPADDED size */
       int valid = 1;
       if (sx * sx + sy * sy > max_sq || fabs(sx) > (double)n / 2 || fabs(sy) > (double)n / 2) valid = 0;
       if (isnan(sx) || isnan(sy)) valid = 0;

@@ -6,11 +6,13 @@
  * The spectrum is held as a full N x N complex array, but only the bins that
  * OpenCV's CCS-packed real spectrum stores are ever computed on; the rest is
  * filled by Hermitian symmetry before the inverse transform. Which arithmetic
- * flavour a bin gets follows where CCS stores it:
+ * flavour a bin gets follows where CCS stores it (N even; for odd N there is no
+ * N/2 column / row and the only real-only slot is DC):
  *   - column-frequency 0 and N/2, row-frequency 0 and N/2 : the 4 real-only slots
  *   - column-frequency 0 and N/2, row-frequency 1..N/2-1  : "column" pairs (double maths)
  *   - column-frequency 1..N/2-1, every row-frequency      : "interior" pairs (working-type maths)
  * (ref: magSpectrums :103-131, divSpectrums :1123-1181).
+ * N is the PADDED size getOptimalDFTSize(n) -- cv::phaseCorrelate zero-pads to it.
  */
 
 #ifndef R
@@ -142,9 +144,14 @@ static FN(cpx) FN(cross_power_bin)(FN(cpx) a, FN(cpx) b, int kind) {
   return c;
 }
 
-int FN(oracle_phase_correlate)(const R* a, size_t a_stride, const R* b, size_t b_stride, int n, double* out_xy,
+int FN(oracle_phase_correlate)(const R* a, size_t a_stride, const R* b, size_t b_stride, int n_in, double* out_xy,
                                oracle_pc_diag* diag, R* surface) {
-  if (!a || !b || !out_xy || n < 2 || (n & 1) || largest_prime_factor(n) > 61) return -1; /* even sizes only */
+  if (!a || !b || !out_xy || n_in < 2) return -1;
+  /* cv::phaseCorrelate pads both images with zeros (copyMakeBorder, BORDER_CONSTANT 0, bottom / right) to
+   * M = N = getOptimalDFTSize(rows / cols) before anything else [published OpenCV algorithm, unpinned]; everything from
+   * here on -- spectra, fftShift, peak, centroid, `center` -- lives on the PADDED n x n image. n may be odd (e.g. 74 -> 75). */
+  const int n = oracle_optimal_dft_size(n_in);
+  if (n < 2) return -1;
   const size_t nn = (size_t)n * n;
   FN(cpx)* A = (FN(cpx)*)malloc(sizeof(FN(cpx)) * nn);
   FN(cpx)* B = (FN(cpx)*)malloc(sizeof(FN(cpx)) * nn);
@@ -158,35 +165,42 @@ int FN(oracle_phase_correlate)(const R* a, size_t a_stride, const R* b, size_t b
   }
   FN(make_twiddles)(tw, n);
 
-  /* dft(a, DFT_REAL_OUTPUT), dft(b, ...) -- ref :1491-1493. No window, no padding
-   * (getOptimalDFTSize(N)=N for the sizes used). */
+  /* dft(a, DFT_REAL_OUTPUT), dft(b, ...) -- ref :1491-1493. No window. */
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
-      A[(size_t)y * n + x].re = a[(size_t)y * a_stride + x];
+      const int inside = y < n_in && x < n_in;
+      A[(size_t)y * n + x].re = inside ? a[(size_t)y * a_stride + x] : (R)0;
       A[(size_t)y * n + x].im = (R)0;
-      B[(size_t)y * n + x].re = b[(size_t)y * b_stride + x];
+      B[(size_t)y * n + x].re = inside ? b[(size_t)y * b_stride + x] : (R)0;
       B[(size_t)y * n + x].im = (R)0;
     }
   FN(fft2d)(A, n, tw, 0, scratch);
   FN(fft2d)(B, n, tw, 0, scratch);
 
-  /* mulSpectrums(conjB) -> magSpectrums -> divSpectrums on the CCS bins (ref :1494-1496). */
-  const int h = n / 2;
+  /* mulSpectrums(conjB) -> magSpectrums -> divSpectrums on the CCS bins (ref :1494-1496). CCS of an n x n real transform:
+   * column-frequency 0 (and n/2 when n is even) is stored down the first (last) column as Re Y[0], (Re, Im) Y[1..], and --
+   * when n is even -- Re Y[n/2]: `for (k = 0; k < (cols % 2 ? 1 : 2); k++)`, `if (rows % 2 == 0)`, `for (j = 1; j <= rows - 2;
+   * j += 2)` (ref :103-119, :1123-1140); the other column-frequencies 1 .. (n-1)/2 are (Re, Im) pairs in every row
+   * (`for (j = j0; j < j1; j += 2)`, j1 = ncols - (cols % 2 == 0), ref :96-97, :121-131). */
+  const int h = n / 2; /* floor */
+  const int even = (n % 2 == 0);
   for (int r = 0; r < n; ++r)
     for (int c = 0; c <= h; ++c) {
-      const int edge_col = (c == 0 || c == h);
+      const int edge_col = (c == 0 || (even && c == h));
       if (edge_col && r > h) continue; /* not stored in CCS; filled by symmetry below */
-      int kind = edge_col ? ((r == 0 || r == h) ? 0 : 1) : 2;
+      int kind = edge_col ? ((r == 0 || (even && r == h)) ? 0 : 1) : 2;
       FN(cpx) av = A[(size_t)r * n + c], bv = B[(size_t)r * n + c];
       if (kind == 0) { av.im = (R)0; bv.im = (R)0; } /* CCS holds only the real part there */
       C[(size_t)r * n + c] = FN(cross_power_bin)(av, bv, kind);
     }
   /* Hermitian fill: C[N-r][N-c] = conj(C[r][c]). */
-  for (int c = 0; c <= h; c += h)
+  for (int c = 0; c <= h; c += (h > 0 ? h : 1)) {
+    if (c == h && !even) break; /* odd n: only column-frequency 0 is an edge column */
     for (int r = h + 1; r < n; ++r) {
       C[(size_t)r * n + c].re = C[(size_t)(n - r) * n + c].re;
       C[(size_t)r * n + c].im = -C[(size_t)(n - r) * n + c].im;
     }
+  }
   for (int r = 0; r < n; ++r)
     for (int c = h + 1; c < n; ++c) {
       FN(cpx) v = C[(size_t)((n - r) % n) * n + (n - c)];
@@ -194,11 +208,12 @@ int FN(oracle_phase_correlate)(const R* a, size_t a_stride, const R* b, size_t b
       C[(size_t)r * n + c].im = -v.im;
     }
 
-  /* idft, unscaled, real output (ref :1497); fftShift (ref :1297-1305: even sizes swap
-   * q0<->q3, q1<->q2 == circular shift by N/2). */
+  /* idft, unscaled, real output (ref :1497); fftShift (ref :1257-1323): even sizes swap q0<->q3, q1<->q2 (:1297-1305), odd
+   * sizes move the (xMid + 1)-wide first block behind the xMid-wide second one (:1306-1317) -- either way source index i
+   * lands at (i + n/2) mod n with n/2 = xMid = n >> 1. */
   FN(fft2d)(C, n, tw, 1, scratch);
   for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) S[(size_t)y * n + x] = C[(size_t)((y + h) % n) * n + ((x + h) % n)].re;
+    for (int x = 0; x < n; ++x) S[(size_t)((y + h) % n) * n + ((x + h) % n)] = C[(size_t)y * n + x].re;
 
   /* minMaxLoc: first maximum in row-major order (ref :1539). */
   int px = 0, py = 0;
@@ -230,7 +245,9 @@ int FN(oracle_phase_correlate)(const R* a, size_t a_stride, const R* b, size_t b
   cx /= sum;
   cy /= sum;
 
-  /* center - t (cv::phaseCorrelate's return value; the caller negates, ref :1836). */
+  /* center - t with center = (padded cols / 2.0, padded rows / 2.0) (cv::phaseCorrelate's return value; the caller
+   * negates, ref :1836). For odd n the centre is a half-integer while the unshifted origin lands on the integer n >> 1:
+   * identical images then give (0.5, 0.5) -- OpenCV's behaviour, reproduced. */
   out_xy[0] = (double)n / 2.0 - cx;
   out_xy[1] = (double)n / 2.0 - cy;
 

@@ -68,6 +68,8 @@ def lib():
     if _lib is None:
         build()
         L = C.CDLL(ORACLE_SO)
+        L.oracle_optimal_dft_size.restype = C.c_int
+        L.oracle_optimal_dft_size.argtypes = [C.c_int]
         L.oracle_phase_correlate_f32.restype = C.c_int
         L.oracle_phase_correlate_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
                                                   C.c_void_p, C.POINTER(PcDiag), C.c_void_p]
@@ -139,6 +141,11 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def optimal_dft_size(n: int) -> int:
+    """cv::getOptimalDFTSize as the oracle restates it."""
+    return int(lib().oracle_optimal_dft_size(int(n)))
+
+
 def phase_correlate(a: np.ndarray, b: np.ndarray, precision: int = 32, want_surface: bool = False):
     """cv::phaseCorrelate(a, b) restated. Returns ((x, y), diag dict[, surface])."""
     n = a.shape[0]
@@ -148,7 +155,8 @@ def phase_correlate(a: np.ndarray, b: np.ndarray, precision: int = 32, want_surf
     b = np.ascontiguousarray(b, dtype=dt)
     out = np.zeros(2, np.float64)
     diag = PcDiag()
-    surf = np.zeros((n, n), dt) if want_surface else None
+    m = optimal_dft_size(n)  # the surface lives on the zero-padded image
+    surf = np.zeros((m, m), dt) if want_surface else None
     fn = lib().oracle_phase_correlate_f32 if precision == 32 else lib().oracle_phase_correlate_f64
     rc = fn(_ptr(a), n, _ptr(b), n, n, _ptr(out), C.byref(diag), _ptr(surf) if want_surface else None)
     if rc:

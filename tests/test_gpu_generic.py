@@ -1,0 +1,179 @@
+"""GPU parity tests of the size-generic paths (round 4): ANY samplePointSize / resolution the reference accepts.
+
+FftMethod takes frameSize / samplePointSize from ROS parameters (/root/reference/src/FftMethod.cpp:1680-1720,
+config/default.yaml:31-32) and hands each patch to cv::phaseCorrelate, which zero-pads to getOptimalDFTSize(N) -- possibly an
+ODD size (74 -> 75). Sizes without a hand-tuned kernel run the planned kernel (csrc/pc_kernel_generic.hip). Same bars as
+tests/test_gpu_fft.py: 1e-4 px against both oracle precisions on well-conditioned patches.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from mrs_optic_flow_amd import FftMethod, MofError, synth
+from mrs_optic_flow_amd.engine import PEAK_OCL
+from test_gpu_fft import TOL
+
+pytestmark = pytest.mark.gpu
+F32_LIMITED = []  # (label, patch, oracle-to-oracle distance): reported by the last test of this file
+
+
+def _compare(got, cur, prev, lay, label=""):
+    """As tests/test_gpu_fft.py::_compare, with one refinement (the rule of tools/fft_sr_fuzz.py, made explicit): where the f32
+    oracle -- the reference's own arithmetic -- is itself further than 2e-5 px from the f64 restatement, a cross-power bin
+    sits at the f32 rounding floor and its unit-magnitude phase is noise (one such bin pair moves the centroid by ~1e-3 px):
+    f32 oracle, f64 oracle and kernel are then three roundings of an ill-conditioned quantity, and the bar is four times the
+    oracle-to-oracle distance. Everywhere else: 1e-4 px against both. Returns the number of well-conditioned patches checked."""
+    want64, _, diags = O.fft_process(cur, prev, lay, 64, want_diag=True)
+    want32, _ = O.fft_process(cur, prev, lay, 32)
+    n_checked = 0
+    for p in range(want64.shape[0]):
+        if not diags[p].second_value < 0.5 * diags[p].peak_value:
+            continue
+        n64, n32 = np.isnan(want64[p]), np.isnan(want32[p])
+        if n64.any() or n32.any():
+            if np.array_equal(n64, n32):
+                assert np.array_equal(np.isnan(got[p]), n64), (label, p, got[p], want64[p])
+            continue
+        dd = float(np.abs(want32[p] - want64[p]).max())
+        slack = TOL if dd <= 2e-5 else TOL + 4.0 * dd
+        if dd > 2e-5:
+            F32_LIMITED.append((label, p, dd))
+        assert np.abs(got[p] - want64[p]).max() <= slack and np.abs(got[p] - want32[p]).max() <= slack, (label, p, got[p], want64[p], want32[p])
+        n_checked += 1
+    return n_checked
+
+# even 5-smooth sizes (no padding), sizes that pad to an even size, sizes that pad to an ODD size, odd sizes, small sizes
+SIZES = [40, 48, 60, 80, 96, 100, 16, 20, 24, 36, 72, 90, 108, 125, 135,  # M = N
+         62, 98, 118, 34, 66, 130,                                       # N -> even M (64, 100, 120, 36, 72, 135 is odd)
+         74, 44, 26, 124, 134,                                           # N -> odd M (75, 45, 27, 125, 135)
+         15, 25, 27, 45, 75, 33, 51]                                     # odd N
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_planned_kernel_matches_oracle_at_every_size(gpu, n):
+    gx, gy = (3, 2) if n <= 100 else (2, 2)
+    stride = (n + 3, n + 1)
+    w, h = 5 + stride[0] * (gx - 1) + n + 2, 3 + stride[1] * (gy - 1) + n + 1
+    B = 6
+    cur, prev, shifts, kinds = synth.batch_np(B, h, w, max(1, n // 8), k0=n)
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(5, 3), stride=stride)
+    assert fm.kernel_variant == "planned"
+    got = fm.process_batch_device(torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)).cpu().numpy()
+    lay = O.fft_layout(w, h, n, gx, gy, (5, 3), stride)
+    checked = sum(_compare(got[k], cur[k], prev[k], lay, f"n{n}/pair{k}/{kinds[k]}") for k in range(B))
+    assert checked > (0.6 if n >= 32 else 0.15) * B * gx * gy, (n, checked)  # (tiny patches: few surfaces have a runner-up below half the peak)
+    for k in range(B):
+        if kinds[k] == "shift" and n >= 40:  # (small patches under a non-circular shift are biased towards zero: the oracle comparison above is the test)
+            # odd transform sizes carry cv::phaseCorrelate's half-pixel centre (M / 2.0 against the integer M >> 1)
+            bias = 0.5 if O.optimal_dft_size(n) % 2 else 0.0
+            assert np.allclose(np.nanmedian(got[k], axis=0) + bias, shifts[k], rtol=0, atol=0.5), (n, k)
+
+
+@pytest.mark.parametrize("fs,n", [(480, 60), (480, 80), (480, 96), (400, 100), (480, 40), (480, 48), (296, 74), (480, 30)])
+def test_reference_tiling_stateful_entry(gpu, fs, n):
+    """new FftMethod(frame_size, sample_point_size, ...) as the node constructs it (optic_flow.cpp:1001-1002), driven through
+    processImage: first frame against itself, then against its predecessor."""
+    fm = FftMethod(fs, n, 80.0)
+    sq = fs // n
+    assert fm.sqNum == sq
+    seq = [synth.pair_np(40 + n, fs, fs, 2 * t, -t, blur=True)[0] for t in range(3)]
+    lay = O.fft_layout(fs, fs, n, sq, sq)
+    out0 = fm.processImage(seq[0])
+    assert np.allclose(out0, O.fft_process(seq[0], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    for t in (1, 2):
+        out = fm.processImage(seq[t])
+        assert _compare(out, seq[t], seq[t - 1], lay, f"fs{fs}/n{n}/t{t}") > 0.7 * sq * sq
+
+
+@pytest.mark.parametrize("n", [60, 96, 100, 74])
+def test_planned_kernel_front_ends(gpu, n):
+    """The three front ends of K1 on a planned size: BGR8 frames (CV_RGB2GRAY fused, optic_flow.cpp:1622), the long-range mode
+    (quarter-resolution pixels formed on the fly, FftMethod.cpp:1905-2007) and a video through the sequence entry."""
+    rng = np.random.default_rng(n)
+    # BGR
+    gx, gy = 2, 2
+    w, h = 2 * n + 9, 2 * n + 5
+    B = 3
+    bgr_c = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+    bgr_p = np.roll(bgr_c, (2, -3), axis=(1, 2))
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(1, 2), stride=(n + 4, n + 2))
+    got = fm.process_batch_device_bgr(torch.from_numpy(bgr_c).to(gpu), torch.from_numpy(bgr_p).to(gpu)).cpu().numpy()
+    gray_c = np.stack([O.rgb2gray(f) for f in bgr_c])
+    gray_p = np.stack([O.rgb2gray(f) for f in bgr_p])
+    same = fm.process_batch_device(torch.from_numpy(gray_c).to(gpu), torch.from_numpy(gray_p).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, same, equal_nan=True)
+    lay = O.fft_layout(w, h, n, gx, gy, (1, 2), (n + 4, n + 2))
+    assert sum(_compare(got[k], gray_c[k], gray_p[k], lay, f"bgr{k}") for k in range(B)) >= B * gx * gy - 2
+    # long range: reference tiling with sqNum = 4 -> one quarter-resolution patch
+    fs = 4 * n
+    flr = FftMethod(fs, n, 80.0)
+    cur, prev = synth.pair_np(n, fs, fs, 8, -12, blur=True)
+    out = flr.process_long_range_batch_device(torch.from_numpy(cur[None]).to(gpu), torch.from_numpy(prev[None]).to(gpu)).cpu().numpy()[0]
+    want, _ = O.fft_process_long_range(cur, prev, O.fft_layout(fs, fs, n, 4, 4), 64)
+    assert np.allclose(out, want, rtol=0, atol=TOL, equal_nan=True), (out, want)
+    # a video: pair k = (frame k + 1, frame k)
+    video = np.stack([synth.pair_np(3 * n, h, w, 2 * t, t, blur=True)[0] for t in range(4)])
+    seq = fm.process_sequence_device(torch.from_numpy(video).to(gpu)).cpu().numpy()
+    for k in range(3):
+        assert _compare(seq[k], video[k + 1], video[k], lay, f"seq{k}") >= gx * gy - 1
+
+
+def test_planned_kernel_degenerate_pairs_and_gate(gpu):
+    """Constant patches (flat surface: the first-index / clamped-centroid artefact), black frames on a PADDED size (the only
+    constant patch that stays constant after cv::phaseCorrelate's zero padding) and the gate against samplePointSize / 2."""
+    for n in (60, 96):  # M = N: the closed form (the oracle's own radix-3/5 DFT of a constant is not exactly zero off DC)
+        tex = synth.canvas_np(5, n, n, True)[:n, :n].copy()
+        fm = FftMethod(n, n, 80.0)
+        for c in (200, 0):
+            const = np.full((n, n), c, np.uint8)
+            for cur, prev in ((const, const), (const, tex), (tex, const)):
+                out = fm.process_batch_host(cur[None], prev[None])[0]
+                P = float(cur.astype(np.float64).sum()) * float(prev.astype(np.float64).sum())
+                c9 = 9.0 * (P / (P * P + float(np.finfo(np.float32).eps))) if P > 0 else 0.0
+                want = (c9 / (c9 + float(np.finfo(np.float64).eps)) if c9 > 0 else 0.0) - n / 2
+                assert np.allclose(out, [[want, want]], rtol=0, atol=1e-4), (n, c, out, want)
+    for n in (62, 74):  # padded: an all-zero patch gives shift -M/2, beyond N/2 -> invalid; oracle agrees
+        tex = synth.canvas_np(6, n, n, True)[:n, :n].copy()
+        zero = np.zeros((n, n), np.uint8)
+        fm = FftMethod(n, n, 80.0)
+        lay = O.fft_layout(n, n, n, 1, 1)
+        for cur, prev in ((zero, zero), (zero, tex), (tex, zero)):
+            out = fm.process_batch_host(cur[None], prev[None])[0]
+            want, _ = O.fft_process(cur, prev, lay, 64)
+            assert np.isnan(want).all() and np.isnan(out).all(), (n, out, want)
+    # the gate: a 7-px shift passes max_px_speed 7.5 and fails 6.5; |shift| <= N/2 is judged on the unpadded size
+    n = 60
+    prev = synth.canvas_np(3, n, n, False)[:n, :n].copy()
+    cur = np.roll(prev, (0, 7), axis=(0, 1))
+    assert np.isnan(FftMethod(n, n, 6.5).process_batch_host(cur[None], prev[None])).all()
+    assert np.allclose(FftMethod(n, n, 7.5).process_batch_host(cur[None], prev[None])[0], [[7.0, 0.0]], rtol=0, atol=1e-5)
+
+
+def test_ocl_peak_model_on_planned_sizes(gpu):
+    """MOF_PEAK_OCL on 5-smooth even sizes without a tuned kernel; sizes the reference's OpenCL branch cannot plan are refused."""
+    n, gx, gy = 60, 2, 2
+    w, h = 2 * n + 6, 2 * n + 4
+    cur, prev, _, kinds = synth.batch_np(4, h, w, 5, k0=3)
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(2, 1), stride=(n + 2, n + 1), peak_model=PEAK_OCL,
+                   search_radius=55)
+    got = fm.process_batch_device(torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)).cpu().numpy()
+    lay = O.fft_layout(w, h, n, gx, gy, (2, 1), (n + 2, n + 1))
+    n_ok = 0
+    for k in range(4):
+        want64, _, diags = O.fft_process_ocl(cur[k], prev[k], lay, 55, 64, want_diag=True)
+        for p in range(gx * gy):
+            if diags[p].second_value < 0.5 * diags[p].peak_value:
+                assert np.allclose(got[k][p], want64[p], rtol=0, atol=TOL, equal_nan=True), (k, p, got[k][p], want64[p])
+                n_ok += 1
+    assert n_ok >= 8
+    for bad in (62, 74, 45):
+        with pytest.raises(MofError) as exc:
+            FftMethod(bad, bad, 80.0, peak_model=PEAK_OCL)
+        assert exc.value.code == -5
+
+
+def test_zz_f32_limited_patches_are_rare(gpu):
+    """The relaxed bar of _compare applies to a handful of patches only (it runs last: the list is filled by the tests above)."""
+    print("f32-limited patches:", F32_LIMITED)
+    assert len(F32_LIMITED) <= 12, F32_LIMITED

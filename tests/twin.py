@@ -13,23 +13,42 @@ FLT_EPS = float(np.finfo(np.float32).eps)
 DBL_EPS = float(np.finfo(np.float64).eps)
 
 
+def optimal_dft_size(n: int) -> int:
+    """cv::getOptimalDFTSize: the smallest 2^a 3^b 5^c >= n (written from OpenCV's documentation)."""
+    m = n
+    while True:
+        r = m
+        for p in (2, 3, 5):
+            while r % p == 0:
+                r //= p
+        if r == 1:
+            return m
+        m += 1
+
+
 def phase_correlate(a: np.ndarray, b: np.ndarray, quirk: bool = True):
-    """cv::phaseCorrelate(a, b) in float64. Returns ((x, y), surface, (px, py))."""
-    n = a.shape[0]
-    assert a.shape == (n, n) == b.shape and n % 2 == 0
-    A = np.fft.fft2(a.astype(np.float64))
-    B = np.fft.fft2(b.astype(np.float64))
+    """cv::phaseCorrelate(a, b) in float64. Returns ((x, y), surface, (px, py)). As OpenCV does, the images are zero-padded
+    (bottom / right) to n = getOptimalDFTSize(size), which may be odd; surface, peak and centre live on the padded image."""
+    n_in = a.shape[0]
+    assert a.shape == (n_in, n_in) == b.shape
+    n = optimal_dft_size(n_in)
+    pa = np.zeros((n, n))
+    pb = np.zeros((n, n))
+    pa[:n_in, :n_in] = a
+    pb[:n_in, :n_in] = b
+    A = np.fft.fft2(pa)
+    B = np.fft.fft2(pb)
     P = A * np.conj(B)
     mag = np.abs(P)
     Cs = P * mag / (mag * mag + FLT_EPS)
-    if quirk:  # the 4 real-only CCS slots: P / (P^2 + eps)   (SURVEY F8)
-        h = n // 2
-        for r in (0, h):
-            for c in (0, h):
+    if quirk:  # the real-only CCS slots (DC, and the Nyquist bins when n is even): P / (P^2 + eps)   (SURVEY F8)
+        slots = (0, n // 2) if n % 2 == 0 else (0,)
+        for r in slots:
+            for c in slots:
                 p = P[r, c].real
                 Cs[r, c] = p / (p * p + FLT_EPS)
     c = np.fft.ifft2(Cs).real * (n * n)  # cv::idft is unscaled
-    s = np.fft.fftshift(c)
+    s = np.roll(c, (n // 2, n // 2), axis=(0, 1))  # fftShift: index i -> (i + n // 2) % n, also for odd n
     flat = int(np.argmax(s))  # first maximum, row-major
     py, px = divmod(flat, n)
     y0, y1 = max(py - 2, 0), min(py + 2, n - 1)
