@@ -118,15 +118,139 @@ struct mof_fft_engine {
   uint8_t* h_stage = nullptr;    // pinned upload staging (tightly packed frame)
   bool first = true;             // FftMethod.cpp:1761
   bool generic = false;          // patch sizes without a hand-tuned instantiation run the planned kernel (pc_kernel_generic.hip)
-  mof::PcPlan plan{};
+  bool large = false;            // ... or, when the padded patch does not fit a CU's LDS, the planned pipeline through HBM
+  mof::PcPlan plan{};            //     scratch (pc_large_kernel.hip)
+  // scratch of the large-patch pipeline, for `cap` patch pairs per pass: row half-spectra of 2 cap patches, Dt, peak
+  // candidates, constant-patch flags, C_dc. Grown by a batch that needs more (never under a graph capture, never while pinned).
+  float *d_zh = nullptr, *d_dt = nullptr, *d_cdc = nullptr;
+  float2* d_cand = nullptr;
+  int* d_flags = nullptr;
+  int cap = 0;
+  hipEvent_t scratch_ev = nullptr;       // behind the last kernel that used the scratch (cross-stream ordering, as mof_sr)
+  hipStream_t scratch_stream = nullptr;
+  bool scratch_used = false;
   std::atomic<bool> busy{false};
   std::atomic<bool> graph_pinned{false};  // a batch call was captured into a HIP graph (capi_graph.hpp)
 };
 
-// every K1 launch of an engine: the hand-tuned instantiation of its patch size, or the planned general kernel
-static hipError_t launch_field(const mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hipStream_t stream) {
-  return e->generic ? mof::launch_pc_generic(a, e->plan, n_pairs, stream) : mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, stream);
+static void large_free(mof_fft_engine* e) {
+  void* bufs[] = {e->d_zh, e->d_dt, e->d_cdc, e->d_cand, e->d_flags};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  e->d_zh = e->d_dt = e->d_cdc = nullptr;
+  e->d_cand = nullptr;
+  e->d_flags = nullptr;
+  e->cap = 0;
 }
+
+static hipError_t large_alloc(mof_fft_engine* e, int cap) {
+  mof::RelaxedCapture relaxed;
+  large_free(e);
+  const size_t zhf = mof::pcl_zh_floats(e->plan);
+  hipError_t err;
+  if ((err = hipMalloc(&e->d_zh, (size_t)2 * cap * zhf * sizeof(float))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_dt, (size_t)cap * zhf * sizeof(float))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_cand, (size_t)cap * mof::pcl_candidates(e->plan) * sizeof(float2))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_flags, (size_t)2 * cap * sizeof(int))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_cdc, (size_t)cap * sizeof(float))) != hipSuccess) return err;
+  e->cap = cap;
+  return hipSuccess;
+}
+
+// Frame pairs per pass of the large-patch pipeline: as many as keep the scratch (three Zh-sized planes per patch pair) under
+// ~1.5 GB, at least one (MOF_FFT_LARGE_PASS overrides, sweeps)
+static int large_pass_pairs(const mof_fft_engine* e, int patches) {
+  static const int forced = [] { const char* v = getenv("MOF_FFT_LARGE_PASS"); return v ? atoi(v) : 0; }();
+  if (forced > 0) return forced;
+  const size_t per_pair = (size_t)3 * patches * mof::pcl_zh_floats(e->plan) * sizeof(float);
+  const size_t n = ((size_t)3 << 29) / (per_pair ? per_pair : 1);
+  return n < 1 ? 1 : (n > 4096 ? 4096 : (int)n);
+}
+
+// The large-patch pipeline on n_pairs frame pairs (a.grid_* patches each; a.downscale / a.channels as K1): passes of whole frame
+// pairs through the engine's scratch. Returns a MOF status.
+static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hipStream_t s) {
+  const int patches = a.grid_x * a.grid_y;
+  const int pass_max = large_pass_pairs(e, patches);
+  const int want_pairs = n_pairs < pass_max ? n_pairs : pass_max;
+  const bool capturing = mof::stream_capturing(s);
+  if ((long)want_pairs * patches > e->cap) {
+    if (e->graph_pinned.load())
+      return fail(MOF_ERR_BUSY, "the large-patch scratch would have to grow, but a captured HIP graph still points into it: run the "
+                                "largest batch once before capturing, or call mof_fft_release_graphs once the graphs are gone");
+    if (capturing)
+      return fail(MOF_ERR_BAD_ARG, "the large-patch scratch must grow to %d patch pairs, which cannot happen inside a graph capture: "
+                                   "run one batch of this size before capturing", want_pairs * patches);
+    if (e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);
+    (void)hipStreamSynchronize(e->stream);
+    const hipError_t err = large_alloc(e, want_pairs * patches);
+    if (err != hipSuccess) {
+      (void)large_alloc(e, e->cfg.grid_x * e->cfg.grid_y);  // keep the stateful entry usable
+      return fail(err == hipErrorOutOfMemory ? MOF_ERR_NO_MEMORY : MOF_ERR_HIP, "large-patch scratch for %d patch pairs: %s",
+                  want_pairs * patches, hipGetErrorString(err));
+    }
+  }
+  if (e->scratch_used && e->scratch_stream != s && !capturing) HIP_TRY(hipStreamWaitEvent(s, e->scratch_ev, 0));
+  const size_t zhf = mof::pcl_zh_floats(e->plan);
+  const int per_pass = e->cap / patches;
+  for (int k0 = 0; k0 < n_pairs; k0 += per_pass) {
+    const int np = n_pairs - k0 < per_pass ? n_pairs - k0 : per_pass, nq = np * patches;
+    mof::PclSrc src{};
+    src.base[0] = a.cur + (size_t)k0 * a.cur_stride;
+    src.base[1] = a.prev + (size_t)k0 * a.prev_stride;
+    src.stride[0] = a.cur_stride;
+    src.stride[1] = a.prev_stride;
+    src.pitch = a.pitch;
+    src.paired = 1;
+    src.grid_x = a.grid_x;
+    src.grid_y = a.grid_y;
+    src.origin_x = a.origin_x;
+    src.origin_y = a.origin_y;
+    src.stride_x = a.stride_x;
+    src.stride_y = a.stride_y;
+    HIP_TRY(hipMemsetAsync(e->d_flags, 0, (size_t)2 * nq * sizeof(int), s));
+    // (launch_pcl_rows splits at 65534 images on pair boundaries: keep a pass's image count a multiple of 2 * patches below that)
+    const int pairs_per_launch = 65534 / (2 * patches) > 0 ? 65534 / (2 * patches) : 1;
+    for (int j0 = 0; j0 < np; j0 += pairs_per_launch) {
+      const int nj = np - j0 < pairs_per_launch ? np - j0 : pairs_per_launch;
+      mof::PclSrc sj = src;
+      sj.base[0] += (size_t)j0 * a.cur_stride;
+      sj.base[1] += (size_t)j0 * a.prev_stride;
+      HIP_TRY(mof::launch_pcl_rows(sj, e->plan, e->d_twiddles, e->d_zh + (size_t)2 * j0 * patches * zhf, zhf,
+                                   e->d_flags + (size_t)2 * j0 * patches, 2 * nj * patches, a.channels, a.downscale, s));
+    }
+    HIP_TRY(mof::launch_pcl_cols(e->d_zh + zhf, e->d_zh, 2 * zhf, e->plan, e->d_twiddles, e->d_dt, e->d_cdc, nq, s));
+    mof::PclFinal f{};
+    f.Dt = e->d_dt;
+    f.cand = e->d_cand;
+    f.twiddles = e->d_twiddles;
+    f.mode = 1;
+    f.max_px_speed_sq = a.max_px_speed_sq;
+    f.out = a.out + (size_t)k0 * patches * 2;
+    f.flags = e->d_flags;
+    f.cdc = e->d_cdc;
+    HIP_TRY(mof::launch_pcl_peak(f, e->plan, nq, s));
+  }
+  if (!capturing) {
+    HIP_TRY(hipEventRecord(e->scratch_ev, s));
+    e->scratch_stream = s;
+    e->scratch_used = true;
+  }
+  return MOF_OK;
+}
+
+// every K1 launch of an engine: the hand-tuned instantiation of its patch size, the planned general kernel, or -- for patches
+// too large for a CU -- the planned pipeline through HBM scratch. Returns a MOF status.
+static int launch_field(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hipStream_t stream) {
+  if (e->large) return launch_large(e, a, n_pairs, stream);
+  HIP_TRY(e->generic ? mof::launch_pc_generic(a, e->plan, n_pairs, stream) : mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, stream));
+  return MOF_OK;
+}
+#define FIELD_TRY(expr)       \
+  do {                        \
+    const int _rc = (expr);   \
+    if (_rc != MOF_OK) return _rc; \
+  } while (0)
 
 struct mof_bm_engine {
   mof_bm_config cfg{};
@@ -194,10 +318,15 @@ static int validate_fft(const mof_fft_config* c) {
     // any other samplePointSize (FftMethod.cpp:1680-1720 takes it from a ROS parameter): the planned kernel on the size
     // cv::phaseCorrelate pads to, M = getOptimalDFTSize(N)
     mof::PcPlan plan;
-    if (!mof::pc_build_plan(c->patch_size, &plan))
-      return fail(MOF_ERR_UNSUPPORTED, "patch_size %d pads to %d: a %d x %d complex tile does not fit one CU's LDS (limit 135)",
-                  c->patch_size, mof::pc_optimal_dft_size(c->patch_size), mof::pc_optimal_dft_size(c->patch_size),
-                  mof::pc_optimal_dft_size(c->patch_size));
+    if (!mof::pc_build_plan(c->patch_size, &plan)) {
+      // the padded patch does not fit one CU's LDS (M > 135): the planned pipeline through HBM scratch (pc_large_kernel.hip)
+      if (!mof::pc_build_line_plan(c->patch_size, &plan))
+        return fail(MOF_ERR_UNSUPPORTED, "patch_size %d pads to %d: beyond the planned transforms (<= 960)", c->patch_size,
+                    mof::pc_optimal_dft_size(c->patch_size));
+      if (c->peak_model == MOF_PEAK_OCL)
+        return fail(MOF_ERR_UNSUPPORTED, "peak_model MOF_PEAK_OCL is available for patches that fit one CU (padded size <= 135); "
+                    "patch_size %d runs the cv::phaseCorrelate model only", c->patch_size);
+    }
     // useOCL=true plans radix-{2,3,4,5,8} passes for the patch size itself and never pads (FftMethod.cpp:481-539, :787-816):
     // sizes with another prime factor have no OpenCL plan in the reference either; its CCS packing assumes an even size
     if (c->peak_model == MOF_PEAK_OCL && (plan.m != plan.n || (plan.n & 1)))
@@ -229,11 +358,15 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   e->cfg = *cfg;
   e->frame_bytes = (size_t)cfg->frame_width * cfg->frame_height;
   e->generic = !mof::pc_patch_size_supported(cfg->patch_size);
-  if (e->generic && !mof::pc_build_plan(cfg->patch_size, &e->plan)) {  // (validate_fft has checked it)
-    delete e;
-    return fail(MOF_ERR_UNSUPPORTED, "no plan for patch_size %d", cfg->patch_size);
+  if (e->generic && !mof::pc_build_plan(cfg->patch_size, &e->plan)) {
+    e->generic = false;
+    e->large = true;
+    if (!mof::pc_build_line_plan(cfg->patch_size, &e->plan)) {  // (validate_fft has checked it)
+      delete e;
+      return fail(MOF_ERR_UNSUPPORTED, "no plan for patch_size %d", cfg->patch_size);
+    }
   }
-  const int n = e->generic ? e->plan.m : cfg->patch_size;  // transform size: the planned kernel works on the padded patch
+  const int n = (e->generic || e->large) ? e->plan.m : cfg->patch_size;  // transform size: the planned kernels work on the padded patch
   // twiddles W_n^k = exp(-2 pi i k / n), double -> float, axis values exact
   std::vector<float> tw(2 * (size_t)n);
   for (int k = 0; k < n; ++k) {
@@ -266,7 +399,10 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   CREATE_TRY(hipMalloc(&e->d_out, res * sizeof(double)));
   CREATE_TRY(hipHostMalloc(&e->h_out, res * sizeof(double), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
-  if (e->generic) {
+  if (e->large) {
+    CREATE_TRY(hipEventCreateWithFlags(&e->scratch_ev, hipEventDisableTiming));
+    CREATE_TRY(large_alloc(e, cfg->grid_x * cfg->grid_y));  // one frame pair; a batch grows it to a whole pass
+  } else if (e->generic) {
     CREATE_TRY(mof::pc_configure_generic());
   } else {
     CREATE_TRY(mof::pc_configure(n));
@@ -281,7 +417,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
 }
 
 const char* mof_fft_kernel_variant(const mof_fft_engine* e) {
-  return !e ? "" : (e->generic ? "planned" : mof::pc_kernel_variant(e->cfg.patch_size));
+  return !e ? "" : (e->large ? "planned-large" : (e->generic ? "planned" : mof::pc_kernel_variant(e->cfg.patch_size)));
 }
 
 static void fft_destroy_now(void* p) {
@@ -289,6 +425,9 @@ static void fft_destroy_now(void* p) {
   mof::RelaxedCapture relaxed;  // frees must not invalidate a capture running on another thread
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
+  large_free(e);
+  if (e->scratch_ev) (void)hipEventDestroy(e->scratch_ev);
   if (e->d_twiddles) (void)hipFree(e->d_twiddles);
   if (e->d_frames[0]) (void)hipFree(e->d_frames[0]);
   if (e->d_frames[1]) (void)hipFree(e->d_frames[1]);
@@ -379,7 +518,7 @@ int mof_fft_process(mof_fft_engine* e, const uint8_t* frame, size_t pitch, doubl
   // `first`: the frame is correlated with itself (FftMethod.cpp:1791-1793)
   const uint8_t* prev = e->first ? e->d_frames[cur_slot] : e->d_frames[e->prev_slot];
   mof::PcArgs a = fft_args(e, e->d_frames[cur_slot], 0, prev, 0, (size_t)e->cfg.frame_width, e->d_out);
-  HIP_TRY(launch_field(e, a, 1, e->stream));
+  FIELD_TRY(launch_field(e, a, 1, e->stream));
   const size_t res = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
   HIP_TRY(hipMemcpyAsync(e->h_out, e->d_out, res * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -433,7 +572,7 @@ int mof_fft_process_long_range(mof_fft_engine* e, const uint8_t* frame, size_t p
   mof::PcArgs a = fft_args(e, e->d_frames[cur_slot], 0, prev, 0, (size_t)e->cfg.frame_width, e->d_out);
   int rc = long_range_args(e, &a);
   if (rc) return rc;
-  HIP_TRY(launch_field(e, a, 1, e->stream));
+  FIELD_TRY(launch_field(e, a, 1, e->stream));
   const size_t res = (size_t)a.grid_x * a.grid_y * 2;
   HIP_TRY(hipMemcpyAsync(e->h_out, e->d_out, res * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -465,7 +604,7 @@ int mof_fft_process_long_range_batch_device(mof_fft_engine* e, const uint8_t* d_
   int rc = long_range_args(e, &a);
   if (rc) return rc;
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
-  HIP_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
+  FIELD_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
 
@@ -482,7 +621,7 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
   HIP_TRY(hipSetDevice(e->cfg.device));
   mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
-  HIP_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
+  FIELD_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
 
@@ -506,10 +645,10 @@ static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame
   static const int run = [] { const char* v = getenv("MOF_FFT_SEQ_RUN"); const int r = v ? atoi(v) : 0; return r >= 1 ? r : 16; }();
   static const bool pairs_only = getenv("MOF_FFT_SEQ_PAIRS") != nullptr, half64 = getenv("MOF_FFT_SEQ_HALF64") != nullptr;
   const int n = e->cfg.patch_size;
-  const bool half = !e->generic && !pairs_only && mof::pc_sequence_half_supported(n) && (n != 64 || half64);
-  const bool full = !e->generic && !pairs_only && !half && mof::pc_sequence_supported(n);
+  const bool half = !e->generic && !e->large && !pairs_only && mof::pc_sequence_half_supported(n) && (n != 64 || half64);
+  const bool full = !e->generic && !e->large && !pairs_only && !half && mof::pc_sequence_supported(n);
   if (!half && !full) {
-    HIP_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
+    FIELD_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
     return MOF_OK;
   }
   // the run index rides gridDim.z (at most 65535 per launch): a very long video goes out in several launches
@@ -550,7 +689,7 @@ int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, si
   mof::PcArgs a = fft_args(e, d_cur, cur_stride, d_prev, prev_stride, pitch, d_out_xy);
   a.channels = 3;
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
-  HIP_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
+  FIELD_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
   return MOF_OK;
 }
 

@@ -49,6 +49,40 @@ bool pc_build_plan(int n, PcPlan* out);                  // false: n needs the l
 hipError_t pc_configure_generic();
 hipError_t launch_pc_generic(const PcArgs& a, const PcPlan& plan, int n_pairs, hipStream_t stream);
 
+// ---- images too large for a CU (padded side m > 135): the planned pipeline through HBM scratch (pc_large_kernel.hip) ----
+bool pc_build_line_plan(int n, PcPlan* out);  // n, m, radix chain only (no LDS tile); false for n < 2 or m > 960
+// where image f of a launch comes from
+struct PclSrc {
+  const uint8_t* base[2];  // paired: [0] = cur frames, [1] = prev frames; else base[0] alone
+  size_t stride[2];        // bytes between consecutive frame pairs (paired) / images (not paired)
+  size_t pitch;            // bytes per frame row
+  int paired;              // 1: image f = 2 (pair * patches + patch) + which (0 cur, 1 prev); 0: image f = base[0] + f * stride[0]
+  int grid_x, grid_y, origin_x, origin_y, stride_x, stride_y;  // patch grid inside a frame (paired)
+};
+struct PclFinal {
+  const float* Dt;         // [pairs][m/2 + 1][m] complex
+  const float2* cand;      // [pairs][n_cand]
+  int n_cand;              // set by the launcher
+  const float* twiddles;   // m (cos, -sin) pairs
+  int m, n;                // set by the launcher from the plan
+  int mode;                // 0: scaleRotationEstimator (out[pair][4] = scale, rot, pt.x, pt.y); 1: FftMethod (out[pair][2] = shift or NaN)
+  double M_log;            // mode 0: log-polar magnitude
+  double max_px_speed_sq;  // mode 1
+  double* out;
+  const int* flags;        // mode 1, nullable: [2 pairs] constant-patch flags written by pcl_rows (bit 0: not constant, bit 1: pixel 0 != 0)
+  const float* cdc;        // mode 1, with flags: [pairs] DC bin of the cross-power spectrum
+};
+size_t pcl_zh_floats(const PcPlan& pl);  // floats of one image's row half-spectra Zh: (m/2 + 1) * m complex
+int pcl_candidates(const PcPlan& pl);    // peak candidates per pair
+// L5: images -> Zh (image f at zh + f * zh_stride floats); flags (nullable, ZEROED by the caller): 1 int per image
+hipError_t launch_pcl_rows(const PclSrc& src, const PcPlan& pl, const float* twiddles, float* zh, size_t zh_stride, int* flags,
+                           int n_images, int channels, int downscale, hipStream_t stream);
+// L6: pair p = (cur: zh_cur + p * zh_stride, prev: zh_prev + p * zh_stride) -> Dt[p]; cdc nullable
+hipError_t launch_pcl_cols(const float* zh_prev, const float* zh_cur, size_t zh_stride, const PcPlan& pl, const float* twiddles,
+                           float* Dt, float* cdc, int n_pairs, hipStream_t stream);
+// L7 + L8 (a.Dt, a.cand, a.twiddles, a.mode, a.out [, a.M_log | a.max_px_speed_sq, a.flags, a.cdc])
+hipError_t launch_pcl_peak(const PclFinal& a, const PcPlan& pl, int n_pairs, hipStream_t stream);
+
 bool pc_patch_size_supported(int n);  // the hand-tuned instantiations: 32, 64, 120, 128
 const char* pc_kernel_variant(int patch_size);
 hipError_t pc_configure(int patch_size);  // once per device before the first launch

@@ -278,6 +278,10 @@ struct mof_sr_engine {
   int scratch_pairs = 0;         // pairs per pass the scratch holds now (1 after create, `chunk` after the first batch)
   bool two_lanes = false;        // remap of pass k+1 beside the transforms of pass k (mof_sr_config.pipeline_lanes == 2)
   bool first = true;             // :31
+  // resolutions without hand-tuned transforms (anything but 240 / 256 / 480) run the planned pipeline of
+  // pc_large_kernel.hip on the size cv::phaseCorrelate pads to, plan.m = getOptimalDFTSize(resolution)
+  bool generic = false;
+  mof::PcPlan plan{};
   std::atomic<bool> busy{false};
   // a batch call was captured into a HIP graph: the graph's kernel nodes hold raw pointers into the scratch below, so
   // from then on the scratch neither grows nor is freed until mof_sr_release_graphs (capi_graph.hpp)
@@ -298,6 +302,34 @@ struct mof_sr_engine {
 };
 
 namespace {
+
+// sizes of the transform scratch and the three transform steps, tuned or planned
+size_t zh_floats(const mof_sr_engine* e) { return e->generic ? mof::pcl_zh_floats(e->plan) : mof::sr_zh_floats(e->cfg.resolution); }
+int peak_candidates(const mof_sr_engine* e) { return e->generic ? mof::pcl_candidates(e->plan) : mof::sr_candidates(e->cfg.resolution); }
+hipError_t rows_real(const mof_sr_engine* e, const uint8_t* lp, size_t lp_stride, float* zh, size_t zh_stride, int n_frames, hipStream_t s) {
+  const int res = e->cfg.resolution;
+  if (!e->generic) return mof::launch_sr_rows_real(lp, lp_stride, e->d_twiddles, zh, zh_stride, res, n_frames, s);
+  mof::PclSrc src{};
+  src.base[0] = lp;
+  src.stride[0] = lp_stride;
+  src.pitch = (size_t)res;  // log-polar images are tightly packed
+  return mof::launch_pcl_rows(src, e->plan, e->d_twiddles, zh, zh_stride, nullptr, n_frames, 1, 1, s);
+}
+hipError_t cols_seq(const mof_sr_engine* e, const float* zh_prev, const float* zh_cur, size_t zh_stride, int n_pairs, int run, hipStream_t s) {
+  if (!e->generic) return mof::launch_sr_cols_seq(zh_prev, zh_cur, zh_stride, e->d_twiddles, e->d_Dt, e->cfg.resolution, n_pairs, run, s);
+  return mof::launch_pcl_cols(zh_prev, zh_cur, zh_stride, e->plan, e->d_twiddles, e->d_Dt, nullptr, n_pairs, s);
+}
+hipError_t peak(const mof_sr_engine* e, const mof::SrPcArgs& a, int n_pairs, hipStream_t s) {
+  if (!e->generic) return mof::launch_sr_peak(a, e->cfg.resolution, n_pairs, s);
+  mof::PclFinal f{};
+  f.Dt = a.Dt;
+  f.cand = a.cand;
+  f.twiddles = a.twiddles;
+  f.mode = 0;
+  f.M_log = a.M;
+  f.out = a.out;
+  return mof::launch_pcl_peak(f, e->plan, n_pairs, s);
+}
 
 // Called with the busy flag held, before the first launch that reads or writes the scratch.
 hipError_t scratch_acquire(mof_sr_engine* e, hipStream_t s) {
@@ -343,12 +375,12 @@ hipError_t scratch_alloc(mof_sr_engine* e, int pairs) {
   {
     // pair pipeline: packed row spectra Zt, nn complex per pair; sequence pipeline: (pairs + 1) frames of half spectra
     // (or, pairs through the frame kernels: 2 * pairs frames of half spectra)
-    const size_t zt = (size_t)pairs * nn * 2 * sizeof(float), zh1 = (size_t)(pairs + 1) * mof::sr_zh_floats(res) * sizeof(float),
-                 zh2 = (size_t)2 * pairs * mof::sr_zh_floats(res) * sizeof(float), zh = zh1 > zh2 ? zh1 : zh2;
+    const size_t zt = e->generic ? 0 : (size_t)pairs * nn * 2 * sizeof(float), zh1 = (size_t)(pairs + 1) * zh_floats(e) * sizeof(float),
+                 zh2 = (size_t)2 * pairs * zh_floats(e) * sizeof(float), zh = zh1 > zh2 ? zh1 : zh2;
     if ((err = hipMalloc(&e->d_Zt, zt > zh ? zt : zh)) != hipSuccess) return err;
   }
-  if ((err = hipMalloc(&e->d_Dt, (size_t)pairs * res * (res / 2 + 1) * 2 * sizeof(float))) != hipSuccess) return err;
-  if ((err = hipMalloc(&e->d_cand, (size_t)pairs * mof::sr_candidates(res) * sizeof(float2))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_Dt, (size_t)pairs * zh_floats(e) * sizeof(float))) != hipSuccess) return err;  // Dt has Zh's shape
+  if ((err = hipMalloc(&e->d_cand, (size_t)pairs * peak_candidates(e) * sizeof(float2))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_out, (size_t)pairs * 4 * sizeof(double))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_degen, (size_t)pairs * sizeof(int))) != hipSuccess) return err;
   e->scratch_pairs = pairs;
@@ -448,8 +480,15 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
     return mof::capi_fail(MOF_ERR_BAD_ARG, "logpolar_variant must be MOF_LOGPOLAR_CV4 (0) or MOF_LOGPOLAR_CV3 (1)");
   if (cfg->batch_chunk < 0 || cfg->batch_chunk > 4096 || cfg->pipeline_lanes < 0 || cfg->pipeline_lanes > 2)
     return mof::capi_fail(MOF_ERR_BAD_ARG, "batch_chunk must be 0..4096 and pipeline_lanes 0..2");
-  if (!mof::sr_resolution_supported(cfg->resolution))
-    return mof::capi_fail(MOF_ERR_UNSUPPORTED, "resolution %d not supported by the HIP pipeline (240, 256, 480)", cfg->resolution);
+  // any even resolution: scaleRotationEstimator takes `res` from a parameter (scaleRotationEstimator.cpp:3-5); 240 / 256 / 480
+  // have hand-tuned transforms, the rest run the planned pipeline on the size cv::phaseCorrelate pads to
+  if (cfg->resolution < 16 || (cfg->resolution & 1))
+    return mof::capi_fail(MOF_ERR_BAD_ARG, "resolution %d: an even resolution >= 16 is required", cfg->resolution);
+  mof::PcPlan plan{};
+  const bool generic = !mof::sr_resolution_supported(cfg->resolution);
+  if (generic && !mof::pc_build_line_plan(cfg->resolution, &plan))
+    return mof::capi_fail(MOF_ERR_UNSUPPORTED, "resolution %d pads to %d: beyond the planned transforms (<= 960)", cfg->resolution,
+                          mof::pc_optimal_dft_size(cfg->resolution));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -471,17 +510,20 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
     sbc = mof::sr_tile_boxes(map, res, 4, &slds_c, 16);
     sbl = mof::sr_tile_boxes(map, res, 8, &slds_l, 16);
   }
-  std::vector<float> tw(2 * (size_t)res);
+  const int tn = generic ? plan.m : res;  // transform size: the planned pipeline works on the padded image
+  std::vector<float> tw(2 * (size_t)tn);
   mof_sr_engine* e = new (std::nothrow) mof_sr_engine();
   if (!e) return mof::capi_fail(MOF_ERR_NO_MEMORY, "out of host memory");
   e->cfg = *cfg;
+  e->generic = generic;
+  e->plan = plan;
   e->chunk = chunk_pairs(cfg->batch_chunk);
   e->two_lanes = two_lane_default(cfg->pipeline_lanes);
-  for (int k = 0; k < res; ++k) {
-    double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)res;
+  for (int k = 0; k < tn; ++k) {
+    double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)tn;
     double c = std::cos(ang), s = std::sin(ang);
-    if ((4 * k) % res == 0) {
-      const int q = (4 * k) / res;
+    if ((4 * k) % tn == 0) {
+      const int q = (4 * k) / tn;
       c = (q == 0) ? 1.0 : (q == 2) ? -1.0 : 0.0;
       s = (q == 1) ? -1.0 : (q == 3) ? 1.0 : 0.0;
     }
@@ -536,9 +578,9 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   CREATE_TRY(mof::copy_on(e->stream, e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&e->d_frame, nn));
   CREATE_TRY(hipMalloc(&e->d_temp_im, nn));
-  CREATE_TRY(hipMalloc(&e->d_zh_prev, mof::sr_zh_floats(res) * sizeof(float)));
+  CREATE_TRY(hipMalloc(&e->d_zh_prev, zh_floats(e) * sizeof(float)));
   CREATE_TRY(mof::fill_on(e->stream, e->d_temp_im, 0, nn));  // tempIm = cv::Mat::zeros, :27
-  CREATE_TRY(mof::fill_on(e->stream, e->d_zh_prev, 0, mof::sr_zh_floats(res) * sizeof(float)));
+  CREATE_TRY(mof::fill_on(e->stream, e->d_zh_prev, 0, zh_floats(e) * sizeof(float)));
   CREATE_TRY(scratch_alloc(e, 1));  // the stateful call needs one pair; a batch grows it to a whole pass (scratch_reserve)
   CREATE_TRY(hipHostMalloc(&e->h_stage, nn, hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_out, 4 * sizeof(double), hipHostMallocDefault));
@@ -586,7 +628,7 @@ static mof::SrPcArgs pc_args(const mof_sr_engine* e, const uint8_t* lp_cur, cons
   a.Zt = e->d_Zt;
   a.Dt = e->d_Dt;
   a.cand = e->d_cand;
-  a.n_cand = mof::sr_candidates(e->cfg.resolution);
+  a.n_cand = peak_candidates(e);
   a.M = e->cfg.magnitude;
   a.out = out;
   return a;
@@ -594,11 +636,10 @@ static mof::SrPcArgs pc_args(const mof_sr_engine* e, const uint8_t* lp_cur, cons
 
 // One pair through the sequence kernels: (cur spectra, prev spectra) -> Dt slot 0 -> (scale, rot, pt) at `out`
 static hipError_t seq_one_pair(mof_sr_engine* e, const float* zh_prev, const float* zh_cur, double* out, hipStream_t s) {
-  const int res = e->cfg.resolution;
-  hipError_t err = mof::launch_sr_cols_seq(zh_prev, zh_cur, 0, e->d_twiddles, e->d_Dt, res, 1, 1, s);
+  hipError_t err = cols_seq(e, zh_prev, zh_cur, 0, 1, 1, s);
   if (err != hipSuccess) return err;
   mof::SrPcArgs a = pc_args(e, nullptr, nullptr, 0, out);
-  return mof::launch_sr_peak(a, res, 1, s);
+  return peak(e, a, 1, s);
 }
 
 int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double* out_scale_rot) {
@@ -608,7 +649,7 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
   BusyGuard g(e->busy);
   if (!g.owned) return mof::capi_fail(MOF_ERR_BUSY, "engine busy");
   SR_TRY(hipSetDevice(e->cfg.device));
-  const size_t nn = (size_t)res * res, zh_bytes = mof::sr_zh_floats(res) * sizeof(float);
+  const size_t nn = (size_t)res * res, zh_bytes = zh_floats(e) * sizeof(float);
   for (int y = 0; y < res; ++y) std::memcpy(e->h_stage + (size_t)y * res, frame + (size_t)y * pitch, (size_t)res);
   SR_TRY(hipMemcpyAsync(e->d_frame, e->h_stage, nn, hipMemcpyHostToDevice, e->stream));
   mof::SrLpArgs lp{};
@@ -624,7 +665,7 @@ int mof_sr_process(mof_sr_engine* e, const uint8_t* frame, size_t pitch, double*
   SR_TRY(mof::launch_sr_logpolar(lp, interp, 1, e->stream));
   SR_TRY(scratch_acquire(e, e->stream));
   // tempIm.convertTo(CV_32FC1) (:47, :115) + the row half of the forward DFT of cv::phaseCorrelate (:117): K5s
-  SR_TRY(mof::launch_sr_rows_real(e->d_temp_im, 0, e->d_twiddles, e->d_Zt, 0, res, 1, e->stream));
+  SR_TRY(rows_real(e, e->d_temp_im, 0, e->d_Zt, 0, 1, e->stream));
   if (e->first) {
     SR_TRY(hipMemcpyAsync(e->d_zh_prev, e->d_Zt, zh_bytes, hipMemcpyDeviceToDevice, e->stream));  // prevIm_F32 = .., :48
     SR_TRY(scratch_release(e, e->stream));
@@ -663,7 +704,7 @@ int mof_sr_process_sequence_device(mof_sr_engine* e, const uint8_t* d_frames, si
   const bool capturing = mof::stream_capturing(s);
   if (capturing && n_gated)
     return mof::capi_fail(MOF_ERR_BAD_ARG, "resolving the gate reads results back on the host: pass n_gated = NULL while capturing");
-  const size_t nn = (size_t)res * res, zhf = mof::sr_zh_floats(res), zh_bytes = zhf * sizeof(float);
+  const size_t nn = (size_t)res * res, zhf = zh_floats(e), zh_bytes = zhf * sizeof(float);
   {
     const int rc = scratch_reserve(e, scratch_want(e, n_frames), s);
     if (rc != MOF_OK) return rc;
@@ -698,7 +739,7 @@ int mof_sr_process_sequence_device(mof_sr_engine* e, const uint8_t* d_frames, si
         lp.dst = e->d_lp;
         lp_tables(e, 2, &lp);
         SR_TRY(mof::launch_sr_logpolar(lp, 2, 1, s));
-        SR_TRY(mof::launch_sr_rows_real(e->d_lp, nn, e->d_twiddles, zh, zhf, res, 1, s));
+        SR_TRY(rows_real(e, e->d_lp, nn, zh, zhf, 1, s));
         SR_TRY(mof::launch_sr_identity(d_out + 4 * (size_t)done, s));
         first = false;  // :73
         ++done;
@@ -714,10 +755,10 @@ int mof_sr_process_sequence_device(mof_sr_engine* e, const uint8_t* d_frames, si
         lp.dst = e->d_lp + nn;
         lp_tables(e, 4, &lp);
         SR_TRY(mof::launch_sr_logpolar(lp, 4, m, s));  // INTER_LANCZOS4, :112 -- every frame once
-        SR_TRY(mof::launch_sr_rows_real(e->d_lp + nn, nn, e->d_twiddles, zh + zhf, zhf, res, m, s));
-        SR_TRY(mof::launch_sr_cols_seq(zh, zh + zhf, zhf, e->d_twiddles, e->d_Dt, res, m, e->seq_run, s));
+        SR_TRY(rows_real(e, e->d_lp + nn, nn, zh + zhf, zhf, m, s));
+        SR_TRY(cols_seq(e, zh, zh + zhf, zhf, m, e->seq_run, s));
         mof::SrPcArgs a = pc_args(e, nullptr, nullptr, 0, d_out + 4 * (size_t)done);
-        SR_TRY(mof::launch_sr_peak(a, res, m, s));
+        SR_TRY(peak(e, a, m, s));
         carry = m;
         if (n_gated) {
           // The gate (:119-121): a frame whose |pt.x| > res/2 returns (1, 0) and does NOT become prev. The pass above
@@ -821,11 +862,11 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
     // Same-box c5: 360 k pairs/s against 354 k for the packed pair kernels (K5 / K6 of sr_kernel.hip, MOF_SR_PAIR_SEQ=0), and
     // the batch entry now computes exactly what the stateful entry computes for a fresh estimator fed (prev, cur): same bits.
     static const bool via_frames = [] { const char* v = getenv("MOF_SR_PAIR_SEQ"); return !v || atoi(v) != 0; }();
-    if (via_frames) {
-      const size_t zhf = mof::sr_zh_floats(res);
-      SR_TRY(mof::launch_sr_rows_real(lp_buf, nn, e->d_twiddles, e->d_Zt, zhf, res, 2 * n, s));
-      SR_TRY(mof::launch_sr_cols_seq(e->d_Zt + zhf, e->d_Zt, 2 * zhf, e->d_twiddles, e->d_Dt, res, n, 1, s));
-      SR_TRY(mof::launch_sr_peak(a, res, n, s));
+    if (via_frames || e->generic) {  // (the packed pair kernels exist for the tuned resolutions only)
+      const size_t zhf = zh_floats(e);
+      SR_TRY(rows_real(e, lp_buf, nn, e->d_Zt, zhf, 2 * n, s));
+      SR_TRY(cols_seq(e, e->d_Zt + zhf, e->d_Zt, 2 * zhf, n, 1, s));
+      SR_TRY(peak(e, a, n, s));
     } else {
       a.degen = e->d_degen;
       SR_TRY(mof::launch_sr_phase_correlate(a, res, n, s));

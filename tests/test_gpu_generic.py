@@ -177,3 +177,117 @@ def test_zz_f32_limited_patches_are_rare(gpu):
     """The relaxed bar of _compare applies to a handful of patches only (it runs last: the list is filled by the tests above)."""
     print("f32-limited patches:", F32_LIMITED)
     assert len(F32_LIMITED) <= 12, F32_LIMITED
+
+
+# ---- patches too large for one CU (padded side > 135): the planned pipeline through HBM scratch (csrc/pc_large_kernel.hip) ----
+@pytest.mark.parametrize("n", [160, 136, 144, 150, 180, 192, 200, 240, 250, 148, 225, 243, 202, 480])
+def test_large_patches_match_oracle(gpu, n):
+    gx, gy = (2, 2) if n <= 250 else (1, 1)
+    stride = (n + 5, n + 2)
+    w, h = 3 + stride[0] * (gx - 1) + n + 4, 2 + stride[1] * (gy - 1) + n + 3
+    B = 5 if n <= 250 else 3
+    cur, prev, shifts, kinds = synth.batch_np(B, h, w, min(n // 8, 24), k0=n)
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(3, 2), stride=stride)
+    assert fm.kernel_variant == "planned-large"
+    got = fm.process_batch_device(torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)).cpu().numpy()
+    lay = O.fft_layout(w, h, n, gx, gy, (3, 2), stride)
+    checked = sum(_compare(got[k], cur[k], prev[k], lay, f"n{n}/pair{k}/{kinds[k]}") for k in range(B))
+    assert checked > 0.6 * B * gx * gy, (n, checked)
+    for k in range(B):
+        if kinds[k] == "shift":
+            bias = 0.5 if O.optimal_dft_size(n) % 2 else 0.0
+            assert np.allclose(np.nanmedian(got[k], axis=0) + bias, shifts[k], rtol=0, atol=0.5), (n, k)
+    # one pair at a time (a pass of one frame pair through the scratch) gives the same bits
+    one = fm.process_batch_device(torch.from_numpy(cur[1:2]).to(gpu), torch.from_numpy(prev[1:2]).to(gpu)).cpu().numpy()
+    assert np.array_equal(one[0], got[1], equal_nan=True)
+
+
+@pytest.mark.parametrize("fs,n", [(480, 160), (480, 240), (480, 480), (450, 150), (470, 100)])
+def test_large_patches_reference_constructor_and_stateful_entry(gpu, fs, n):
+    """FftMethod(frame_size, sample_point_size) as the node constructs it, incl. the reference's fallback to ONE patch = the whole
+    frame when frameSize is not a multiple of samplePointSize (FftMethod.cpp:1709-1716: 470 / 100 -> one 470 x 470 patch)."""
+    fm = FftMethod(fs, n, 80.0)
+    sps = n if fs % n == 0 else fs
+    sq = fs // sps
+    assert fm.cfg.patch_size == sps and fm.sqNum == sq and fm.kernel_variant == "planned-large"
+    seq = [synth.pair_np(7 + n, fs, fs, 3 * t, -2 * t, blur=True)[0] for t in range(3)]
+    lay = O.fft_layout(fs, fs, sps, sq, sq)
+    out0 = fm.processImage(seq[0])
+    assert np.allclose(out0, O.fft_process(seq[0], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
+    for t in (1, 2):
+        out = fm.processImage(seq[t])
+        assert _compare(out, seq[t], seq[t - 1], lay, f"fs{fs}/n{n}/t{t}") >= max(1, sq * sq - 1)
+    # degenerate pairs: a black frame against texture (flat zero surface -> shift -M/2, valid only if it passes the gate)
+    black = np.zeros((fs, fs), np.uint8)
+    for cur, prev in ((black, seq[0]), (seq[0], black), (black, black)):
+        got = fm.process_batch_host(cur[None], prev[None])[0]
+        want, _ = O.fft_process(cur, prev, lay, 64)
+        assert np.allclose(got, want, rtol=0, atol=TOL, equal_nan=True), (got, want)
+
+
+def test_large_patches_front_ends_and_passes(gpu):
+    """BGR8 frames, the long-range mode and a video on a large patch size; a batch that spans several passes of the scratch
+    (MOF_FFT_LARGE_PASS is not set: the pass size follows from the 1.5 GB budget, so force small passes through a second engine
+    that has only seen small batches)."""
+    n, gx, gy = 160, 2, 1
+    w, h = 2 * n + 7, n + 5
+    rng = np.random.default_rng(5)
+    B = 4
+    bgr_c = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+    bgr_p = np.roll(bgr_c, (3, -5), axis=(1, 2))
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(2, 3), stride=(n + 3, 1))
+    got = fm.process_batch_device_bgr(torch.from_numpy(bgr_c).to(gpu), torch.from_numpy(bgr_p).to(gpu)).cpu().numpy()
+    gray_c = np.stack([O.rgb2gray(f) for f in bgr_c])
+    gray_p = np.stack([O.rgb2gray(f) for f in bgr_p])
+    same = fm.process_batch_device(torch.from_numpy(gray_c).to(gpu), torch.from_numpy(gray_p).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, same, equal_nan=True)
+    lay = O.fft_layout(w, h, n, gx, gy, (2, 3), (n + 3, 1))
+    assert sum(_compare(got[k], gray_c[k], gray_p[k], lay, f"bgr{k}") for k in range(B)) >= B * gx * gy - 1
+    video = np.stack([synth.pair_np(77, h, w, 3 * t, t, blur=True)[0] for t in range(4)])
+    seq = fm.process_sequence_device(torch.from_numpy(video).to(gpu)).cpu().numpy()
+    for k in range(3):
+        assert _compare(seq[k], video[k + 1], video[k], lay, f"seq{k}") >= gx * gy - 1
+    fs = 4 * n
+    flr = FftMethod(fs, n, 80.0)
+    cur, prev = synth.pair_np(n, fs, fs, 8, -12, blur=True)
+    out = flr.process_long_range_batch_device(torch.from_numpy(cur[None]).to(gpu), torch.from_numpy(prev[None]).to(gpu)).cpu().numpy()[0]
+    want, _ = O.fft_process_long_range(cur, prev, O.fft_layout(fs, fs, n, 4, 4), 64)
+    assert np.allclose(out, want, rtol=0, atol=TOL, equal_nan=True), (out, want)
+
+
+# ---- scaleRotationEstimator at any even resolution (scaleRotationEstimator.cpp:3-32) ----
+@pytest.mark.parametrize("res,M", [(320, 45.0), (360, 49.9), (400, 49.9), (128, 25.0), (200, 35.0), (250, 40.0), (300, 49.9),
+                                    (350, 49.9), (500, 60.0), (192, 30.0)])
+def test_scale_rotation_at_any_resolution(gpu, res, M):
+    import sr_scenes
+    from mrs_optic_flow_amd import ScaleRotationEstimator
+    from mrs_optic_flow_amd.engine import INTER_CUBIC, INTER_LANCZOS4
+
+    base = sr_scenes.canvas(11 + res, res)
+    params = [(1.0, 0.0), (1.03, 2.0), (0.96, -3.0), (1.0, 5.0), (1.05, -1.0)]
+    frames = np.stack([sr_scenes.view(base, res, s, r) for s, r in params])
+    est = ScaleRotationEstimator(res, M)
+    tv = torch.from_numpy(frames).to(gpu)
+    # the remap, byte for byte
+    lp = est.logpolar_batch_device(tv, INTER_LANCZOS4).cpu().numpy()
+    lc = est.logpolar_batch_device(tv[:2], INTER_CUBIC).cpu().numpy()
+    for k in range(len(params)):
+        assert np.array_equal(lp[k], O.logpolar(frames[k], M, INTER_LANCZOS4)), (res, k)
+    for k in range(2):
+        assert np.array_equal(lc[k], O.logpolar(frames[k], M, INTER_CUBIC)), (res, k)
+    # independent pairs (each the two-call sequence of a fresh estimator)
+    got = est.process_batch_device(tv[1:], tv[:-1]).cpu().numpy()
+    for k in range(len(params) - 1):
+        ref = O.ScaleRotationEstimator(res, M, 64)
+        ref.processImage(frames[k])
+        s, r = ref.processImage(frames[k + 1])
+        assert np.allclose(got[k, 2:], ref.pt, rtol=0, atol=1e-4), (res, k, got[k], ref.pt)
+        assert abs(got[k, 0] - s) < 1e-5 and abs(got[k, 1] - r) < 1e-5
+    # the stateful entry and the sequence entry: same bits as each other, the oracle's frame-by-frame loop within tolerance
+    one, ref = ScaleRotationEstimator(res, M), O.ScaleRotationEstimator(res, M, 64)
+    seq = ScaleRotationEstimator(res, M).process_sequence_device(tv).cpu().numpy()
+    for t in range(len(params)):
+        s1, r1 = one.processImage(frames[t])
+        ws, wr = ref.processImage(frames[t])
+        assert (s1, r1) == (seq[t, 0], seq[t, 1]), (res, t)
+        assert abs(s1 - ws) < 1e-5 and abs(r1 - wr) < 1e-5, (res, t, s1, r1, ws, wr)
