@@ -34,8 +34,13 @@ int main() {
   mof_fft_engine* fe = nullptr;
   CHECK(mof_fft_config_reference(&fc, 480, 120, 80.0) == MOF_OK);
   mof_fft_config bad = fc;
-  bad.patch_size = 48;
+  bad.patch_size = 1000;  // pads to 1000: beyond the planned transforms
+  bad.frame_width = bad.frame_height = 4000;
   CHECK(mof_fft_create(&bad, &fe) == MOF_ERR_UNSUPPORTED && fe == nullptr && std::strlen(mof_last_error()) > 0);
+  bad = fc; bad.patch_size = 62; bad.peak_model = MOF_PEAK_OCL;  // 62 = 2 * 31: no OpenCL plan in the reference either
+  CHECK(mof_fft_create(&bad, &fe) == MOF_ERR_UNSUPPORTED && fe == nullptr);
+  bad = fc; bad.patch_size = 1;
+  CHECK(mof_fft_create(&bad, &fe) == MOF_ERR_BAD_ARG && fe == nullptr);
   bad = fc; bad.grid_x = 5;
   CHECK(mof_fft_create(&bad, &fe) == MOF_ERR_BAD_ARG);
   bad = fc; bad.max_px_speed = NAN;
@@ -86,8 +91,10 @@ int main() {
   mof_sr_engine* se = nullptr;
   mof_sr_config sc{480, 49.9, 0, MOF_LOGPOLAR_CV4, 0, 0};
   mof_sr_config sbad = sc;
-  sbad.resolution = 100;
+  sbad.resolution = 2000;  // pads to 2000: beyond the planned transforms
   CHECK(mof_sr_create(&sbad, &se) == MOF_ERR_UNSUPPORTED);
+  sbad.resolution = 101;   // odd
+  CHECK(mof_sr_create(&sbad, &se) == MOF_ERR_BAD_ARG);
   sbad = sc; sbad.magnitude = 0;
   CHECK(mof_sr_create(&sbad, &se) == MOF_ERR_BAD_ARG);
   sbad = sc; sbad.logpolar_variant = 2;

@@ -52,8 +52,17 @@ def test_bm_geometry_helpers():
 def test_argument_validation_happens_before_any_device_use():
     lib = _capi.load()
     h = C.c_void_p()
-    bad = _capi.FftConfig(752, 480, 60, 8, 8, 0, 0, 90, 59, 80.0, 0)  # patch size 60 unsupported
+    bad = _capi.FftConfig(2000, 2000, 1000, 2, 2, 0, 0, 1000, 1000, 80.0, 0)  # pads to 1000: beyond the planned transforms (<= 960)
     assert lib.mof_fft_create(C.byref(bad), C.byref(h)) == _capi.MOF_ERR_UNSUPPORTED
+    bad = _capi.FftConfig(752, 480, 62, 8, 8, 0, 0, 90, 59, 80.0, 0, 1, 55)  # the OpenCL model cannot plan 62 = 2 * 31 (nor can the reference)
+    assert lib.mof_fft_create(C.byref(bad), C.byref(h)) == _capi.MOF_ERR_UNSUPPORTED
+    bad = _capi.FftConfig(752, 480, 1, 8, 8, 0, 0, 90, 59, 80.0, 0)
+    assert lib.mof_fft_create(C.byref(bad), C.byref(h)) == _capi.MOF_ERR_BAD_ARG
+    ok = _capi.FftConfig(752, 480, 60, 8, 8, 0, 0, 90, 59, 80.0, 0)  # any other patch size has a kernel: only the device is missing here
+    assert lib.mof_fft_create(C.byref(ok), C.byref(h)) in (_capi.MOF_ERR_NO_DEVICE, _capi.MOF_OK)
+    if h:
+        lib.mof_fft_destroy(h)
+        h = C.c_void_p()
     bad = _capi.FftConfig(752, 480, 64, 8, 8, 0, 0, 100, 59, 80.0, 0)  # 7*100+64 > 752
     assert lib.mof_fft_create(C.byref(bad), C.byref(h)) == _capi.MOF_ERR_BAD_ARG
     assert b"leaves the frame" in lib.mof_last_error()

@@ -316,8 +316,9 @@ def test_edge_cases_and_error_paths(gpu):
     with pytest.raises(ValueError):
         fm.processImage(np.zeros((64, 64), np.uint8))
     with pytest.raises(MofError) as exc:
-        FftMethod(sample_point_size=48, frame_shape=(96, 96))  # 48 is not a supported patch size
+        FftMethod(sample_point_size=1000, frame_shape=(1000, 1000))  # pads to 1000: beyond the planned transforms (<= 960)
     assert exc.value.code == _capi.MOF_ERR_UNSUPPORTED
+    assert FftMethod(sample_point_size=48, frame_shape=(96, 96)).kernel_variant == "planned"  # (any other size has a kernel, r04)
     lib = _capi.load()
     assert lib.mof_fft_process_batch_device(fm._h, None, 0, None, 0, 128, 1, None, None) == _capi.MOF_ERR_BAD_ARG
     assert b"bad batch" in lib.mof_last_error()

@@ -124,10 +124,62 @@ def test_quirk_moves_centroid_by_more_than_parity_tolerance():
     assert worst > 1e-4
 
 
-def test_rejects_unsupported_sizes():
-    a = np.zeros((63, 63), np.float32)
+def test_rejects_degenerate_sizes():
+    a = np.zeros((1, 1), np.float32)
     with pytest.raises(ValueError):
         O.phase_correlate(a, a, 32)
+
+
+def test_optimal_dft_size_is_the_next_5_smooth_number():
+    """cv::getOptimalDFTSize (restated; cv::phaseCorrelate pads both images to it): oracle, twin and a brute-force definition."""
+    def smooth(m):
+        for p in (2, 3, 5):
+            while m % p == 0:
+                m //= p
+        return m == 1
+    for n in list(range(1, 700)) + [959, 960, 961, 1000, 4097]:
+        want = next(m for m in range(n, 2 * n + 8) if smooth(m))
+        assert O.optimal_dft_size(n) == want == twin.optimal_dft_size(n), n
+    assert [O.optimal_dft_size(n) for n in (60, 62, 74, 118, 124, 130, 136, 470)] == [60, 64, 75, 120, 125, 135, 144, 480]
+
+
+@pytest.mark.parametrize("n", [16, 20, 30, 40, 48, 60, 80, 96, 100, 160,   # 5-smooth, even: no padding
+                               62, 98, 118, 136, 22,                     # padded to an even size
+                               74, 44, 26, 124, 134,                     # padded to an ODD size (75, 45, 27, 125, 135)
+                               15, 25, 27, 45, 75, 9, 21])               # odd sizes
+def test_any_patch_size_against_twin(n):
+    """cv::phaseCorrelate on any size: zero padding to getOptimalDFTSize (bottom / right), CCS kinds of odd sizes (DC is the
+    only real-only slot, no Nyquist row / column), fftShift by size >> 1, the centre at size / 2.0. The C oracle (CCS bookkeeping,
+    own mixed-radix DFT) against the numpy twin (full Hermitian arrays, pocketfft): surfaces to 1e-9 relative, results to 1e-9."""
+    m = O.optimal_dft_size(n)
+    for k, (dx, dy) in enumerate([(0, 0), (2, -1), (-3, 2)]):
+        if max(abs(dx), abs(dy)) >= max(2, n // 4):
+            continue
+        cur, prev = synth.pair_np(900 + n + k, n, n, dx, dy, blur=(k != 1))
+        (x64, y64), d, surf = O.phase_correlate(cur, prev, 64, want_surface=True)
+        (tx, ty), ts, (px, py) = twin.phase_correlate(cur, prev)
+        assert surf.shape == (m, m) == ts.shape
+        assert np.abs(surf - ts).max() <= 1e-9 * max(1.0, np.abs(ts).max()), (n, k)
+        if k == 0:  # identical images: peak at the shifted origin m >> 1 -- (0, 0) for even m, OpenCV's (0.5, 0.5) for odd m
+            assert d["peak"] == (m // 2, m // 2) == (px, py)
+            want0 = 0.5 if m % 2 else 0.0
+            assert abs(x64 - want0) < 1e-6 and abs(y64 - want0) < 1e-6, (n, x64, y64)
+        if d["second_value"] < 0.5 * d["peak_value"]:
+            assert d["peak"] == (px, py), (n, k)
+            assert abs(x64 - tx) < 1e-9 and abs(y64 - ty) < 1e-9, (n, k, x64, tx)
+            (x32, y32), _ = O.phase_correlate(cur, prev, 32)
+            assert abs(x32 - x64) < 5e-4 and abs(y32 - y64) < 5e-4, (n, k)  # f32 arithmetic (smooth content is f32-limited)
+
+
+def test_fft_process_gates_against_the_unpadded_patch_size():
+    """FftMethod.cpp:1841-1842 compares |shift| with samplePointSize / 2 while cv::phaseCorrelate's centre is that of the padded
+    image: an all-zero 62 x 62 patch (padded to 64) gives -32 > 31 -> invalid; an all-zero 60 x 60 one gives -30 -> valid."""
+    for n, valid in ((62, False), (60, True), (74, False)):
+        z = np.zeros((n, n), np.uint8)
+        out, ninv = O.fft_process(z, z, O.fft_layout(n, n, n, 1, 1), 64)
+        assert (ninv == 0) == valid and (np.isnan(out).all() != valid)
+        if valid:
+            assert np.allclose(out, -n / 2)
 
 
 def test_golden_vectors_reproduce():
