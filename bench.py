@@ -504,6 +504,42 @@ def measure_other(tag: str, dev, steps: int, warmup: int):
     return rec
 
 
+def self_launch(n_ranks: int) -> int:
+    """One process per GPU, started by bench.py itself: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT are set for
+    every child BEFORE anything in it touches a GPU (the children are fresh interpreters of this script with the same
+    arguments; under torch.distributed.run those variables are already there and this function is never reached). Rank 0's
+    stdout -- the JSON line -- is relayed; the other ranks' stdout goes to stderr. Returns non-zero if any rank failed (the
+    remaining ranks are then ended by their exact PIDs, never by pattern)."""
+    import socket
+    import subprocess
+    import time
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(n_ranks):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 1
+                for q in alive:  # a rank died: the others would wait for it in the next collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -525,6 +561,11 @@ def main() -> None:
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph and replay it (helps the multi-launch c5 pipeline)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` run bare: this process becomes the launcher. It touches no GPU (nothing below has
+        # imported torch or loaded the library yet), starts N fresh rank processes of this same script and relays rank 0's line.
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist

@@ -77,7 +77,7 @@ int mof_deferred_count(void);  /* engines parked now */
 
 typedef struct mof_fft_config {
   int frame_width, frame_height; /* pixels                                                    */
-  int patch_size;                /* samplePointSize N: 32, 64, 120 (reference default) or 128 */
+  int patch_size;                /* samplePointSize N, any >= 2 up to 960 after padding (see below) */
   int grid_x, grid_y;            /* patches per row / per column                              */
   int origin_x, origin_y;        /* top-left pixel of patch (0,0)                             */
   int stride_x, stride_y;        /* distance between patch origins                            */
@@ -108,9 +108,19 @@ int mof_fft_config_reference(mof_fft_config* cfg, int frame_size, int sample_poi
 
 typedef struct mof_fft_engine mof_fft_engine;
 
+/* Patch sizes (FftMethod.cpp:1680-1720 takes frameSize / samplePointSize from ROS parameters, config/default.yaml:31-32, and
+ * falls back to ONE patch = the whole frame when they do not divide): every patch goes through cv::phaseCorrelate (:1836),
+ * which zero-pads it to M = cv::getOptimalDFTSize(N), the smallest 2^a 3^b 5^c >= N (possibly odd: 74 -> 75); peak, centroid and
+ * centre (M / 2.0) live on the padded image, the gate compares with N / 2 (:1841-1842). Three kernel families serve this
+ * (mof_fft_kernel_variant): hand-tuned instantiations for N = 32, 64, 120 (reference default), 128 ("stockham"); a run-time
+ * planned kernel for every other N with M <= 135 ("planned", csrc/pc_kernel_generic.hip); a planned pipeline through HBM scratch
+ * for larger patches up to M = 960 ("planned-large", csrc/pc_large_kernel.hip). mof_fft_create fails with MOF_ERR_UNSUPPORTED
+ * only beyond that, and for MOF_PEAK_OCL on sizes the reference's OpenCL branch cannot plan either (odd, not 5-smooth) or M > 135.
+ * The large-patch pipeline owns scratch (three half-spectrum planes per patch pair of a pass); it grows with the first batch
+ * that needs more -- never inside a HIP graph capture: run the largest batch once before capturing. */
 int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out);
-/* Diagnostics: name of the kernel formulation the engine launches: "stockham" (pc_kernel.hip / pc_kernel_mixed.hip) in
- * the product library; "quad" only in the A/B build csrc/ab/libmof_hip_quad.so with MOF_PC_QUAD=1 (pc_kernel_quad.hip,
+/* Diagnostics: name of the kernel formulation the engine launches: "stockham" (pc_kernel.hip / pc_kernel_mixed.hip),
+ * "planned" or "planned-large" (above) in the product library; "quad" only in the A/B build csrc/ab/libmof_hip_quad.so with MOF_PC_QUAD=1 (pc_kernel_quad.hip,
  * a measured-slower alternative kept for comparison, not shipped). */
 const char* mof_fft_kernel_variant(const mof_fft_engine* e);
 void mof_fft_destroy(mof_fft_engine* e);
@@ -180,6 +190,38 @@ int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur
 int mof_fft_sync(mof_fft_engine* e);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Batched-frames mode across the GPUs of one node (BASELINE north_star)  */
+/* ------------------------------------------------------------------------------------------ */
+/* Frame pairs are independent: a batch of B pairs is cut into contiguous shards of ceil(B / G) pairs, shard g is owned and
+ * processed by device g (no data-path collective), and ONE all-gather of the per-rank result slabs (RCCL over xGMI) hands every
+ * device the whole result. Native and single-process: one FftMethod engine and one HIP stream per device inside the group,
+ * ncclCommInitAll + one in-place ncclAllGather per batch; RCCL is bound at run time on the first gather (dlopen of
+ * librccl.so.1), so single-GPU hosts never load it. No reference counterpart (the reference is one synchronous call per frame
+ * on one device); per device the work is exactly mof_fft_process_batch_device. */
+
+/* The partition: shard `shard` of `n_shards` owns pairs [*first, *first + *count), slabs of ceil(n_pairs / n_shards) pairs,
+ * the last one ragged (or empty). Pure host arithmetic, no device needed. */
+int mof_shard_slab_pairs(int n_pairs, int n_shards); /* ceil(n_pairs / n_shards) */
+int mof_shard_partition(int n_pairs, int n_shards, int shard, int* first, int* count);
+
+typedef struct mof_shard_fft mof_shard_fft;
+/* One engine of `cfg` per listed device (cfg->device is ignored; devices == NULL: 0 .. n_devices - 1). */
+int mof_shard_fft_create(const mof_fft_config* cfg, const int* devices, int n_devices, mof_shard_fft** out);
+void mof_shard_fft_destroy(mof_shard_fft* g);
+int mof_shard_fft_devices(const mof_shard_fft* g);
+void* mof_shard_fft_stream(const mof_shard_fft* g, int shard); /* the hipStream_t shard's work is enqueued on */
+/* d_cur[g] / d_prev[g]: device g's OWN shard of the batch (its first pair at the pointer; strides and pitch as in
+ * mof_fft_process_batch_device) -- frames are generated or loaded directly on the owning GPU. d_out[g]: on device g,
+ * n_shards * mof_shard_slab_pairs(n_pairs, n_shards) * grid_x * grid_y * 2 doubles; pair k's vectors land at pair index k
+ * (slabs are contiguous; the padding behind a ragged last shard is not written). gather != 0: after the all-gather every
+ * d_out[g] holds all n_pairs results; gather == 0: each device holds only its own slab (at its place). Asynchronous: enqueued on
+ * the group's per-device streams; mof_shard_fft_sync waits for all of them. */
+int mof_shard_fft_process_batch_device(mof_shard_fft* g, const uint8_t* const* d_cur, size_t cur_stride,
+                                       const uint8_t* const* d_prev, size_t prev_stride, size_t pitch, int n_pairs,
+                                       double* const* d_out, int gather);
+int mof_shard_fft_sync(mof_shard_fft* g);
+
+/* ------------------------------------------------------------------------------------------ */
 /* SAD block matching (BlockMethod / FastSpacedBMMethod)                                      */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -244,7 +286,8 @@ int mof_bm_sync(mof_bm_engine* e);
 /* ------------------------------------------------------------------------------------------ */
 
 typedef struct mof_sr_config {
-  int resolution;   /* side of the square image (scaleRotationEstimator.cpp:5): 240, 256 or 480       */
+  int resolution;   /* side of the square image (scaleRotationEstimator.cpp:5): any even value >= 16; 240, 256 and 480
+                       have hand-tuned transforms, the rest run the planned pipeline on the padded size (<= 960)     */
   double magnitude; /* log-polar magnitude M (scale_rot_magnitude, config/default.yaml:13: 49.9)      */
   int device;
   int logpolar_variant; /* MOF_LOGPOLAR_CV4 (0, default) or MOF_LOGPOLAR_CV3: see below              */

@@ -82,6 +82,14 @@ SYMBOLS = {
     "mof_fft_process_batch_device_bgr": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_fft_process_batch_host": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP]),
     "mof_fft_sync": (_I, [_VP]),
+    "mof_shard_slab_pairs": (_I, [_I, _I]),
+    "mof_shard_partition": (_I, [_I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "mof_shard_fft_create": (_I, [C.POINTER(FftConfig), C.POINTER(_I), _I, C.POINTER(_VP)]),
+    "mof_shard_fft_destroy": (None, [_VP]),
+    "mof_shard_fft_devices": (_I, [_VP]),
+    "mof_shard_fft_stream": (_VP, [_VP, _I]),
+    "mof_shard_fft_process_batch_device": (_I, [_VP, C.POINTER(_VP), _SZ, C.POINTER(_VP), _SZ, _SZ, _I, C.POINTER(_VP), _I]),
+    "mof_shard_fft_sync": (_I, [_VP]),
     "mof_bm_config_block_method": (_I, [C.POINTER(BmConfig), _I, _I, _I]),
     "mof_bm_config_fast_spaced": (_I, [C.POINTER(BmConfig), _I, _I, _I, _I, _I]),
     "mof_bm_create": (_I, [C.POINTER(BmConfig), C.POINTER(_VP)]),

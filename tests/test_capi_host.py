@@ -80,3 +80,27 @@ def test_no_cpu_fallback_without_a_device():
     with pytest.raises(MofError) as exc:
         FftMethod(448, 64)
     assert exc.value.code == _capi.MOF_ERR_NO_DEVICE
+
+
+def test_shard_partition_is_the_contiguous_ceil_split():
+    """mof_shard_partition: rank g of G takes pairs [g ceil(B/G), min(B, (g+1) ceil(B/G))) -- the same split as
+    mrs_optic_flow_amd.sharding.shard_bounds -- for G in {1, 2, 4, 8} and ragged B. Pure host arithmetic: no device needed."""
+    from mrs_optic_flow_amd import sharding
+
+    lib = _capi.load()
+    for G in (1, 2, 3, 4, 8):
+        for B in (0, 1, 7, 8, 9, 37, 1000, 1024, 8191, 8192):
+            slab = lib.mof_shard_slab_pairs(B, G)
+            assert slab == -(-B // G)
+            covered = 0
+            for g in range(G):
+                first, count = C.c_int(-1), C.c_int(-1)
+                assert lib.mof_shard_partition(B, G, g, C.byref(first), C.byref(count)) == _capi.MOF_OK
+                lo, hi = sharding.shard_bounds(B, g, G)
+                assert (first.value, first.value + count.value) == (lo, hi) or (count.value == 0 and hi == lo)
+                covered += count.value
+            assert covered == B
+    f, c = C.c_int(), C.c_int()
+    assert lib.mof_shard_partition(8, 4, 4, C.byref(f), C.byref(c)) == _capi.MOF_ERR_BAD_ARG
+    assert lib.mof_shard_partition(-1, 4, 0, C.byref(f), C.byref(c)) == _capi.MOF_ERR_BAD_ARG
+    assert lib.mof_shard_fft_devices(None) == 0 and lib.mof_shard_fft_sync(None) == _capi.MOF_ERR_NOT_INIT
