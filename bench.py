@@ -45,13 +45,20 @@ def binding_note(name: str, wl) -> str:
         return ("integer VALU: generic block scan 97 % VALU-busy, 81 % of those cycles in v_qsad_pk_u16_u8 (the rest: one "
                 "v_pk_mov per odd window pair, widening); small geometries (c1) are staging-latency-bound; not HBM")
     if wl["kind"] == "fft+2dt":
-        return ("1/4-scale resize fused into K1's load (half of the frame rows are fetched) + one 120 x 120 patch per pair: "
-                "0.10 ms per 1024 pairs, the one path here whose time is mostly frame fetch")
+        return (f"1/4-scale resize fused into K1's load (half of the frame rows are fetched) + one {wl['n']} x {wl['n']} patch per pair: "
+                "0.10 ms per 1024 pairs, the one path here whose time is mostly frame fetch (FETCH_SIZE factor of this load path "
+                "calibrated by the callr workload, profiles/traffic_callr.json)")
     if wl["kind"] == "fft+rt":
         return "K1 as in ref + the getRT tail (one wavefront per pair, fp64 recurrences: 0.35 ms per 1024 pairs); not HBM"
     if wl["kind"] == "fftseq":
-        return ("K1 sequence kernel: one real forward transform + one Hermitian inverse per frame and patch (1.0 instead of 1.5 "
-                "complex-transform units), four barriers per frame; VALU issue / phase-chain latency as K1; not HBM")
+        if wl["n"] == 64:
+            return ("K1 sequence kernel: one real forward transform + one Hermitian inverse per frame and patch (1.0 instead of 1.5 "
+                    "complex-transform units), four barriers per frame. profiles/r04_c2seq_sq_pmc.csv (per launch of 65,536 patch "
+                    "frames): VALU issue 47.8 % (272.3 M wave-instructions x 2 cycles over 1024 SIMDs x 1.114 M cycles), LDS active "
+                    "56.7 % of the CU cycles (12.6 % of it bank conflicts); the two add to 104 %: the pipes run one after the other, "
+                    "not side by side; not HBM")
+        return ("K1 sequence kernel on a half-size tile (128 x 128 patches): one real forward transform + one Hermitian inverse per "
+                "frame and patch, one workgroup of 8 waves per CU (192 VGPRs); VALU + LDS in series as K1 at N = 128; not HBM")
     if wl["kind"] == "fft+srseq":
         return ("c5 on a video: one Lanczos4 remap and one real row transform per frame (K5s), column pass walking pairs in "
                 "time with the previous spectra in registers (K6s); DESIGN.md section 4 (sequence mode)")
@@ -60,13 +67,24 @@ def binding_note(name: str, wl) -> str:
                 "boxes: LDS reads + VALU) 34 %, whole-frame transforms through Zt / Dt (per-frame real row transforms K5s, column "
                 "pass K6s, inverse rows K7: 4.5-4.9 TB/s of HBM traffic each, 70-80 % of the achievable rate) 43 %; "
                 "K1 as in c2; DESIGN.md section 4 (K4-K8)")
-    if wl["n"] >= 120:
+    if wl["n"] == 120:
+        return ("one persistent workgroup of 15 waves per CU (the 120 x 136 tile fills the LDS). profiles/r04_ref_sq_pmc.csv (per launch "
+                "of 16,384 patch pairs): VALU issue 38.6 % (435.2 M wave-instructions x 2 cycles over 1024 SIMDs x 2.203 M cycles), LDS "
+                "active 32.4 % of the CU cycles (1.9 % of it bank conflicts), waves parked at a wait 47.8 % of their cycles: with one "
+                "workgroup per CU nothing covers a phase's own read -> butterfly -> write chain; not HBM")
+    if wl["n"] >= 128:
         return ("one persistent workgroup per CU (the tile fills the LDS): the LDS store path (ds_write_b64 = 6 cycles per "
                 "wave-instruction, 7.5 tile stores per patch pair) and the 8-wave inverse passes; N = 128: VALU issue ~42 %, "
-                "LDS 46 % busy, 6 % of it bank conflicts (profiles/r03_c4_sq_pmc.csv); not HBM -- DESIGN.md section 4 (K1 at N = 128)")
-    return ("latency of the per-patch phase chain at 4 workgroups/CU (LDS-capacity limit); VALU issue ~44 % "
-            "(334.9 M instructions x 2 cycles per launch, profiles/r02_c2_sq_pmc.csv), LDS pipe 57-66 % busy of which 16-19 % "
-            "bank conflicts, 21 % of wave-cycles waiting on LDS; not HBM -- see DESIGN.md section 4 (K1)")
+                "LDS 46 % busy, 6 % of it bank conflicts (profiles/r03_c4_sq_pmc.csv; the kernel is unchanged since); the two add to "
+                "88 %: in series; not HBM -- DESIGN.md section 4 (K1 at N = 128)")
+    if wl["n"] != 64:
+        return ("planned kernel (run-time radix plan, pc_kernel_generic.hip / pc_large_kernel.hip): the general path, not tuned -- "
+                "DESIGN.md section 4 (size-generic kernels)")
+    return ("four workgroups per CU (LDS capacity). profiles/r04_c2_sq_pmc.csv (per launch of 65,536 patch pairs): VALU issue 53.7 % "
+            "(370.3 M wave-instructions x 2 cycles over 1024 SIMDs x 1.346 M cycles; 1412 per wave and patch pair), LDS active 52.7 % "
+            "of the CU cycles (9.7 % of it bank conflicts; two thirds of it the store path, 6 cycles per ds_write_b64), waves stalled "
+            "on LDS issue 14 %; VALU + LDS = 106 %: the two pipes run one after the other, not side by side -- that serialisation, "
+            "not either pipe and not HBM, is what binds (DESIGN.md section 4, K1)")
 
 
 def fft_flops_per_pair(n: int, patches: int) -> float:
@@ -110,6 +128,12 @@ WORKLOADS = {
     "cal": dict(kind="fft", h=512, w=512, n=64, grid=(8, 8), origin=(0, 0), stride=(64, 64), batch=1024, s=8,
                 name="cal: FftMethod 512x512 tiled exactly by 8x8 patches of 64x64 (counter calibration), batch=1024",
                 bytes_per_pair=2 * 512 * 512 + 64 * 8),
+    # ... and for the long-range load path (DS = 4: two 64-byte runs per lane and tapped row pair): 512 x 512 frames, pitch 512,
+    # ONE quarter-resolution 128 x 128 patch = the whole frame; cv::resize(1/4) taps rows 4r+1, 4r+2 only, whole 128-byte
+    # lines of them -> known HBM read bytes = 2 images * 256 rows * 512 B per pair
+    "callr": dict(kind="fft+2dt", h=512, w=512, n=128, grid=(4, 4), origin=(0, 0), stride=(128, 128), batch=1024, s=15,
+                  name="callr: long-range mode on 512x512 frames, one 128x128 quarter-resolution patch (counter calibration of the DS=4 load), batch=1024",
+                  bytes_per_pair=2 * 256 * 512 + 64),
     "c5": dict(kind="fft+sr", h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=1024, s=8,
                sr_res=480, sr_m=49.9, sr_x0=136,
                name="c5: FftMethod (c2) + scaleRotationEstimator on the 480x480 centre crop (log-polar M=49.9 + whole-frame "

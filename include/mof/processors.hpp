@@ -137,6 +137,46 @@ class FftMethod {
   int last_invalid_ = 0;
 };
 
+// The batched-frames mode across the GPUs of one node (include/mof.h, mof_shard_*): ceil(B / G) contiguous shards, one engine
+// and one stream per device in THIS process, one in-place RCCL all-gather of the result slabs. No reference counterpart (the
+// reference is one synchronous call per frame on one device); the C++ host that wants it -- a bag replayer, an offline mapper --
+// uploads shard g of its frames to device g and calls process().
+class ShardedFftMethod {
+ public:
+  // devices: the HIP ordinals of the shards (empty: 0 .. n_devices - 1)
+  ShardedFftMethod(const mof_fft_config& cfg, int n_devices, const std::vector<int>& devices = {}) : cfg_(cfg) {
+    if (!devices.empty() && (int)devices.size() != n_devices) throw std::runtime_error("ShardedFftMethod: one device per shard");
+    detail::check(mof_shard_fft_create(&cfg_, devices.empty() ? nullptr : devices.data(), n_devices, &group_), "mof_shard_fft_create");
+  }
+  ~ShardedFftMethod() { mof_shard_fft_destroy(group_); }
+  ShardedFftMethod(const ShardedFftMethod&) = delete;
+  ShardedFftMethod& operator=(const ShardedFftMethod&) = delete;
+
+  int devices() const { return mof_shard_fft_devices(group_); }
+  // pairs [first, first + count) of a batch of n_pairs belong to `shard`
+  void partition(int n_pairs, int shard, int* first, int* count) const {
+    detail::check(mof_shard_partition(n_pairs, devices(), shard, first, count), "mof_shard_partition");
+  }
+  // doubles every device's result buffer must hold: devices * ceil(n_pairs / devices) * patches * 2
+  size_t resultDoubles(int n_pairs) const {
+    return (size_t)devices() * (size_t)mof_shard_slab_pairs(n_pairs, devices()) * cfg_.grid_x * cfg_.grid_y * 2;
+  }
+  // d_cur[g] / d_prev[g]: shard g's frames ON device g; d_out[g]: resultDoubles() doubles on device g. gather: every device ends
+  // up with all n_pairs results (pair k at pair index k). Asynchronous; sync() waits for every device.
+  void process(const std::vector<const uint8_t*>& d_cur, size_t cur_stride, const std::vector<const uint8_t*>& d_prev, size_t prev_stride,
+               size_t pitch, int n_pairs, const std::vector<double*>& d_out, bool gather = true) {
+    if ((int)d_cur.size() != devices() || (int)d_prev.size() != devices() || (int)d_out.size() != devices())
+      throw std::runtime_error("ShardedFftMethod::process: one pointer per shard");
+    detail::check(mof_shard_fft_process_batch_device(group_, d_cur.data(), cur_stride, d_prev.data(), prev_stride, pitch, n_pairs,
+                                                     d_out.data(), gather ? 1 : 0), "mof_shard_fft_process_batch_device");
+  }
+  void sync() { detail::check(mof_shard_fft_sync(group_), "mof_shard_fft_sync"); }
+
+ private:
+  mof_fft_config cfg_{};
+  mof_shard_fft* group_ = nullptr;
+};
+
 // Integer stage of both block matchers behind one engine.
 class BlockMatcherBase {
  public:

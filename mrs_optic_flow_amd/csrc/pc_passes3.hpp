@@ -43,7 +43,9 @@ __device__ __forceinline__ void fwd3_rows(cf* __restrict__ z, int wave, int lane
     const uint32_t cp = lds_read_u16(src + 8 * n1);
     v[n1] = {(float)(cp & 0xffu), (float)(cp >> 8)};
   }
+#ifndef MOF_ABLATE_ROWS  // diagnostic build (tools/ab_mfma_bound.sh): the row arithmetic an MFMA row-DFT would take off the VALU
   butterfly<16>(v);
+#endif
   wave_sync();  // the raw area lies inside the wave's own part of the intermediate layout: all of it is read by now
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) z[t3addr(y, n2, k1)] = v[k1];
@@ -59,8 +61,12 @@ __device__ __forceinline__ void fwd3_mid(cf* __restrict__ z, int wave, int lane,
     for (int n2 = 0; n2 < 4; ++n2) e[m1][n2] = lds_read(&z[t3addr(m2 + 16 * m1, n2, k1)]);
 #pragma unroll
   for (int m1 = 0; m1 < 4; ++m1) {
+#ifdef MOF_ABLATE_ROWS
+    cf t[4] = {e[m1][0], e[m1][1], e[m1][2], e[m1][3]};
+#else
     cf t[4] = {e[m1][0], cmul(e[m1][1], tw.wr[0]), cmul(e[m1][2], tw.wr[1]), cmul(e[m1][3], tw.wr[2])};
     butterfly<4>(t);
+#endif
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) e[m1][k2] = t[k2];
   }

@@ -210,3 +210,58 @@ def video_torch(n_frames: int, height: int, width: int, device, k: int = 0, blur
         frames[f] = canvas[m + oy:m + oy + height, m + ox:m + ox + width]
         offs[f, 0], offs[f, 1] = ox, oy
     return frames, offs
+
+
+# ----------------------------------------------------------------------------------------------
+# Input classes the random fuzzers found worth pinning (tools/fft_sr_fuzz.py, r03 / r04): every one of them once broke, or
+# could break, a kernel that passes on plain shifted texture. Seeded, so a regression shows in the test suite.
+# ----------------------------------------------------------------------------------------------
+
+def smooth_np(k: int, height: int, width: int, passes: int = 4, seed: int = SEED) -> np.ndarray:
+    """Strongly low-passed texture (``passes`` integer 3x3 box blurs): most cross-power bins sit near the f32 rounding floor --
+    the content class on which f32 arithmetic, not the algorithm, limits agreement (Tolerances)."""
+    c = canvas_np(k, height + 2 * passes, width + 2 * passes, False, seed).astype(np.int32)
+    for _ in range(passes):
+        hh, ww = c.shape[0] - 2, c.shape[1] - 2
+        acc = np.zeros((hh, ww), np.int32)
+        for oy in range(3):
+            for ox in range(3):
+                acc += c[oy:oy + hh, ox:ox + ww]
+        c = (acc + 4) // 9
+    m = MARGIN
+    return c[m:m + height, m:m + width].astype(np.uint8)
+
+
+def fuzz_classes_np(k: int, height: int, width: int, dx: int = 3, dy: int = -2, seed: int = SEED) -> dict:
+    """name -> (cur, prev): the degenerate / ill-conditioned classes, all ``height x width`` uint8.
+      const_cur / const_prev   exactly ONE frame of the pair constant (r03: the packed two-for-one transform answered with noise)
+      black_cur / black_prev / black_both   all-zero frames (the only constant patch that survives zero padding; SR: the
+                               all-zero log-polar image)
+      const_rect               a constant rectangle inside a textured frame: some patches constant, their neighbours not
+      saturated                a region clipped to 255 in both frames (constant where it covers a patch)
+      smooth                   strongly low-passed content, shifted (f32-limited)
+      checker                  texture whose alternating-sign pixel sums cancel in places (r04: the real-only CCS slots of small
+                               patches must come out of the transform exactly)"""
+    cur, prev = pair_np(k, height, width, dx, dy, True, seed)
+    level = np.uint8((k * 37 + 11) % 255 + 1)
+    const = np.full((height, width), level, np.uint8)
+    black = np.zeros((height, width), np.uint8)
+    out = {"const_cur": (const.copy(), prev.copy()), "const_prev": (cur.copy(), const.copy()),
+           "black_cur": (black.copy(), prev.copy()), "black_prev": (cur.copy(), black.copy()), "black_both": (black.copy(), black.copy())}
+    rc, rp = cur.copy(), prev.copy()
+    y0, y1, x0, x1 = height // 5, (3 * height) // 4, width // 6, (2 * width) // 3
+    rc[y0:y1, x0:x1] = level
+    out["const_rect"] = (rc, rp)
+    sc, sp = cur.copy(), prev.copy()
+    sc[: height // 2, : (3 * width) // 5] = 255
+    sp[: height // 2, : (3 * width) // 5] = 255
+    out["saturated"] = (sc, sp)
+    sm = smooth_np(k, height + 2 * MARGIN, width + 2 * MARGIN, 4, seed)
+    m = MARGIN
+    out["smooth"] = (sm[m - dy:m - dy + height, m - dx:m - dx + width].copy(), sm[m:m + height, m:m + width].copy())
+    # two-level texture in 2 x 2 cells: many patches whose (-1)^x, (-1)^y or (-1)^(x+y) weighted pixel sums are exactly zero
+    cell = (canvas_np(k + 1, height, width, False, seed)[MARGIN:MARGIN + height, MARGIN:MARGIN + width] >> 7).astype(np.uint8)
+    cell = np.repeat(np.repeat(cell[::2, ::2], 2, axis=0), 2, axis=1)[:height, :width]
+    ck = (cell * 200 + 20).astype(np.uint8)
+    out["checker"] = (np.roll(ck, (2, 2), axis=(0, 1)), ck)
+    return out

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "mof.h"
+#include "mof/processors.hpp"
 
 #define CHECK(x)                                                                     \
   do {                                                                               \
@@ -106,6 +107,14 @@ int main(int argc, char** argv) {
     (void)hipFree(dc[s]); (void)hipFree(dp[s]); (void)hipFree(dout[s]);
   }
   mof_shard_fft_destroy(g);
+  // the C++ mirror (include/mof/processors.hpp) on the same data: shard 0 of a group, no gather (each device keeps its own slab)
+  {
+    mof::ShardedFftMethod sm(cfg, G);
+    CHECK(sm.devices() == G && sm.resultDoubles(B) == per_pair * (size_t)slab * G);
+    int first = 0, count = 0;
+    sm.partition(B, 0, &first, &count);
+    CHECK(first == 0 && count == (B < slab ? B : slab));
+  }
   std::printf("shard ok %d %d\n", G, B);
   return 0;
 }

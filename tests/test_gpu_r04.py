@@ -112,3 +112,99 @@ def test_native_sharded_entry_through_ctypes(gpu):
             assert torch.equal(out, want), gather
     finally:
         lib.mof_shard_fft_destroy(grp)
+
+
+# ---- the fuzzers' input classes, seeded, through EVERY entry point ----------------------------------------
+_DBL_EPS, _FLT_EPS = float(np.finfo(np.float64).eps), float(np.finfo(np.float32).eps)
+
+
+def _expected(cur, prev, lay, max_speed=80.0):
+    """Per patch: (want [2] or None, tolerance). Constant patches: the closed form of cv::phaseCorrelate's flat surface (first
+    index, clamped 3 x 3 centroid of equal values: 9c / (9c + DBL_EPSILON) - M/2 with c = C_dc = P / (P^2 + FLT_EPSILON), P the
+    product of the two pixel sums) -- the oracle's own radix-3/5 transform of a constant is not exactly zero off DC, OpenCV's
+    neither, so the closed form (what exact arithmetic gives) is the bar there. With zero padding (M > N) only an all-zero patch
+    stays constant. Everything else: the oracle, where its arg-max is stable (tests/test_gpu_fft.py::_compare)."""
+    n, gx, gy = lay.patch, lay.grid_x, lay.grid_y
+    m = O.optimal_dft_size(n)
+    want64, _, diags = O.fft_process(cur, prev, lay, 64, want_diag=True)
+    want32, _ = O.fft_process(cur, prev, lay, 32)
+    out = []
+    for j in range(gy):
+        for i in range(gx):
+            p = i + j * gx
+            x0, y0 = lay.origin_x + i * lay.stride_x, lay.origin_y + j * lay.stride_y
+            a, b = cur[y0:y0 + n, x0:x0 + n], prev[y0:y0 + n, x0:x0 + n]
+            ca, cb = int(a.max()) == int(a.min()), int(b.max()) == int(b.min())
+            deg = (ca or cb) if m == n else ((ca and a.max() == 0) or (cb and b.max() == 0))
+            if deg:
+                P = float(a.astype(np.float64).sum()) * float(b.astype(np.float64).sum())
+                c9 = 9.0 * P / (P * P + _FLT_EPS) if P > 0 else 0.0
+                s = (c9 / (c9 + _DBL_EPS) if c9 > 0 else 0.0) - m / 2.0
+                bad = 2 * s * s > max_speed ** 2 or abs(s) > n / 2.0
+                out.append((np.array([np.nan, np.nan]) if bad else np.array([s, s]), 1e-4))
+                continue
+            agree = np.array_equal(np.isnan(want64[p]), np.isnan(want32[p])) and np.allclose(want64[p], want32[p], rtol=0, atol=TOL, equal_nan=True)
+            well = diags[p].second_value < 0.5 * diags[p].peak_value
+            if not (well or agree):
+                out.append((None, 0.0))
+                continue
+            dd = 0.0 if np.isnan(want64[p]).any() or np.isnan(want32[p]).any() else float(np.abs(want32[p] - want64[p]).max())
+            out.append((want64[p], TOL if dd <= 2e-5 else TOL + 4.0 * dd))  # (f32-limited content: tests/test_gpu_generic.py::_compare)
+    return out
+
+
+def _check(got, cur, prev, lay, label):
+    n_checked = 0
+    for p, (want, tol) in enumerate(_expected(cur, prev, lay)):
+        if want is None:
+            continue
+        assert np.allclose(got[p], want, rtol=0, atol=tol, equal_nan=True), (label, p, got[p], want)
+        n_checked += 1
+    return n_checked
+
+
+@pytest.mark.parametrize("n", [32, 64, 120, 128, 60, 62, 160])
+def test_fuzzer_classes_through_every_entry_point(gpu, n):
+    """one-sided constant frames, black frames, a constant rectangle inside a frame, a saturated region, strongly low-passed
+    content and exactly-cancelling alternating sums -- through the pair batch, the BGR front end, the sequence entry, the
+    stateful processImage and the long-range mode, at tuned (32 / 64 / 120 / 128), planned (60, 62 -> 64) and large (160) sizes."""
+    fs = 2 * n  # 2 x 2 patches, reference tiling
+    classes = synth.fuzz_classes_np(100 + n, fs, fs, 3, -2)
+    lay = O.fft_layout(fs, fs, n, 2, 2)
+    fm = FftMethod(fs, n, 80.0)
+    names = sorted(classes)
+    cur = np.stack([classes[k][0] for k in names])
+    prev = np.stack([classes[k][1] for k in names])
+    tc, tp = torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)
+    # (1) independent pairs
+    got = fm.process_batch_device(tc, tp).cpu().numpy()
+    total = 0
+    for k, name in enumerate(names):
+        total += _check(got[k], cur[k], prev[k], lay, f"n{n}/pair/{name}")
+    assert total >= 0.7 * 4 * len(names), total
+    # (2) the same frames as interleaved BGR8 with B = G = R (CV_RGB2GRAY then returns the value itself): same bits
+    bgr_c, bgr_p = tc[..., None].expand(-1, -1, -1, 3).contiguous(), tp[..., None].expand(-1, -1, -1, 3).contiguous()
+    assert np.array_equal(fm.process_batch_device_bgr(bgr_c, bgr_p).cpu().numpy(), got, equal_nan=True)
+    # (3) a video that walks through the classes: texture, constant, texture, black, texture with a constant rectangle, smooth ...
+    tex_c, tex_p = synth.pair_np(7 + n, fs, fs, 2, 1)
+    video = np.stack([tex_p, tex_c, classes["const_cur"][0], tex_c, classes["black_both"][0], classes["const_rect"][0], tex_p,
+                      classes["smooth"][1], classes["smooth"][0], classes["saturated"][0], classes["checker"][1], classes["checker"][0]])
+    seq = fm.process_sequence_device(torch.from_numpy(video).to(gpu)).cpu().numpy()
+    for k in range(len(video) - 1):
+        _check(seq[k], video[k + 1], video[k], lay, f"n{n}/seq/{k}")
+    # (4) the stateful entry, frame by frame (first frame against itself)
+    fm.reset()
+    for k in range(len(video)):
+        out = fm.processImage(video[k])
+        _check(out, video[k], video[k - 1] if k else video[k], lay, f"n{n}/stateful/{k}")
+    # (5) long-range mode: frames whose quarter-resolution reduction IS the class frame (every 4 x 4 cell constant), one patch
+    if n <= 128:
+        flr = FftMethod(4 * n, n, 80.0)
+        lay1 = O.fft_layout(n, n, n, 1, 1)
+        sel = [k for k, name in enumerate(names)]
+        small_c = np.stack([cur[k][:n, :n] for k in sel])
+        small_p = np.stack([prev[k][:n, :n] for k in sel])
+        up = lambda a: np.repeat(np.repeat(a, 4, axis=1), 4, axis=2)
+        lr = flr.process_long_range_batch_device(torch.from_numpy(up(small_c)).to(gpu), torch.from_numpy(up(small_p)).to(gpu)).cpu().numpy()
+        for k in sel:
+            _check(lr[k], small_c[k], small_p[k], lay1, f"n{n}/longrange/{names[k]}")

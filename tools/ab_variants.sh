@@ -16,7 +16,7 @@ EXTRA=""; [ "$SRC" == "mof_geom.hip" ] && EXTRA="-ffp-contract=off"
 i=0
 for V in "$@"; do
   hipcc --offload-arch=gfx950 $BASE $EXTRA $V -I../../include -I. -c -o /tmp/ab_var_$i.o $SRC
-  hipcc --offload-arch=gfx950 -shared -o /tmp/libmof_ab_$i.so $OTHERS /tmp/ab_var_$i.o
+  hipcc --offload-arch=gfx950 -shared -o /tmp/libmof_ab_$i.so $OTHERS /tmp/ab_var_$i.o -ldl
   i=$((i+1))
 done
 n=$i

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Random FftMethod layouts (N in 32 / 64 / 120 / 128, any grid, origin, stride, frame size, batch classes) and random
-scale / rotation estimator settings (resolution, M, both OpenCV generations, both interpolations) through the GPU path
-against the oracle: shifts within 1e-4 px wherever the correlation surface has a stable arg-max, remap to the byte.
+"""Random FftMethod layouts (ANY patch size since r04: the tuned 32 / 64 / 120 / 128, random sizes 8..200 incl. odd ones and
+ones that pad to an odd transform size, occasionally a large patch up to 300; any grid, origin, stride, frame size, batch
+classes) and random scale / rotation estimator settings (ANY even resolution 64..512, M, both OpenCV generations, both
+interpolations) through the GPU path against the oracle: shifts within 1e-4 px wherever the correlation surface has a stable
+arg-max (four times the f32-to-f64 oracle distance where the reference's own f32 arithmetic is the limit), remap to the byte.
 usage (GPU box): python tools/fft_sr_fuzz.py [seed] [fft_trials] [sr_trials]"""
 import os
 import sys
@@ -24,14 +26,15 @@ rng = np.random.default_rng(seed)
 dev = torch.device("cuda")
 bad = checked = total = soft = 0
 for trial in range(n_fft):
-    n = int(rng.choice([32, 64, 64, 120, 128]))
-    gx, gy = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+    r = rng.integers(0, 10)
+    n = int(rng.choice([32, 64, 64, 120, 128])) if r < 4 else (int(rng.integers(8, 201)) if r < 9 else int(rng.integers(136, 301)))
+    gx, gy = (int(rng.integers(1, 6)), int(rng.integers(1, 5))) if n <= 135 else (int(rng.integers(1, 3)), int(rng.integers(1, 3)))
     sx, sy = int(rng.integers(max(1, n // 3), n + 40)), int(rng.integers(max(1, n // 3), n + 40))
     ox, oy = int(rng.integers(0, 9)), int(rng.integers(0, 9))
     w = ox + (gx - 1) * sx + n + int(rng.integers(0, 13))
     h = oy + (gy - 1) * sy + n + int(rng.integers(0, 13))
     B = 3
-    cur, prev, shifts, kinds = synth.batch_np(B, h, w, max(1, n // 8), k0=int(rng.integers(0, 1000)))
+    cur, prev, shifts, kinds = synth.batch_np(B, h, w, min(24, max(1, n // 8)), k0=int(rng.integers(0, 1000)))
     fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(ox, oy), stride=(sx, sy))
     got = fm.process_batch_device(torch.from_numpy(cur).to(dev), torch.from_numpy(prev).to(dev)).cpu().numpy()
     lay = O.fft_layout(w, h, n, gx, gy, (ox, oy), (sx, sy))
@@ -49,8 +52,8 @@ for trial in range(n_fft):
                 # (smooth patches: many cross-power bins sit at the f32 rounding floor and are normalised to unit magnitude):
                 # the GPU must stay as close to the f32 oracle as that one is to the f64 one
                 soft += 1
-                lim = TOL + float(np.nanmax(np.abs(want32[p] - want64[p])))
-                if not np.allclose(got[k, p], want32[p], rtol=0, atol=lim, equal_nan=True):
+                lim = TOL + 4.0 * float(np.nanmax(np.abs(want32[p] - want64[p])))  # three roundings of an ill-conditioned quantity
+                if not (np.allclose(got[k, p], want32[p], rtol=0, atol=lim, equal_nan=True) and np.allclose(got[k, p], want64[p], rtol=0, atol=lim, equal_nan=True)):
                     bad += 1
                     print("FFT MISMATCH (f32-limited patch)", trial, n, k, p, got[k, p], want64[p], want32[p])
                 continue
@@ -62,7 +65,7 @@ for trial in range(n_fft):
 print(f"fft: {checked}/{total} patches with a stable arg-max checked at 1e-4 px (+ {soft} where f32 and f64 oracle differ by more: checked against the f32 oracle), mismatches {bad}")
 sr_bad = 0
 for trial in range(n_sr):
-    res = int(rng.choice([240, 256, 480]))
+    res = int(rng.choice([240, 256, 480])) if rng.integers(0, 3) == 0 else 2 * int(rng.integers(32, 257))
     M = float(rng.uniform(28.0, 90.0)) * res / 480.0
     variant = int(rng.integers(0, 2))
     interp = INTER_CUBIC if rng.integers(0, 2) else INTER_LANCZOS4
@@ -96,8 +99,8 @@ print(f"sr: {n_sr} settings, mismatches {sr_bad}")
 #      the pair kernel on the two views) and mof_sr_process_sequence_device, against the oracle and the non-sequence entries
 seq_bad = seq_checked = 0
 for trial in range(max(4, n_fft // 4)):
-    n = int(rng.choice([32, 64, 64, 120, 128, 128]))
-    gx, gy = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    n = int(rng.choice([32, 64, 64, 120, 128, 128])) if rng.integers(0, 2) else int(rng.integers(8, 180))
+    gx, gy = (int(rng.integers(1, 4)), int(rng.integers(1, 4))) if n <= 135 else (1, int(rng.integers(1, 3)))
     sx, sy = int(rng.integers(max(1, n // 3), n + 30)), int(rng.integers(max(1, n // 3), n + 30))
     ox, oy = int(rng.integers(0, 9)), int(rng.integers(0, 9))
     w = ox + (gx - 1) * sx + n + int(rng.integers(0, 13))
@@ -129,7 +132,7 @@ for trial in range(max(4, n_fft // 4)):
                 # (smooth patches: many cross-power bins sit at the f32 rounding floor and are normalised to unit magnitude):
                 # the GPU must stay as close to the f32 oracle as that one is to the f64 one
                 soft += 1
-                lim = TOL + float(np.nanmax(np.abs(want32[p] - want64[p])))
+                lim = TOL + 4.0 * float(np.nanmax(np.abs(want32[p] - want64[p])))
                 if not np.allclose(got[k, p], want32[p], rtol=0, atol=lim, equal_nan=True):
                     seq_bad += 1
                     print("SEQ FFT MISMATCH (f32-limited patch)", trial, n, k, p, got[k, p], want64[p], want32[p])
@@ -140,7 +143,7 @@ for trial in range(max(4, n_fft // 4)):
                 seq_bad += 1
                 print("SEQ FFT MISMATCH", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), nf, k, p, got[k, p], want64[p], pairs[k, p])
 for trial in range(max(2, n_sr // 3)):
-    res = int(rng.choice([240, 256, 480]))
+    res = int(rng.choice([240, 256, 480])) if rng.integers(0, 2) else 2 * int(rng.integers(32, 200))
     M = float(rng.uniform(28.0, 90.0)) * res / 480.0
     variant = int(rng.integers(0, 2))
     nf = int(rng.choice([2, 5, 11]))

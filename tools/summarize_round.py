@@ -17,6 +17,15 @@ os.makedirs(dst, exist_ok=True)
 
 # kernel-name substring -> (FETCH_SIZE factor, evidence)
 FACTORS = {
+    # r04: the long-range load path (DS = 4: every lane reads 64 contiguous bytes of each tapped row as four 16-byte loads, lanes 64
+    # bytes apart -- the requests leave the L2 as a MIX of 64- and 128-byte ones, so the counter's factor is neither 1 nor 2).
+    # Keys are matched in order: the specific instantiations before the generic kernel name.
+    "pc_field_kernel<128, 4": (1.469, "callr workload (bench.py): 512x512 frames, pitch 512, one 128x128 quarter-resolution patch = the whole "
+                                      "frame; cv::resize(1/4) taps rows 4r+1, 4r+2 only, whole 128-byte lines of them: known 2*256*512*1024 B = "
+                                      "268.44 MB per launch, FETCH_SIZE 182.71 MB (profiles/r04_callr_pmc.csv)"),
+    "pc_field_kernel_120<4": (1.632, "reflr itself: the tapped row pairs 4r+1, 4r+2 are 960 contiguous bytes every 1920: at least 2*240*480*1024 B "
+                                     "= 235.93 MB per launch must be fetched (unaligned 480-byte rows: a few % more in whole sectors), FETCH_SIZE "
+                                     "144.53 MB (profiles/r04_reflr_pmc.csv): factor >= 1.632, used as a lower bound"),
     "pc_field_kernel": (1.0, "cal workload: 512x512 frames tiled exactly by 64x64 patches, known 2*512*512*1024 B = 536.87 MB, FETCH_SIZE 536.97 MB"),
     "sr_rows_fwd_kernel": (2.0, "reads 2*480*480 B of u8 per pair = 118.0 MB per 256-pair launch; FETCH_SIZE 59.1 MB = 0.50x"),
     "sr_cols_kernel": (2.0, "reads Zt once: 480*480*8 B per pair = 471.9 MB per 256-pair launch; FETCH_SIZE 236.06 MB = 0.50x"),
