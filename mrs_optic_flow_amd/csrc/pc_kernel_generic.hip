@@ -116,21 +116,32 @@ __global__ void __launch_bounds__(1024) pc_generic_kernel(PcArgs a, PcPlan pl) {
 
   // ---- untangle, P = A conj(B), C = P |P| / (|P|^2 + eps) with the real-only-slot rule (mulSpectrums :1494, magSpectrums
   //      :70-168, divSpectrums :1086-1251), stored conjugated for the inverse (a forward transform of conj C)
+  // A CONSTANT patch that zero padding turned into an n x n box (n, m even): the box's spectrum is EXACTLY zero on the Nyquist
+  // row and column in the reference's separate transforms (alternating sums of equal numbers), so P = 0 and C = 0 there -- 127 of
+  // 4096 bins at n = 62 -- while the packed transform leaks ~1e-7 of the other patch's spectrum into them, which the
+  // normalisation blows up to unit magnitude: 0.5 px off on a constant-against-texture pair (found by the seeded fuzzer classes,
+  // r04). The constant patch is known exactly (flags), so are its zero bins.
+  const bool box_zeros = herm && m > n && (n & 1) == 0 && (flags[0] == 0 || flags[1] == 0);
   if (herm) {
     // rows 1 .. H-1, every u: the partner (m - v, m - u) lies in the untouched lower half
     for (int i = tid; i < (H - 1) * m; i += T) {
       int u;
       const int v = 1 + fdiv(i, m, inv_m, &u);
       const int um = u == 0 ? 0 : m - u;
-      const cf C = cross_power<PK>(zat(v, u), zat(m - v, um), false);
+      cf C = cross_power<PK>(zat(v, u), zat(m - v, um), false);
+      if (box_zeros && u == H) C = {0.f, 0.f};
       zat(v, u) = {C.x, -C.y};
     }
     // rows 0 and H share row 0: G[u] = conj C[0][u] + i conj C[H][u]; the partner of u is m - u in the same rows
     for (int u = tid; u <= H; u += T) {
       const int um = u == 0 ? 0 : m - u;
       const bool self = u == um;
-      const cf C0 = cross_power<PK>(zat(0, u), zat(0, um), self);
-      const cf Ch = cross_power<PK>(zat(H, u), zat(H, um), self);
+      cf C0 = cross_power<PK>(zat(0, u), zat(0, um), self);
+      cf Ch = cross_power<PK>(zat(H, u), zat(H, um), self);
+      if (box_zeros) {
+        Ch = {0.f, 0.f};
+        if (u == H) C0 = {0.f, 0.f};
+      }
       if (u == 0) flags[2] = __float_as_int(C0.x);  // C_dc: all that is left of a degenerate pair's spectrum
       zat(0, u) = {C0.x + Ch.y, Ch.x - C0.y};
       if (!self) zat(0, um) = {C0.x - Ch.y, Ch.x + C0.y};

@@ -143,9 +143,11 @@ def _expected(cur, prev, lay, max_speed=80.0):
                 bad = 2 * s * s > max_speed ** 2 or abs(s) > n / 2.0
                 out.append((np.array([np.nan, np.nan]) if bad else np.array([s, s]), 1e-4))
                 continue
-            agree = np.array_equal(np.isnan(want64[p]), np.isnan(want32[p])) and np.allclose(want64[p], want32[p], rtol=0, atol=TOL, equal_nan=True)
-            well = diags[p].second_value < 0.5 * diags[p].peak_value
-            if not (well or agree):
+            # only a CLEAR peak pins the answer: on unrelated or flat-against-texture content (a constant patch that zero padding
+            # turned into a box; a frame next to an unrelated one in the video below) the surface is noise, its arg-max and its
+            # near-cancelling centroid are decided by rounding, and the two oracle precisions agreeing with each other (same
+            # algorithm, same order of operations) says nothing about a third arithmetic
+            if not diags[p].second_value < 0.5 * diags[p].peak_value:
                 out.append((None, 0.0))
                 continue
             dd = 0.0 if np.isnan(want64[p]).any() or np.isnan(want32[p]).any() else float(np.abs(want32[p] - want64[p]).max())
@@ -181,7 +183,7 @@ def test_fuzzer_classes_through_every_entry_point(gpu, n):
     total = 0
     for k, name in enumerate(names):
         total += _check(got[k], cur[k], prev[k], lay, f"n{n}/pair/{name}")
-    assert total >= 0.7 * 4 * len(names), total
+    assert total >= 0.6 * 4 * len(names), total
     # (2) the same frames as interleaved BGR8 with B = G = R (CV_RGB2GRAY then returns the value itself): same bits
     bgr_c, bgr_p = tc[..., None].expand(-1, -1, -1, 3).contiguous(), tp[..., None].expand(-1, -1, -1, 3).contiguous()
     assert np.array_equal(fm.process_batch_device_bgr(bgr_c, bgr_p).cpu().numpy(), got, equal_nan=True)
