@@ -16,7 +16,7 @@ def test_export_and_compare_round_trip(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     man = json.load(open(os.path.join(out, "manifest.json")))
     kinds = {c["kind"] for c in man["cases"]}
-    assert kinds == {"pc", "lp", "srseq", "resize_quarter", "resize_2x", "gray", "undistort", "homography"}
+    assert kinds == {"pc", "optdft", "lp", "srseq", "resize_quarter", "resize_2x", "gray", "undistort", "homography"}
     lines = open(os.path.join(out, "manifest.txt")).read().strip().splitlines()
     assert len(lines) == len(man["cases"])
     for c in man["cases"]:

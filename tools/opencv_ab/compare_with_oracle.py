@@ -38,6 +38,13 @@ for c in man["cases"]:
         o = oracle(c["oracle"])
         err = float(np.abs(cv - o).max())
         report(name, "cv::phaseCorrelate", err <= 1e-4, f"cv {cv} oracle {o} |d| {err:.2e} (bar 1e-4 px)")
+    elif k == "optdft":
+        cv = rd(name + "_cv", np.int32)
+        if cv is None:
+            continue
+        o = oracle(c["oracle"])
+        n = int((cv != o).sum())
+        report(name, "cv::getOptimalDFTSize", n == 0, f"{n} of {o.size} sizes differ")
     elif k == "lp":
         res = c["res"]
         for interp in (2, 4):

@@ -66,6 +66,13 @@ int main(int argc, char** argv) {
       const cv::Point2d p = cv::phaseCorrelate(A, B);
       const double out[2] = {p.x, p.y};
       save(name + "_cv", out, 2);
+    } else if (kind == "optdft") {
+      int count;
+      is >> count;
+      auto sizes = load<int>(name + "_sizes", (size_t)count);
+      std::vector<int> out((size_t)count);
+      for (int i = 0; i < count; ++i) out[(size_t)i] = cv::getOptimalDFTSize(sizes[(size_t)i]);  // what cv::phaseCorrelate pads to
+      save(name + "_cv", out.data(), (size_t)count);
     } else if (kind == "lp") {
       int res;
       double M;

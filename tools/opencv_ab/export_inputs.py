@@ -45,6 +45,28 @@ for n in (64, 120, 128, 480):
         cases.append({"kind": "pc", "name": f"pc_{k}", "n": n, "a": put(f"pc_{k}_a", a), "b": put(f"pc_{k}_b", base),
                       "oracle": put(f"pc_{k}_oracle", np.array([x, y]))})
         k += 1
+# r04: sizes without a tuned kernel -- 5-smooth even sizes, sizes cv::phaseCorrelate pads (62 -> 64, 98 -> 100), sizes it pads to an
+# ODD transform (74 -> 75, 124 -> 125), odd sizes, a large patch -- on NON-circular shifts (real padding / windowing effects) and on
+# identical images (an odd padded size answers (0.5, 0.5): the centre M / 2.0 against the shifted origin M >> 1)
+for n in (60, 80, 96, 100, 62, 98, 74, 124, 75, 45, 160, 144):
+    for (dx, dy) in ((3, -2), (0, 0)):
+        cur, prev = synth.pair_np(500 + n, n, n, dx, dy, True)
+        a, b = cur.astype(np.float32), prev.astype(np.float32)
+        (x, y), _ = O.phase_correlate(a, b, 32)
+        cases.append({"kind": "pc", "name": f"pc_{k}", "n": n, "a": put(f"pc_{k}_a", a), "b": put(f"pc_{k}_b", b),
+                      "oracle": put(f"pc_{k}_oracle", np.array([x, y]))})
+        k += 1
+# cv::getOptimalDFTSize, which decides those paddings
+sizes = np.array(list(range(1, 520)) + [959, 960, 961, 1000, 4097], np.int32)
+cases.append({"kind": "optdft", "name": "optdft_0", "count": int(sizes.size), "sizes": put("optdft_0_sizes", sizes),
+              "oracle": put("optdft_0_oracle", np.array([O.optimal_dft_size(int(v)) for v in sizes], np.int32))})
+# one-sided constant patch on a padded size: the reference's box spectrum has exact Nyquist zeros (r04)
+cur62 = np.full((62, 62), 197, np.float32)
+prev62 = synth.canvas_np(9, 62, 62, True)[:62, :62].astype(np.float32)
+(x, y), _ = O.phase_correlate(cur62, prev62, 32)
+cases.append({"kind": "pc", "name": f"pc_{k}", "n": 62, "a": put(f"pc_{k}_a", cur62), "b": put(f"pc_{k}_b", prev62),
+              "oracle": put(f"pc_{k}_oracle", np.array([x, y]))})
+k += 1
 const = np.full((64, 64), 200, np.float32)
 (x, y), _ = O.phase_correlate(const, const, 32)
 cases.append({"kind": "pc", "name": f"pc_{k}", "n": 64, "a": put(f"pc_{k}_a", const), "b": put(f"pc_{k}_b", const),
@@ -52,7 +74,7 @@ cases.append({"kind": "pc", "name": f"pc_{k}", "n": 64, "a": put(f"pc_{k}_a", co
 
 # ---- log-polar remap (both interpolations, both OpenCV generations) and the bare maps
 k = 0
-for res, M in ((240, 40.0), (256, 45.0), (480, 49.9)):
+for res, M in ((240, 40.0), (256, 45.0), (480, 49.9), (320, 45.0), (350, 49.9)):  # (320 / 350: planned transforms, r04; 350 pads to 360)
     base = sr_scenes.canvas(5 + res, res)
     src = sr_scenes.view(base, res, 1.05, 7.0)
     src[:5] = 255
@@ -71,7 +93,7 @@ for res, M in ((240, 40.0), (256, 45.0), (480, 49.9)):
 # ---- the estimator as a STREAM (scaleRotationEstimator.cpp:34-148): first frame INTER_CUBIC -> (1, 0); then INTER_LANCZOS4,
 #      cv::phaseCorrelate(tempIm_F32, prevIm_F32), the gate of :119-121, prev <- cur. What the sequence entry
 #      (mof_sr_process_sequence_device) and the stateful mof_sr_process reproduce.
-for k, (res, M, nf) in enumerate(((240, 40.0, 6), (480, 49.9, 4))):
+for k, (res, M, nf) in enumerate(((240, 40.0, 6), (480, 49.9, 4), (350, 49.9, 4))):
     base = sr_scenes.canvas(31 + res, res)
     video = np.stack([sr_scenes.view(base, res, 1.0 + 0.015 * t, 1.7 * t) for t in range(nf)])
     ref = O.ScaleRotationEstimator(res, M, 32)
@@ -123,6 +145,8 @@ with open(os.path.join(out, "manifest.txt"), "w") as f:
             f.write(f"undistort {c['name']} {c['pts']['shape'][0]} " + " ".join(repr(v) for v in c["camera"]) + f" {c['ul_corner_x']!r}\n")
         elif c["kind"] == "homography":
             f.write(f"homography {c['name']} {c['a']['shape'][0]}\n")
+        elif c["kind"] == "optdft":
+            f.write(f"optdft {c['name']} {c['count']}\n")
         elif c["kind"] == "srseq":
             f.write(f"srseq {c['name']} {c['res']} {c['M']!r} {c['frames']}\n")
 json.dump({"cases": cases, "oracle_version": O.lib().oracle_version().decode()}, open(os.path.join(out, "manifest.json"), "w"), indent=1)
