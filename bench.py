@@ -108,6 +108,23 @@ WORKLOADS = {
     "ref": dict(kind="fft", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
                 name="ref: FftMethod 480x480, 4x4 grid of 120x120 patches (reference default.yaml), batch=1024 per GPU",
                 bytes_per_pair=2 * 480 * 480 + 16 * 8),
+    # sizes WITHOUT a tuned kernel (r04): the run-time planned kernel (pc_kernel_generic.hip) and, beyond one CU's LDS, the planned
+    # pipeline through HBM scratch (pc_large_kernel.hip) -- reference tiling of a 480 x 480 crop at other sample_point_size settings
+    "p60": dict(kind="fft", h=480, w=480, n=60, grid=(8, 8), origin=(0, 0), stride=(60, 60), batch=1024, s=7,
+                name="p60: FftMethod 480x480, 8x8 grid of 60x60 patches (planned kernel), batch=1024 per GPU",
+                bytes_per_pair=2 * 480 * 480 + 64 * 8),
+    "p96": dict(kind="fft", h=480, w=480, n=96, grid=(5, 5), origin=(0, 0), stride=(96, 96), batch=1024, s=12,
+                name="p96: FftMethod 480x480, 5x5 grid of 96x96 patches (planned kernel), batch=1024 per GPU",
+                bytes_per_pair=2 * 480 * 480 + 25 * 8),
+    "p62": dict(kind="fft", h=496, w=496, n=62, grid=(8, 8), origin=(0, 0), stride=(62, 62), batch=1024, s=7,
+                name="p62: FftMethod 496x496, 8x8 grid of 62x62 patches padded to 64 (planned kernel), batch=1024 per GPU",
+                bytes_per_pair=2 * 496 * 496 + 64 * 8),
+    "l160": dict(kind="fft", h=480, w=480, n=160, grid=(3, 3), origin=(0, 0), stride=(160, 160), batch=512, s=15,
+                 name="l160: FftMethod 480x480, 3x3 grid of 160x160 patches (planned pipeline through HBM scratch), batch=512 per GPU",
+                 bytes_per_pair=2 * 480 * 480 + 9 * 8),
+    "l480": dict(kind="fft", h=480, w=480, n=480, grid=(1, 1), origin=(0, 0), stride=(480, 480), batch=512, s=15,
+                 name="l480: FftMethod 480x480, ONE 480x480 patch (the reference's whole-frame fallback), batch=512 per GPU",
+                 bytes_per_pair=2 * 480 * 480 + 8),
     # the node's whole per-frame chain on the device: u8 frame pairs -> K1 shifts -> getRT (undistort,
     # RANSAC homography, decomposition, IMU-consistent pick) -> rotation + velocity; nothing but 64 B per pair leaves the GPU
     "refrt": dict(kind="fft+rt", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,

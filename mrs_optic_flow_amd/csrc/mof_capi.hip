@@ -357,8 +357,12 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   if (!e) return fail(MOF_ERR_NO_MEMORY, "out of host memory");
   e->cfg = *cfg;
   e->frame_bytes = (size_t)cfg->frame_width * cfg->frame_height;
-  e->generic = !mof::pc_patch_size_supported(cfg->patch_size);
-  if (e->generic && !mof::pc_build_plan(cfg->patch_size, &e->plan)) {
+  // diagnostics (A/B of the kernel families on one size, and their parity tests against each other):
+  // MOF_FFT_FORCE_PLANNED=1 runs the planned LDS kernel also where a tuned instantiation exists, MOF_FFT_FORCE_LARGE=1 the
+  // planned pipeline through HBM scratch at any size (cv::phaseCorrelate model only)
+  static const bool force_planned = getenv("MOF_FFT_FORCE_PLANNED") != nullptr, force_large = getenv("MOF_FFT_FORCE_LARGE") != nullptr;
+  e->generic = !mof::pc_patch_size_supported(cfg->patch_size) || force_planned || force_large;
+  if (e->generic && (force_large && cfg->peak_model == MOF_PEAK_OPENCV ? true : !mof::pc_build_plan(cfg->patch_size, &e->plan))) {
     e->generic = false;
     e->large = true;
     if (!mof::pc_build_line_plan(cfg->patch_size, &e->plan)) {  // (validate_fft has checked it)

@@ -75,17 +75,42 @@ __global__ void __launch_bounds__(1024) pc_generic_kernel(PcArgs a, PcPlan pl) {
   {
     const uint32_t c00 = fetch_px<DS, CH>(cur, a.pitch, 0, 0), p00 = fetch_px<DS, CH>(prev, a.pitch, 0, 0);
     uint32_t dc = 0u, dp = 0u;
-    for (int i = tid; i < m * m; i += T) {
-      int x;
-      const int y = fdiv(i, m, inv_m, &x);
-      cf v = {0.f, 0.f};
-      if (y < n && x < n) {
-        const uint32_t c = fetch_px<DS, CH>(cur, a.pitch, y, x), q = fetch_px<DS, CH>(prev, a.pitch, y, x);
-        dc |= c ^ c00;
-        dp |= q ^ p00;
-        v = {(float)c, (float)q};
+    // Pixel loads go out in batches of SB per lane and image before the first of a batch is used (a load -> convert -> store
+    // loop pays the memory latency once per trip -- 16 trips per patch in the first form of this kernel; one batch of 18 held
+    // 36 pixel registers plus their addresses and spilled 646 VGPRs). Element i = tid + t T of the padded tile sits at
+    // (y, x) = divmod(i, m); the pair advances by divmod(T, m) per step -- one division per lane instead of one per element.
+    constexpr int SB = 6, NSB = 3;  // the plan sizes the workgroup so that a lane owns at most SB * NSB = 18 elements
+    int sx;
+    const int sy = fdiv(T, m, inv_m, &sx);
+    int x;
+    int y = fdiv(tid, m, inv_m, &x);
+#pragma unroll 1
+    for (int sb = 0; sb < NSB; ++sb) {
+      uint32_t cpx[SB], ppx[SB];
+      int ys[SB], xs[SB];
+#pragma unroll
+      for (int t = 0; t < SB; ++t) {
+        ys[t] = y;
+        xs[t] = x;
+        cpx[t] = ppx[t] = 0u;
+        if (y < n && x < n) {  // (y < n <= m also bounds the tile)
+          cpx[t] = fetch_px<DS, CH>(cur, a.pitch, y, x);
+          ppx[t] = fetch_px<DS, CH>(prev, a.pitch, y, x);
+        }
+        x += sx;
+        y += sy;
+        if (x >= m) { x -= m; ++y; }
       }
-      z[y * pl.pitch + x + ((x >> 3) & pl.skew_mask)] = v;
+#pragma unroll
+      for (int t = 0; t < SB; ++t) {
+        if (ys[t] < m) {
+          if (ys[t] < n && xs[t] < n) {
+            dc |= cpx[t] ^ c00;
+            dp |= ppx[t] ^ p00;
+          }
+          z[ys[t] * pl.pitch + xs[t] + ((xs[t] >> 3) & pl.skew_mask)] = {(float)cpx[t], (float)ppx[t]};
+        }
+      }
     }
     __syncthreads();  // flags[] zeroed, twiddles in place
     if (__builtin_amdgcn_ballot_w64(dc != 0u) != 0ull && lane == 0) flags[0] = 1;
@@ -93,7 +118,7 @@ __global__ void __launch_bounds__(1024) pc_generic_kernel(PcArgs a, PcPlan pl) {
   }
   __syncthreads();
 
-  const Walk rows = {pl.pitch, 1, 0, pl.skew_mask}, cols = {1, pl.pitch, pl.skew_mask, 0};
+  const Walk rows = {pl.pitch, 1, 0, pl.skew_mask, 0}, cols = {1, pl.pitch, pl.skew_mask, 0, 1};
   auto zat = [&](int r, int c) -> cf& { return z[r * pl.pitch + c + ((c >> 3) & pl.skew_mask)]; };
   // wave w owns lines [w lpw, min((w + 1) lpw, L))
   auto my_lines = [&](int L, int* l0, int* nl) {
@@ -108,9 +133,9 @@ __global__ void __launch_bounds__(1024) pc_generic_kernel(PcArgs a, PcPlan pl) {
   {
     int l0, nl;
     my_lines(m, &l0, &nl);
-    if (nl > 0) pass_lines<false>(z, tw, pl, rows, l0, nl, lane);
+    if (nl > 0) pass_lines(z, tw, pl, rows, l0, nl, lane, false);
     __syncthreads();
-    if (nl > 0) pass_lines<false>(z, tw, pl, cols, l0, nl, lane);
+    if (nl > 0) pass_lines(z, tw, pl, cols, l0, nl, lane, false);
     __syncthreads();
   }
 
@@ -166,12 +191,10 @@ __global__ void __launch_bounds__(1024) pc_generic_kernel(PcArgs a, PcPlan pl) {
   {
     int l0, nl;
     my_lines(herm ? H : m, &l0, &nl);
-    if (nl > 0) pass_lines<false>(z, tw, pl, rows, l0, nl, lane);
+    if (nl > 0) pass_lines(z, tw, pl, rows, l0, nl, lane, false);
     __syncthreads();
-    if (nl > 0) {
-      if (herm) pass_lines<true>(z, tw, pl, cols, l0, nl, lane);   // column pairs (c, c + H): z(y, c) = (S[y][c], S[y][c + H])
-      else pass_lines<false>(z, tw, pl, cols, l0, nl, lane);       // z(y, x).x = S[y][x]
-    }
+    // herm: column pairs (c, c + H), z(y, c) = (S[y][c], S[y][c + H]); else z(y, x).x = S[y][x]
+    if (nl > 0) pass_lines(z, tw, pl, cols, l0, nl, lane, herm);
     __syncthreads();
   }
 
@@ -327,6 +350,7 @@ bool pc_build_plan(int n, PcPlan* out) {
   pl.lds_bytes = (int)((size_t)pl.m * pl.pitch * 8 + extra);
   int t = (pl.m * pl.m / 16 + 63) / 64 * 64;  // ~16 complex elements per lane
   pl.threads = t < 64 ? 64 : (t > 1024 ? 1024 : t);
+  if ((pl.m * pl.m + pl.threads - 1) / pl.threads > 18) return false;  // (the kernel's load phase holds at most 18 pixels per lane and image)
   *out = pl;
   return true;
 }

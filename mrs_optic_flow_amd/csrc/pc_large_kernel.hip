@@ -73,16 +73,36 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, 
   // (copyMakeBorder of cv::phaseCorrelate), u8 -> f32 (convertTo, FftMethod.cpp:1805-1806 / scaleRotationEstimator.cpp:115)
   const uint32_t p00 = fetch_px_l<DS, CH>(base, src.pitch, 0, 0);
   uint32_t diff = 0u;
+  {
+    // all of the lane's pixel loads go out before the first is used (a load-use loop pays the memory latency once per trip)
+    constexpr int NX = 15;  // ceil(960 / 64)
+    uint32_t px[2][2][NX];
 #pragma unroll
-  for (int ll = 0; ll < 2; ++ll) {
-    const int l = 2 * wave + ll, y0 = row0 + 2 * l, y1 = y0 + 1;
-    for (int x = lane; x < m; x += 64) {
-      cf v = {0.f, 0.f};
-      if (x < n) {
-        if (y0 < n) { const uint32_t a = fetch_px_l<DS, CH>(base, src.pitch, y0, x); diff |= a ^ p00; v.x = (float)a; }
-        if (y1 < n) { const uint32_t b = fetch_px_l<DS, CH>(base, src.pitch, y1, x); diff |= b ^ p00; v.y = (float)b; }
+    for (int ll = 0; ll < 2; ++ll) {
+      const int y0 = row0 + 2 * (2 * wave + ll), y1 = y0 + 1;
+#pragma unroll
+      for (int t = 0; t < NX; ++t) {
+        const int x = lane + 64 * t;
+        px[ll][0][t] = px[ll][1][t] = 0x100u;  // 0x100: "no pixel" (zero padding)
+        if (x < n) {
+          if (y0 < n) px[ll][0][t] = fetch_px_l<DS, CH>(base, src.pitch, y0, x);
+          if (y1 < n) px[ll][1][t] = fetch_px_l<DS, CH>(base, src.pitch, y1, x);
+        }
       }
-      z[l * line + sk(x)] = v;
+    }
+#pragma unroll
+    for (int ll = 0; ll < 2; ++ll) {
+      const int l = 2 * wave + ll;
+#pragma unroll
+      for (int t = 0; t < NX; ++t) {
+        const int x = lane + 64 * t;
+        if (x < m) {
+          const uint32_t a = px[ll][0][t], b = px[ll][1][t];
+          if (a < 0x100u) diff |= a ^ p00;
+          if (b < 0x100u) diff |= b ^ p00;
+          z[l * line + sk(x)] = {(float)(a & 0xffu), (float)(b & 0xffu)};
+        }
+      }
     }
   }
   if (flags) {  // bit 0: some pixel differs from pixel (0, 0); bit 1: pixel (0, 0) is not zero (zeroed by the caller before the launch)
@@ -90,8 +110,8 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, 
     if (blockIdx.x == 0 && tid == 0 && p00 != 0u) atomicOr(&flags[img], 2);
   }
   __syncthreads();
-  const Walk rows = {line, 1, 0, ~0};
-  if (row0 + 4 * wave < m) pass_lines<false>(z, tw, pl, rows, 2 * wave, 2, lane);
+  const Walk rows = {line, 1, 0, ~0, 0};
+  if (row0 + 4 * wave < m) pass_lines(z, tw, pl, rows, 2 * wave, 2, lane, false);
   __syncthreads();
   // untangle the two rows of every line (doubled: the 1/2 is folded into cross_power_ab's eps) and store transposed
   cf* out = reinterpret_cast<cf*>(zh + (size_t)img * zh_stride) + row0;
@@ -122,15 +142,29 @@ __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict
   if (active) {
     const cf* c = reinterpret_cast<const cf*>(zh_cur + (size_t)pair * zh_stride) + (size_t)u * m;
     const cf* p = reinterpret_cast<const cf*>(zh_prev + (size_t)pair * zh_stride) + (size_t)u * m;
-    for (int v = lane; v < m; v += 64) {
-      z[sk(v)] = c[v];
-      z[line + sk(v)] = p[v];
+    constexpr int NX = 15;
+    cf cv[NX], pv[NX];  // both lines in flight before the first LDS write
+#pragma unroll
+    for (int t = 0; t < NX; ++t) {
+      const int v = lane + 64 * t;
+      if (v < m) {
+        cv[t] = c[v];
+        pv[t] = p[v];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NX; ++t) {
+      const int v = lane + 64 * t;
+      if (v < m) {
+        z[sk(v)] = cv[t];
+        z[line + sk(v)] = pv[t];
+      }
     }
   }
   __syncthreads();
   if (!active) return;
-  const Walk w = {line, 1, 0, ~0};
-  pass_lines<false>(z, tw, pl, w, 0, 2, lane);
+  const Walk w = {line, 1, 0, ~0, 0};
+  pass_lines(z, tw, pl, w, 0, 2, lane, false);
   // normalised cross-power spectrum of bins (v, u), conjugated in place (rules: pc_common.hpp)
   const bool u_edge = u == 0 || (even && u == hu);
   for (int v0 = 0; v0 < m; v0 += 64) {
@@ -141,7 +175,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict
     if (cdc && u == 0 && v == 0) cdc[pair] = C.x;  // C_dc: all that is left of a degenerate pair's spectrum (pc_common.hpp)
   }
   wave_sync();
-  pass_lines<false>(z, tw, pl, w, 0, 1, lane);
+  pass_lines(z, tw, pl, w, 0, 1, lane, false);
   cf* D = reinterpret_cast<cf*>(Dt) + ((size_t)pair * NU + u) * m;
   for (int v = lane; v < m; v += 64) D[v] = z[sk(v)];
 }
@@ -158,22 +192,35 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_inv_kernel(const float* __rest
   for (int k = tid; k < m; k += PCL_T) tw[k] = {twiddles[2 * k], twiddles[2 * k + 1]};
   const cf* D = reinterpret_cast<const cf*>(Dt) + (size_t)pair * NU * m;
   // line l carries rows y1 = 2 (p0 + l), y2 = y1 + 1: E[u] = G[y1][u] + i G[y2][u], G[y][M - u] = conj G[y][u]
-  for (int i = tid; i < PCL_LINES * NU; i += PCL_T) {
-    const int u = i >> 3, l = i & 7, y1 = 2 * (p0 + l);
-    if (y1 >= m) continue;
-    const cf g1 = D[(size_t)u * m + y1];
-    const cf g2 = y1 + 1 < m ? D[(size_t)u * m + y1 + 1] : cf{0.f, 0.f};
-    z[l * line + sk(u)] = {g1.x - g2.y, g1.y + g2.x};
-    const int um = m - u;
-    if (u > 0 && um != u) z[l * line + sk(um)] = {g1.x + g2.y, g2.x - g1.y};
+  {
+    constexpr int NI = 16;  // ceil(8 * 481 / 256)
+    cf g1[NI], g2[NI];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+      const int i = tid + PCL_T * t, u = i >> 3, l = i & 7, y1 = 2 * (p0 + l);
+      g1[t] = g2[t] = cf{0.f, 0.f};
+      if (i < PCL_LINES * NU && y1 < m) {
+        g1[t] = D[(size_t)u * m + y1];
+        if (y1 + 1 < m) g2[t] = D[(size_t)u * m + y1 + 1];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+      const int i = tid + PCL_T * t, u = i >> 3, l = i & 7, y1 = 2 * (p0 + l);
+      if (i < PCL_LINES * NU && y1 < m) {
+        z[l * line + sk(u)] = {g1[t].x - g2[t].y, g1[t].y + g2[t].x};
+        const int um = m - u;
+        if (u > 0 && um != u) z[l * line + sk(um)] = {g1[t].x + g2[t].y, g2[t].x - g1[t].y};
+      }
+    }
   }
   __syncthreads();
   int nl = 0;
 #pragma unroll
   for (int ll = 0; ll < 2; ++ll)
     if (2 * (p0 + 2 * wave + ll) < m) ++nl;
-  const Walk w = {line, 1, 0, ~0};
-  if (nl > 0) pass_lines<false>(z, tw, pl, w, 2 * wave, nl, lane);
+  const Walk w = {line, 1, 0, ~0, 0};
+  if (nl > 0) pass_lines(z, tw, pl, w, 2 * wave, nl, lane, false);
   // first maximum of the fft-shifted surface (fftShift: index i -> (i + (m >> 1)) mod m for even and odd m; minMaxLoc)
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
   for (int ll = 0; ll < nl; ++ll) {

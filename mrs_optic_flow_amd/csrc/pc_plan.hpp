@@ -31,106 +31,190 @@ __device__ __forceinline__ int fdiv(int q, int d, float inv, int* rem) {
 struct Walk {
   int ls, es;        // strides (complex elements) of the line index / the element index before the skew
   int lmask, emask;  // ~0 where the skew applies to that coordinate
+  int line_fast;     // lane map of a stage: 0 = the butterfly index in the fast lane bits (row walks), 1 = the line (column walks)
   __device__ __forceinline__ int at(int l, int e) const { return l * ls + ((l >> 3) & lmask) + e * es + ((e >> 3) & emask); }
 };
 
-template <int R>
-__device__ __forceinline__ void bfly_r(cf* v) {
-  if constexpr (R == 3) butterfly3(v);
-  else if constexpr (R == 5) butterfly5(v);
-  else butterfly<R>(v);
+// the butterfly of a run-time radix R <= SLOTS (wave-uniform: a scalar branch)
+template <int SLOTS>
+__device__ __forceinline__ void bfly_rt(int R, cf* v) {
+  if constexpr (SLOTS == 8) {
+    if (R == 8) butterfly<8>(v);
+    else butterfly5(v);
+  } else {
+    if (R == 4) butterfly<4>(v);
+    else if (R == 3) butterfly3(v);
+    else butterfly<2>(v);
+  }
 }
 
-// One Stockham stage (radix R, `np` = product of the earlier radices) on lines [line0, line0 + nlines) owned by ONE wave,
-// in place. Butterfly x of a line reads elements x + j (m / R), multiplies them by W_{np R}^{j (x mod np)} and writes the
-// R outputs to (x - x mod np) R + x mod np + p np. HERM: the first stage of the Hermitian inverse column pass -- "line" c is
-// the column PAIR (c, c + m/2), element v is E[v] = F1[v][c] + i F1[v][c + m/2] built from rows 0 .. m/2 - 1 of the tile
-// (row 0 = F1[0] + i F1[m/2], both real; F1[m - v] = conj F1[v]) -- see col_pass_inv in pc_passes.hpp.
-template <int R, bool HERM>
-__device__ __attribute__((noinline)) void stage(cf* __restrict__ z, const cf* __restrict__ tw, const Walk w, int m, int np, float inv_np,
-                                                int tstep, int line0, int nlines, int lane) {
-  constexpr int NB = 16 / R;  // butterflies per lane and group
-  const int bpl = m / R;      // butterflies per line
-  const float inv_bpl = 1.0f / (float)bpl;  // (one v_rcp per stage; fdiv corrects the last bit)
-  int G = (64 * NB) / bpl;    // lines per group
-  if (G < 1) G = 1;           // (the plan guarantees bpl <= 64 NB)
+// One Stockham stage (radix R <= SLOTS, `np` = product of the earlier radices, bpl = m / R butterflies per line, tstep =
+// m / (np R)) on lines [line0, line0 + nlines) owned by ONE wave, in place. Butterfly x of a line reads elements x + j bpl,
+// multiplies them by W_{np R}^{j (x mod np)} and writes the R outputs to (x - x mod np) R + x mod np + p np.
+// herm_first: the first stage of the Hermitian inverse column pass -- "line" c is the column PAIR (c, c + m/2), element v is
+// E[v] = F1[v][c] + i F1[v][c + m/2] built from rows 0 .. m/2 - 1 of the tile (row 0 = F1[0] + i F1[m/2], both real;
+// F1[m - v] = conj F1[v]) -- see col_pass_inv in pc_passes.hpp.
+// Lane map. bpl <= 64 (every patch that fits a CU): a lane keeps ONE butterfly index x for the whole call and walks lines --
+// lpg = 64 / bpl lines side by side, NB = 16 / SLOTS of those rows per group -- so its R - 1 twiddles and its R + R element
+// offsets are formed once per call and live in registers. Row walks put x in the fast lane bits (8 consecutive elements per
+// line and 32-lane read group), column walks the line (8 neighbouring columns per row and group): both conflict-free on reads
+// with the plan's pitch = 8 (mod 16). bpl > 64 (long lines of the large-patch pipeline): one line at a time, x = lane + 64 t.
+// History (r04, p62 = 65,536 patches of 62 x 62 padded to 64): the first form -- lines packed densely into the lanes, one
+// division, R address computations and R - 1 twiddle reads from LDS per butterfly, stages as out-of-line functions per radix
+// (270 scratch accesses per wave for their call frames) -- issued 5383 VALU + 1561 SALU instructions per wave and patch
+// against the tuned kernel's 1412, with 61 % of its LDS cycles bank conflicts (profiles/r04_p62_planned_v1_sq_pmc.csv).
+template <int SLOTS>
+__device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restrict__ tw, const Walk& w, int m, int R, int np, int bpl,
+                                         int tstep, int line0, int nlines, int lane, bool herm_first) {
+  constexpr int NB = 16 / SLOTS;  // butterflies per lane and group
   const int H = m >> 1;
-  for (int g0 = 0; g0 < nlines; g0 += G) {
-    const int gl = nlines - g0 < G ? nlines - g0 : G;
-    const int nbf = gl * bpl;
-    cf v[NB][R];
-    int li[NB], xx[NB], kk[NB];
+  const float inv_np = 1.0f / (float)np;
+  if (bpl <= 64) {
+    const float inv_bpl = 1.0f / (float)bpl;
+    int rem64;
+    const int lpg = fdiv(64, bpl, inv_bpl, &rem64);  // lines side by side in the wave
+    int x, sub;
+    if (w.line_fast) {
+      const float inv_lpg = 1.0f / (float)lpg;
+      x = fdiv(lane, lpg, inv_lpg, &sub);
+    } else {
+      sub = fdiv(lane, bpl, inv_bpl, &x);
+    }
+    const bool lane_on = w.line_fast ? x < bpl : sub < lpg;
+    int k = 0;
+    if (np > 1) (void)fdiv(x, np, inv_np, &k);
+    cf t[SLOTS - 1];
+    int eoff[SLOTS], ooff[SLOTS], ee[SLOTS];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int q = lane + 64 * b;
-      li[b] = xx[b] = kk[b] = 0;
-      if (q < nbf) {
-        int x;
-        const int l = line0 + g0 + fdiv(q, bpl, inv_bpl, &x);
-        int k = 0;
-        if (np > 1) (void)fdiv(x, np, inv_np, &k);
-        li[b] = l;
-        xx[b] = x;
-        kk[b] = k;
+    for (int j = 0; j < SLOTS; ++j) {
+      eoff[j] = ooff[j] = ee[j] = 0;
+      if (j < R) {
+        const int e = x + j * bpl, o = (x - k) * R + k + j * np;
+        const int r = herm_first ? (e < H ? e : (e == H ? 0 : m - e)) : e;
+        ee[j] = e;
+        eoff[j] = r * w.es + ((r >> 3) & w.emask);
+        ooff[j] = o * w.es + ((o >> 3) & w.emask);
+        if (j > 0 && np > 1) t[j - 1] = lds_read(&tw[j * k * tstep]);
+      }
+    }
+    const int group = NB * lpg;
+    for (int g0 = 0; g0 < nlines; g0 += group) {
+      cf v[NB][SLOTS];
+      int loff[NB];
+      bool on[NB];
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const int e = x + j * bpl;
-          cf a;
-          if constexpr (HERM) {
-            const int r = e < H ? e : (e == H ? 0 : m - e);
-            const cf p = lds_read(&z[w.at(l, r)]), c = lds_read(&z[w.at(l + H, r)]);  // tile (row r, col l) and (row r, col l + H)
-            if (e == 0) a = {p.x, c.x};
-            else if (e == H) a = {p.y, c.y};
-            else if (e < H) a = {p.x - c.y, p.y + c.x};
-            else a = {p.x + c.y, c.x - p.y};
-          } else {
-            a = lds_read(&z[w.at(l, e)]);
-          }
-          if (j > 0 && np > 1) a = cmul(a, lds_read(&tw[j * k * tstep]));
-          v[b][j] = a;
+      for (int b = 0; b < NB; ++b) {
+        const int li = g0 + b * lpg + sub;
+        const int l = line0 + li;
+        on[b] = lane_on && li < nlines;
+        loff[b] = l * w.ls + ((l >> 3) & w.lmask);
+        if (on[b]) {
+          const int l2off = (l + H) * w.ls + (((l + H) >> 3) & w.lmask);  // (herm_first only)
+#pragma unroll
+          for (int j = 0; j < SLOTS; ++j)
+            if (j < R) {
+              cf a;
+              if (herm_first) {
+                const cf pp = lds_read(&z[loff[b] + eoff[j]]), c = lds_read(&z[l2off + eoff[j]]);  // tile (row r, col l) and (row r, col l + H)
+                const int e = ee[j];
+                if (e == 0) a = {pp.x, c.x};
+                else if (e == H) a = {pp.y, c.y};
+                else if (e < H) a = {pp.x - c.y, pp.y + c.x};
+                else a = {pp.x + c.y, c.x - pp.y};
+              } else {
+                a = lds_read(&z[loff[b] + eoff[j]]);
+              }
+              if (j > 0 && np > 1) a = cmul(a, t[j - 1]);
+              v[b][j] = a;
+            }
+          bfly_rt<SLOTS>(R, v[b]);
         }
-        bfly_r<R>(v[b]);
       }
+      wave_sync();
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (on[b]) {
+#pragma unroll
+          for (int p = 0; p < SLOTS; ++p)
+            if (p < R) z[loff[b] + ooff[p]] = v[b][p];
+        }
+      wave_sync();
     }
-    wave_sync();
+    return;
+  }
+  // long lines: one line at a time, up to NB * 64 butterflies (the plan guarantees bpl <= 64 * floor(16 / R))
+  for (int li = 0; li < nlines; ++li) {
+    const int l = line0 + li;
+    const int loff = l * w.ls + ((l >> 3) & w.lmask);
+    for (int x0 = 0; x0 < bpl; x0 += 64 * NB) {
+      cf v[NB][SLOTS];
+      int xx[NB], kk[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int q = lane + 64 * b;
-      if (q < nbf) {
-        const int base = (xx[b] - kk[b]) * R + kk[b];
+      for (int b = 0; b < NB; ++b) {
+        const int x = x0 + lane + 64 * b;
+        xx[b] = x;
+        kk[b] = 0;
+        if (x < bpl) {
+          int k = 0;
+          if (np > 1) (void)fdiv(x, np, inv_np, &k);
+          kk[b] = k;
 #pragma unroll
-        for (int p = 0; p < R; ++p) z[w.at(li[b], base + p * np)] = v[b][p];
+          for (int j = 0; j < SLOTS; ++j)
+            if (j < R) {
+              const int e = x + j * bpl;
+              cf a;
+              if (herm_first) {
+                const int r = e < H ? e : (e == H ? 0 : m - e);
+                const cf pp = lds_read(&z[w.at(l, r)]), c = lds_read(&z[w.at(l + H, r)]);
+                if (e == 0) a = {pp.x, c.x};
+                else if (e == H) a = {pp.y, c.y};
+                else if (e < H) a = {pp.x - c.y, pp.y + c.x};
+                else a = {pp.x + c.y, c.x - pp.y};
+              } else {
+                a = lds_read(&z[loff + e * w.es + ((e >> 3) & w.emask)]);
+              }
+              if (j > 0 && np > 1) a = cmul(a, lds_read(&tw[j * k * tstep]));
+              v[b][j] = a;
+            }
+          bfly_rt<SLOTS>(R, v[b]);
+        }
       }
+      // (in place is safe across the x0 chunks too: butterfly x reads elements x + j bpl and writes (x - k) R + k + p np, and the
+      // chunks of one line are separated by the wave's in-order LDS queue only when every chunk's reads precede ITS writes AND no
+      // later chunk reads what an earlier one wrote -- which does not hold in general, hence all reads of a LINE happen first:
+      // the plan keeps bpl <= 64 NB, so there is exactly one chunk)
+      wave_sync();
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (xx[b] < bpl) {
+          const int base = (xx[b] - kk[b]) * R + kk[b];
+#pragma unroll
+          for (int p = 0; p < SLOTS; ++p)
+            if (p < R) {
+              const int o = base + p * np;
+              z[loff + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
+            }
+        }
+      wave_sync();
     }
-    wave_sync();
   }
 }
 
 // all stages of one 1-D pass over the wave's lines
-template <bool HERM>
-__device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl, const Walk& w, int line0, int nlines, int lane) {
-  int np = 1;
+__device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl, const Walk& w, int line0, int nlines, int lane,
+                                           bool herm) {
+  int np = 1, rest = pl.m;
   for (int s = 0; s < pl.n_stages; ++s) {
     const int R = (int)((pl.radix_packed >> (4 * s)) & 15u);  // (a dynamic index into the kernel argument would go through scratch)
-    const int tstep = pl.m / (np * R);
-    const float inv_np = 1.0f / (float)np;
-    if (HERM && s == 0) {
-      switch (R) {
-        case 8: stage<8, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-        case 5: stage<5, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-        case 4: stage<4, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-        case 3: stage<3, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-        default: stage<2, true>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-      }
-    } else {
-      switch (R) {
-        case 8: stage<8, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-        case 5: stage<5, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-        case 4: stage<4, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-        case 3: stage<3, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-        default: stage<2, false>(z, tw, w, pl.m, np, inv_np, tstep, line0, nlines, lane); break;
-      }
+    switch (R) {  // rest = m / (np R): divisions by constants
+      case 8: rest >>= 3; break;
+      case 5: rest /= 5; break;
+      case 4: rest >>= 2; break;
+      case 3: rest /= 3; break;
+      default: rest >>= 1; break;
     }
+    if (R > 4) stage_rt<8>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, herm && s == 0);
+    else stage_rt<4>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, herm && s == 0);
     np *= R;
   }
 }
