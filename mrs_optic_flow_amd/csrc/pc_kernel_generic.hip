@@ -24,6 +24,7 @@
 #include "mof_kernels.h"
 #include "pc_common.hpp"
 #include "pc_plan.hpp"
+#include "pc_plan_build.hpp"
 
 namespace mof {
 
@@ -48,10 +49,33 @@ __device__ __forceinline__ uint32_t fetch_px(const uint8_t* __restrict__ base, s
 
 }  // namespace
 
-template <int DS, int CH, int PK>
-__global__ void __launch_bounds__(1024) pc_generic_kernel(PcArgs a, PcPlan pl) {
+// MS > 0: the instantiation for ONE transform size, whose plan is a compile-time constant (pc_static_plan(MS) is what the host
+// builds for it; only n -- the unpadded size -- and the launch geometry stay run-time values): radices, strides, divisions and
+// loop counts fold away. MS = 0: the plan is read from the argument (sizes below 16, and the BGR / long-range / OpenCL-model
+// front ends, which keep one general kernel each).
+template <int MS>
+struct StaticPlanOf {
+  static constexpr PcPlan P = pc_static_plan(MS > 0 ? MS : 16);
+  static constexpr int T = MS > 0 ? P.threads : 1024;
+  static constexpr int WPE = MS > 0 ? pc_plan_waves_per_eu(P) : 1;
+  static_assert(MS == 0 || P.threads > 0, "no static plan for this size");
+};
+
+template <int DS, int CH, int PK, int MS>
+__global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc_generic_kernel(PcArgs a, PcPlan pl_arg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
-  const int m = pl.m, n = pl.n, H = m >> 1, T = (int)blockDim.x, WAVES = T >> 6;
+  PcPlan pl = pl_arg;
+  if constexpr (MS > 0) {
+    constexpr PcPlan SP = StaticPlanOf<MS>::P;
+    pl.m = SP.m;
+    pl.pitch = SP.pitch;
+    pl.skew_mask = SP.skew_mask;
+    pl.threads = SP.threads;
+    pl.n_stages = SP.n_stages;
+    pl.radix_packed = SP.radix_packed;
+    pl.hermitian = SP.hermitian;
+  }
+  const int m = pl.m, n = pl.n, H = m >> 1, T = MS > 0 ? pl.threads : (int)blockDim.x, WAVES = T >> 6;
   cf* z = reinterpret_cast<cf*>(smem_g);
   cf* tw = z + (size_t)m * pl.pitch;
   Best* red = reinterpret_cast<Best*>(tw + m);
@@ -282,98 +306,47 @@ __global__ void __launch_bounds__(1024) pc_generic_kernel(PcArgs a, PcPlan pl) {
   }
 }
 
-// ---- host: the plan ------------------------------------------------------------------------------------------------------
+// ---- host: the plan (pc_plan_build.hpp holds it as constexpr functions; these are its run-time entry points) --------------
 
-int pc_optimal_dft_size(int n) {
-  if (n < 1) return -1;
-  for (int m = n; m < (1 << 30); ++m) {
-    int r = m;
-    while (r % 2 == 0) r /= 2;
-    while (r % 3 == 0) r /= 3;
-    while (r % 5 == 0) r /= 5;
-    if (r == 1) return m;
-  }
-  return -1;
-}
-
-// radix chain of a 5-smooth m: the 5s and the 3s first, then 8s and one 4 or 2 for what is left of the power of two (the
-// radix set of ocl_getRadixes, FftMethod.cpp:494-520). The LAST radix is even whenever m is: bin m/2 of a Stockham chain is
-// then output R/2 of a twiddle-free last butterfly whose inputs are the p = 0 outputs of twiddle-free butterflies all the way
-// down -- sums and differences only, like bin 0. On u8 pixels those are exact in f32 (|sum| < 2^24), so the four real-only CCS
-// slots (0 | m/2, 0 | m/2) come out of the PACKED transform exactly as the reference's separate transforms produce them. It
-// matters: there C = P / (P^2 + eps), which is 0 for P = 0 but up to 1 / (2 sqrt(eps)) = 1448 for a P of rounding
-// noise -- a checkerboard higher than the peak. (Found on 30 x 30 patches: alternating pixel sums cancel exactly in about one
-// patch per 480 x 480 frame; with the odd radix last the result was off by 0.1 .. 0.9 px there.)
-int pc_radix_chain(int m, int* radix, int max_stages) {
-  int ns = 0, r = m, p2 = 0, p3 = 0, p5 = 0;
-  while (r % 2 == 0) { r /= 2; ++p2; }
-  while (r % 3 == 0) { r /= 3; ++p3; }
-  while (r % 5 == 0) { r /= 5; ++p5; }
-  if (r != 1) return -1;
-  auto push = [&](int R) { if (ns < max_stages) radix[ns] = R; ++ns; };
-  while (p5-- > 0) push(5);
-  while (p3-- > 0) push(3);
-  const int rest = p2 % 3;  // 8s, then the 4 or 2 (an even radix last either way)
-  for (int i = 0; i < p2 / 3; ++i) push(8);
-  if (rest == 2) push(4);
-  if (rest == 1) push(2);
-  return ns <= max_stages ? ns : -1;
-}
-
+int pc_optimal_dft_size(int n) { return pc_optimal_dft_size_c(n); }
+int pc_radix_chain(int m, int* radix, int max_stages) { return pc_radix_chain_c(m, radix, max_stages); }
 bool pc_build_plan(int n, PcPlan* out) {
-  if (n < 2) return false;
   PcPlan pl{};
-  pl.n = n;
-  pl.m = pc_optimal_dft_size(n);
-  if (pl.m < 2) return false;
-  pl.n_stages = pc_radix_chain(pl.m, pl.radix, 8);
-  if (pl.n_stages < 1) return false;
-  for (int s = 0; s < pl.n_stages; ++s)
-    if (pl.m / pl.radix[s] > 64 * (16 / pl.radix[s])) return false;  // a line's butterflies must fit one group (m <= 960)
-  for (int s = 0; s < pl.n_stages; ++s) pl.radix_packed |= (uint32_t)pl.radix[s] << (4 * s);
-  pl.hermitian = pl.m % 2 == 0 ? 1 : 0;
-  const size_t extra = sizeof(float) * 2 * (size_t)pl.m + 16 * sizeof(Best) + 64, cap = 160u * 1024u;
-  auto pitch_for = [](int row) { int p = row; while (p % 16 != 8) ++p; return p; };  // = 8 (mod 16): column walks spread over the banks
-  const int skew_row = pl.m + ((pl.m - 1) >> 3);
-  if ((size_t)pl.m * pitch_for(skew_row) * 8 + extra <= cap) {
-    pl.skew_mask = ~0;
-    pl.pitch = pitch_for(skew_row);
-  } else if ((size_t)pl.m * pitch_for(pl.m) * 8 + extra <= cap) {
-    pl.skew_mask = 0;
-    pl.pitch = pitch_for(pl.m);
-  } else if ((size_t)pl.m * pl.m * 8 + extra <= cap) {
-    pl.skew_mask = 0;
-    pl.pitch = pl.m;
-  } else {
-    return false;  // the tile does not fit one CU's LDS
-  }
-  pl.lds_bytes = (int)((size_t)pl.m * pl.pitch * 8 + extra);
-  int t = (pl.m * pl.m / 16 + 63) / 64 * 64;  // ~16 complex elements per lane
-  pl.threads = t < 64 ? 64 : (t > 1024 ? 1024 : t);
-  if ((pl.m * pl.m + pl.threads - 1) / pl.threads > 18) return false;  // (the kernel's load phase holds at most 18 pixels per lane and image)
+  if (!pc_tile_plan_c(n, pl)) return false;
   *out = pl;
   return true;
 }
 
-template <int DS, int CH, int PK>
+// the transform sizes with a compile-time instantiation: every 5-smooth m in [16, 135] (what getOptimalDFTSize can return there)
+#define MOF_STATIC_SIZES(X) \
+  X(16) X(18) X(20) X(24) X(25) X(27) X(30) X(32) X(36) X(40) X(45) X(48) X(50) X(54) X(60) X(64) X(72) X(75) X(80) X(81) \
+  X(90) X(96) X(100) X(108) X(120) X(125) X(128) X(135)
+
+template <int DS, int CH, int PK, int MS>
 static hipError_t configure_generic_one() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_generic_kernel<DS, CH, PK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_generic_kernel<DS, CH, PK, MS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              160 * 1024);
 }
 
 hipError_t pc_configure_generic() {
   hipError_t e;
-  if ((e = configure_generic_one<1, 1, 0>()) != hipSuccess) return e;
-  if ((e = configure_generic_one<1, 3, 0>()) != hipSuccess) return e;
-  if ((e = configure_generic_one<4, 1, 0>()) != hipSuccess) return e;
-  if ((e = configure_generic_one<1, 1, 1>()) != hipSuccess) return e;
-  if ((e = configure_generic_one<1, 3, 1>()) != hipSuccess) return e;
-  return configure_generic_one<4, 1, 1>();
+  if ((e = configure_generic_one<1, 1, 0, 0>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<1, 3, 0, 0>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<4, 1, 0, 0>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<1, 1, 1, 0>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<1, 3, 1, 0>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<4, 1, 1, 0>()) != hipSuccess) return e;
+#define X(M) if ((e = configure_generic_one<1, 1, 0, M>()) != hipSuccess) return e;
+  MOF_STATIC_SIZES(X)
+#undef X
+  return hipSuccess;
 }
 
 hipError_t launch_pc_generic(const PcArgs& a_in, const PcPlan& pl, int n_pairs, hipStream_t stream) {
   if (a_in.downscale == 4 && a_in.channels == 3) return hipErrorInvalidValue;
   if (pl.threads < 64 || pl.threads > 1024 || pl.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  // MOF_PLANNED_STATIC=0: the run-time plan also where a compile-time instantiation exists (A/B and the tests of that form)
+  static const bool use_static = [] { const char* v = getenv("MOF_PLANNED_STATIC"); return !v || atoi(v) != 0; }();
   const int patches = a_in.grid_x * a_in.grid_y;
   const dim3 b((unsigned)pl.threads);
   for (int k0 = 0; k0 < n_pairs; k0 += 65535) {  // the pair index rides gridDim.z
@@ -385,13 +358,28 @@ hipError_t launch_pc_generic(const PcArgs& a_in, const PcPlan& pl, int n_pairs, 
     c.total = nk * patches;
     const dim3 g((unsigned)c.grid_x, (unsigned)c.grid_y, (unsigned)nk);
     if (c.peak_model == 1) {
-      if (c.downscale == 4) hipLaunchKernelGGL((pc_generic_kernel<4, 1, 1>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
-      else if (c.channels == 3) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 1>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
-      else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 1>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      if (c.downscale == 4) hipLaunchKernelGGL((pc_generic_kernel<4, 1, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      else if (c.channels == 3) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+    } else if (c.downscale == 4) {
+      hipLaunchKernelGGL((pc_generic_kernel<4, 1, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+    } else if (c.channels == 3) {
+      hipLaunchKernelGGL((pc_generic_kernel<1, 3, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
     } else {
-      if (c.downscale == 4) hipLaunchKernelGGL((pc_generic_kernel<4, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
-      else if (c.channels == 3) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
-      else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      bool done = false;
+      if (use_static) {
+        switch (pl.m) {
+#define X(M)                                                                                                      \
+  case M:                                                                                                         \
+    hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0, M>), g, b, (size_t)pl.lds_bytes, stream, c, pl);               \
+    done = true;                                                                                                  \
+    break;
+          MOF_STATIC_SIZES(X)
+#undef X
+          default: break;
+        }
+      }
+      if (!done) hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
     }
   }
   return hipGetLastError();

@@ -26,6 +26,7 @@
 #include "mof_kernels.h"
 #include "pc_common.hpp"
 #include "pc_plan.hpp"
+#include "pc_plan_build.hpp"
 
 namespace mof {
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ uint32_t fetch_px_l(const uint8_t* __restrict__ base,
 }
 
 // ---- L5 ------------------------------------------------------------------------------------------------------------------
-template <int DS, int CH>
+template <int DS, int CH, bool EXACT>
 __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, const float* __restrict__ twiddles,
                                                          float* __restrict__ zh, size_t zh_stride, int* __restrict__ flags, int line) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pcl_lds[];
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, 
   }
   __syncthreads();
   const Walk rows = {line, 1, 0, ~0, 0};
-  if (row0 + 4 * wave < m) pass_lines(z, tw, pl, rows, 2 * wave, 2, lane, false);
+  if (row0 + 4 * wave < m) pass_lines<EXACT>(z, tw, pl, rows, 2 * wave, 2, lane, false);
   __syncthreads();
   // untangle the two rows of every line (doubled: the 1/2 is folded into cross_power_ab's eps) and store transposed
   cf* out = reinterpret_cast<cf*>(zh + (size_t)img * zh_stride) + row0;
@@ -127,6 +128,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, 
 }
 
 // ---- L6 ------------------------------------------------------------------------------------------------------------------
+template <bool EXACT>
 __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur,
                                                          size_t zh_stride, PcPlan pl, const float* __restrict__ twiddles,
                                                          float* __restrict__ Dt, float* __restrict__ cdc, int line) {
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict
   __syncthreads();
   if (!active) return;
   const Walk w = {line, 1, 0, ~0, 0};
-  pass_lines(z, tw, pl, w, 0, 2, lane, false);
+  pass_lines<EXACT>(z, tw, pl, w, 0, 2, lane, false);
   // normalised cross-power spectrum of bins (v, u), conjugated in place (rules: pc_common.hpp)
   const bool u_edge = u == 0 || (even && u == hu);
   for (int v0 = 0; v0 < m; v0 += 64) {
@@ -175,12 +177,13 @@ __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict
     if (cdc && u == 0 && v == 0) cdc[pair] = C.x;  // C_dc: all that is left of a degenerate pair's spectrum (pc_common.hpp)
   }
   wave_sync();
-  pass_lines(z, tw, pl, w, 0, 1, lane, false);
+  pass_lines<EXACT>(z, tw, pl, w, 0, 1, lane, false);
   cf* D = reinterpret_cast<cf*>(Dt) + ((size_t)pair * NU + u) * m;
   for (int v = lane; v < m; v += 64) D[v] = z[sk(v)];
 }
 
 // ---- L7 ------------------------------------------------------------------------------------------------------------------
+template <bool EXACT>
 __global__ void __launch_bounds__(PCL_T) pcl_rows_inv_kernel(const float* __restrict__ Dt, PcPlan pl, const float* __restrict__ twiddles,
                                                              float2* __restrict__ cand, int n_cand, int line) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pcl_lds[];
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_inv_kernel(const float* __rest
   for (int ll = 0; ll < 2; ++ll)
     if (2 * (p0 + 2 * wave + ll) < m) ++nl;
   const Walk w = {line, 1, 0, ~0, 0};
-  if (nl > 0) pass_lines(z, tw, pl, w, 2 * wave, nl, lane, false);
+  if (nl > 0) pass_lines<EXACT>(z, tw, pl, w, 2 * wave, nl, lane, false);
   // first maximum of the fft-shifted surface (fftShift: index i -> (i + (m >> 1)) mod m for even and odd m; minMaxLoc)
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
   for (int ll = 0; ll < nl; ++ll) {
@@ -352,6 +355,17 @@ int pcl_line(int m) { return (m + ((m - 1) >> 3) + 1) | 1; }  // skewed line len
 
 size_t pcl_lds_bytes(int m) { return sizeof(float) * 2 * ((size_t)PCL_LINES * pcl_line(m) + m) + 64; }
 
+// The two-body stage routine (8 and 4 register slots per butterfly, pc_plan.hpp) holds 64 * 16 / slots butterflies of a line:
+// enough unless a radix-5 stage meets m > 640, a radix-3 one m > 768 or a radix-2 one m > 512 -- those plans take the kernels
+// built with one body per radix (more registers: three waves per SIMD instead of four).
+bool needs_exact(const PcPlan& pl) {
+  for (int s = 0; s < pl.n_stages; ++s) {
+    const int R = pl.radix[s], slots = R > 4 ? 8 : 4;
+    if (pl.m / R > 64 * (16 / slots)) return true;
+  }
+  return false;
+}
+
 template <class K>
 hipError_t allow_lds(K kernel, size_t bytes) {
   return bytes > 48 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
@@ -361,18 +375,8 @@ hipError_t allow_lds(K kernel, size_t bytes) {
 }  // namespace
 
 bool pc_build_line_plan(int n, PcPlan* out) {
-  if (n < 2) return false;
   PcPlan pl{};
-  pl.n = n;
-  pl.m = pc_optimal_dft_size(n);
-  if (pl.m < 2) return false;
-  pl.n_stages = pc_radix_chain(pl.m, pl.radix, 8);
-  if (pl.n_stages < 1) return false;
-  for (int s = 0; s < pl.n_stages; ++s) {
-    if (pl.m / pl.radix[s] > 64 * (16 / pl.radix[s])) return false;  // a line's butterflies must fit one group (m <= 960)
-    pl.radix_packed |= (uint32_t)pl.radix[s] << (4 * s);
-  }
-  pl.hermitian = pl.m % 2 == 0 ? 1 : 0;
+  if (!pc_line_plan_c(n, pl)) return false;
   *out = pl;
   return true;
 }
@@ -386,9 +390,11 @@ hipError_t launch_pcl_rows(const PclSrc& src, const PcPlan& pl, const float* twi
   if ((channels != 1 && channels != 3) || (downscale != 1 && downscale != 4) || (channels == 3 && downscale == 4)) return hipErrorInvalidValue;
   const int line = pcl_line(pl.m);
   const size_t lds = pcl_lds_bytes(pl.m);
+  const bool ex = needs_exact(pl);
   hipError_t e;
-  if ((e = allow_lds(&pcl_rows_kernel<1, 1>, lds)) != hipSuccess || (e = allow_lds(&pcl_rows_kernel<1, 3>, lds)) != hipSuccess ||
-      (e = allow_lds(&pcl_rows_kernel<4, 1>, lds)) != hipSuccess)
+  if ((e = allow_lds(&pcl_rows_kernel<1, 1, false>, lds)) != hipSuccess || (e = allow_lds(&pcl_rows_kernel<1, 3, false>, lds)) != hipSuccess ||
+      (e = allow_lds(&pcl_rows_kernel<4, 1, false>, lds)) != hipSuccess || (e = allow_lds(&pcl_rows_kernel<1, 1, true>, lds)) != hipSuccess ||
+      (e = allow_lds(&pcl_rows_kernel<1, 3, true>, lds)) != hipSuccess || (e = allow_lds(&pcl_rows_kernel<4, 1, true>, lds)) != hipSuccess)
     return e;
   const unsigned gx = (unsigned)((pl.m + 2 * PCL_LINES - 1) / (2 * PCL_LINES));
   for (int f0 = 0; f0 < n_images; f0 += 65534) {  // the image index rides gridDim.y (an even count keeps cur / prev pairs together)
@@ -406,9 +412,15 @@ hipError_t launch_pcl_rows(const PclSrc& src, const PcPlan& pl, const float* twi
       s.base[0] += (size_t)f0 * s.stride[0];
     }
     const dim3 g(gx, (unsigned)nf);
-    if (downscale == 4) hipLaunchKernelGGL((pcl_rows_kernel<4, 1>), g, dim3(PCL_T), lds, stream, s, pl, twiddles, z0, zh_stride, fl, line);
-    else if (channels == 3) hipLaunchKernelGGL((pcl_rows_kernel<1, 3>), g, dim3(PCL_T), lds, stream, s, pl, twiddles, z0, zh_stride, fl, line);
-    else hipLaunchKernelGGL((pcl_rows_kernel<1, 1>), g, dim3(PCL_T), lds, stream, s, pl, twiddles, z0, zh_stride, fl, line);
+#define PCL_ROWS(DS_, CH_)                                                                                                              \
+  do {                                                                                                                                  \
+    if (ex) hipLaunchKernelGGL((pcl_rows_kernel<DS_, CH_, true>), g, dim3(PCL_T), lds, stream, s, pl, twiddles, z0, zh_stride, fl, line); \
+    else hipLaunchKernelGGL((pcl_rows_kernel<DS_, CH_, false>), g, dim3(PCL_T), lds, stream, s, pl, twiddles, z0, zh_stride, fl, line);   \
+  } while (0)
+    if (downscale == 4) PCL_ROWS(4, 1);
+    else if (channels == 3) PCL_ROWS(1, 3);
+    else PCL_ROWS(1, 1);
+#undef PCL_ROWS
   }
   return hipGetLastError();
 }
@@ -418,13 +430,19 @@ hipError_t launch_pcl_cols(const float* zh_prev, const float* zh_cur, size_t zh_
   if (n_pairs <= 0) return hipSuccess;
   const int line = pcl_line(pl.m), NU = (pl.m >> 1) + 1;
   const size_t lds = pcl_lds_bytes(pl.m);
-  hipError_t e = allow_lds(&pcl_cols_kernel, lds);
+  const bool ex = needs_exact(pl);
+  hipError_t e = ex ? allow_lds(&pcl_cols_kernel<true>, lds) : allow_lds(&pcl_cols_kernel<false>, lds);
   if (e != hipSuccess) return e;
   for (int p0 = 0; p0 < n_pairs; p0 += 65535) {
     const int np = n_pairs - p0 < 65535 ? n_pairs - p0 : 65535;
-    hipLaunchKernelGGL(pcl_cols_kernel, dim3((unsigned)((NU + 3) / 4), (unsigned)np), dim3(PCL_T), lds, stream,
-                       zh_prev + (size_t)p0 * zh_stride, zh_cur + (size_t)p0 * zh_stride, zh_stride, pl, twiddles,
-                       Dt + (size_t)p0 * NU * pl.m * 2, cdc ? cdc + p0 : nullptr, line);
+    if (ex)
+      hipLaunchKernelGGL(pcl_cols_kernel<true>, dim3((unsigned)((NU + 3) / 4), (unsigned)np), dim3(PCL_T), lds, stream,
+                         zh_prev + (size_t)p0 * zh_stride, zh_cur + (size_t)p0 * zh_stride, zh_stride, pl, twiddles,
+                         Dt + (size_t)p0 * NU * pl.m * 2, cdc ? cdc + p0 : nullptr, line);
+    else
+      hipLaunchKernelGGL(pcl_cols_kernel<false>, dim3((unsigned)((NU + 3) / 4), (unsigned)np), dim3(PCL_T), lds, stream,
+                         zh_prev + (size_t)p0 * zh_stride, zh_cur + (size_t)p0 * zh_stride, zh_stride, pl, twiddles,
+                         Dt + (size_t)p0 * NU * pl.m * 2, cdc ? cdc + p0 : nullptr, line);
   }
   return hipGetLastError();
 }
@@ -433,7 +451,8 @@ hipError_t launch_pcl_peak(const PclFinal& a_in, const PcPlan& pl, int n_pairs, 
   if (n_pairs <= 0) return hipSuccess;
   const int line = pcl_line(pl.m), NU = (pl.m >> 1) + 1, n_cand = pcl_candidates(pl);
   const size_t lds = pcl_lds_bytes(pl.m);
-  hipError_t e = allow_lds(&pcl_rows_inv_kernel, lds);
+  const bool ex = needs_exact(pl);
+  hipError_t e = ex ? allow_lds(&pcl_rows_inv_kernel<true>, lds) : allow_lds(&pcl_rows_inv_kernel<false>, lds);
   if (e != hipSuccess) return e;
   for (int p0 = 0; p0 < n_pairs; p0 += 65535) {
     const int np = n_pairs - p0 < 65535 ? n_pairs - p0 : 65535;
@@ -446,8 +465,12 @@ hipError_t launch_pcl_peak(const PclFinal& a_in, const PcPlan& pl, int n_pairs, 
     a.out = a_in.out + (size_t)p0 * (a.mode == 0 ? 4 : 2);
     if (a.flags) a.flags = a_in.flags + 2 * (size_t)p0;
     if (a.cdc) a.cdc = a_in.cdc + p0;
-    hipLaunchKernelGGL(pcl_rows_inv_kernel, dim3((unsigned)n_cand, (unsigned)np), dim3(PCL_T), lds, stream, a.Dt, pl, a.twiddles,
-                       const_cast<float2*>(a.cand), n_cand, line);
+    if (ex)
+      hipLaunchKernelGGL(pcl_rows_inv_kernel<true>, dim3((unsigned)n_cand, (unsigned)np), dim3(PCL_T), lds, stream, a.Dt, pl, a.twiddles,
+                         const_cast<float2*>(a.cand), n_cand, line);
+    else
+      hipLaunchKernelGGL(pcl_rows_inv_kernel<false>, dim3((unsigned)n_cand, (unsigned)np), dim3(PCL_T), lds, stream, a.Dt, pl, a.twiddles,
+                         const_cast<float2*>(a.cand), n_cand, line);
     hipLaunchKernelGGL(pcl_final_kernel, dim3((unsigned)np), dim3(64), 0, stream, a);
   }
   return hipGetLastError();

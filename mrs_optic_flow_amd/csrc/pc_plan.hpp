@@ -17,6 +17,10 @@ namespace {
 // q / d and q % d for 0 <= q < 2^22, 1 <= d < 2^12, inv = 1.0f / d: the float quotient is within one of the true one,
 // one correction step makes it exact
 __device__ __forceinline__ int fdiv(int q, int d, float inv, int* rem) {
+  if (__builtin_constant_p(d)) {  // compile-time instantiations of a plan: the compiler's multiply-shift
+    *rem = q % d;
+    return q / d;
+  }
   int li = (int)(((float)q + 0.5f) * inv);
   int r = q - li * d;
   if (r < 0) { --li; r += d; }
@@ -41,10 +45,16 @@ __device__ __forceinline__ void bfly_rt(int R, cf* v) {
   if constexpr (SLOTS == 8) {
     if (R == 8) butterfly<8>(v);
     else butterfly5(v);
-  } else {
+  } else if constexpr (SLOTS == 5) {
+    butterfly5(v);
+  } else if constexpr (SLOTS == 4) {
     if (R == 4) butterfly<4>(v);
     else if (R == 3) butterfly3(v);
     else butterfly<2>(v);
+  } else if constexpr (SLOTS == 3) {
+    butterfly3(v);
+  } else {
+    butterfly<2>(v);
   }
 }
 
@@ -200,7 +210,10 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
   }
 }
 
-// all stages of one 1-D pass over the wave's lines
+// all stages of one 1-D pass over the wave's lines. EXACT = false: two stage bodies (8 and 4 register slots per butterfly; radix 5
+// rides in the 8-slot body, 3 and 2 in the 4-slot one) -- enough for every line of a tile that fits a CU (m / R <= 67) and the
+// smallest code; EXACT = true: one body per radix with 16 / R butterflies per lane, which long lines need (m / R up to 64 * 16 / R).
+template <bool EXACT = false>
 __device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl, const Walk& w, int line0, int nlines, int lane,
                                            bool herm) {
   int np = 1, rest = pl.m;
@@ -213,8 +226,19 @@ __device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl
       case 3: rest /= 3; break;
       default: rest >>= 1; break;
     }
-    if (R > 4) stage_rt<8>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, herm && s == 0);
-    else stage_rt<4>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, herm && s == 0);
+    const bool h = herm && s == 0;
+    if constexpr (EXACT) {
+      switch (R) {
+        case 8: stage_rt<8>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+        case 5: stage_rt<5>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+        case 4: stage_rt<4>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+        case 3: stage_rt<3>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+        default: stage_rt<2>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+      }
+    } else {
+      if (R > 4) stage_rt<8>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h);
+      else stage_rt<4>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h);
+    }
     np *= R;
   }
 }

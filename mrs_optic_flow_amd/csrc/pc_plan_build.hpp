@@ -1,0 +1,113 @@
+// pc_plan_build.hpp -- the plan of the size-generic K1 as constexpr functions: the host builds it per engine (pc_build_plan),
+// and the kernel's compile-time instantiations for the 5-smooth transform sizes (pc_kernel_generic.hip, MS > 0) rebuild the very
+// same plan as a constant, so that every run-time quantity of the planned passes (radices, strides, divisions, loop counts)
+// folds away. Reference citations as in pc_kernel_generic.hip.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mof_kernels.h"
+
+namespace mof {
+
+// cv::getOptimalDFTSize: the smallest 2^a 3^b 5^c >= n (published OpenCV algorithm)
+constexpr int pc_optimal_dft_size_c(int n) {
+  if (n < 1) return -1;
+  for (int m = n; m < (1 << 30); ++m) {
+    int r = m;
+    while (r % 2 == 0) r /= 2;
+    while (r % 3 == 0) r /= 3;
+    while (r % 5 == 0) r /= 5;
+    if (r == 1) return m;
+  }
+  return -1;
+}
+
+// radix chain of a 5-smooth m: the 5s and the 3s first, then 8s and one 4 or 2 for what is left of the power of two (the
+// radix set of ocl_getRadixes, FftMethod.cpp:494-520). The LAST radix is even whenever m is: bin m/2 of a Stockham chain is
+// then output R/2 of a twiddle-free last butterfly whose inputs are the p = 0 outputs of twiddle-free butterflies all the way
+// down -- sums and differences only, like bin 0. On u8 pixels those are exact in f32 (|sum| < 2^24), so the four real-only CCS
+// slots (0 | m/2, 0 | m/2) come out of the PACKED transform exactly as the reference's separate transforms produce them. It
+// matters: there C = P / (P^2 + eps), which is 0 for P = 0 but up to 1 / (2 sqrt(eps)) = 1448 for a P of rounding
+// noise -- a checkerboard higher than the peak. (Found on 30 x 30 patches: alternating pixel sums cancel exactly in about one
+// patch per 480 x 480 frame; with the odd radix last the result was off by 0.1 .. 0.9 px there.)
+constexpr int pc_radix_chain_c(int m, int* radix, int max_stages) {
+  int ns = 0, r = m, p2 = 0, p3 = 0, p5 = 0;
+  while (r % 2 == 0) { r /= 2; ++p2; }
+  while (r % 3 == 0) { r /= 3; ++p3; }
+  while (r % 5 == 0) { r /= 5; ++p5; }
+  if (r != 1) return -1;
+  for (; p5 > 0; --p5) { if (ns < max_stages) radix[ns] = 5; ++ns; }
+  for (; p3 > 0; --p3) { if (ns < max_stages) radix[ns] = 3; ++ns; }
+  const int rest = p2 % 3;  // 8s, then the 4 or 2 (an even radix last either way)
+  for (int i = 0; i < p2 / 3; ++i) { if (ns < max_stages) radix[ns] = 8; ++ns; }
+  if (rest == 2) { if (ns < max_stages) radix[ns] = 4; ++ns; }
+  if (rest == 1) { if (ns < max_stages) radix[ns] = 2; ++ns; }
+  return ns <= max_stages ? ns : -1;
+}
+
+constexpr int pc_pitch_for(int row) {  // = 8 (mod 16): column walks spread over the banks
+  int p = row;
+  while (p % 16 != 8) ++p;
+  return p;
+}
+
+// the transform part of a plan (n, m, radix chain); ok = false for n < 2 or lines beyond the stage routine (m > 960)
+constexpr bool pc_line_plan_c(int n, PcPlan& pl) {
+  if (n < 2) return false;
+  pl = PcPlan{};
+  pl.n = n;
+  pl.m = pc_optimal_dft_size_c(n);
+  if (pl.m < 2) return false;
+  pl.n_stages = pc_radix_chain_c(pl.m, pl.radix, 8);
+  if (pl.n_stages < 1) return false;
+  for (int s = 0; s < pl.n_stages; ++s) {
+    if (pl.m / pl.radix[s] > 64 * (16 / pl.radix[s])) return false;  // a line's butterflies must fit one group of the stage routine (m <= 960)
+    pl.radix_packed |= (uint32_t)pl.radix[s] << (4 * s);
+  }
+  pl.hermitian = pl.m % 2 == 0 ? 1 : 0;
+  return true;
+}
+
+// the whole plan of the in-LDS kernel; false when the padded tile does not fit one CU's LDS (m > 135)
+constexpr bool pc_tile_plan_c(int n, PcPlan& pl) {
+  if (!pc_line_plan_c(n, pl)) return false;
+  const size_t extra = sizeof(float) * 2 * (size_t)pl.m + 16 * 8 + 64, cap = 160u * 1024u;  // twiddles, 16 (value, index) slots, flags
+  const int skew_row = pl.m + ((pl.m - 1) >> 3);
+  if ((size_t)pl.m * pc_pitch_for(skew_row) * 8 + extra <= cap) {
+    pl.skew_mask = ~0;
+    pl.pitch = pc_pitch_for(skew_row);
+  } else if ((size_t)pl.m * pc_pitch_for(pl.m) * 8 + extra <= cap) {
+    pl.skew_mask = 0;
+    pl.pitch = pc_pitch_for(pl.m);
+  } else if ((size_t)pl.m * pl.m * 8 + extra <= cap) {
+    pl.skew_mask = 0;
+    pl.pitch = pl.m;
+  } else {
+    return false;
+  }
+  pl.lds_bytes = (int)((size_t)pl.m * pl.pitch * 8 + extra);
+  const int t = (pl.m * pl.m / 16 + 63) / 64 * 64;  // ~16 complex elements per lane
+  pl.threads = t < 64 ? 64 : (t > 1024 ? 1024 : t);
+  if ((pl.m * pl.m + pl.threads - 1) / pl.threads > 18) return false;  // (the kernel's load phase holds at most 18 pixels per lane and image)
+  return true;
+}
+
+constexpr PcPlan pc_static_plan(int m) {  // for a 5-smooth m (n = m); threads == 0 when there is none
+  PcPlan pl{};
+  if (!pc_tile_plan_c(m, pl) || pl.m != m) pl = PcPlan{};
+  return pl;
+}
+
+// waves per SIMD a kernel of this plan should be compiled for: what the LDS lets sit on a CU, at most 4 (128 VGPRs)
+constexpr int pc_plan_waves_per_eu(const PcPlan& pl) {
+  if (pl.threads <= 0) return 1;
+  int wgs = (160 * 1024) / (pl.lds_bytes > 0 ? pl.lds_bytes : 1);
+  const int by_waves = 32 / (pl.threads / 64);
+  wgs = wgs < by_waves ? wgs : by_waves;
+  const int per_eu = (wgs * (pl.threads / 64) + 3) / 4;
+  return per_eu < 1 ? 1 : (per_eu > 4 ? 4 : per_eu);
+}
+
+}  // namespace mof

@@ -180,12 +180,12 @@ def test_zz_f32_limited_patches_are_rare(gpu):
 
 
 # ---- patches too large for one CU (padded side > 135): the planned pipeline through HBM scratch (csrc/pc_large_kernel.hip) ----
-@pytest.mark.parametrize("n", [160, 136, 144, 150, 180, 192, 200, 240, 250, 148, 225, 243, 202, 480])
+@pytest.mark.parametrize("n", [160, 136, 144, 150, 180, 192, 200, 240, 250, 148, 225, 243, 202, 480, 750, 810])  # (750, 810: one stage body per radix)
 def test_large_patches_match_oracle(gpu, n):
     gx, gy = (2, 2) if n <= 250 else (1, 1)
     stride = (n + 5, n + 2)
     w, h = 3 + stride[0] * (gx - 1) + n + 4, 2 + stride[1] * (gy - 1) + n + 3
-    B = 5 if n <= 250 else 3
+    B = 5 if n <= 250 else (3 if n <= 480 else 2)
     cur, prev, shifts, kinds = synth.batch_np(B, h, w, min(n // 8, 24), k0=n)
     fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(3, 2), stride=stride)
     assert fm.kernel_variant == "planned-large"
@@ -291,3 +291,16 @@ def test_scale_rotation_at_any_resolution(gpu, res, M):
         ws, wr = ref.processImage(frames[t])
         assert (s1, r1) == (seq[t, 0], seq[t, 1]), (res, t)
         assert abs(s1 - ws) < 1e-5 and abs(r1 - wr) < 1e-5, (res, t, s1, r1, ws, wr)
+
+
+def test_planned_kernel_run_time_form(gpu):
+    """The run-time-plan form of the planned kernel (what sizes below 16 and the BGR / long-range / OpenCL-model front ends run)
+    on sizes that normally take a compile-time instantiation: MOF_PLANNED_STATIC=0 in a child process (the knob is read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_generic.py"), "-m", "gpu", "-x", "-q",
+                        "-k", "every_size and (60 or 62 or 74 or 96 or 135 or 45)", "-p", "no:cacheprovider"], capture_output=True,
+                       text=True, timeout=900, cwd=root, env=dict(os.environ, MOF_PLANNED_STATIC="0"))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
