@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   const size_t p = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 
   if (tid < 2) flags[tid] = 0;
+#pragma unroll 1
   for (int k = tid; k < m; k += T) tw[k] = {a.twiddles[2 * k], a.twiddles[2 * k + 1]};
 
   // ---- load: u8 -> f32 (convertTo, :1805-1806), z = cur + i prev, zero rows / columns beyond N (copyMakeBorder of
@@ -153,13 +154,17 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
     *nl = cnt;
   };
 
+  auto run_pass = [&](const Walk& w, int l0, int nl, bool h) {
+    if constexpr (MS > 0) pass_lines_static<StaticPlanOf<MS>>(z, tw, w, l0, nl, lane, h);
+    else pass_lines<false, false>(z, tw, pl, w, l0, nl, lane, h);
+  };
   // ---- forward 2-D transform (dft x2, :1491-1493)
   {
     int l0, nl;
     my_lines(m, &l0, &nl);
-    if (nl > 0) pass_lines(z, tw, pl, rows, l0, nl, lane, false);
+    if (nl > 0) run_pass(rows, l0, nl, false);
     __syncthreads();
-    if (nl > 0) pass_lines(z, tw, pl, cols, l0, nl, lane, false);
+    if (nl > 0) run_pass(cols, l0, nl, false);
     __syncthreads();
   }
 
@@ -173,6 +178,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   const bool box_zeros = herm && m > n && (n & 1) == 0 && (flags[0] == 0 || flags[1] == 0);
   if (herm) {
     // rows 1 .. H-1, every u: the partner (m - v, m - u) lies in the untouched lower half
+#pragma unroll 1
     for (int i = tid; i < (H - 1) * m; i += T) {
       int u;
       const int v = 1 + fdiv(i, m, inv_m, &u);
@@ -182,6 +188,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
       zat(v, u) = {C.x, -C.y};
     }
     // rows 0 and H share row 0: G[u] = conj C[0][u] + i conj C[H][u]; the partner of u is m - u in the same rows
+#pragma unroll 1
     for (int u = tid; u <= H; u += T) {
       const int um = u == 0 ? 0 : m - u;
       const bool self = u == um;
@@ -197,6 +204,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
     }
   } else {
     // odd M: no Nyquist row to pack, the only real-only slot is DC; every bin pair (k, -k) is formed once
+#pragma unroll 1
     for (int i = tid; i < m * m; i += T) {
       int u;
       const int v = fdiv(i, m, inv_m, &u);
@@ -215,10 +223,10 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   {
     int l0, nl;
     my_lines(herm ? H : m, &l0, &nl);
-    if (nl > 0) pass_lines(z, tw, pl, rows, l0, nl, lane, false);
+    if (nl > 0) run_pass(rows, l0, nl, false);
     __syncthreads();
     // herm: column pairs (c, c + H), z(y, c) = (S[y][c], S[y][c + H]); else z(y, x).x = S[y][x]
-    if (nl > 0) pass_lines(z, tw, pl, cols, l0, nl, lane, herm);
+    if (nl > 0) run_pass(cols, l0, nl, herm);
     __syncthreads();
   }
 
@@ -243,8 +251,10 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   // ---- first maximum of the fft-shifted surface in row-major order (fftShift :1257-1323: index i -> (i + (m >> 1)) mod m for
   //      even and odd m alike; minMaxLoc :1539)
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
+#pragma unroll 1
   for (int y = wave; y < m; y += WAVES) {
     const int ys = y + H >= m ? y + H - m : y + H;
+#pragma unroll 1
     for (int x = lane; x < m; x += 64) {
       const int xs = x + H >= m ? x + H - m : x + H;
       best = better(best, Best{surf(y, x), ys * m + xs});
@@ -336,7 +346,9 @@ hipError_t pc_configure_generic() {
   if ((e = configure_generic_one<1, 1, 1, 0>()) != hipSuccess) return e;
   if ((e = configure_generic_one<1, 3, 1, 0>()) != hipSuccess) return e;
   if ((e = configure_generic_one<4, 1, 1, 0>()) != hipSuccess) return e;
-#define X(M) if ((e = configure_generic_one<1, 1, 0, M>()) != hipSuccess) return e;
+#define X(M)                                                                    \
+  if ((e = configure_generic_one<1, 1, 0, M>()) != hipSuccess) return e;          \
+  if ((e = configure_generic_one<1, 3, 0, M>()) != hipSuccess) return e;
   MOF_STATIC_SIZES(X)
 #undef X
   return hipSuccess;
@@ -363,23 +375,28 @@ hipError_t launch_pc_generic(const PcArgs& a_in, const PcPlan& pl, int n_pairs, 
       else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
     } else if (c.downscale == 4) {
       hipLaunchKernelGGL((pc_generic_kernel<4, 1, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
-    } else if (c.channels == 3) {
-      hipLaunchKernelGGL((pc_generic_kernel<1, 3, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
     } else {
+      // gray and BGR8 frames (the latter promise the gray path's bits, include/mof.h): the compile-time instantiation of the
+      // transform size where there is one
+      const bool bgr = c.channels == 3;
       bool done = false;
       if (use_static) {
         switch (pl.m) {
-#define X(M)                                                                                                      \
-  case M:                                                                                                         \
-    hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0, M>), g, b, (size_t)pl.lds_bytes, stream, c, pl);               \
-    done = true;                                                                                                  \
+#define X(M)                                                                                                                            \
+  case M:                                                                                                                               \
+    if (bgr) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 0, M>), g, dim3((unsigned)StaticPlanOf<M>::T), (size_t)pl.lds_bytes, stream, c, pl); \
+    else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0, M>), g, dim3((unsigned)StaticPlanOf<M>::T), (size_t)pl.lds_bytes, stream, c, pl);     \
+    done = true;                                                                                                                        \
     break;
           MOF_STATIC_SIZES(X)
 #undef X
           default: break;
         }
       }
-      if (!done) hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      if (!done) {
+        if (bgr) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+        else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      }
     }
   }
   return hipGetLastError();

@@ -39,11 +39,73 @@ struct Walk {
   __device__ __forceinline__ int at(int l, int e) const { return l * ls + ((l >> 3) & lmask) + e * es + ((e >> 3) & emask); }
 };
 
+// Composite radices for the compile-time plans (two stages per 1-D transform for every 5-smooth size up to 135, as the tuned
+// kernels have): Cooley-Tukey in registers, n = R2 n1 + n2, k = k1 + R1 k2 -- R1 butterflies over n1, twiddles W_R^{n2 k1}, R2
+// butterflies over n2. R1 is the odd factor, R2 the even one: output R/2 = (k1 = 0, k2 = R2/2) then passes no twiddle and is a
+// sum of differences, exact on integers (the real-only CCS slots, pc_plan_build.hpp).
+template <int R1, int R2>
+__device__ __forceinline__ void butterfly_ct(cf* v, const cf* w) {
+  cf t[R2][R1];
+#pragma unroll
+  for (int n2 = 0; n2 < R2; ++n2) {
+    cf a[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) a[n1] = v[n2 + R2 * n1];
+    if constexpr (R1 == 3) butterfly3(a);
+    else if constexpr (R1 == 5) butterfly5(a);
+    else butterfly<R1>(a);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) t[n2][k1] = (n2 * k1 == 0) ? a[k1] : cmul(a[k1], w[n2 * k1]);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1) {
+    cf b[R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) b[n2] = t[n2][k1];
+    if constexpr (R2 == 3) butterfly3(b);
+    else butterfly<R2>(b);
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = b[k2];
+  }
+}
+__device__ __forceinline__ void butterfly6(cf* v) {  // 3 x 2
+  const cf w[3] = {{1.f, 0.f}, {0.5f, -0.86602540378443864676f}, {-0.5f, -0.86602540378443864676f}};
+  butterfly_ct<3, 2>(v, w);
+}
+__device__ __forceinline__ void butterfly9(cf* v) {  // 3 x 3
+  const cf w[5] = {{1.f, 0.f},
+                   {0.76604444311897803520f, -0.64278760968653932632f},
+                   {0.17364817766693034885f, -0.98480775301220805937f},
+                   {-0.5f, -0.86602540378443864676f},
+                   {-0.93969262078590838405f, -0.34202014332566873304f}};
+  butterfly_ct<3, 3>(v, w);
+}
+__device__ __forceinline__ void butterfly10(cf* v) {  // 5 x 2
+  const cf w[5] = {{1.f, 0.f},
+                   {0.80901699437494742410f, -0.58778525229247312917f},
+                   {0.30901699437494742410f, -0.95105651629515357212f},
+                   {-0.30901699437494742410f, -0.95105651629515357212f},
+                   {-0.80901699437494742410f, -0.58778525229247312917f}};
+  butterfly_ct<5, 2>(v, w);
+}
+__device__ __forceinline__ void butterfly12(cf* v) {  // 3 x 4
+  const cf w[7] = {{1.f, 0.f},  {0.86602540378443864676f, -0.5f}, {0.5f, -0.86602540378443864676f}, {0.f, -1.f},
+                   {-0.5f, -0.86602540378443864676f}, {-0.86602540378443864676f, -0.5f}, {-1.f, 0.f}};
+  butterfly_ct<3, 4>(v, w);
+}
+
 // the butterfly of a run-time radix R <= SLOTS (wave-uniform: a scalar branch)
 template <int SLOTS>
 __device__ __forceinline__ void bfly_rt(int R, cf* v) {
-  if constexpr (SLOTS == 8) {
+  if constexpr (SLOTS == 16) {  // compile-time plans only: R is a constant there and one branch survives
+    if (R == 16) butterfly<16>(v);
+    else if (R == 15) butterfly15(v);
+    else if (R == 12) butterfly12(v);
+    else if (R == 10) butterfly10(v);
+    else butterfly9(v);
+  } else if constexpr (SLOTS == 8) {
     if (R == 8) butterfly<8>(v);
+    else if (R == 6) butterfly6(v);
     else butterfly5(v);
   } else if constexpr (SLOTS == 5) {
     butterfly5(v);
@@ -94,20 +156,16 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
     int k = 0;
     if (np > 1) (void)fdiv(x, np, inv_np, &k);
     cf t[SLOTS - 1];
-    int eoff[SLOTS], ooff[SLOTS], ee[SLOTS];
+    if (np > 1) {
 #pragma unroll
-    for (int j = 0; j < SLOTS; ++j) {
-      eoff[j] = ooff[j] = ee[j] = 0;
-      if (j < R) {
-        const int e = x + j * bpl, o = (x - k) * R + k + j * np;
-        const int r = herm_first ? (e < H ? e : (e == H ? 0 : m - e)) : e;
-        ee[j] = e;
-        eoff[j] = r * w.es + ((r >> 3) & w.emask);
-        ooff[j] = o * w.es + ((o >> 3) & w.emask);
-        if (j > 0 && np > 1) t[j - 1] = lds_read(&tw[j * k * tstep]);
-      }
+      for (int j = 1; j < SLOTS; ++j)
+        if (j < R) t[j - 1] = lds_read(&tw[j * k * tstep]);
     }
+    // (element offsets are formed where they are used: holding R + R of them across the group loop cost 32 VGPRs in the
+    // 16-slot body and spilled)
+    const int obase = (x - k) * R + k;
     const int group = NB * lpg;
+#pragma unroll 1
     for (int g0 = 0; g0 < nlines; g0 += group) {
       cf v[NB][SLOTS];
       int loff[NB];
@@ -123,16 +181,18 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
 #pragma unroll
           for (int j = 0; j < SLOTS; ++j)
             if (j < R) {
+              const int e = x + j * bpl;
               cf a;
               if (herm_first) {
-                const cf pp = lds_read(&z[loff[b] + eoff[j]]), c = lds_read(&z[l2off + eoff[j]]);  // tile (row r, col l) and (row r, col l + H)
-                const int e = ee[j];
+                const int r = e < H ? e : (e == H ? 0 : m - e);
+                const int ro = r * w.es + ((r >> 3) & w.emask);
+                const cf pp = lds_read(&z[loff[b] + ro]), c = lds_read(&z[l2off + ro]);  // tile (row r, col l) and (row r, col l + H)
                 if (e == 0) a = {pp.x, c.x};
                 else if (e == H) a = {pp.y, c.y};
                 else if (e < H) a = {pp.x - c.y, pp.y + c.x};
                 else a = {pp.x + c.y, c.x - pp.y};
               } else {
-                a = lds_read(&z[loff[b] + eoff[j]]);
+                a = lds_read(&z[loff[b] + e * w.es + ((e >> 3) & w.emask)]);
               }
               if (j > 0 && np > 1) a = cmul(a, t[j - 1]);
               v[b][j] = a;
@@ -146,7 +206,10 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
         if (on[b]) {
 #pragma unroll
           for (int p = 0; p < SLOTS; ++p)
-            if (p < R) z[loff[b] + ooff[p]] = v[b][p];
+            if (p < R) {
+              const int o = obase + p * np;
+              z[loff[b] + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
+            }
         }
       wave_sync();
     }
@@ -210,36 +273,67 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
   }
 }
 
-// all stages of one 1-D pass over the wave's lines. EXACT = false: two stage bodies (8 and 4 register slots per butterfly; radix 5
-// rides in the 8-slot body, 3 and 2 in the 4-slot one) -- enough for every line of a tile that fits a CU (m / R <= 67) and the
-// smallest code; EXACT = true: one body per radix with 16 / R butterflies per lane, which long lines need (m / R up to 64 * 16 / R).
-template <bool EXACT = false>
+// all stages of one 1-D pass over the wave's lines. EXACT = false: stage bodies with 8 and 4 register slots per butterfly (radix 5
+// and 6 ride in the 8-slot body, 3 and 2 in the 4-slot one; WIDE adds the 16-slot body for the composite radices 9 .. 16 of the
+// compile-time plans) -- enough for every line of a tile that fits a CU (m / R <= 67) and the smallest code; EXACT = true: one body
+// per radix with 16 / R butterflies per lane, which long lines need (m / R up to 64 * 16 / R).
+template <bool EXACT, bool WIDE>
+__device__ __forceinline__ void pass_stage(cf* z, const cf* tw, const PcPlan& pl, const Walk& w, int line0, int nlines, int lane, bool herm,
+                                           int s, int& np, int& rest) {
+  const int R = (int)((pl.radix_packed >> (5 * s)) & 31u);  // (a dynamic index into the kernel argument would go through scratch)
+  switch (R) {  // rest = m / (np R): divisions by constants
+    case 16: rest >>= 4; break;
+    case 15: rest /= 15; break;
+    case 12: rest /= 12; break;
+    case 10: rest /= 10; break;
+    case 9: rest /= 9; break;
+    case 8: rest >>= 3; break;
+    case 6: rest /= 6; break;
+    case 5: rest /= 5; break;
+    case 4: rest >>= 2; break;
+    case 3: rest /= 3; break;
+    default: rest >>= 1; break;
+  }
+  const bool h = herm && s == 0;
+  if constexpr (EXACT) {
+    switch (R) {
+      case 8: stage_rt<8>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+      case 5: stage_rt<5>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+      case 4: stage_rt<4>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+      case 3: stage_rt<3>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+      default: stage_rt<2>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
+    }
+  } else {
+    if (WIDE && R > 8) stage_rt<16>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h);
+    else if (R > 4) stage_rt<8>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h);
+    else stage_rt<4>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h);
+  }
+  np *= R;
+}
+
+template <bool EXACT = false, bool WIDE = false>
 __device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl, const Walk& w, int line0, int nlines, int lane,
                                            bool herm) {
   int np = 1, rest = pl.m;
-  for (int s = 0; s < pl.n_stages; ++s) {
-    const int R = (int)((pl.radix_packed >> (4 * s)) & 15u);  // (a dynamic index into the kernel argument would go through scratch)
-    switch (R) {  // rest = m / (np R): divisions by constants
-      case 8: rest >>= 3; break;
-      case 5: rest /= 5; break;
-      case 4: rest >>= 2; break;
-      case 3: rest /= 3; break;
-      default: rest >>= 1; break;
-    }
-    const bool h = herm && s == 0;
-    if constexpr (EXACT) {
-      switch (R) {
-        case 8: stage_rt<8>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
-        case 5: stage_rt<5>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
-        case 4: stage_rt<4>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
-        case 3: stage_rt<3>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
-        default: stage_rt<2>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h); break;
-      }
-    } else {
-      if (R > 4) stage_rt<8>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h);
-      else stage_rt<4>(z, tw, w, pl.m, R, np, rest * np, rest, line0, nlines, lane, h);
-    }
-    np *= R;
+  if constexpr (WIDE) {  // compile-time plan: the stage loop MUST unroll for the radices to be constants
+#pragma unroll
+    for (int s = 0; s < pl.n_stages; ++s) pass_stage<EXACT, WIDE>(z, tw, pl, w, line0, nlines, lane, herm, s, np, rest);
+  } else {
+#pragma unroll 1
+    for (int s = 0; s < pl.n_stages; ++s) pass_stage<EXACT, WIDE>(z, tw, pl, w, line0, nlines, lane, herm, s, np, rest);
+  }
+}
+
+// The same for a compile-time plan (SP::P a constexpr PcPlan): the stages are a compile-time recursion, so every radix, stride and
+// count reaches the stage routine as a constant (a `#pragma unroll` on the run-time loop is not honoured once the 16-slot bodies make
+// it large, and the radix dispatch then stays in the code).
+template <class SP, int S = 0, int NP = 1>
+__device__ __forceinline__ void pass_lines_static(cf* z, const cf* tw, const Walk& w, int line0, int nlines, int lane, bool herm) {
+  if constexpr (S < SP::P.n_stages) {
+    constexpr int R = SP::P.radix[S], M = SP::P.m, REST = M / (NP * R);
+    constexpr int SL = R > 8 ? 16 : (R > 4 ? 8 : 4);
+    stage_rt<SL>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm && S == 0);
+    pass_lines_static<SP, S + 1, NP * R>(z, tw, w, line0, nlines, lane, herm);
   }
 }
 

@@ -64,7 +64,7 @@ constexpr bool pc_line_plan_c(int n, PcPlan& pl) {
   if (pl.n_stages < 1) return false;
   for (int s = 0; s < pl.n_stages; ++s) {
     if (pl.m / pl.radix[s] > 64 * (16 / pl.radix[s])) return false;  // a line's butterflies must fit one group of the stage routine (m <= 960)
-    pl.radix_packed |= (uint32_t)pl.radix[s] << (4 * s);
+    pl.radix_packed |= (uint32_t)pl.radix[s] << (5 * s);
   }
   pl.hermitian = pl.m % 2 == 0 ? 1 : 0;
   return true;
@@ -94,9 +94,54 @@ constexpr bool pc_tile_plan_c(int n, PcPlan& pl) {
   return true;
 }
 
+// ---- compile-time plans: composite radices, two stages per 1-D transform ----------------------------------------------------
+// register slots a butterfly of radix R occupies in the stage routine (pc_plan.hpp), butterflies per lane and group
+constexpr int pc_slots(int R) { return R > 8 ? 16 : (R > 4 ? 8 : 4); }
+constexpr bool pc_radix_ok(int R) {
+  return R == 2 || R == 3 || R == 4 || R == 5 || R == 6 || R == 8 || R == 9 || R == 10 || R == 12 || R == 15 || R == 16;
+}
+// lines one group of a two-stage pass (Ra, then Rb) covers: stage 0 has m / Ra = Rb butterflies per line, stage 1 has Ra
+constexpr int pc_group_lines(int Ra, int Rb) {
+  const int g0 = (16 / pc_slots(Ra)) * (64 / Rb), g1 = (16 / pc_slots(Rb)) * (64 / Ra);
+  return g0 < g1 ? g0 : g1;
+}
+// m = Ra * Rb with both radices available; Rb even when m is (the exactness of bin m / 2, above); the pair whose groups cover the
+// most lines (one LDS round trip per stage and wave), ties to the smaller Rb (its Rb - 1 twiddles sit in registers)
+constexpr bool pc_two_stage_chain(int m, int& Ra, int& Rb) {
+  int best = 0;
+  for (int a = 2; a <= 16; ++a) {
+    if (m % a != 0 || !pc_radix_ok(a)) continue;
+    const int b = m / a;
+    if (b > 16 || !pc_radix_ok(b) || ((m & 1) == 0 && (b & 1) != 0)) continue;
+    const int g = pc_group_lines(a, b);
+    if (g > best || (g == best && b < Rb)) {
+      best = g;
+      Ra = a;
+      Rb = b;
+    }
+  }
+  return best > 0;
+}
+
 constexpr PcPlan pc_static_plan(int m) {  // for a 5-smooth m (n = m); threads == 0 when there is none
   PcPlan pl{};
-  if (!pc_tile_plan_c(m, pl) || pl.m != m) pl = PcPlan{};
+  if (!pc_tile_plan_c(m, pl) || pl.m != m) return PcPlan{};
+  int Ra = 0, Rb = 0;
+  if (pc_two_stage_chain(m, Ra, Rb)) {
+    pl.n_stages = 2;
+    pl.radix[0] = Ra;
+    pl.radix[1] = Rb;
+    for (int s = 2; s < 8; ++s) pl.radix[s] = 0;
+    pl.radix_packed = (uint32_t)Ra | ((uint32_t)Rb << 5);
+    // as many waves as make one group per stage cover a wave's lines, within 16 waves and 18 pixels per lane
+    int lines = pc_group_lines(Ra, Rb);
+    lines = lines > m ? m : lines;
+    int waves = (m + lines - 1) / lines;
+    const int min_waves = (m * m + 18 * 64 - 1) / (18 * 64);
+    waves = waves < min_waves ? min_waves : waves;
+    waves = waves > 16 ? 16 : waves;
+    pl.threads = 64 * waves;
+  }
   return pl;
 }
 
