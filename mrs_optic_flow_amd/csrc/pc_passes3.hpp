@@ -43,8 +43,8 @@ __device__ __forceinline__ void fwd3_rows(cf* __restrict__ z, int wave, int lane
     const uint32_t cp = lds_read_u16(src + 8 * n1);
     v[n1] = {(float)(cp & 0xffu), (float)(cp >> 8)};
   }
-#ifndef MOF_ABLATE_ROWS  // diagnostic build (tools/ab_mfma_bound.sh): the row arithmetic an MFMA row-DFT would take off the VALU
-  butterfly<16>(v);
+#if !defined(MOF_ABLATE_ROWS) && !defined(MOF_ABLATE_S1)  // diagnostic builds (tools/ab_mfma_bound.sh): the row arithmetic an
+  butterfly<16>(v);                                       // MFMA row-DFT would take off the VALU (S1 alone, or S1 and S2's row part)
 #endif
   wave_sync();  // the raw area lies inside the wave's own part of the intermediate layout: all of it is read by now
 #pragma unroll

@@ -7,6 +7,8 @@
 #   v2  v1 with 16 KB more LDS per workgroup (MOF_PC_EXTRA_LDS): where the hi + lo f16 DFT matrix (2 x 64 x 64 x 2 B) has
 #       to live -- 64 VGPRs of B fragments do not fit beside K1's 109 -- which costs the fourth workgroup per CU
 #   v3  the product kernel with the same 16 KB (what 3 workgroups per CU cost on their own)
+#   v4  only S1's radix-16 butterfly removed (-DMOF_ABLATE_S1): the ceiling of the one MFMA form whose matrix fits in registers
+#       (W16 hi + lo = 32 x 64 f16 = 16 VGPRs of A fragments; 8 v_mfma_f32_32x32x16_f16 per wave)
 # usage (GPU box): bash tools/ab_mfma_bound.sh
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -15,6 +17,8 @@ BASE="-O3 -std=c++17 -fPIC -fno-slp-vectorize -Wno-unused-parameter -Wno-unused-
 OTHERS=$(ls *.hip | grep -v "^pc_kernel.hip$" | grep -v "^pc_kernel_quad.hip$" | sed 's/\.hip$/.o/')
 hipcc --offload-arch=gfx950 $BASE -I../../include -I. -c -o /tmp/abm_0.o pc_kernel.hip
 hipcc --offload-arch=gfx950 $BASE -DMOF_ABLATE_ROWS -I../../include -I. -c -o /tmp/abm_1.o pc_kernel.hip
+hipcc --offload-arch=gfx950 $BASE -DMOF_ABLATE_S1 -I../../include -I. -c -o /tmp/abm_4.o pc_kernel.hip
+hipcc --offload-arch=gfx950 -shared -o /tmp/libmof_abm_4.so $OTHERS /tmp/abm_4.o -ldl
 hipcc --offload-arch=gfx950 -shared -o /tmp/libmof_abm_0.so $OTHERS /tmp/abm_0.o -ldl
 hipcc --offload-arch=gfx950 -shared -o /tmp/libmof_abm_1.so $OTHERS /tmp/abm_1.o -ldl
 run() {  # <lib> <extra lds>
@@ -25,4 +29,5 @@ for rep in 1 2 3; do
   echo "rep $rep v1 rows off the VALU  : $(run /tmp/libmof_abm_1.so 0)"
   echo "rep $rep v2 v1 + 16 KB LDS     : $(run /tmp/libmof_abm_1.so 16384)"
   echo "rep $rep v3 product + 16 KB LDS: $(run /tmp/libmof_abm_0.so 16384)"
+  echo "rep $rep v4 S1 butterfly off   : $(run /tmp/libmof_abm_4.so 0)"
 done
