@@ -384,6 +384,12 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     tw[2 * k] = (float)c;
     tw[2 * k + 1] = (float)s;
   }
+  if (!e->generic && !e->large && n == 64) {  // the tuned N = 64 kernel's matrix-core stage reads its DFT-16 fragments from behind the twiddles
+    std::vector<uint32_t> frag(1024, 0u);
+    mof::pc_mfma_s1_fragments(frag.data());
+    tw.resize(128 + 1024);
+    std::memcpy(tw.data() + 128, frag.data(), 4096);
+  }
 #define CREATE_TRY(expr)                                                                        \
   do {                                                                                          \
     hipError_t _e = (expr);                                                                     \

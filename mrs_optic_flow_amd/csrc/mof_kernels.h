@@ -30,6 +30,10 @@ struct PcArgs {
   double* out;            // device, [pair][patch] (x, y)
 };
 
+// 1024 dwords behind the 64 twiddles of an N = 64 engine: the f16 hi / lo fragments of the radix-16 DFT matrix, in the lane order
+// of v_mfma_f32_32x32x16_f16's A operand (pc_passes3.hpp, fwd3_rows_mfma)
+void pc_mfma_s1_fragments(uint32_t* out);
+
 // Run-time plan of the general K1 (pc_kernel_generic.hip): any samplePointSize n whose padded transform size
 // m = cv::getOptimalDFTSize(n) gives an m x m complex tile that fits one CU's LDS (m <= 135)
 struct PcPlan {

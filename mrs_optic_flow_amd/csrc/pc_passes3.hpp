@@ -51,6 +51,74 @@ __device__ __forceinline__ void fwd3_rows(cf* __restrict__ z, int wave, int lane
   for (int k1 = 0; k1 < 16; ++k1) z[t3addr(y, n2, k1)] = v[k1];
 }
 
+// S1 on the matrix cores (MOF_K1_MFMA_S1). The radix-16 DFT over n1 of a column (y, n2) of z = cur + i prev is
+// a real 32 x 32 product: rows r = (k1, re | im), K slots (n1, cur | prev),
+//   re_k1 = sum_n1 cur cos(t) + prev sin(t),  im_k1 = sum_n1 -cur sin(t) + prev cos(t),  t = 2 pi k1 n1 / 16.
+// u8 pixels are exact in f16; the matrix is split W = W_hi + W_lo in f16 (both products exact in f32, f32 accumulation), so
+// the pass is as accurate as the fp32 butterfly and its k1 = 0, 4, 8, 12 outputs are the same exact integer sums.
+// v_mfma_f32_32x32x16_f16: A = W (row r = lane % 32; k = 8 (lane / 32) + j), B = pixels (column = lane % 32 = 8 rows x 4 n2,
+// same k), D: column = lane % 32, row (i % 4) + 8 (i / 4) + 4 (lane / 32) -- re and im of a k1 in one lane. A wave owns
+// 16 rows x 4 n2 = two column tiles x (2 K steps x (hi, lo)) = 8 MFMA; the 16 dwords of W fragments per lane come from the
+// table behind the twiddles (pc_mfma_s1_fragments, built by the host).
+typedef _Float16 mof_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mof_half2 __attribute__((ext_vector_type(2)));
+typedef float mof_float16 __attribute__((ext_vector_type(16)));
+struct Fwd3Mfma {
+  mof_half8 w[4];  // hi n1 0..7, hi n1 8..15, lo, lo
+  __device__ __forceinline__ void load(const float* __restrict__ table, int lane) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4* frag = reinterpret_cast<const u4*>(table + 128);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[s] = __builtin_bit_cast(mof_half8, frag[64 * s + lane]);
+  }
+};
+__device__ __forceinline__ void fwd3_rows_mfma(cf* __restrict__ z, int wave, int lane, const float* __restrict__ table) {
+  constexpr int N = 64;
+  Fwd3Mfma m;  // (L1 / L2 hits, requested ahead of the LDS reads below; held only for this stage)
+  m.load(table, lane);
+  const int n = lane & 31, h = lane >> 5, n2 = n & 3;
+  // column tile t: rows 16 wave + 8 t + (n >> 2); pixel n1 = 8 ks + 4 h + q of column n2: all 16 reads in flight, then the conversions
+  uint32_t cp[2][2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const unsigned char* src = raw_area<N>(z, 16 * wave) + (8 * t + (n >> 2)) * RawCfg<N>::PITCH + 2 * n2 + 32 * h;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cp[t][ks][q] = lds_read_u16(src + 64 * ks + 8 * q);
+  }
+  mof_half8 b[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint32_t d[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // (cur, prev) bytes -> the halves 1024 + cur, 1024 + prev -> - 1024
+        const mof_half2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
+        const mof_half2 v = __builtin_bit_cast(mof_half2, __builtin_amdgcn_perm(0x64646464u, cp[t][ks][q], 0x04010400u)) - k1024;
+        d[q] = __builtin_bit_cast(uint32_t, v);
+      }
+      __builtin_memcpy(&b[t][ks], d, 16);
+    }
+  wave_sync();  // (the raw area lies inside the wave's own part of the intermediate layout)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    mof_float16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m.w[0], b[t][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m.w[1], b[t][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m.w[2], b[t][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(m.w[3], b[t][1], acc, 0, 0, 0);
+    const int y = 16 * wave + 8 * t + (n >> 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) z[t3addr(y, n2, 4 * q + 2 * h + e)] = {acc[4 * q + 2 * e], acc[4 * q + 2 * e + 1]};
+  }
+}
+
 // S2: in place
 __device__ __forceinline__ void fwd3_mid(cf* __restrict__ z, int wave, int lane, const Fwd3Tw& tw) {
   const int k1 = 4 * wave + (lane & 3), m2 = lane >> 2;

@@ -210,3 +210,22 @@ def test_fuzzer_classes_through_every_entry_point(gpu, n):
         lr = flr.process_long_range_batch_device(torch.from_numpy(up(small_c)).to(gpu), torch.from_numpy(up(small_p)).to(gpu)).cpu().numpy()
         for k in sel:
             _check(lr[k], small_c[k], small_p[k], lay1, f"n{n}/longrange/{names[k]}")
+
+
+def test_mfma_first_stage_variant_of_k1_passes_the_parity_tests(gpu):
+    """VERDICT r03 item 5: K1 (N = 64) with S1 of its forward transform on the matrix cores (pc_passes3.hpp, fwd3_rows_mfma;
+    f16 hi + lo split of the DFT-16 matrix, f32 accumulation) is an A/B library (`make mfma`), measured slower than the product
+    (profiles/r04_mfma_s1_ab.txt) and therefore not shipped -- but it has to stay correct for that comparison to mean anything:
+    a child process re-runs the N = 64 parity cases of test_gpu_fft.py on it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "mrs_optic_flow_amd", "csrc", "ab", "libmof_hip_mfma.so")
+    if not os.path.exists(lib):
+        pytest.skip("csrc/ab/libmof_hip_mfma.so not built (`make -C mrs_optic_flow_amd/csrc mfma`)")
+    env = dict(os.environ, MOF_LIB_PATH=lib)
+    sel = "golden or seeded or ocl_peak or bgr or long_range or gating or circular or expected_variant"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_fft.py"), "-q", "-x", "-k", sel,
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
