@@ -201,5 +201,11 @@ hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float*
 // many consecutive pairs re-using cur(p) as prev(p + 1) -- only valid when zh_cur == zh_prev + zh_stride (a sequence)
 hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* twiddles, float* Dt, int res,
                               int n_pairs, int run, hipStream_t stream);
+// K56 (sr_fused_kernel.hip): K5s + K6s in one kernel, the row transforms as a dense product on the matrix cores -- reads the u8
+// log-polar images instead of Zh. `frags` = sr_fused_fragments(res) on the device. Same pair / run semantics as K6s.
+bool sr_fused_supported(int res);
+std::vector<uint32_t> sr_fused_fragments(int res);
+hipError_t launch_sr_cols_fused(const uint8_t* lp_prev, const uint8_t* lp_cur, size_t lp_stride, const uint32_t* frags,
+                                const float* twiddles, float* Dt, int res, int n_pairs, int run, hipStream_t stream);
 
 }  // namespace mof

@@ -263,6 +263,7 @@ struct mof_sr_engine {
   float* d_twiddles = nullptr;
   uint8_t* d_frame = nullptr;    // staging for the stateful path (res*res)
   uint8_t* d_temp_im = nullptr;  // tempIm, :27
+  uint32_t* d_wfrag = nullptr;   // K56 (sr_fused_kernel.hip): f16 hi / lo fragments of the row-DFT matrix, tuned resolutions only
   float* d_zh_prev = nullptr;    // prevIm_F32 (:48, :128), kept as what the correlation needs of it: its row half-spectra
                                  // (sr_seq_kernel.hip, K5s) -- each frame is remapped and row-transformed ONCE
   uint8_t* d_lp = nullptr;       // batch: [kChunk][2][res*res] log-polar images (cur, prev)
@@ -314,6 +315,14 @@ hipError_t rows_real(const mof_sr_engine* e, const uint8_t* lp, size_t lp_stride
   src.stride[0] = lp_stride;
   src.pitch = (size_t)res;  // log-polar images are tightly packed
   return mof::launch_pcl_rows(src, e->plan, e->d_twiddles, zh, zh_stride, nullptr, n_frames, 1, 1, s);
+}
+// K56: K5s + K6s in one kernel on the u8 log-polar images (MOF_SR_FUSED, tuned resolutions)
+bool use_fused(const mof_sr_engine* e) {
+  static const bool on = [] { const char* v = getenv("MOF_SR_FUSED"); return v && atoi(v) != 0; }();
+  return on && e->d_wfrag != nullptr;
+}
+hipError_t cols_fused(const mof_sr_engine* e, const uint8_t* lp_prev, const uint8_t* lp_cur, size_t lp_stride, int n_pairs, int run, hipStream_t s) {
+  return mof::launch_sr_cols_fused(lp_prev, lp_cur, lp_stride, e->d_wfrag, e->d_twiddles, e->d_Dt, e->cfg.resolution, n_pairs, run, s);
 }
 hipError_t cols_seq(const mof_sr_engine* e, const float* zh_prev, const float* zh_cur, size_t zh_stride, int n_pairs, int run, hipStream_t s) {
   if (!e->generic) return mof::launch_sr_cols_seq(zh_prev, zh_cur, zh_stride, e->d_twiddles, e->d_Dt, e->cfg.resolution, n_pairs, run, s);
@@ -439,7 +448,7 @@ static void sr_destroy_now(void* p) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
-  void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_sboxes[0], e->d_sboxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_wp[0], e->d_wp[1], e->d_twiddles, e->d_frame, e->d_temp_im, e->d_zh_prev,
+  void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_sboxes[0], e->d_sboxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_wp[0], e->d_wp[1], e->d_twiddles, e->d_frame, e->d_temp_im, e->d_zh_prev, e->d_wfrag,
                  e->d_lp,  e->d_Zt,      e->d_Dt,        e->d_cand,     e->d_out, e->d_degen};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -576,6 +585,11 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   }
   CREATE_TRY(hipMalloc(&e->d_twiddles, tw.size() * sizeof(float)));
   CREATE_TRY(mof::copy_on(e->stream, e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (!e->generic && mof::sr_fused_supported(res)) {
+    const std::vector<uint32_t> fr = mof::sr_fused_fragments(res);
+    CREATE_TRY(hipMalloc(&e->d_wfrag, fr.size() * sizeof(uint32_t)));
+    CREATE_TRY(mof::copy_on(e->stream, e->d_wfrag, fr.data(), fr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   CREATE_TRY(hipMalloc(&e->d_frame, nn));
   CREATE_TRY(hipMalloc(&e->d_temp_im, nn));
   CREATE_TRY(hipMalloc(&e->d_zh_prev, zh_floats(e) * sizeof(float)));
@@ -864,8 +878,12 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
     static const bool via_frames = [] { const char* v = getenv("MOF_SR_PAIR_SEQ"); return !v || atoi(v) != 0; }();
     if (via_frames || e->generic) {  // (the packed pair kernels exist for the tuned resolutions only)
       const size_t zhf = zh_floats(e);
-      SR_TRY(rows_real(e, lp_buf, nn, e->d_Zt, zhf, 2 * n, s));
-      SR_TRY(cols_seq(e, e->d_Zt + zhf, e->d_Zt, 2 * zhf, n, 1, s));
+      if (use_fused(e)) {
+        SR_TRY(cols_fused(e, lp_buf + nn, lp_buf, 2 * nn, n, 1, s));
+      } else {
+        SR_TRY(rows_real(e, lp_buf, nn, e->d_Zt, zhf, 2 * n, s));
+        SR_TRY(cols_seq(e, e->d_Zt + zhf, e->d_Zt, 2 * zhf, n, 1, s));
+      }
       SR_TRY(peak(e, a, n, s));
     } else {
       a.degen = e->d_degen;

@@ -34,6 +34,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "mfma_frag.hpp"
 #include "mof_kernels.h"
 #include "pc_common.hpp"
 
@@ -442,29 +443,6 @@ static bool classic64() {
 }
 #endif
 
-// float -> f16 bits, round to nearest even (normal and subnormal halves; the inputs are |x| <= 1)
-static uint16_t f16_bits(float x) {
-  uint32_t u;
-  std::memcpy(&u, &x, 4);
-  const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
-  const float ax = std::fabs(x);
-  if (ax == 0.f) return sign;
-  int ex;
-  (void)std::frexp(ax, &ex);                          // ax = f * 2^ex, f in [0.5, 1)
-  const int e = ex - 1 < -14 ? -14 : ex - 1;          // exponent of the half's leading (or subnormal) bit
-  const double q = std::nearbyint(std::ldexp((double)ax, 10 - e));  // integer significand in units of 2^(e-10); ties to even
-  uint32_t sig = (uint32_t)q;
-  int be = e + 15;
-  if (sig >= 2048u) sig >>= 1, ++be;                  // rounded up to the next binade
-  if (sig < 1024u) return (uint16_t)(sign | sig);     // subnormal (be == 1 here)
-  return (uint16_t)(sign | (be << 10) | (sig - 1024u));
-}
-static float f16_value(uint16_t hbits) {
-  const int be = (hbits >> 10) & 31, sig = hbits & 1023;
-  const float v = be ? std::ldexp((float)(1024 + sig), be - 25) : std::ldexp((float)sig, -24);
-  return (hbits & 0x8000u) ? -v : v;
-}
-
 void pc_mfma_s1_fragments(uint32_t* out) {
   // step s = (hi | lo, n1 half ks); lane l = (row r = l % 32 = (k1, re | im), h = l / 32); slot j = 2 q + (cur | prev), n1 = 8 ks + 4 h + q
   for (int s = 0; s < 4; ++s)
@@ -472,13 +450,11 @@ void pc_mfma_s1_fragments(uint32_t* out) {
       for (int j = 0; j < 8; ++j) {
         const int ks = s & 1, lo = s >> 1, r = l & 31, h = l >> 5, q = j >> 1, c = j & 1;
         const int k1 = r >> 1, part = r & 1, n1 = 8 * ks + 4 * h + q, idx = (k1 * n1) & 15;
-        double cs = std::cos(2.0 * 3.14159265358979323846 * idx / 16.0), sn = std::sin(2.0 * 3.14159265358979323846 * idx / 16.0);
-        if (idx % 4 == 0) {
-          cs = idx == 0 ? 1.0 : idx == 8 ? -1.0 : 0.0;
-          sn = idx == 4 ? 1.0 : idx == 12 ? -1.0 : 0.0;
-        }
+        double cs, sn;
+        unit_root(idx, 16, &cs, &sn);
         const float w = (float)(part == 0 ? (c == 0 ? cs : sn) : (c == 0 ? -sn : cs));
-        const uint16_t hi = f16_bits(w), lw = f16_bits(w - f16_value(hi));
+        uint16_t hi, lw;
+        f16_split(w, &hi, &lw);
         const uint16_t v = lo ? lw : hi;
         uint32_t& d = out[(64 * s + l) * 4 + (j >> 1)];
         d = (j & 1) ? (d & 0xffffu) | ((uint32_t)v << 16) : (d & 0xffff0000u) | v;

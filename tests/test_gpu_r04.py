@@ -229,3 +229,17 @@ def test_mfma_first_stage_variant_of_k1_passes_the_parity_tests(gpu):
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+def test_fused_estimator_kernel_passes_the_estimator_parity_tests(gpu):
+    """K56 (sr_fused_kernel.hip, MOF_SR_FUSED=1): the estimator's row transforms as a dense product on the matrix cores inside the
+    column kernel -- no row spectra in HBM (5.1 GB -> 1.4 GB per 1024-pair pass of c5), but measured slower than K5s + K6s
+    (profiles/r04_sr_fused_*), so it is an opt-in path of the batch entry. It has to stay correct: a child process re-runs the
+    estimator's parity tests (all three tuned resolutions, golden vectors, full-size c5 case) with the knob set."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOF_SR_FUSED="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_sr.py"),
+                          os.path.join(root, "tests", "test_gpu_r03.py"), "-q", "-x", "-m", "gpu", "-k", "not stateful and not sequence",
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout

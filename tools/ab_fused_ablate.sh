@@ -1,0 +1,6 @@
+#!/bin/bash
+# Where K56's time goes: the kernel without its product (1) and without its column transforms (2), per-kernel times on one box
+R=${GRAFT_REPO_ROOT:-/root/repo}
+export MOF_SR_FUSED=1
+bash $R/tools/ab_variants.sh sr_fused_kernel.hip "--workload c5 --steps 10 --warmup 3" "" "-DMOF_FUSED_ABLATE=1" "-DMOF_FUSED_ABLATE=2" > /dev/null 2>&1
+bash $R/tools/ab_stats.sh "--workload c5 --steps 10 --warmup 3" 3 2>&1 | grep "variant\|fused"
