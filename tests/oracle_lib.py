@@ -168,6 +168,23 @@ def phase_correlate(a: np.ndarray, b: np.ndarray, precision: int = 32, want_surf
     return (out[0], out[1]), d
 
 
+def f32_floor_bins(a: np.ndarray, b: np.ndarray) -> int:
+    """Number of spectral bins of EITHER patch (zero-padded to cv::phaseCorrelate's transform size) that are zero in exact
+    arithmetic, i.e. lie below the rounding floor of any f32 transform (32 eps32 ||x||_2). What an f32 transform leaves in
+    such a bin -- an exact zero or 1e-7-relative noise, which the cross-power normalisation then blows up to unit magnitude --
+    depends on its radix order; the reference's value there is an accident of OpenCV's factorisation, and each such bin pair
+    moves the centroid by about 1 / (M^2 peak) px. A few of them occur by coincidence in integer data (three residue-class
+    sums equal at a bin made of cube roots of unity: found by tools/fft_sr_fuzz.py seed 20261004); constant patches have
+    nothing else. Test-side diagnostic (numpy), not part of the C oracle."""
+    m = optimal_dft_size(a.shape[0])
+    n = 0
+    for x in (a, b):
+        xf = x.astype(np.float64)
+        spec = np.abs(np.fft.fft2(xf, s=(m, m)))
+        n += int((spec < 32.0 * float(np.finfo(np.float32).eps) * np.sqrt((xf * xf).sum())).sum())
+    return n
+
+
 def fft_layout(width, height, patch, grid_x, grid_y, origin=(0, 0), stride=None, max_px_speed=80.0) -> FftLayout:
     stride = stride or (patch, patch)
     return FftLayout(width, height, patch, grid_x, grid_y, origin[0], origin[1], stride[0], stride[1],
