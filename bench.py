@@ -738,7 +738,8 @@ def main() -> None:
             # driver-visible records of the other BASELINE configurations (same protocol, fewer steps)
             line["other_workloads"] = {tag: measure_other(tag, dev, st, 5)
                                        for tag, st in (("c3", 50), ("c4", 10), ("c5", 20), ("c2seq", 50), ("c4seq", 10), ("c5seq", 20), ("ref", 50),
-                                                       ("bmref", 50), ("refrt", 50), ("reflr", 50))}
+                                                       ("bmref", 50), ("refrt", 50), ("reflr", 50),
+                                                       ("p60", 50), ("l480", 20))}  # r04: the planned kernel and the large-patch pipeline
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

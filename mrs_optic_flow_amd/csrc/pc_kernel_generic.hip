@@ -384,8 +384,8 @@ hipError_t launch_pc_generic(const PcArgs& a_in, const PcPlan& pl, int n_pairs, 
         switch (pl.m) {
 #define X(M)                                                                                                                            \
   case M:                                                                                                                               \
-    if (bgr) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 0, M>), g, dim3((unsigned)StaticPlanOf<M>::T), (size_t)pl.lds_bytes, stream, c, pl); \
-    else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0, M>), g, dim3((unsigned)StaticPlanOf<M>::T), (size_t)pl.lds_bytes, stream, c, pl);     \
+    if (bgr) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 0, M>), g, dim3((unsigned)StaticPlanOf<M>::T), (size_t)StaticPlanOf<M>::P.lds_bytes, stream, c, pl); \
+    else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 0, M>), g, dim3((unsigned)StaticPlanOf<M>::T), (size_t)StaticPlanOf<M>::P.lds_bytes, stream, c, pl);     \
     done = true;                                                                                                                        \
     break;
           MOF_STATIC_SIZES(X)

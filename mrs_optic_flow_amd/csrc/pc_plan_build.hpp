@@ -123,11 +123,38 @@ constexpr bool pc_two_stage_chain(int m, int& Ra, int& Rb) {
   return best > 0;
 }
 
+// Tile pitch of a two-stage plan: the one with the fewest LDS cycles in the bank model of tools/design/planned_banks.py (every
+// ds_read_b64 / ds_write_b64 of the four passes with the lane groups and bank widths of MI355X_MICROARCH.md) among the pitches that
+// keep the workgroups per CU. The generic rule (pitch = 8 mod 16) is tuned for power-of-two radices; with 4 or 6 butterflies per
+// line sixteen lines sit side by side in a wave and their rows land on a quarter of the banks (p60: 42 % of the LDS cycles were
+// conflicts, profiles/r04_p60_sq_pmc.csv). 0 = keep the generic rule.
+#ifndef MOF_PLANNED_PITCH_TABLE
+#define MOF_PLANNED_PITCH_TABLE 1
+#endif
+constexpr int pc_static_pitch(int m) {
+  if (!MOF_PLANNED_PITCH_TABLE) return 0;
+  switch (m) {
+    case 16: return 20;  case 18: return 20;  case 20: return 28;  case 25: return 45;  case 27: return 39;  case 30: return 39;
+    case 36: return 42;  case 40: return 44;  case 45: return 52;  case 48: return 55;  case 50: return 59;  case 54: return 71;
+    case 60: return 76;  case 64: return 76;  case 72: return 85;  case 75: return 84;  case 80: return 108; case 81: return 103;
+    case 90: return 108; case 96: return 108; case 100: return 134; case 108: return 122; case 120: return 152; case 128: return 148;
+    default: return 0;
+  }
+}
+
 constexpr PcPlan pc_static_plan(int m) {  // for a 5-smooth m (n = m); threads == 0 when there is none
   PcPlan pl{};
   if (!pc_tile_plan_c(m, pl) || pl.m != m) return PcPlan{};
   int Ra = 0, Rb = 0;
   if (pc_two_stage_chain(m, Ra, Rb)) {
+    const int tp = pc_static_pitch(m);
+    if (tp > 0 && pl.skew_mask != 0 && tp >= m + ((m - 1) >> 3)) {
+      const size_t extra = sizeof(float) * 2 * (size_t)m + 16 * 8 + 64;
+      if ((size_t)m * tp * 8 + extra <= 160u * 1024u) {
+        pl.pitch = tp;
+        pl.lds_bytes = (int)((size_t)m * tp * 8 + extra);
+      }
+    }
     pl.n_stages = 2;
     pl.radix[0] = Ra;
     pl.radix[1] = Rb;
