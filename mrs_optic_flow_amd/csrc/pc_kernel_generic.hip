@@ -61,6 +61,10 @@ struct StaticPlanOf {
   static_assert(MS == 0 || P.threads > 0, "no static plan for this size");
 };
 
+#ifndef MOF_GABL  // diagnostic builds (results wrong by design): 1 no transform passes, 2 no cross-power, 3 no arg-max scan, 4 no pixel loads,
+                  // 5 no centroid tail, 6 no load phase at all, 7 none of 1-6 (what is left: launch, twiddles, barriers)
+#define MOF_GABL 0
+#endif
 template <int DS, int CH, int PK, int MS>
 __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc_generic_kernel(PcArgs a, PcPlan pl_arg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
@@ -83,6 +87,10 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float inv_m = 1.0f / (float)m;
   const bool herm = pl.hermitian != 0;
+  // the element loops of the phases between the passes (cross-power, arg-max scan): with a compile-time plan their trip counts are
+  // constants and a few trips in flight hide the LDS and sqrt / reciprocal latencies (p60, phase ablation: those phases were more
+  // than half of the kernel); the run-time-plan form keeps them rolled (registers)
+  constexpr int UNR = MS > 0 ? 4 : 1;
 
   // ---- patch origin (one workgroup per patch on a 3-D grid: column, row, pair)
   const int px0 = a.origin_x + (int)blockIdx.x * a.stride_x, py0 = a.origin_y + (int)blockIdx.y * a.stride_y;
@@ -110,7 +118,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
     int x;
     int y = fdiv(tid, m, inv_m, &x);
 #pragma unroll 1
-    for (int sb = 0; sb < NSB; ++sb) {
+    for (int sb = 0; sb < ((MOF_GABL == 6 || MOF_GABL == 7) ? 0 : NSB); ++sb) {
       uint32_t cpx[SB], ppx[SB];
       int ys[SB], xs[SB];
 #pragma unroll
@@ -118,7 +126,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
         ys[t] = y;
         xs[t] = x;
         cpx[t] = ppx[t] = 0u;
-        if (y < n && x < n) {  // (y < n <= m also bounds the tile)
+        if (MOF_GABL != 4 && MOF_GABL != 7 && y < n && x < n) {  // (y < n <= m also bounds the tile)
           cpx[t] = fetch_px<DS, CH>(cur, a.pitch, y, x);
           ppx[t] = fetch_px<DS, CH>(prev, a.pitch, y, x);
         }
@@ -155,6 +163,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   };
 
   auto run_pass = [&](const Walk& w, int l0, int nl, bool h) {
+    if (MOF_GABL == 1 || MOF_GABL == 7) return;
     if constexpr (MS > 0) pass_lines_static<StaticPlanOf<MS>>(z, tw, w, l0, nl, lane, h);
     else pass_lines<false, false>(z, tw, pl, w, l0, nl, lane, h);
   };
@@ -176,16 +185,22 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   // normalisation blows up to unit magnitude: 0.5 px off on a constant-against-texture pair (found by the seeded fuzzer classes,
   // r04). The constant patch is known exactly (flags), so are its zero bins.
   const bool box_zeros = herm && m > n && (n & 1) == 0 && (flags[0] == 0 || flags[1] == 0);
-  if (herm) {
+  if (MOF_GABL == 2 || MOF_GABL == 7) {
+  } else if (herm) {
     // rows 1 .. H-1, every u: the partner (m - v, m - u) lies in the untouched lower half
-#pragma unroll 1
-    for (int i = tid; i < (H - 1) * m; i += T) {
-      int u;
-      const int v = 1 + fdiv(i, m, inv_m, &u);
-      const int um = u == 0 ? 0 : m - u;
-      cf C = cross_power<PK>(zat(v, u), zat(m - v, um), false);
-      if (box_zeros && u == H) C = {0.f, 0.f};
-      zat(v, u) = {C.x, -C.y};
+    // (a counted loop: with a compile-time plan the trip count is a constant and UNR trips are in flight)
+    const int xtrips = ((H - 1) * m + T - 1) / T;
+#pragma clang loop unroll_count(UNR)
+    for (int k = 0; k < xtrips; ++k) {
+      const int i = tid + k * T;
+      if (i < (H - 1) * m) {
+        int u;
+        const int v = 1 + fdiv(i, m, inv_m, &u);
+        const int um = u == 0 ? 0 : m - u;
+        cf C = cross_power<PK>(zat(v, u), zat(m - v, um), false);
+        if (box_zeros && u == H) C = {0.f, 0.f};
+        zat(v, u) = {C.x, -C.y};
+      }
     }
     // rows 0 and H share row 0: G[u] = conj C[0][u] + i conj C[H][u]; the partner of u is m - u in the same rows
 #pragma unroll 1
@@ -251,8 +266,8 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   // ---- first maximum of the fft-shifted surface in row-major order (fftShift :1257-1323: index i -> (i + (m >> 1)) mod m for
   //      even and odd m alike; minMaxLoc :1539)
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
-#pragma unroll 1
-  for (int y = wave; y < m; y += WAVES) {
+#pragma clang loop unroll_count(UNR)
+  for (int y = wave; y < ((MOF_GABL == 3 || MOF_GABL == 7) ? 0 : m); y += WAVES) {
     const int ys = y + H >= m ? y + H - m : y + H;
 #pragma unroll 1
     for (int x = lane; x < m; x += 64) {
@@ -269,7 +284,8 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   __syncthreads();
 
   // ---- weighted centroid in double + validity gate (:1337-1383, :1838-1856), wave 0
-  if (wave == 0) {
+  if ((MOF_GABL == 5 || MOF_GABL == 7) && tid == 0) a.out[2 * p] = a.out[2 * p + 1] = (double)best.v;
+  if (wave == 0 && MOF_GABL != 5 && MOF_GABL != 7) {
     for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
     constexpr int RAD = PeakModel<PK>::RAD, W = PeakModel<PK>::W;
     const bool have = best.idx != 0x7fffffff;
