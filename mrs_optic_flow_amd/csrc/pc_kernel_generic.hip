@@ -112,36 +112,78 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
     // loop pays the memory latency once per trip -- 16 trips per patch in the first form of this kernel; one batch of 18 held
     // 36 pixel registers plus their addresses and spilled 646 VGPRs). Element i = tid + t T of the padded tile sits at
     // (y, x) = divmod(i, m); the pair advances by divmod(T, m) per step -- one division per lane instead of one per element.
-    constexpr int SB = 6, NSB = 3;  // the plan sizes the workgroup so that a lane owns at most SB * NSB = 18 elements
-    int sx;
-    const int sy = fdiv(T, m, inv_m, &sx);
-    int x;
-    int y = fdiv(tid, m, inv_m, &x);
-#pragma unroll 1
-    for (int sb = 0; sb < ((MOF_GABL == 6 || MOF_GABL == 7) ? 0 : NSB); ++sb) {
-      uint32_t cpx[SB], ppx[SB];
-      int ys[SB], xs[SB];
+    if constexpr (DS == 1 && CH == 1 && MS > 0) {
+      // Compile-time plan on gray frames: FOUR pixels per load (an unaligned dword; the byte form issued 36 loads per lane and
+      // was 8 % of the kernel), chunk q = tid + k T of the padded tile's rows of ceil(M / 4) chunks; every division is by a constant.
+      constexpr int M_ = StaticPlanOf<MS>::P.m, T_ = StaticPlanOf<MS>::T, CPR = (M_ + 3) / 4, NCHK = (M_ * CPR + T_ - 1) / T_;
+      uint32_t cw[NCHK], pw[NCHK];
 #pragma unroll
-      for (int t = 0; t < SB; ++t) {
-        ys[t] = y;
-        xs[t] = x;
-        cpx[t] = ppx[t] = 0u;
-        if (MOF_GABL != 4 && MOF_GABL != 7 && y < n && x < n) {  // (y < n <= m also bounds the tile)
-          cpx[t] = fetch_px<DS, CH>(cur, a.pitch, y, x);
-          ppx[t] = fetch_px<DS, CH>(prev, a.pitch, y, x);
-        }
-        x += sx;
-        y += sy;
-        if (x >= m) { x -= m; ++y; }
-      }
-#pragma unroll
-      for (int t = 0; t < SB; ++t) {
-        if (ys[t] < m) {
-          if (ys[t] < n && xs[t] < n) {
-            dc |= cpx[t] ^ c00;
-            dp |= ppx[t] ^ p00;
+      for (int k = 0; k < NCHK; ++k) {
+        const int q = tid + k * T_, y = q / CPR, x0 = 4 * (q % CPR);
+        cw[k] = pw[k] = 0u;
+        if (MOF_GABL != 4 && MOF_GABL != 6 && MOF_GABL != 7 && q < M_ * CPR && y < n && x0 < n) {
+          const uint8_t* pc = cur + (size_t)y * a.pitch + x0;
+          const uint8_t* pp = prev + (size_t)y * a.pitch + x0;
+          if (x0 + 3 < n) {
+            __builtin_memcpy(&cw[k], pc, 4);
+            __builtin_memcpy(&pw[k], pp, 4);
+          } else {  // the last chunk of a row whose length is not a multiple of four: the bytes inside the patch
+            for (int b = 0; x0 + b < n; ++b) {
+              cw[k] |= (uint32_t)pc[b] << (8 * b);
+              pw[k] |= (uint32_t)pp[b] << (8 * b);
+            }
           }
-          z[ys[t] * pl.pitch + xs[t] + ((xs[t] >> 3) & pl.skew_mask)] = {(float)cpx[t], (float)ppx[t]};
+        }
+      }
+      const uint32_t c4 = c00 * 0x01010101u, p4 = p00 * 0x01010101u;
+#pragma unroll
+      for (int k = 0; k < NCHK; ++k) {
+        const int q = tid + k * T_, y = q / CPR, x0 = 4 * (q % CPR);
+        if ((MOF_GABL == 6 || MOF_GABL == 7) || q >= M_ * CPR) continue;
+        if (y < n && x0 < n) {
+          const uint32_t inside = x0 + 3 < n ? 0xffffffffu : (1u << (8 * (n - x0))) - 1u;
+          dc |= (cw[k] ^ c4) & inside;
+          dp |= (pw[k] ^ p4) & inside;
+        }
+        cf* row = z + y * pl.pitch;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int x = x0 + b;
+          if (x < M_) row[x + ((x >> 3) & pl.skew_mask)] = {(float)((cw[k] >> (8 * b)) & 0xffu), (float)((pw[k] >> (8 * b)) & 0xffu)};
+        }
+      }
+    } else {
+      constexpr int SB = 6, NSB = 3;  // the plan sizes the workgroup so that a lane owns at most SB * NSB = 18 elements
+      int sx;
+      const int sy = fdiv(T, m, inv_m, &sx);
+      int x;
+      int y = fdiv(tid, m, inv_m, &x);
+  #pragma unroll 1
+      for (int sb = 0; sb < ((MOF_GABL == 6 || MOF_GABL == 7) ? 0 : NSB); ++sb) {
+        uint32_t cpx[SB], ppx[SB];
+        int ys[SB], xs[SB];
+  #pragma unroll
+        for (int t = 0; t < SB; ++t) {
+          ys[t] = y;
+          xs[t] = x;
+          cpx[t] = ppx[t] = 0u;
+          if (MOF_GABL != 4 && MOF_GABL != 7 && y < n && x < n) {  // (y < n <= m also bounds the tile)
+            cpx[t] = fetch_px<DS, CH>(cur, a.pitch, y, x);
+            ppx[t] = fetch_px<DS, CH>(prev, a.pitch, y, x);
+          }
+          x += sx;
+          y += sy;
+          if (x >= m) { x -= m; ++y; }
+        }
+  #pragma unroll
+        for (int t = 0; t < SB; ++t) {
+          if (ys[t] < m) {
+            if (ys[t] < n && xs[t] < n) {
+              dc |= cpx[t] ^ c00;
+              dp |= ppx[t] ^ p00;
+            }
+            z[ys[t] * pl.pitch + xs[t] + ((xs[t] >> 3) & pl.skew_mask)] = {(float)cpx[t], (float)ppx[t]};
+          }
         }
       }
     }
