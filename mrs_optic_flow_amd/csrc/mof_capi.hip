@@ -219,7 +219,7 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
       HIP_TRY(mof::launch_pcl_rows(sj, e->plan, e->d_twiddles, e->d_zh + (size_t)2 * j0 * patches * zhf, zhf,
                                    e->d_flags + (size_t)2 * j0 * patches, 2 * nj * patches, a.channels, a.downscale, s));
     }
-    HIP_TRY(mof::launch_pcl_cols(e->d_zh + zhf, e->d_zh, 2 * zhf, e->plan, e->d_twiddles, e->d_dt, e->d_cdc, nq, s));
+    HIP_TRY(mof::launch_pcl_cols(e->d_zh + zhf, e->d_zh, 2 * zhf, e->plan, e->d_twiddles, e->d_dt, e->d_cdc, e->d_flags, nq, s));
     mof::PclFinal f{};
     f.Dt = e->d_dt;
     f.cand = e->d_cand;

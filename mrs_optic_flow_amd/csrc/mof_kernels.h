@@ -83,7 +83,7 @@ hipError_t launch_pcl_rows(const PclSrc& src, const PcPlan& pl, const float* twi
                            int n_images, int channels, int downscale, hipStream_t stream);
 // L6: pair p = (cur: zh_cur + p * zh_stride, prev: zh_prev + p * zh_stride) -> Dt[p]; cdc nullable
 hipError_t launch_pcl_cols(const float* zh_prev, const float* zh_cur, size_t zh_stride, const PcPlan& pl, const float* twiddles,
-                           float* Dt, float* cdc, int n_pairs, hipStream_t stream);
+                           float* Dt, float* cdc, const int* flags, int n_pairs, hipStream_t stream);
 // L7 + L8 (a.Dt, a.cand, a.twiddles, a.mode, a.out [, a.M_log | a.max_px_speed_sq, a.flags, a.cdc])
 hipError_t launch_pcl_peak(const PclFinal& a, const PcPlan& pl, int n_pairs, hipStream_t stream);
 

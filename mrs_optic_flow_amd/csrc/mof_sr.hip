@@ -326,7 +326,7 @@ hipError_t cols_fused(const mof_sr_engine* e, const uint8_t* lp_prev, const uint
 }
 hipError_t cols_seq(const mof_sr_engine* e, const float* zh_prev, const float* zh_cur, size_t zh_stride, int n_pairs, int run, hipStream_t s) {
   if (!e->generic) return mof::launch_sr_cols_seq(zh_prev, zh_cur, zh_stride, e->d_twiddles, e->d_Dt, e->cfg.resolution, n_pairs, run, s);
-  return mof::launch_pcl_cols(zh_prev, zh_cur, zh_stride, e->plan, e->d_twiddles, e->d_Dt, nullptr, n_pairs, s);
+  return mof::launch_pcl_cols(zh_prev, zh_cur, zh_stride, e->plan, e->d_twiddles, e->d_Dt, nullptr, nullptr, n_pairs, s);
 }
 hipError_t peak(const mof_sr_engine* e, const mof::SrPcArgs& a, int n_pairs, hipStream_t s) {
   if (!e->generic) return mof::launch_sr_peak(a, e->cfg.resolution, n_pairs, s);

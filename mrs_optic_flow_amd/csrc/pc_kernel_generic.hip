@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   cf* z = reinterpret_cast<cf*>(smem_g);
   cf* tw = z + (size_t)m * pl.pitch;
   Best* red = reinterpret_cast<Best*>(tw + m);
-  int* flags = reinterpret_cast<int*>(red + 16);  // [0] cur differs from its first pixel, [1] prev does, [2] C_dc bits
+  int* flags = reinterpret_cast<int*>(red + 16);  // [0] cur differs from its first pixel, [1] prev does, [2] C_dc bits, [3] / [4] first pixel of cur / prev
+  cf* dbox = reinterpret_cast<cf*>(flags + 16);   // [m] spectrum of the zero-padded constant line (one_box, below)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float inv_m = 1.0f / (float)m;
   const bool herm = pl.hermitian != 0;
@@ -91,6 +92,16 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   // constants and a few trips in flight hide the LDS and sqrt / reciprocal latencies (p60, phase ablation: those phases were more
   // than half of the kernel); the run-time-plan form keeps them rolled (registers)
   constexpr int UNR = MS > 0 ? 4 : 1;
+  // (i / m, i % m): by a constant under a compile-time plan (multiply-high), by the float reciprocal otherwise
+  auto divmod_m = [&](int i, int* rem) -> int {
+    if constexpr (MS > 0) {
+      constexpr int M_ = StaticPlanOf<MS>::P.m;
+      *rem = i % M_;
+      return i / M_;
+    } else {
+      return fdiv(i, m, inv_m, rem);
+    }
+  };
 
   // ---- patch origin (one workgroup per patch on a 3-D grid: column, row, pair)
   const int px0 = a.origin_x + (int)blockIdx.x * a.stride_x, py0 = a.origin_y + (int)blockIdx.y * a.stride_y;
@@ -190,9 +201,31 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
     __syncthreads();  // flags[] zeroed, twiddles in place
     if (__builtin_amdgcn_ballot_w64(dc != 0u) != 0ull && lane == 0) flags[0] = 1;
     if (__builtin_amdgcn_ballot_w64(dp != 0u) != 0ull && lane == 0) flags[1] = 1;
+    if (tid == 0) flags[3] = (int)c00, flags[4] = (int)p00;
   }
   __syncthreads();
 
+  // EXACTLY ONE constant patch that zero padding turned into an n x n box: its spectrum is known in closed form,
+  // B[v][u] = level D[v] D[u] with D the transform of n ones in a line of m. The packed transform would deliver it with the
+  // rounding noise of the TEXTURED patch's spectrum on top (1e-7 of 1e5 against box bins that fall to zero towards the Nyquist
+  // lines): 1e-3 px on a 118 x 118 constant-against-texture pair (tools/fft_sr_fuzz.py seed 202). So D goes into LDS here (m sums
+  // of n table twiddles) and the cross-power below takes the box from it and the textured spectrum as Z -+ i box: no untangle.
+  const bool one_box = m > n && ((flags[0] == 0) != (flags[1] == 0));
+  if (one_box) {
+#pragma unroll 1
+    for (int k = tid; k < m; k += T) {
+      cf acc = {0.f, 0.f};
+      int idx = 0;
+#pragma unroll 1
+      for (int j = 0; j < n; ++j) {
+        const cf t = tw[idx];
+        acc = {acc.x + t.x, acc.y + t.y};
+        idx += k;
+        idx = idx >= m ? idx - m : idx;
+      }
+      dbox[k] = (k == H && herm && (n & 1) == 0) ? cf{0.f, 0.f} : acc;  // (an even number of alternating ones)
+    }
+  }
   const Walk rows = {pl.pitch, 1, 0, pl.skew_mask, 0}, cols = {1, pl.pitch, pl.skew_mask, 0, 1};
   auto zat = [&](int r, int c) -> cf& { return z[r * pl.pitch + c + ((c >> 3) & pl.skew_mask)]; };
   // wave w owns lines [w lpw, min((w + 1) lpw, L))
@@ -227,21 +260,52 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   // normalisation blows up to unit magnitude: 0.5 px off on a constant-against-texture pair (found by the seeded fuzzer classes,
   // r04). The constant patch is known exactly (flags), so are its zero bins.
   const bool box_zeros = herm && m > n && (n & 1) == 0 && (flags[0] == 0 || flags[1] == 0);
+  const bool box_is_cur = flags[0] == 0;
+  const float box_level = (float)(box_is_cur ? flags[3] : flags[4]);
+  // cross-power of bin (v, u): from the packed pair (untangle), or -- one_box -- from the closed-form box and Z(v, u) alone
+  auto xpow = [&](int v, int u, int vm, int um, bool real_only) -> cf {
+    if (!one_box) return cross_power<PK>(zat(v, u), zat(vm, um), real_only);
+    const cf dv = dbox[v], du = dbox[u], zk = zat(v, u);
+    const cf bx = {box_level * (dv.x * du.x - dv.y * du.y), box_level * (dv.x * du.y + dv.y * du.x)};
+    cf A, B;
+    if (box_is_cur) {
+      A = bx;
+      B = {zk.y - bx.y, bx.x - zk.x};  // -i (Z - A)
+    } else {
+      B = bx;
+      A = {zk.x + bx.y, zk.y - bx.x};  // Z - i B
+    }
+    return cross_power_ab<PK>(cf{2.f * A.x, 2.f * A.y}, cf{2.f * B.x, 2.f * B.y}, real_only);
+  };
   if (MOF_GABL == 2 || MOF_GABL == 7) {
   } else if (herm) {
     // rows 1 .. H-1, every u: the partner (m - v, m - u) lies in the untouched lower half
     // (a counted loop: with a compile-time plan the trip count is a constant and UNR trips are in flight)
     const int xtrips = ((H - 1) * m + T - 1) / T;
+    if (!one_box) {  // (the hot loop keeps the packed form alone: the closed-form branch inside it cost 4 % on every pair)
 #pragma clang loop unroll_count(UNR)
-    for (int k = 0; k < xtrips; ++k) {
-      const int i = tid + k * T;
-      if (i < (H - 1) * m) {
-        int u;
-        const int v = 1 + fdiv(i, m, inv_m, &u);
-        const int um = u == 0 ? 0 : m - u;
-        cf C = cross_power<PK>(zat(v, u), zat(m - v, um), false);
-        if (box_zeros && u == H) C = {0.f, 0.f};
-        zat(v, u) = {C.x, -C.y};
+      for (int k = 0; k < xtrips; ++k) {
+        const int i = tid + k * T;
+        if (i < (H - 1) * m) {
+          int u;
+          const int v = 1 + divmod_m(i, &u);
+          const int um = u == 0 ? 0 : m - u;
+          cf C = cross_power<PK>(zat(v, u), zat(m - v, um), false);
+          if (box_zeros && u == H) C = {0.f, 0.f};
+          zat(v, u) = {C.x, -C.y};
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < xtrips; ++k) {
+        const int i = tid + k * T;
+        if (i < (H - 1) * m) {
+          int u;
+          const int v = 1 + divmod_m(i, &u);
+          cf C = xpow(v, u, m - v, u == 0 ? 0 : m - u, false);
+          if (box_zeros && u == H) C = {0.f, 0.f};
+          zat(v, u) = {C.x, -C.y};
+        }
       }
     }
     // rows 0 and H share row 0: G[u] = conj C[0][u] + i conj C[H][u]; the partner of u is m - u in the same rows
@@ -249,8 +313,8 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
     for (int u = tid; u <= H; u += T) {
       const int um = u == 0 ? 0 : m - u;
       const bool self = u == um;
-      cf C0 = cross_power<PK>(zat(0, u), zat(0, um), self);
-      cf Ch = cross_power<PK>(zat(H, u), zat(H, um), self);
+      cf C0 = xpow(0, u, 0, um, self);
+      cf Ch = xpow(H, u, H, um, self);
       if (box_zeros) {
         Ch = {0.f, 0.f};
         if (u == H) C0 = {0.f, 0.f};
@@ -264,11 +328,11 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
 #pragma unroll 1
     for (int i = tid; i < m * m; i += T) {
       int u;
-      const int v = fdiv(i, m, inv_m, &u);
+      const int v = divmod_m(i, &u);
       const int vm = v == 0 ? 0 : m - v, um = u == 0 ? 0 : m - u;
       const int ip = vm * m + um;
       if (i > ip) continue;
-      const cf C = cross_power<PK>(zat(v, u), zat(vm, um), i == 0);
+      const cf C = xpow(v, u, vm, um, i == 0);
       if (i == 0) flags[2] = __float_as_int(C.x);
       zat(v, u) = {C.x, -C.y};
       if (i != ip) zat(vm, um) = {C.x, C.y};  // C[-k] = conj C[k]

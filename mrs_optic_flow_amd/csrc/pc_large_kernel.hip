@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, 
 template <bool EXACT>
 __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur,
                                                          size_t zh_stride, PcPlan pl, const float* __restrict__ twiddles,
-                                                         float* __restrict__ Dt, float* __restrict__ cdc, int line) {
+                                                         float* __restrict__ Dt, float* __restrict__ cdc, const int* __restrict__ flags,
+                                                         int line) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pcl_lds[];
   cf* zall = reinterpret_cast<cf*>(pcl_lds);  // [4 waves][2][line]
   cf* tw = zall + 8 * line;
@@ -169,10 +170,18 @@ __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict
   pass_lines<EXACT>(z, tw, pl, w, 0, 2, lane, false);
   // normalised cross-power spectrum of bins (v, u), conjugated in place (rules: pc_common.hpp)
   const bool u_edge = u == 0 || (even && u == hu);
+  // A CONSTANT patch that zero padding turned into an n x n box (n, m even): its spectrum is EXACTLY zero on the Nyquist row and
+  // column in the reference (alternating sums of equal numbers), so C = 0 there. Here the rows were transformed in pairs (L5): the
+  // spectra of rows 2j and 2j + 1 of a constant image differ by rounding, and their alternating column sum is 79 x that
+  // difference instead of 0 -- which the normalisation blows up to unit magnitude (0.04 px on a 158 x 158 constant-against-texture
+  // pair: tools/fft_sr_fuzz.py seed 101). The constant patch is known exactly (L5's flags), so are its zero bins -- the rule of
+  // the in-LDS planned kernel (pc_kernel_generic.hip, box_zeros).
+  const bool box_zeros = flags && even && m > pl.n && (pl.n & 1) == 0 && (((flags[2 * pair] & 1) == 0) || ((flags[2 * pair + 1] & 1) == 0));
   for (int v0 = 0; v0 < m; v0 += 64) {
     const int v = v0 + lane, vv = v < m ? v : m - 1;  // (lanes past the line repeat its last bin: cross_power_ab's wave-uniform
     const cf a = lds_read(&z[sk(vv)]), b = lds_read(&z[line + sk(vv)]);  //  branch wants every lane to take part)
-    const cf C = cross_power_ab(a, b, u_edge && (vv == 0 || (even && vv == hu)));
+    cf C = cross_power_ab(a, b, u_edge && (vv == 0 || (even && vv == hu)));
+    if (box_zeros && (u == hu || vv == hu)) C = {0.f, 0.f};
     if (v < m) z[sk(v)] = {C.x, -C.y};
     if (cdc && u == 0 && v == 0) cdc[pair] = C.x;  // C_dc: all that is left of a degenerate pair's spectrum (pc_common.hpp)
   }
@@ -426,7 +435,7 @@ hipError_t launch_pcl_rows(const PclSrc& src, const PcPlan& pl, const float* twi
 }
 
 hipError_t launch_pcl_cols(const float* zh_prev, const float* zh_cur, size_t zh_stride, const PcPlan& pl, const float* twiddles,
-                           float* Dt, float* cdc, int n_pairs, hipStream_t stream) {
+                           float* Dt, float* cdc, const int* flags, int n_pairs, hipStream_t stream) {
   if (n_pairs <= 0) return hipSuccess;
   const int line = pcl_line(pl.m), NU = (pl.m >> 1) + 1;
   const size_t lds = pcl_lds_bytes(pl.m);
@@ -438,11 +447,11 @@ hipError_t launch_pcl_cols(const float* zh_prev, const float* zh_cur, size_t zh_
     if (ex)
       hipLaunchKernelGGL(pcl_cols_kernel<true>, dim3((unsigned)((NU + 3) / 4), (unsigned)np), dim3(PCL_T), lds, stream,
                          zh_prev + (size_t)p0 * zh_stride, zh_cur + (size_t)p0 * zh_stride, zh_stride, pl, twiddles,
-                         Dt + (size_t)p0 * NU * pl.m * 2, cdc ? cdc + p0 : nullptr, line);
+                         Dt + (size_t)p0 * NU * pl.m * 2, cdc ? cdc + p0 : nullptr, flags ? flags + 2 * (size_t)p0 : nullptr, line);
     else
       hipLaunchKernelGGL(pcl_cols_kernel<false>, dim3((unsigned)((NU + 3) / 4), (unsigned)np), dim3(PCL_T), lds, stream,
                          zh_prev + (size_t)p0 * zh_stride, zh_cur + (size_t)p0 * zh_stride, zh_stride, pl, twiddles,
-                         Dt + (size_t)p0 * NU * pl.m * 2, cdc ? cdc + p0 : nullptr, line);
+                         Dt + (size_t)p0 * NU * pl.m * 2, cdc ? cdc + p0 : nullptr, flags ? flags + 2 * (size_t)p0 : nullptr, line);
   }
   return hipGetLastError();
 }

@@ -70,10 +70,14 @@ constexpr bool pc_line_plan_c(int n, PcPlan& pl) {
   return true;
 }
 
+// LDS behind the tile: twiddles (m complex), 16 (value, index) slots, 16 flag words, and the box table (m complex: the 1-D spectrum
+// of the zero-padded constant line, pc_kernel_generic.hip)
+constexpr size_t pc_tile_extra(int m) { return sizeof(float) * 2 * (size_t)m + 16 * 8 + 64 + sizeof(float) * 2 * (size_t)m; }
+
 // the whole plan of the in-LDS kernel; false when the padded tile does not fit one CU's LDS (m > 135)
 constexpr bool pc_tile_plan_c(int n, PcPlan& pl) {
   if (!pc_line_plan_c(n, pl)) return false;
-  const size_t extra = sizeof(float) * 2 * (size_t)pl.m + 16 * 8 + 64, cap = 160u * 1024u;  // twiddles, 16 (value, index) slots, flags
+  const size_t extra = pc_tile_extra(pl.m), cap = 160u * 1024u;
   const int skew_row = pl.m + ((pl.m - 1) >> 3);
   if ((size_t)pl.m * pc_pitch_for(skew_row) * 8 + extra <= cap) {
     pl.skew_mask = ~0;
@@ -149,7 +153,7 @@ constexpr PcPlan pc_static_plan(int m) {  // for a 5-smooth m (n = m); threads =
   if (pc_two_stage_chain(m, Ra, Rb)) {
     const int tp = pc_static_pitch(m);
     if (tp > 0 && pl.skew_mask != 0 && tp >= m + ((m - 1) >> 3)) {
-      const size_t extra = sizeof(float) * 2 * (size_t)m + 16 * 8 + 64;
+      const size_t extra = pc_tile_extra(m);
       if ((size_t)m * tp * 8 + extra <= 160u * 1024u) {
         pl.pitch = tp;
         pl.lds_bytes = (int)((size_t)m * tp * 8 + extra);

@@ -271,3 +271,38 @@ def test_patch_with_an_exactly_zero_spectral_bin(gpu):
     others = np.delete(np.arange(gx * gy), p)
     assert np.abs(got[others] - want64[others]).max() < 1e-4
     assert np.abs(got[p] - want64[p]).max() <= slack, (got[p], want64[p], slack)
+
+
+@pytest.mark.parametrize("case", ["in_lds_118", "large_158", "large_146"])
+def test_constant_frame_against_texture_on_padded_patches(gpu, case):
+    """Found by tools/fft_sr_fuzz.py's sequence trials (seeds 101 / 202): ONE frame of the pair constant, patch size below its
+    transform size. cv::phaseCorrelate pads the constant patch to an n x n box whose spectrum is level x D[v] D[u], exactly zero on
+    the Nyquist lines. (a) large-patch pipeline: rows are transformed in pairs, the spectra of rows 2j and 2j + 1 of a constant
+    image differ by rounding and their alternating column sum is 79 x that instead of 0 -- 0.04 px off; L6 now zeroes those
+    bins from L5's flags (box_zeros). (b) in-LDS planned kernel: the packed transform delivers the box with the textured
+    patch's rounding noise on top -- 1e-3 px off; the kernel now takes the box from its closed form (D in LDS) and the textured
+    spectrum as Z -+ i box. Both the pair entry and the sequence entry, 1e-4 px against the oracle."""
+    n, grid, origin, stride, (h, w), k, const = {
+        "in_lds_118": (118, (3, 3), (4, 5), (76, 84), (294, 281), 68, (0, 120)),
+        "large_158": (158, (1, 2), (3, 2), (154, 169), (331, 166), 777, (1, 169)),
+        "large_146": (146, (1, 2), (4, 2), (53, 156), (308, 156), 634, (0, 84)),
+    }[case]
+    video, _ = synth.video_torch(2, h, w, "cpu", k=k)
+    video[const[0]] = const[1]
+    frames = video.numpy()
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=grid, origin=origin, stride=stride)
+    assert fm.kernel_variant == ("planned" if n <= 135 else "planned-large")
+    dv = video.to(gpu)
+    pair = fm.process_batch_device(dv[1:], dv[:-1]).cpu().numpy()[0]
+    seq = fm.process_sequence_device(dv).cpu().numpy()[0]
+    lay = O.fft_layout(w, h, n, grid[0], grid[1], origin, stride)
+    want64, _, diags = O.fft_process(frames[1], frames[0], lay, 64, want_diag=True)
+    want32, _ = O.fft_process(frames[1], frames[0], lay, 32)
+    checked = 0
+    for p in range(want64.shape[0]):
+        if not diags[p].second_value < 0.5 * diags[p].peak_value or np.abs(want64[p] - want32[p]).max() > 2e-5:
+            continue
+        checked += 1
+        assert np.abs(pair[p] - want64[p]).max() <= 1e-4, (case, p, pair[p], want64[p])
+        assert np.abs(seq[p] - want64[p]).max() <= 1e-4, (case, p, seq[p], want64[p])
+    assert checked >= want64.shape[0] - 1, (case, checked)
