@@ -49,6 +49,19 @@ __device__ __forceinline__ uint32_t fetch_px(const uint8_t* __restrict__ base, s
 
 }  // namespace
 
+// the planned kernel's arg-max as a sink of the inverse transform's last stage (pc_plan.hpp: stage_rt): line c, element y of the
+// Hermitian column-pair pass carries the surface values at (y, c) and (y, c + H)
+struct ScanSink {
+  static constexpr bool active = true;
+  Best* best;
+  int m, H;
+  __device__ __forceinline__ void operator()(int c, int y, cf v) const {
+    const int ys = y + H >= m ? y + H - m : y + H;
+    *best = better(*best, Best{v.x, ys * m + c + H});  // x = c < H -> shifted c + H
+    *best = better(*best, Best{v.y, ys * m + c});      // x = c + H -> shifted c
+  }
+};
+
 // MS > 0: the instantiation for ONE transform size, whose plan is a compile-time constant (pc_static_plan(MS) is what the host
 // builds for it; only n -- the unpadded size -- and the launch geometry stay run-time values): radices, strides, divisions and
 // loop counts fold away. MS = 0: the plan is read from the argument (sizes below 16, and the BGR / long-range / OpenCL-model
@@ -61,6 +74,9 @@ struct StaticPlanOf {
   static_assert(MS == 0 || P.threads > 0, "no static plan for this size");
 };
 
+#ifndef MOF_PLANNED_SCAN_FUSED  // 0: the arg-max as a sweep of its own (A/B)
+#define MOF_PLANNED_SCAN_FUSED 1
+#endif
 #ifndef MOF_GABL  // diagnostic builds (results wrong by design): 1 no transform passes, 2 no cross-power, 3 no arg-max scan, 4 no pixel loads,
                   // 5 no centroid tail, 6 no load phase at all, 7 none of 1-6 (what is left: launch, twiddles, barriers)
 #define MOF_GABL 0
@@ -340,6 +356,11 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   }
   __syncthreads();
 
+  // Compile-time plan, even M, cv::phaseCorrelate's peak model: the first maximum of the shifted surface (fftShift :1257-1323,
+  // minMaxLoc :1539) is taken from the registers of the inverse transform's last stage -- the separate sweep over the tile was 9 %
+  // of the kernel (p60, tools/ab_planned_phases.sh). Ties go to the smaller shifted index either way (better()).
+  constexpr bool SCAN_FUSED = MS > 0 && PK == 0 && (StaticPlanOf<MS>::P.m % 2 == 0) && MOF_PLANNED_SCAN_FUSED;
+  Best best = {-__builtin_huge_valf(), 0x7fffffff};
   // ---- inverse (unscaled, idft :1497) as forward transforms of conj C
   {
     int l0, nl;
@@ -347,7 +368,13 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
     if (nl > 0) run_pass(rows, l0, nl, false);
     __syncthreads();
     // herm: column pairs (c, c + H), z(y, c) = (S[y][c], S[y][c + H]); else z(y, x).x = S[y][x]
-    if (nl > 0) run_pass(cols, l0, nl, herm);
+    if constexpr (SCAN_FUSED) {
+      // the arg-max rides the last stage: line c, element y carries the surface values at (y, c) and (y, c + H)
+      if (nl > 0 && MOF_GABL != 1 && MOF_GABL != 7)
+        pass_lines_static<StaticPlanOf<MS>, 0, 1, ScanSink>(z, tw, cols, l0, nl, lane, herm, ScanSink{&best, m, H});
+    } else {
+      if (nl > 0) run_pass(cols, l0, nl, herm);
+    }
     __syncthreads();
   }
 
@@ -371,9 +398,8 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
 
   // ---- first maximum of the fft-shifted surface in row-major order (fftShift :1257-1323: index i -> (i + (m >> 1)) mod m for
   //      even and odd m alike; minMaxLoc :1539)
-  Best best = {-__builtin_huge_valf(), 0x7fffffff};
 #pragma clang loop unroll_count(UNR)
-  for (int y = wave; y < ((MOF_GABL == 3 || MOF_GABL == 7) ? 0 : m); y += WAVES) {
+  for (int y = wave; y < ((SCAN_FUSED || MOF_GABL == 3 || MOF_GABL == 7) ? 0 : m); y += WAVES) {
     const int ys = y + H >= m ? y + H - m : y + H;
 #pragma unroll 1
     for (int x = lane; x < m; x += 64) {

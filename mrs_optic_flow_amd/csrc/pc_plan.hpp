@@ -135,9 +135,16 @@ __device__ __forceinline__ void bfly_rt(int R, cf* v) {
 // division, R address computations and R - 1 twiddle reads from LDS per butterfly, stages as out-of-line functions per radix
 // (270 scratch accesses per wave for their call frames) -- issued 5383 VALU + 1561 SALU instructions per wave and patch
 // against the tuned kernel's 1412, with 61 % of its LDS cycles bank conflicts (profiles/r04_p62_planned_v1_sq_pmc.csv).
-template <int SLOTS>
+// Sink: what the LAST stage of a pass hands its outputs to besides the tile (line l, element o of the line, value): the planned
+// kernel's arg-max rides the final stage of the inverse transform that way instead of a sweep of its own over the tile.
+struct NoSink {
+  static constexpr bool active = false;
+  __device__ __forceinline__ void operator()(int, int, cf) const {}
+};
+
+template <int SLOTS, class Sink = NoSink>
 __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restrict__ tw, const Walk& w, int m, int R, int np, int bpl,
-                                         int tstep, int line0, int nlines, int lane, bool herm_first) {
+                                         int tstep, int line0, int nlines, int lane, bool herm_first, Sink sink = Sink{}) {
   constexpr int NB = 16 / SLOTS;  // butterflies per lane and group
   const int H = m >> 1;
   const float inv_np = 1.0f / (float)np;
@@ -209,6 +216,7 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
             if (p < R) {
               const int o = obase + p * np;
               z[loff[b] + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
+              if constexpr (Sink::active) sink(line0 + g0 + b * lpg + sub, o, v[b][p]);
             }
         }
       wave_sync();
@@ -327,13 +335,15 @@ __device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl
 // The same for a compile-time plan (SP::P a constexpr PcPlan): the stages are a compile-time recursion, so every radix, stride and
 // count reaches the stage routine as a constant (a `#pragma unroll` on the run-time loop is not honoured once the 16-slot bodies make
 // it large, and the radix dispatch then stays in the code).
-template <class SP, int S = 0, int NP = 1>
-__device__ __forceinline__ void pass_lines_static(cf* z, const cf* tw, const Walk& w, int line0, int nlines, int lane, bool herm) {
+template <class SP, int S = 0, int NP = 1, class Sink = NoSink>
+__device__ __forceinline__ void pass_lines_static(cf* z, const cf* tw, const Walk& w, int line0, int nlines, int lane, bool herm,
+                                                  Sink sink = Sink{}) {
   if constexpr (S < SP::P.n_stages) {
     constexpr int R = SP::P.radix[S], M = SP::P.m, REST = M / (NP * R);
     constexpr int SL = R > 8 ? 16 : (R > 4 ? 8 : 4);
-    stage_rt<SL>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm && S == 0);
-    pass_lines_static<SP, S + 1, NP * R>(z, tw, w, line0, nlines, lane, herm);
+    if constexpr (S + 1 == SP::P.n_stages) stage_rt<SL, Sink>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm && S == 0, sink);
+    else stage_rt<SL>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm && S == 0);
+    pass_lines_static<SP, S + 1, NP * R, Sink>(z, tw, w, line0, nlines, lane, herm, sink);
   }
 }
 
