@@ -62,6 +62,23 @@ struct ScanSink {
   }
 };
 
+// the conjugated normalised cross-power spectrum as the source of the inverse row pass (rows 1 .. H-1; row 0 holds the packed rows
+// 0 and H already): bin (v, u) from Z(v, u) and its partner Z(m - v, m - u) in the untouched lower half of the tile
+struct XpowSrc {
+  static constexpr bool active = true;
+  int m, H, pitch, skew_mask;
+  bool box_zeros;
+  __device__ __forceinline__ cf operator()(const cf* z, int v, int u) const {
+    const cf zk = lds_read(&z[v * pitch + u + ((u >> 3) & skew_mask)]);
+    if (v == 0) return zk;
+    const int um = u == 0 ? 0 : m - u;
+    const cf zm = lds_read(&z[(m - v) * pitch + um + ((um >> 3) & skew_mask)]);
+    cf C = cross_power<0>(zk, zm, false);
+    if (box_zeros && u == H) C = {0.f, 0.f};
+    return {C.x, -C.y};
+  }
+};
+
 // MS > 0: the instantiation for ONE transform size, whose plan is a compile-time constant (pc_static_plan(MS) is what the host
 // builds for it; only n -- the unpadded size -- and the launch geometry stay run-time values): radices, strides, divisions and
 // loop counts fold away. MS = 0: the plan is read from the argument (sizes below 16, and the BGR / long-range / OpenCL-model
@@ -74,6 +91,11 @@ struct StaticPlanOf {
   static_assert(MS == 0 || P.threads > 0, "no static plan for this size");
 };
 
+#ifndef MOF_PLANNED_XPOW_FUSED  // 1: the cross-power spectrum formed on the way into the inverse row pass (XpowSrc). Measured r04, same box:
+                                // SLOWER (p96 753 -> 689 k, p60 1.05 -> 1.03 M pairs/s): it puts the whole cross-power on the waves that own
+                                // the H inverse rows, the sweep of its own spreads it over every thread (as K1 found at N = 128)
+#define MOF_PLANNED_XPOW_FUSED 0
+#endif
 #ifndef MOF_PLANNED_SCAN_FUSED  // 0: the arg-max as a sweep of its own (A/B)
 #define MOF_PLANNED_SCAN_FUSED 1
 #endif
@@ -293,11 +315,15 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
     }
     return cross_power_ab<PK>(cf{2.f * A.x, 2.f * A.y}, cf{2.f * B.x, 2.f * B.y}, real_only);
   };
+  // Compile-time plan, even M, cv::phaseCorrelate's model, no closed-form box: rows 1 .. H-1 get their cross-power spectrum on the
+  // way INTO the inverse row pass (XpowSrc) -- one tile sweep (a write and a read of half the tile, its index arithmetic) less
+  constexpr bool XPOW_FUSABLE = MS > 0 && PK == 0 && (StaticPlanOf<MS>::P.m % 2 == 0) && MOF_PLANNED_XPOW_FUSED;
+  const bool xpow_fused = XPOW_FUSABLE && !one_box;
   if (MOF_GABL == 2 || MOF_GABL == 7) {
   } else if (herm) {
     // rows 1 .. H-1, every u: the partner (m - v, m - u) lies in the untouched lower half
     // (a counted loop: with a compile-time plan the trip count is a constant and UNR trips are in flight)
-    const int xtrips = ((H - 1) * m + T - 1) / T;
+    const int xtrips = xpow_fused ? 0 : ((H - 1) * m + T - 1) / T;
     if (!one_box) {  // (the hot loop keeps the packed form alone: the closed-form branch inside it cost 4 % on every pair)
 #pragma clang loop unroll_count(UNR)
       for (int k = 0; k < xtrips; ++k) {
@@ -365,7 +391,17 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   {
     int l0, nl;
     my_lines(herm ? H : m, &l0, &nl);
-    if (nl > 0) run_pass(rows, l0, nl, false);
+    if constexpr (XPOW_FUSABLE) {
+      if (xpow_fused) {
+        if (nl > 0 && MOF_GABL != 1 && MOF_GABL != 7)
+          pass_lines_static<StaticPlanOf<MS>, 0, 1, NoSink, XpowSrc>(z, tw, rows, l0, nl, lane, false, NoSink{},
+                                                                     XpowSrc{m, H, pl.pitch, pl.skew_mask, box_zeros});
+      } else if (nl > 0) {
+        run_pass(rows, l0, nl, false);
+      }
+    } else {
+      if (nl > 0) run_pass(rows, l0, nl, false);
+    }
     __syncthreads();
     // herm: column pairs (c, c + H), z(y, c) = (S[y][c], S[y][c + H]); else z(y, x).x = S[y][x]
     if constexpr (SCAN_FUSED) {

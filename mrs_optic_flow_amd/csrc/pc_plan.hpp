@@ -142,9 +142,16 @@ struct NoSink {
   __device__ __forceinline__ void operator()(int, int, cf) const {}
 };
 
-template <int SLOTS, class Sink = NoSink>
+// Src: where the FIRST stage of a pass takes its inputs from instead of the tile element (line l, element e): the planned kernel's
+// inverse row pass forms the conjugated cross-power spectrum on the way in that way instead of in a sweep of its own.
+struct NoSrc {
+  static constexpr bool active = false;
+  __device__ __forceinline__ cf operator()(const cf*, int, int) const { return cf{0.f, 0.f}; }
+};
+
+template <int SLOTS, class Sink = NoSink, class Src = NoSrc>
 __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restrict__ tw, const Walk& w, int m, int R, int np, int bpl,
-                                         int tstep, int line0, int nlines, int lane, bool herm_first, Sink sink = Sink{}) {
+                                         int tstep, int line0, int nlines, int lane, bool herm_first, Sink sink = Sink{}, Src src = Src{}) {
   constexpr int NB = 16 / SLOTS;  // butterflies per lane and group
   const int H = m >> 1;
   const float inv_np = 1.0f / (float)np;
@@ -190,7 +197,9 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
             if (j < R) {
               const int e = x + j * bpl;
               cf a;
-              if (herm_first) {
+              if constexpr (Src::active) {
+                a = src(z, l, e);
+              } else if (herm_first) {
                 const int r = e < H ? e : (e == H ? 0 : m - e);
                 const int ro = r * w.es + ((r >> 3) & w.emask);
                 const cf pp = lds_read(&z[loff[b] + ro]), c = lds_read(&z[l2off + ro]);  // tile (row r, col l) and (row r, col l + H)
@@ -244,7 +253,9 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
             if (j < R) {
               const int e = x + j * bpl;
               cf a;
-              if (herm_first) {
+              if constexpr (Src::active) {
+                a = src(z, l, e);
+              } else if (herm_first) {
                 const int r = e < H ? e : (e == H ? 0 : m - e);
                 const cf pp = lds_read(&z[w.at(l, r)]), c = lds_read(&z[w.at(l + H, r)]);
                 if (e == 0) a = {pp.x, c.x};
@@ -335,15 +346,17 @@ __device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl
 // The same for a compile-time plan (SP::P a constexpr PcPlan): the stages are a compile-time recursion, so every radix, stride and
 // count reaches the stage routine as a constant (a `#pragma unroll` on the run-time loop is not honoured once the 16-slot bodies make
 // it large, and the radix dispatch then stays in the code).
-template <class SP, int S = 0, int NP = 1, class Sink = NoSink>
+template <class SP, int S = 0, int NP = 1, class Sink = NoSink, class Src = NoSrc>
 __device__ __forceinline__ void pass_lines_static(cf* z, const cf* tw, const Walk& w, int line0, int nlines, int lane, bool herm,
-                                                  Sink sink = Sink{}) {
+                                                  Sink sink = Sink{}, Src src = Src{}) {
   if constexpr (S < SP::P.n_stages) {
     constexpr int R = SP::P.radix[S], M = SP::P.m, REST = M / (NP * R);
     constexpr int SL = R > 8 ? 16 : (R > 4 ? 8 : 4);
+    static_assert(SP::P.n_stages >= 2 || !(Sink::active && Src::active), "sink and source ride different stages");
     if constexpr (S + 1 == SP::P.n_stages) stage_rt<SL, Sink>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm && S == 0, sink);
-    else stage_rt<SL>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm && S == 0);
-    pass_lines_static<SP, S + 1, NP * R, Sink>(z, tw, w, line0, nlines, lane, herm, sink);
+    else if constexpr (S == 0) stage_rt<SL, NoSink, Src>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm, NoSink{}, src);
+    else stage_rt<SL>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, false);
+    pass_lines_static<SP, S + 1, NP * R, Sink, Src>(z, tw, w, line0, nlines, lane, herm, sink, src);
   }
 }
 
