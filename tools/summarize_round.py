@@ -32,6 +32,10 @@ FACTORS = {
     "sr_rows_inv_kernel": (2.0, "reads Dt once: 241*480*8 B per pair = 236.9 MB per 256-pair launch; FETCH_SIZE 118.59 MB = 0.50x"),
     # r03 (sequence pipeline, gpurun_out/prof_r03b_c5seq): known bytes per 512-frame pass
     "sr_rows_real_kernel": (2.0, "reads 480*480 B of u8 per frame = 118.0 MB per 512-frame launch; FETCH_SIZE 58.9 MB = 0.50x"),
+    # r04, the planned large-patch pipeline on l480 (512 pairs of ONE 480 x 480 patch per launch; profiles/r04_l480_pmc.csv)
+    "pcl_rows_kernel": (2.0, "reads 480*480 B of u8 per image = 235.9 MB per 1024-image launch; FETCH_SIZE 118.8 MB = 0.50x"),
+    "pcl_cols_kernel": (2.0, "reads the Zh of both images once: 2 * 925,440 B per pair = 947.6 MB per 512-pair launch; FETCH_SIZE 474.1 MB = 0.50x"),
+    "pcl_rows_inv_kernel": (2.0, "reads Dt once: 925,440 B per pair = 473.8 MB per 512-pair launch; FETCH_SIZE 237.1 MB = 0.50x"),
     "sr_cols_fused_kernel": (2.0, "r04, K56: every log-polar image comes from HBM once (TCC_HIT 96 %): 2*480*480 B per pair = 471.9 MB per 1024-pair "
                                   "launch; FETCH_SIZE 234.5 MB = 0.50x (profiles/r04_sr_fused_pmc.csv)"),
     "sr_cols_seq_kernel": (2.0, "reads 17 frames of Zh (925,440 B) per 16-pair run = 503.4 MB per 512-pair launch; FETCH_SIZE 251.5 MB = 0.50x"),
