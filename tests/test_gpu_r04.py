@@ -273,7 +273,7 @@ def test_patch_with_an_exactly_zero_spectral_bin(gpu):
     assert np.abs(got[p] - want64[p]).max() <= slack, (got[p], want64[p], slack)
 
 
-@pytest.mark.parametrize("case", ["in_lds_118", "large_158", "large_146"])
+@pytest.mark.parametrize("case", ["in_lds_118", "in_lds_124_odd", "large_158", "large_146"])
 def test_constant_frame_against_texture_on_padded_patches(gpu, case):
     """Found by tools/fft_sr_fuzz.py's sequence trials (seeds 101 / 202): ONE frame of the pair constant, patch size below its
     transform size. cv::phaseCorrelate pads the constant patch to an n x n box whose spectrum is level x D[v] D[u], exactly zero on
@@ -281,9 +281,11 @@ def test_constant_frame_against_texture_on_padded_patches(gpu, case):
     image differ by rounding and their alternating column sum is 79 x that instead of 0 -- 0.04 px off; L6 now zeroes those
     bins from L5's flags (box_zeros). (b) in-LDS planned kernel: the packed transform delivers the box with the textured
     patch's rounding noise on top -- 1e-3 px off; the kernel now takes the box from its closed form (D in LDS) and the textured
-    spectrum as Z -+ i box. Both the pair entry and the sequence entry, 1e-4 px against the oracle."""
+    spectrum as Z -+ i box (D summed in f64: 124 f32 additions lose 4e-4 of it, 1e-3 px on the 124 -> 125 case). Both the pair entry
+    and the sequence entry, 1e-4 px against the oracle (f32-limited patches: 1e-4 + 4 x the oracle-to-oracle distance)."""
     n, grid, origin, stride, (h, w), k, const = {
         "in_lds_118": (118, (3, 3), (4, 5), (76, 84), (294, 281), 68, (0, 120)),
+        "in_lds_124_odd": (124, (1, 2), (7, 8), (136, 123), (256, 136), 988, (0, 39)),  # pads to 125: no Nyquist lines, |box bin| = level everywhere
         "large_158": (158, (1, 2), (3, 2), (154, 169), (331, 166), 777, (1, 169)),
         "large_146": (146, (1, 2), (4, 2), (53, 156), (308, 156), 634, (0, 84)),
     }[case]
@@ -300,9 +302,12 @@ def test_constant_frame_against_texture_on_padded_patches(gpu, case):
     want32, _ = O.fft_process(frames[1], frames[0], lay, 32)
     checked = 0
     for p in range(want64.shape[0]):
-        if not diags[p].second_value < 0.5 * diags[p].peak_value or np.abs(want64[p] - want32[p]).max() > 2e-5:
+        if not diags[p].second_value < 0.5 * diags[p].peak_value:
             continue
+        dd = float(np.abs(want64[p] - want32[p]).max())  # (the f32-limited rule of test_gpu_generic.py::_compare)
+        slack = 1e-4 if dd <= 2e-5 else 1e-4 + 4.0 * dd
+        assert dd < 2e-4, (case, p, dd)
         checked += 1
-        assert np.abs(pair[p] - want64[p]).max() <= 1e-4, (case, p, pair[p], want64[p])
-        assert np.abs(seq[p] - want64[p]).max() <= 1e-4, (case, p, seq[p], want64[p])
+        assert np.abs(pair[p] - want64[p]).max() <= slack, (case, p, pair[p], want64[p], slack)
+        assert np.abs(seq[p] - want64[p]).max() <= slack, (case, p, seq[p], want64[p], slack)
     assert checked >= want64.shape[0] - 1, (case, checked)
