@@ -114,7 +114,8 @@ typedef struct mof_fft_engine mof_fft_engine;
  * centre (M / 2.0) live on the padded image, the gate compares with N / 2 (:1841-1842). Three kernel families serve this
  * (mof_fft_kernel_variant): hand-tuned instantiations for N = 32, 64, 120 (reference default), 128 ("stockham"); a run-time
  * planned kernel for every other N with M <= 135 ("planned", csrc/pc_kernel_generic.hip); a planned pipeline through HBM scratch
- * for larger patches up to M = 960 ("planned-large", csrc/pc_large_kernel.hip). mof_fft_create fails with MOF_ERR_UNSUPPORTED
+ * for larger patches up to M = 960 ("planned-large", csrc/pc_large_kernel.hip; unpadded patches of 240 / 256 / 480 pixels run the
+ * scale / rotation estimator's tuned transform kernels inside it). mof_fft_create fails with MOF_ERR_UNSUPPORTED
  * only beyond that, and for MOF_PEAK_OCL on sizes the reference's OpenCL branch cannot plan either (odd, not 5-smooth) or M > 135.
  * The large-patch pipeline owns scratch (three half-spectrum planes per patch pair of a pass); it grows with the first batch
  * that needs more -- never inside a HIP graph capture: run the largest batch once before capturing. */

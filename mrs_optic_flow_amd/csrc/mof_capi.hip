@@ -192,6 +192,12 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
   }
   if (e->scratch_used && e->scratch_stream != s && !capturing) HIP_TRY(hipStreamWaitEvent(s, e->scratch_ev, 0));
   const size_t zhf = mof::pcl_zh_floats(e->plan);
+  // Unpadded patches of 240 / 256 / 480 pixels (the reference's whole-frame fallback among them, FftMethod.cpp:1709-1716) are the
+  // scale / rotation estimator's transform sizes: its tuned K5s / K6s / K7 (sr_seq_kernel.hip, sr_kernel.hip) run instead of the planned
+  // L5 / L6 / L7 -- same Zh / Dt / candidate formats, 2.5 x faster; L8 (the FftMethod tail) stays. Gray and BGR8 frames alike (the
+  // latter promise the gray path's bits); the long-range mode keeps the planned kernels. MOF_FFT_LARGE_TUNED=0: planned kernels (A/B).
+  static const bool tuned_on = [] { const char* v = getenv("MOF_FFT_LARGE_TUNED"); return !v || atoi(v) != 0; }();
+  const bool tuned = tuned_on && a.downscale == 1 && e->plan.m == e->plan.n && (e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 480);
   const int per_pass = e->cap / patches;
   for (int k0 = 0; k0 < n_pairs; k0 += per_pass) {
     const int np = n_pairs - k0 < per_pass ? n_pairs - k0 : per_pass, nq = np * patches;
@@ -216,10 +222,20 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
       mof::PclSrc sj = src;
       sj.base[0] += (size_t)j0 * a.cur_stride;
       sj.base[1] += (size_t)j0 * a.prev_stride;
-      HIP_TRY(mof::launch_pcl_rows(sj, e->plan, e->d_twiddles, e->d_zh + (size_t)2 * j0 * patches * zhf, zhf,
-                                   e->d_flags + (size_t)2 * j0 * patches, 2 * nj * patches, a.channels, a.downscale, s));
+      if (tuned)
+        HIP_TRY(mof::launch_sr_rows_real_src(sj, e->d_twiddles, e->d_zh + (size_t)2 * j0 * patches * zhf, zhf,
+                                             e->d_flags + (size_t)2 * j0 * patches, e->plan.m, 2 * nj * patches, a.channels, s));
+      else
+        HIP_TRY(mof::launch_pcl_rows(sj, e->plan, e->d_twiddles, e->d_zh + (size_t)2 * j0 * patches * zhf, zhf,
+                                     e->d_flags + (size_t)2 * j0 * patches, 2 * nj * patches, a.channels, a.downscale, s));
     }
-    HIP_TRY(mof::launch_pcl_cols(e->d_zh + zhf, e->d_zh, 2 * zhf, e->plan, e->d_twiddles, e->d_dt, e->d_cdc, e->d_flags, nq, s));
+    if (tuned) {
+      HIP_TRY(mof::launch_sr_cols_seq(e->d_zh + zhf, e->d_zh, 2 * zhf, e->d_twiddles, e->d_dt, e->plan.m, nq, 1, s));
+      HIP_TRY(mof::launch_pcl_cdc(e->d_zh + zhf, e->d_zh, 2 * zhf, e->plan.m, e->d_cdc, nq, s));
+      HIP_TRY(mof::launch_sr_rows_inv(e->d_dt, e->d_twiddles, e->d_cand, e->plan.m, nq, s));
+    } else {
+      HIP_TRY(mof::launch_pcl_cols(e->d_zh + zhf, e->d_zh, 2 * zhf, e->plan, e->d_twiddles, e->d_dt, e->d_cdc, e->d_flags, nq, s));
+    }
     mof::PclFinal f{};
     f.Dt = e->d_dt;
     f.cand = e->d_cand;
@@ -229,7 +245,7 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
     f.out = a.out + (size_t)k0 * patches * 2;
     f.flags = e->d_flags;
     f.cdc = e->d_cdc;
-    HIP_TRY(mof::launch_pcl_peak(f, e->plan, nq, s));
+    HIP_TRY(mof::launch_pcl_peak(f, e->plan, nq, s, tuned));
   }
   if (!capturing) {
     HIP_TRY(hipEventRecord(e->scratch_ev, s));

@@ -85,7 +85,9 @@ hipError_t launch_pcl_rows(const PclSrc& src, const PcPlan& pl, const float* twi
 hipError_t launch_pcl_cols(const float* zh_prev, const float* zh_cur, size_t zh_stride, const PcPlan& pl, const float* twiddles,
                            float* Dt, float* cdc, const int* flags, int n_pairs, hipStream_t stream);
 // L7 + L8 (a.Dt, a.cand, a.twiddles, a.mode, a.out [, a.M_log | a.max_px_speed_sq, a.flags, a.cdc])
-hipError_t launch_pcl_peak(const PclFinal& a, const PcPlan& pl, int n_pairs, hipStream_t stream);
+hipError_t launch_pcl_peak(const PclFinal& a, const PcPlan& pl, int n_pairs, hipStream_t stream, bool candidates_done = false);
+// C_dc of every pair from its row spectra (for pipelines whose column kernel does not hand it out)
+hipError_t launch_pcl_cdc(const float* zh_prev, const float* zh_cur, size_t zh_stride, int m, float* cdc, int n_pairs, hipStream_t stream);
 
 bool pc_patch_size_supported(int n);  // the hand-tuned instantiations: 32, 64, 120, 128
 const char* pc_kernel_variant(int patch_size);
@@ -199,6 +201,11 @@ hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float*
                                int n_frames, hipStream_t stream);
 // K6s: pair p = (cur: zh_cur + p * zh_stride, prev: zh_prev + p * zh_stride) -> Dt[p]; `run` > 1 lets one wave walk that
 // many consecutive pairs re-using cur(p) as prev(p + 1) -- only valid when zh_cur == zh_prev + zh_stride (a sequence)
+// K5s on patches of frames (FftMethod patches of 240 / 256 / 480 pixels) and K7 alone: the tuned transforms under the FFT engine's
+// large-patch pipeline; flags as launch_pcl_rows
+hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, float* zh, size_t zh_stride, int* flags, int res, int n_images,
+                                   int channels, hipStream_t stream);
+hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* cand, int res, int n_pairs, hipStream_t stream);
 hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* twiddles, float* Dt, int res,
                               int n_pairs, int run, hipStream_t stream);
 // K56 (sr_fused_kernel.hip): K5s + K6s in one kernel, the row transforms as a dense product on the matrix cores -- reads the u8

@@ -191,6 +191,26 @@ __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict
   for (int v = lane; v < m; v += 64) D[v] = z[sk(v)];
 }
 
+// C_dc of a pair from the row spectra alone (the tuned K6s does not hand it out): the 2-D DC bins are the sums of line u = 0
+// (exact integers 2 x row sum each; summed in f64), and the DC slot is real-only (pc_common.hpp)
+__global__ void __launch_bounds__(64) pcl_cdc_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur, size_t zh_stride, int m,
+                                                     float* __restrict__ cdc) {
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  const cf* c = reinterpret_cast<const cf*>(zh_cur + (size_t)pair * zh_stride);
+  const cf* p = reinterpret_cast<const cf*>(zh_prev + (size_t)pair * zh_stride);
+  double sc = 0.0, sp = 0.0;
+  for (int v = lane; v < m; v += 64) {
+    sc += (double)c[v].x;
+    sp += (double)p[v].x;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sc += __shfl_xor(sc, off, 64);
+    sp += __shfl_xor(sp, off, 64);
+  }
+  if (lane == 0) cdc[pair] = cross_power_ab(cf{(float)sc, 0.f}, cf{(float)sp, 0.f}, true).x;
+}
+
 // ---- L7 ------------------------------------------------------------------------------------------------------------------
 template <bool EXACT>
 __global__ void __launch_bounds__(PCL_T) pcl_rows_inv_kernel(const float* __restrict__ Dt, PcPlan pl, const float* __restrict__ twiddles,
@@ -456,7 +476,16 @@ hipError_t launch_pcl_cols(const float* zh_prev, const float* zh_cur, size_t zh_
   return hipGetLastError();
 }
 
-hipError_t launch_pcl_peak(const PclFinal& a_in, const PcPlan& pl, int n_pairs, hipStream_t stream) {
+hipError_t launch_pcl_cdc(const float* zh_prev, const float* zh_cur, size_t zh_stride, int m, float* cdc, int n_pairs, hipStream_t stream) {
+  for (int p0 = 0; p0 < n_pairs; p0 += 65535) {
+    const int np = n_pairs - p0 < 65535 ? n_pairs - p0 : 65535;
+    hipLaunchKernelGGL(pcl_cdc_kernel, dim3((unsigned)np), dim3(64), 0, stream, zh_prev + (size_t)p0 * zh_stride, zh_cur + (size_t)p0 * zh_stride,
+                       zh_stride, m, cdc + p0);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pcl_peak(const PclFinal& a_in, const PcPlan& pl, int n_pairs, hipStream_t stream, bool candidates_done) {
   if (n_pairs <= 0) return hipSuccess;
   const int line = pcl_line(pl.m), NU = (pl.m >> 1) + 1, n_cand = pcl_candidates(pl);
   const size_t lds = pcl_lds_bytes(pl.m);
@@ -474,7 +503,9 @@ hipError_t launch_pcl_peak(const PclFinal& a_in, const PcPlan& pl, int n_pairs, 
     a.out = a_in.out + (size_t)p0 * (a.mode == 0 ? 4 : 2);
     if (a.flags) a.flags = a_in.flags + 2 * (size_t)p0;
     if (a.cdc) a.cdc = a_in.cdc + p0;
-    if (ex)
+    if (candidates_done) {
+      // (L7 was run by somebody else: the tuned K7 for patches of 240 / 256 / 480 pixels)
+    } else if (ex)
       hipLaunchKernelGGL(pcl_rows_inv_kernel<true>, dim3((unsigned)n_cand, (unsigned)np), dim3(PCL_T), lds, stream, a.Dt, pl, a.twiddles,
                          const_cast<float2*>(a.cand), n_cand, line);
     else

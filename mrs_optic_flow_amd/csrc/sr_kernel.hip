@@ -860,6 +860,33 @@ hipError_t launch_sr_peak(const SrPcArgs& a, int res, int n_pairs, hipStream_t s
   }
 }
 
+// K7 alone (r04): Dt -> peak candidates, for the FFT engine's large patches of 240 / 256 / 480 pixels (pc_large_kernel.hip's L8 follows)
+template <int N>
+static hipError_t launch_sr_rows_inv_n(const SrPcArgs& a, int n_pairs, hipStream_t stream) {
+  for (int p0 = 0; p0 < n_pairs; p0 += 65535) {
+    const int np = n_pairs - p0 < 65535 ? n_pairs - p0 : 65535;
+    SrPcArgs b = a;
+    b.Dt = a.Dt + (size_t)p0 * (N / 2 + 1) * N * 2;
+    b.cand = a.cand + (size_t)p0 * a.n_cand;
+    hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3((N / 2) / SR_LINES, (unsigned)np), dim3(SR_T), 0, stream, b);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* cand, int res, int n_pairs, hipStream_t stream) {
+  if (n_pairs <= 0) return hipSuccess;
+  SrPcArgs a{};
+  a.Dt = const_cast<float*>(Dt);
+  a.twiddles = twiddles;
+  a.cand = cand;
+  a.n_cand = sr_candidates(res);
+  switch (res) {
+    case 240: return launch_sr_rows_inv_n<240>(a, n_pairs, stream);
+    case 256: return launch_sr_rows_inv_n<256>(a, n_pairs, stream);
+    case 480: return launch_sr_rows_inv_n<480>(a, n_pairs, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_sr_phase_correlate(const SrPcArgs& a, int res, int n_pairs, hipStream_t stream) {
   switch (res) {
     case 240: return launch_sr_pc_n<240>(a, n_pairs, stream);

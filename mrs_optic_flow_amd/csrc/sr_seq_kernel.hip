@@ -89,6 +89,83 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint
   }
 }
 
+// ---- K5s on PATCHES OF FRAMES (r04): FftMethod patches of 240 / 256 / 480 pixels -- the reference's whole-frame fallback
+// (FftMethod.cpp:1709-1716) among them -- are exactly this estimator's transform sizes, so the large-patch pipeline of the FFT
+// engine (pc_large_kernel.hip) hands them to the tuned K5s / K6s / K7 instead of its planned L5 / L6 / L7. The only difference
+// to sr_rows_real_kernel is where the pixels come from (image f = 2 (pair * patches + patch) + (0 cur | 1 prev), any row pitch,
+// gray or BGR8 through the node's CV_RGB2GRAY) and the constant-image flags the FFT tail wants (as pcl_rows_kernel sets them).
+template <int N, int CH>
+__global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc src, const float* __restrict__ twiddles,
+                                                                           float* __restrict__ zh, size_t zh_stride, int* __restrict__ flags) {
+  using P = SrPlan<N>;
+  using R = RowsReal<N>;
+  constexpr int H = N / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char rr_lds[];
+  cf* z = reinterpret_cast<cf*>(rr_lds);  // [LINES][LINE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, img = blockIdx.y, row0 = blockIdx.x * R::ROWS;
+  const int which = img & 1, q = img >> 1, patches = src.grid_x * src.grid_y;
+  const int pair = q / patches, pt = q - pair * patches, by = pt / src.grid_x, bx = pt - by * src.grid_x;
+  const uint8_t* base = src.base[which] + (size_t)pair * src.stride[which] + (size_t)(src.origin_y + by * src.stride_y) * src.pitch +
+                        (size_t)(CH * (src.origin_x + bx * src.stride_x));
+  SrTw<N> tw;
+  tw.load(twiddles, lane);
+  auto px4 = [&](int y, int d) -> uint32_t {  // pixels 4d .. 4d+3 of patch row y, one byte each
+    const uint8_t* r = base + (size_t)y * src.pitch + (size_t)CH * 4 * d;
+    if constexpr (CH == 1) {
+      uint32_t v;
+      __builtin_memcpy(&v, r, 4);  // (any alignment: the patch origin and the pitch are the caller's)
+      return v;
+    } else {
+      uint32_t v = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v |= rgb2gray_fixed(r[3 * b], r[3 * b + 1], r[3 * b + 2]) << (8 * b);
+      return v;
+    }
+  };
+  const uint32_t p00 = px4(0, 0) & 0xffu, pat = p00 * 0x01010101u;
+  uint32_t diff = 0u;
+  cf* mine = z + 4 * wave * P::LINE;
+  {
+    constexpr int ND = N / 4, NL = (4 * ND + 63) / 64;
+    uint32_t c[NL], p[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = lane + 64 * k;
+      if (i < 4 * ND) {
+        const int l = i / ND, d = i % ND, y = row0 + 8 * wave + 2 * l;
+        c[k] = px4(y, d);
+        p[k] = px4(y + 1, d);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = lane + 64 * k;
+      if (i < 4 * ND) {
+        const int l = i / ND, d = i % ND;
+        diff |= (c[k] ^ pat) | (p[k] ^ pat);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          mine[l * P::LINE + 4 * d + b] = {(float)((c[k] >> (8 * b)) & 0xffu), (float)((p[k] >> (8 * b)) & 0xffu)};
+      }
+    }
+  }
+  if (flags) {  // bit 0: some pixel differs from pixel (0, 0); bit 1: pixel (0, 0) is not zero (zeroed by the caller)
+    if (__builtin_amdgcn_ballot_w64(diff != 0u) != 0ull && lane == 0) atomicOr(&flags[img], 1);
+    if (blockIdx.x == 0 && tid == 0 && p00 != 0u) atomicOr(&flags[img], 2);
+  }
+  wave_sync();
+  wave_fft<N>(mine, 4, lane, tw, StoreNatural<N>{});
+  __syncthreads();
+  cf* out = reinterpret_cast<cf*>(zh + (size_t)img * zh_stride) + row0;
+  for (int i = tid; i < R::LINES * (H + 1); i += R::T) {
+    const int u = i / R::LINES, j = i % R::LINES;
+    const cf zk = z[j * P::LINE + u], zm = z[j * P::LINE + (N - u) % N];
+    cf a2, b2;
+    untangle2(zk, zm, &a2, &b2);
+    stream_store(reinterpret_cast<float4*>(out + (size_t)u * N + 2 * j), make_float4(a2.x, a2.y, b2.x, b2.y));
+  }
+}
+
 // ---- K6s: column transforms + cross-power + inverse columns, one wave walking a run of pairs -------------------------
 #ifndef MOF_SEQ_CW
 #define MOF_SEQ_CW 4
@@ -204,6 +281,33 @@ hipError_t launch_rows_real_n(const uint8_t* lp, size_t lp_stride, const float* 
 }
 
 template <int N>
+hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh, size_t zh_stride, int* flags, int n_images, int channels,
+                                  hipStream_t stream) {
+  using R = RowsReal<N>;
+  constexpr size_t lds = sizeof(cf) * R::LINES * SrPlan<N>::LINE;
+  const void* f = channels == 3 ? reinterpret_cast<const void*>(&sr_rows_real_src_kernel<N, 3>) : reinterpret_cast<const void*>(&sr_rows_real_src_kernel<N, 1>);
+  if (lds > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  for (int f0 = 0; f0 < n_images; f0 += 65534) {  // (the image index rides gridDim.y; even chunks keep cur | prev pairs together)
+    const int nf = n_images - f0 < 65534 ? n_images - f0 : 65534;
+    PclSrc s = src;
+    const int patches = src.grid_x * src.grid_y;
+    if (f0 % (2 * patches) != 0) return hipErrorInvalidValue;  // (the caller splits at whole frame pairs: mof_capi.hip)
+    s.base[0] += (size_t)(f0 / (2 * patches)) * src.stride[0];
+    s.base[1] += (size_t)(f0 / (2 * patches)) * src.stride[1];
+    if (channels == 3)
+      hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3>), dim3(N / R::ROWS, (unsigned)nf), dim3(R::T), lds, stream, s, tw,
+                         zh + (size_t)f0 * zh_stride, zh_stride, flags ? flags + f0 : nullptr);
+    else
+      hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 1>), dim3(N / R::ROWS, (unsigned)nf), dim3(R::T), lds, stream, s, tw,
+                         zh + (size_t)f0 * zh_stride, zh_stride, flags ? flags + f0 : nullptr);
+  }
+  return hipGetLastError();
+}
+
+template <int N>
 hipError_t launch_cols_seq_n(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* tw, float* Dt, int n_pairs,
                              int run, hipStream_t stream) {
   constexpr int H = N / 2;
@@ -228,6 +332,18 @@ hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float*
     case 240: return launch_rows_real_n<240>(lp, lp_stride, twiddles, zh, zh_stride, n_frames, stream);
     case 256: return launch_rows_real_n<256>(lp, lp_stride, twiddles, zh, zh_stride, n_frames, stream);
     case 480: return launch_rows_real_n<480>(lp, lp_stride, twiddles, zh, zh_stride, n_frames, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, float* zh, size_t zh_stride, int* flags, int res, int n_images,
+                                   int channels, hipStream_t stream) {
+  if (n_images <= 0) return hipSuccess;
+  if (!src.paired || (channels != 1 && channels != 3)) return hipErrorInvalidValue;
+  switch (res) {
+    case 240: return launch_rows_real_src_n<240>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
+    case 256: return launch_rows_real_src_n<256>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
+    case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
     default: return hipErrorInvalidValue;
   }
 }

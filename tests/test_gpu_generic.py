@@ -180,12 +180,13 @@ def test_zz_f32_limited_patches_are_rare(gpu):
 
 
 # ---- patches too large for one CU (padded side > 135): the planned pipeline through HBM scratch (csrc/pc_large_kernel.hip) ----
-@pytest.mark.parametrize("n", [160, 136, 144, 150, 180, 192, 200, 240, 250, 148, 225, 243, 202, 480, 750, 810])  # (750, 810: one stage body per radix)
+@pytest.mark.parametrize("n", [160, 136, 144, 150, 180, 192, 200, 240, 250, 256, 148, 225, 243, 202, 480, 750, 810])  # (750, 810: one stage body per radix;
+                                                                                                               #  240 / 256 / 480: the estimator's tuned transforms)
 def test_large_patches_match_oracle(gpu, n):
-    gx, gy = (2, 2) if n <= 250 else (1, 1)
+    gx, gy = (2, 2) if n <= 256 else (1, 1)
     stride = (n + 5, n + 2)
     w, h = 3 + stride[0] * (gx - 1) + n + 4, 2 + stride[1] * (gy - 1) + n + 3
-    B = 5 if n <= 250 else (3 if n <= 480 else 2)
+    B = 5 if n <= 256 else (3 if n <= 480 else 2)
     cur, prev, shifts, kinds = synth.batch_np(B, h, w, min(n // 8, 24), k0=n)
     fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(3, 2), stride=stride)
     assert fm.kernel_variant == "planned-large"
@@ -304,3 +305,46 @@ def test_planned_kernel_run_time_form(gpu):
                         "-k", "every_size and (60 or 62 or 74 or 96 or 135 or 45)", "-p", "no:cacheprovider"], capture_output=True,
                        text=True, timeout=900, cwd=root, env=dict(os.environ, MOF_PLANNED_STATIC="0"))
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
+
+
+@pytest.mark.parametrize("n", [240, 256])
+def test_large_patches_of_the_estimators_sizes_front_ends(gpu, n):
+    """Unpadded patches of 240 / 256 / 480 pixels run the estimator's tuned K5s / K6s / K7 under the large-patch pipeline (mof_capi.hip,
+    launch_large): BGR8 frames give the gray path's bits there too, a video gives the pair entry's, a constant patch its closed form."""
+    gx, gy = 2, 1
+    w, h = 2 * n + 9, n + 6
+    rng = np.random.default_rng(n)
+    B = 3
+    bgr_c = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+    bgr_p = np.roll(bgr_c, (2, -3), axis=(1, 2))
+    bgr_p[1, 3:3 + n, 1:1 + n] = (40, 90, 200)  # pair 1, patch 0: a constant previous patch
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(1, 3), stride=(n + 5, 1))
+    got = fm.process_batch_device_bgr(torch.from_numpy(bgr_c).to(gpu), torch.from_numpy(bgr_p).to(gpu)).cpu().numpy()
+    gray_c = np.stack([O.rgb2gray(f) for f in bgr_c])
+    gray_p = np.stack([O.rgb2gray(f) for f in bgr_p])
+    same = fm.process_batch_device(torch.from_numpy(gray_c).to(gpu), torch.from_numpy(gray_p).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, same, equal_nan=True)
+    lay = O.fft_layout(w, h, n, gx, gy, (1, 3), (n + 5, 1))
+    for k in range(B):
+        want, _ = O.fft_process(gray_c[k], gray_p[k], lay, 64)
+        assert np.allclose(got[k], want, rtol=0, atol=2e-4, equal_nan=True), (k, got[k], want)  # (unrelated noise: no clear peak, see _compare)
+    video = np.stack([synth.pair_np(5 + n, h, w, 2 * t, -t, blur=True)[0] for t in range(4)])
+    seq = fm.process_sequence_device(torch.from_numpy(video).to(gpu)).cpu().numpy()
+    pairs = fm.process_batch_device(torch.from_numpy(video[1:]).to(gpu), torch.from_numpy(video[:-1]).to(gpu)).cpu().numpy()
+    assert np.array_equal(seq, pairs, equal_nan=True)
+    for k in range(3):
+        assert _compare(seq[k], video[k + 1], video[k], lay, f"tuned-large{n}/seq{k}") >= gx * gy - 1
+
+
+def test_large_patches_planned_kernels_at_the_estimators_sizes(gpu):
+    """MOF_FFT_LARGE_TUNED=0 keeps the planned L5 / L6 / L7 for 240 / 256 / 480 (the A/B form): a child process re-runs the large-patch
+    parity cases of those sizes with the knob."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MOF_FFT_LARGE_TUNED="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                          "large_patches_match_oracle and (240 or 256 or 480)", "-p", "no:cacheprovider"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout

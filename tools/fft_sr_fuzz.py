@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Random FftMethod layouts (ANY patch size since r04: the tuned 32 / 64 / 120 / 128, random sizes 8..200 incl. odd ones and
+"""Random FftMethod layouts (ANY patch size since r04: the tuned 32 / 64 / 120 / 128, the estimator's 240 / 256 under the large-patch
+pipeline, random sizes 8..200 incl. odd ones and
 ones that pad to an odd transform size, occasionally a large patch up to 300; any grid, origin, stride, frame size, batch
 classes) and random scale / rotation estimator settings (ANY even resolution 64..512, M, both OpenCV generations, both
 interpolations) through the GPU path against the oracle: shifts within 1e-4 px wherever the correlation surface has a stable
@@ -44,7 +45,7 @@ dev = torch.device("cuda")
 bad = checked = total = soft = unpinned = 0
 for trial in range(n_fft):
     r = rng.integers(0, 10)
-    n = int(rng.choice([32, 64, 64, 120, 128])) if r < 4 else (int(rng.integers(8, 201)) if r < 9 else int(rng.integers(136, 301)))
+    n = int(rng.choice([32, 64, 64, 120, 128, 240, 256])) if r < 4 else (int(rng.integers(8, 201)) if r < 9 else int(rng.integers(136, 301)))
     gx, gy = (int(rng.integers(1, 6)), int(rng.integers(1, 5))) if n <= 135 else (int(rng.integers(1, 3)), int(rng.integers(1, 3)))
     sx, sy = int(rng.integers(max(1, n // 3), n + 40)), int(rng.integers(max(1, n // 3), n + 40))
     ox, oy = int(rng.integers(0, 9)), int(rng.integers(0, 9))
@@ -126,7 +127,7 @@ print(f"sr: {n_sr} settings, mismatches {sr_bad}")
 #      the pair kernel on the two views) and mof_sr_process_sequence_device, against the oracle and the non-sequence entries
 seq_bad = seq_checked = 0
 for trial in range(max(4, n_fft // 4)):
-    n = int(rng.choice([32, 64, 64, 120, 128, 128])) if rng.integers(0, 2) else int(rng.integers(8, 180))
+    n = int(rng.choice([32, 64, 64, 120, 128, 128, 240, 256])) if rng.integers(0, 2) else int(rng.integers(8, 180))
     gx, gy = (int(rng.integers(1, 4)), int(rng.integers(1, 4))) if n <= 135 else (1, int(rng.integers(1, 3)))
     sx, sy = int(rng.integers(max(1, n // 3), n + 30)), int(rng.integers(max(1, n // 3), n + 30))
     ox, oy = int(rng.integers(0, 9)), int(rng.integers(0, 9))
