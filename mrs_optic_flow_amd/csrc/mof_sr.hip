@@ -317,10 +317,11 @@ hipError_t rows_real(const mof_sr_engine* e, const uint8_t* lp, size_t lp_stride
   return mof::launch_pcl_rows(src, e->plan, e->d_twiddles, zh, zh_stride, nullptr, n_frames, 1, 1, s);
 }
 // K56: K5s + K6s in one kernel on the u8 log-polar images (MOF_SR_FUSED, tuned resolutions)
-bool use_fused(const mof_sr_engine* e) {
+bool fused_requested() {
   static const bool on = [] { const char* v = getenv("MOF_SR_FUSED"); return v && atoi(v) != 0; }();
-  return on && e->d_wfrag != nullptr;
+  return on;
 }
+bool use_fused(const mof_sr_engine* e) { return e->d_wfrag != nullptr; }  // (the fragments exist only when the knob was set at create)
 hipError_t cols_fused(const mof_sr_engine* e, const uint8_t* lp_prev, const uint8_t* lp_cur, size_t lp_stride, int n_pairs, int run, hipStream_t s) {
   return mof::launch_sr_cols_fused(lp_prev, lp_cur, lp_stride, e->d_wfrag, e->d_twiddles, e->d_Dt, e->cfg.resolution, n_pairs, run, s);
 }
@@ -585,7 +586,7 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   }
   CREATE_TRY(hipMalloc(&e->d_twiddles, tw.size() * sizeof(float)));
   CREATE_TRY(mof::copy_on(e->stream, e->d_twiddles, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
-  if (!e->generic && mof::sr_fused_supported(res)) {
+  if (!e->generic && fused_requested() && mof::sr_fused_supported(res)) {  // (1 MB of f16 matrix fragments at 480: only for the opt-in path)
     const std::vector<uint32_t> fr = mof::sr_fused_fragments(res);
     CREATE_TRY(hipMalloc(&e->d_wfrag, fr.size() * sizeof(uint32_t)));
     CREATE_TRY(mof::copy_on(e->stream, e->d_wfrag, fr.data(), fr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
