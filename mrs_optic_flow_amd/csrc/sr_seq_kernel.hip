@@ -30,6 +30,9 @@ namespace {
 // ---- K5s: row half-spectra of one real image -------------------------------------------------------------------------
 // ROWS image rows per workgroup = ROWS / 2 packed lines, four lines per wave. The transposed store writes ROWS * 8
 // contiguous bytes per u.
+#ifndef MOF_K5S_ROTATE
+#define MOF_K5S_ROTATE 1
+#endif
 template <int N>
 struct RowsReal {
   static constexpr int ROWS = (N % 32 == 0) ? 32 : 16;
@@ -69,9 +72,13 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint
       const int i = lane + 64 * k;
       if (i < 4 * ND) {
         const int l = i / ND, d = i % ND;
+        // (a lane's four pixels go out in the order rotated by d / 4: lanes 4 apart -- 32 B x 4 = one bank wrap -- would otherwise
+        //  hit the same bank with every one of their four stores: 38 % of this kernel's LDS cycles were conflicts, r04 counters)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          mine[l * P::LINE + 4 * d + q] = {(float)((c[k] >> (8 * q)) & 0xffu), (float)((p[k] >> (8 * q)) & 0xffu)};
+        for (int q = 0; q < 4; ++q) {
+          const int r = MOF_K5S_ROTATE ? (q + (d >> 2)) & 3 : q;
+          mine[l * P::LINE + 4 * d + r] = {(float)((c[k] >> (8 * r)) & 0xffu), (float)((p[k] >> (8 * r)) & 0xffu)};
+        }
       }
     }
   }
@@ -213,8 +220,11 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
     wave_fft<N>(z, CW, lane, tw, StoreNatural<N>{});
   };
 
+#ifndef MOF_K6S_ABLATE  // diagnostic build (results wrong by design): 1 = every wave reads pair 0's lines (L2 hits instead of HBM reads)
+#define MOF_K6S_ABLATE 0
+#endif
   cf ap[CW][MV];  // column spectra of the previous frame (doubled): 2 B[v][u]
-  load_cols(zh_prev + (size_t)p0 * zh_stride);
+  load_cols(zh_prev + (size_t)(MOF_K6S_ABLATE ? 0 : p0) * zh_stride);
 #pragma unroll
   for (int s = 0; s < CW; ++s)
 #pragma unroll
@@ -224,7 +234,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
     }
   wave_sync();
   for (int j = 0; j < np; ++j) {
-    load_cols(zh_cur + (size_t)(p0 + j) * zh_stride);
+    load_cols(zh_cur + (size_t)(MOF_K6S_ABLATE ? 0 : p0 + j) * zh_stride);
     // normalised cross-power spectrum of bins (v, u), conjugated in place; the current spectra move into the registers
 #pragma unroll
     for (int s = 0; s < CW; ++s) {
