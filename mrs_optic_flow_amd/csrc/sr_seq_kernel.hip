@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mof_kernels.h"
 #include "pc_common.hpp"
@@ -269,6 +270,136 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
   }
 }
 
+// ---- K6p: K6s with the radix-32 stage split over lane PAIRS (r04; N = 480 = 15 x 32) ----------------------------------------
+// K6s is bound by its own work at two waves per SIMD, not by HBM (every wave reading pair 0's lines from L2 instead: 595 -> 582 us;
+// VALU 33 %, LDS 38 %, 7.8 waves per CU -- profiles/r04_c5_sq_pmc.csv): four lines in LDS (16 KB) and 213 VGPRs per wave hold the
+// occupancy down, and each transform makes three LDS round trips (staging, exchange, natural-order output). Here a wave owns TWO
+// columns and a transform makes ONE round trip:
+//   forward:  lane (line, n2) loads x[32 n1 + n2] straight from HBM (256 contiguous bytes per line and load), radix 15 over n1,
+//             twiddle W480^{n2 k1}, -> LDS [line][k1][n2];  lane (line, k1, h) reads the 16 values n2 = 2 j + h, radix 16 over j,
+//             the odd half times W32^q, halves swapped with the partner lane (DPP quad_perm xor 1):
+//             X[k1 + 15 q] = E + O' in lane h = 0, X[k1 + 15 (q + 16)] = E - O' in lane h = 1      (16 bins = 32 VGPRs per lane)
+//   cross-power elementwise against the previous frame's spectra in the same layout (32 VGPRs);
+//   inverse:  halves swapped, s = c[q] + c[q + 16] (h = 0) | d = (c[q] - c[q + 16]) W32^q (h = 1), radix 16 over q -> t[m2 = 2 r + h],
+//             -> LDS [line][k1][m2];  lane (line, m2) reads k1 = 0..14, twiddle W480^{k1 m2} (the SAME per-lane table), radix 15:
+//             S[32 m1 + m2] -> Dt (256 contiguous bytes per line and store).
+// 8 KB of LDS and ~half the registers per wave: four waves per SIMD.
+#ifndef MOF_K6P_WPE
+#define MOF_K6P_WPE 3
+#endif
+template <int N>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MOF_K6P_WPE, MOF_K6P_WPE))) sr_cols_split_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur,
+                                                           size_t zh_stride, const float* __restrict__ twiddles,
+                                                           float* __restrict__ Dt, int n_pairs, int run) {
+  static_assert(N == 480, "15 x 32 only");
+  constexpr int H = N / 2, R1 = 15, Y2 = 34, LSZ = R1 * Y2;  // Y2 = 34: the pair lanes' 16-byte-apart reads of 15 rows hit distinct banks
+  typedef float v2f_t __attribute__((ext_vector_type(2)));
+  __shared__ cf x[2 * LSZ];
+  const int lane = threadIdx.x, u0 = blockIdx.x * 2, p0 = blockIdx.y * run;
+  const int np = n_pairs - p0 < run ? n_pairs - p0 : run;
+  const int l1 = lane >> 5, n2 = lane & 31;                                   // stage 1 / stage B: (line, n2 | m2)
+  const int k1 = ((lane & 31) >> 1) < R1 ? ((lane & 31) >> 1) : R1 - 1, h = lane & 1;  // stage 2 / stage A: (line l1, k1, half); the two
+  const bool on2 = ((lane & 31) >> 1) < R1;                                   // spare lanes of a line repeat k1 = 14 (finite numbers)
+  const int u1 = u0 + l1 > H ? H : u0 + l1;                                   // this lane's column (the tail group repeats u = H)
+  // (the 14 inter-stage twiddles W480^{n2 k} of a lane are re-read from the 3.8 KB table -- L1 hits -- at each of their three uses per
+  //  pair instead of living in 28 VGPRs: what separates this kernel from four waves per SIMD)
+  const float* twl = twiddles + 2 * n2;
+  auto twk = [&](int k) -> cf {
+    const float2 t = *reinterpret_cast<const float2*>(twl + 2 * (size_t)(n2 * (k - 1)));  // W_N^{n2 k} sits at index n2 k
+    return {t.x, t.y};
+  };
+  // W32^q = (cos(pi q / 16), -sin(pi q / 16))
+  const cf w32[16] = {{1.f, 0.f}, {0.98078528040323044913f, -0.19509032201612826785f}, {0.92387953251128675613f, -0.38268343236508977173f},
+                      {0.83146961230254523708f, -0.55557023301960222474f}, {0.70710678118654752440f, -0.70710678118654752440f},
+                      {0.55557023301960222474f, -0.83146961230254523708f}, {0.38268343236508977173f, -0.92387953251128675613f},
+                      {0.19509032201612826785f, -0.98078528040323044913f}, {0.f, -1.f}, {-0.19509032201612826785f, -0.98078528040323044913f},
+                      {-0.38268343236508977173f, -0.92387953251128675613f}, {-0.55557023301960222474f, -0.83146961230254523708f},
+                      {-0.70710678118654752440f, -0.70710678118654752440f}, {-0.83146961230254523708f, -0.55557023301960222474f},
+                      {-0.92387953251128675613f, -0.38268343236508977173f}, {-0.98078528040323044913f, -0.19509032201612826785f}};
+  auto swap1 = [](cf v) -> cf {  // the partner lane's value (lane ^ 1)
+    return {__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0xB1, 0xf, 0xf, true)),
+            __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.y), 0xB1, 0xf, 0xf, true))};
+  };
+  // column spectra of one frame's two lines: out[q] = X[k1 + 15 (q + 16 h)]. ONE instance of this code serves every frame (the loop
+  // below starts at the run's previous frame): a run walked in one launch and the same frames fed one at a time round identically.
+  auto forward = [&](const float* __restrict__ frame, cf* out) {
+    const cf* line = reinterpret_cast<const cf*>(frame) + (size_t)u1 * N + n2;
+    cf a[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) {
+      const v2f_t t = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(line + 32 * n1));
+      a[n1] = {t.x, t.y};
+    }
+    butterfly15(a);
+    cf* row = x + l1 * LSZ + n2;
+    row[0] = a[0];
+#pragma unroll
+    for (int k = 1; k < R1; ++k) row[k * Y2] = cmul(a[k], twk(k));
+    wave_sync();
+    const cf* src = x + l1 * LSZ + k1 * Y2 + h;
+    cf e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[j] = lds_read(&src[2 * j]);
+    butterfly<16>(e);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const cf o = h ? cmul(e[q], w32[q]) : e[q];  // the odd half carries W32^q
+      const cf r = swap1(o);
+      out[q] = h ? csub(r, o) : cadd(o, r);        // h = 0: E + O';  h = 1: E - O'
+    }
+    wave_sync();  // (the exchange buffer is reused)
+  };
+
+  cf ap[16], ac[16];
+#pragma unroll 1
+  for (int j = -1; j < np; ++j) {
+    forward(j < 0 ? zh_prev + (size_t)p0 * zh_stride : zh_cur + (size_t)(p0 + j) * zh_stride, ac);
+    if (j < 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ap[q] = ac[q];
+      continue;
+    }
+    // normalised cross-power spectrum of bins (v = k1 + 15 (q + 16 h), u), conjugated; the current spectra become the previous ones
+    const bool u_edge = u1 == 0 || u1 == H;
+    cf c[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int v = k1 + 15 * (q + 16 * h);
+      const cf C = cross_power_ab(ac[q], ap[q], u_edge && (v == 0 || v == H));
+      ap[q] = ac[q];
+      c[q] = {C.x, -C.y};
+    }
+    // inverse (a forward transform of conj C): stage A on the lane pair, exchange, stage B
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const cf r = swap1(c[q]);
+      c[q] = h ? cmul(csub(r, c[q]), w32[q]) : cadd(c[q], r);  // h = 1 holds c[q + 16], its partner c[q]
+    }
+    butterfly<16>(c);  // c[r] = t[m2 = 2 r + h]
+    if (on2) {
+      cf* dst = x + l1 * LSZ + k1 * Y2 + h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[2 * r] = c[r];
+    }
+    wave_sync();
+    const cf* col = x + l1 * LSZ + n2;
+    cf b[R1];
+    b[0] = lds_read(&col[0]);
+#pragma unroll
+    for (int k = 1; k < R1; ++k) b[k] = cmul(lds_read(&col[k * Y2]), twk(k));
+    butterfly15(b);
+    if (u0 + l1 <= H) {
+      cf* D = reinterpret_cast<cf*>(Dt) + ((size_t)(p0 + j) * (H + 1) + (u0 + l1)) * N + n2;
+#pragma unroll
+      for (int m1 = 0; m1 < R1; ++m1) {
+        const v2f_t t = {b[m1].x, b[m1].y};
+        __builtin_nontemporal_store(t, reinterpret_cast<v2f_t*>(D + 32 * m1));
+      }
+    }
+    wave_sync();
+  }
+}
+
 // what processImage returns for the very first frame of a sequence (scaleRotationEstimator.cpp:74): (1, 0), no pt
 __global__ void sr_identity_kernel(double* __restrict__ out) {
   if (threadIdx.x < 4) out[threadIdx.x] = threadIdx.x == 0 ? 1.0 : 0.0;
@@ -322,6 +453,14 @@ hipError_t launch_cols_seq_n(const float* zh_prev, const float* zh_cur, size_t z
                              int run, hipStream_t stream) {
   constexpr int H = N / 2;
   const unsigned groups = (H + 1 + SEQ_CW - 1) / SEQ_CW, runs = (unsigned)((n_pairs + run - 1) / run);
+  if constexpr (N == 480) {
+    // MOF_SR_COLS_SPLIT=1: K6p, two columns per wave and the radix-32 stage on lane pairs
+    static const bool split = [] { const char* v = getenv("MOF_SR_COLS_SPLIT"); return v && atoi(v) != 0; }();
+    if (split) {
+      hipLaunchKernelGGL(sr_cols_split_kernel<N>, dim3((H + 2) / 2, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(sr_cols_seq_kernel<N>, dim3(groups, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run);
   return hipGetLastError();
 }

@@ -311,3 +311,17 @@ def test_constant_frame_against_texture_on_padded_patches(gpu, case):
         assert np.abs(pair[p] - want64[p]).max() <= slack, (case, p, pair[p], want64[p], slack)
         assert np.abs(seq[p] - want64[p]).max() <= slack, (case, p, seq[p], want64[p], slack)
     assert checked >= want64.shape[0] - 1, (case, checked)
+
+
+def test_split_lane_column_kernel_passes_the_estimator_parity_tests(gpu):
+    """K6p (sr_seq_kernel.hip: sr_cols_split_kernel, MOF_SR_COLS_SPLIT=1, resolution 480): two columns per wave, the radix-32 stage of a
+    column transform split over lane pairs, one LDS round trip per transform, three waves per SIMD -- 558 against 585 us per 1024 pairs,
+    c5 unchanged within the noise (profiles/r04_k6p_ab.txt), so it is an opt-in form. A child process re-runs the estimator's parity
+    tests with the knob, incl. the bit-identity of a sequence with its frame-by-frame stateful calls."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOF_SR_COLS_SPLIT="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_sr.py"),
+                          os.path.join(root, "tests", "test_gpu_sr_sequence.py"), "-q", "-x", "-m", "gpu", "-k", "480 or golden or batch",
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
