@@ -15,9 +15,13 @@ template <int N>
 struct SrPlan;
 // LINE = complex elements per line buffer: >= R1 * Y2 (the padded stage-1 output), odd so that the 8 lines of a
 // workgroup start on different banks; Y2 = row pitch of the stage-1 output (R2 + 1: stride-Y2 reads hit distinct banks)
+#ifndef MOF_SR_LINE480  // (A/B: tools/ab_sr_line.sh)
+#define MOF_SR_LINE480 497
+#endif
 template <>
 struct SrPlan<480> {
-  static constexpr int R1 = 15, R2 = 32, Y2 = 33, LINE = 497;
+  static constexpr int R1 = 15, R2 = 32, Y2 = 33, LINE = MOF_SR_LINE480;
+  static_assert(LINE >= R1 * Y2, "the padded stage-1 output fits a line");
 };
 template <>
 struct SrPlan<240> {
