@@ -34,9 +34,12 @@ namespace {
 #ifndef MOF_K5S_ROTATE
 #define MOF_K5S_ROTATE 1
 #endif
+#ifndef MOF_K5S_ROWS32  // 32 image rows per workgroup where N allows (256-byte segments of the transposed store); 0: 16 rows (more workgroups per CU)
+#define MOF_K5S_ROWS32 1
+#endif
 template <int N>
 struct RowsReal {
-  static constexpr int ROWS = (N % 32 == 0) ? 32 : 16;
+  static constexpr int ROWS = (N % 32 == 0 && MOF_K5S_ROWS32) ? 32 : 16;
   static constexpr int LINES = ROWS / 2;
   static constexpr int T = LINES * 16;
 };
