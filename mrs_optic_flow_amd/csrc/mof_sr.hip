@@ -568,6 +568,9 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   if (!sbc.empty()) {
     e->sbox_dwords[0] = slds_c / 4;
     e->sbox_dwords[1] = slds_l / 4;
+    if (const char* v = getenv("MOF_SR_VERBOSE"); v && atoi(v) != 0)  // diagnostics: the staged remap's largest boxes (dwords)
+      fprintf(stderr, "mof_sr: res %d: largest super-tile box cubic %d, lanczos4 %d dwords; per-wave boxes %d / %d bytes\n", res, e->sbox_dwords[0],
+              e->sbox_dwords[1], lds_c, lds_l);
     CREATE_TRY(hipMalloc(&e->d_sboxes[0], sbc.size() * sizeof(mof::SrTileBox)));
     CREATE_TRY(mof::copy_on(e->stream, e->d_sboxes[0], sbc.data(), sbc.size() * sizeof(mof::SrTileBox), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&e->d_sboxes[1], sbl.size() * sizeof(mof::SrTileBox)));
