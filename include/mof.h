@@ -195,10 +195,11 @@ int mof_fft_sync(mof_fft_engine* e);
 /* ------------------------------------------------------------------------------------------ */
 /* Frame pairs are independent: a batch of B pairs is cut into contiguous shards of ceil(B / G) pairs, shard g is owned and
  * processed by device g (no data-path collective), and ONE all-gather of the per-rank result slabs (RCCL over xGMI) hands every
- * device the whole result. Native and single-process: one FftMethod engine and one HIP stream per device inside the group,
- * ncclCommInitAll + one in-place ncclAllGather per batch; RCCL is bound at run time on the first gather (dlopen of
- * librccl.so.1), so single-GPU hosts never load it. No reference counterpart (the reference is one synchronous call per frame
- * on one device); per device the work is exactly mof_fft_process_batch_device. */
+ * device the whole result. Native and single-process: one engine and one HIP stream per device inside the group,
+ * ncclCommInitAll (mof_shard_*_init_gather, explicit) + one in-place ncclAllGather per batch; RCCL is bound at run time by
+ * init_gather (dlopen of librccl.so.1), so single-GPU hosts never load it. No reference counterpart (the reference is one
+ * synchronous call per frame on one device); per device the work is exactly mof_fft_process_batch_device /
+ * mof_bm_process_batch_device. */
 
 /* The partition: shard `shard` of `n_shards` owns pairs [*first, *first + *count), slabs of ceil(n_pairs / n_shards) pairs,
  * the last one ragged (or empty). Pure host arithmetic, no device needed. */
@@ -206,17 +207,26 @@ int mof_shard_slab_pairs(int n_pairs, int n_shards); /* ceil(n_pairs / n_shards)
 int mof_shard_partition(int n_pairs, int n_shards, int shard, int* first, int* count);
 
 typedef struct mof_shard_fft mof_shard_fft;
-/* One engine of `cfg` per listed device (cfg->device is ignored; devices == NULL: 0 .. n_devices - 1). */
+/* One engine of `cfg` per listed device (cfg->device is ignored; devices == NULL: 0 .. n_devices - 1). A device may be listed
+ * once -- except under the rehearsal knob MOF_SHARD_SHARE_DEVICE=1 (environment; tests only), which admits several shards on one
+ * device so that the G > 1 slab arithmetic can run on a one-GPU box; such a group cannot gather (MOF_ERR_UNSUPPORTED).
+ * No entry point of the group changes the calling thread's current HIP device. */
 int mof_shard_fft_create(const mof_fft_config* cfg, const int* devices, int n_devices, mof_shard_fft** out);
 void mof_shard_fft_destroy(mof_shard_fft* g);
 int mof_shard_fft_devices(const mof_shard_fft* g);
 void* mof_shard_fft_stream(const mof_shard_fft* g, int shard); /* the hipStream_t shard's work is enqueued on */
+/* The gather's set-up, explicit and BLOCKING (~0.1 s): binds RCCL (dlopen of librccl.so.1) and builds one communicator per device
+ * (ncclCommInitAll). Call it once before the first batch with gather != 0; a batch that asks for the gather without it fails
+ * with MOF_ERR_NOT_INIT -- the asynchronous batch call never builds communicators itself. Idempotent. */
+int mof_shard_fft_init_gather(mof_shard_fft* g);
+int mof_shard_fft_gather_ready(const mof_shard_fft* g); /* 1 once init_gather succeeded */
 /* d_cur[g] / d_prev[g]: device g's OWN shard of the batch (its first pair at the pointer; strides and pitch as in
  * mof_fft_process_batch_device) -- frames are generated or loaded directly on the owning GPU. d_out[g]: on device g,
  * n_shards * mof_shard_slab_pairs(n_pairs, n_shards) * grid_x * grid_y * 2 doubles; pair k's vectors land at pair index k
  * (slabs are contiguous; the padding behind a ragged last shard is not written). gather != 0: after the all-gather every
  * d_out[g] holds all n_pairs results; gather == 0: each device holds only its own slab (at its place). Asynchronous: enqueued on
- * the group's per-device streams; mof_shard_fft_sync waits for all of them. */
+ * the group's per-device streams; mof_shard_fft_sync waits for all of them. Arguments are checked for every shard before
+ * anything is launched; if a later shard's launch fails, the shards already launched are waited for before the error returns. */
 int mof_shard_fft_process_batch_device(mof_shard_fft* g, const uint8_t* const* d_cur, size_t cur_stride,
                                        const uint8_t* const* d_prev, size_t prev_stride, size_t pitch, int n_pairs,
                                        double* const* d_out, int gather);
@@ -281,6 +291,28 @@ int mof_bm_process_batch_device_bgr(mof_bm_engine* e, const uint8_t* d_cur, size
 int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
                               size_t prev_stride, size_t pitch, int n_pairs, int8_t* dx, int8_t* dy, int8_t* mode);
 int mof_bm_sync(mof_bm_engine* e);
+
+/* The same group for the block matchers (BlockMethod / FastSpacedBMMethod): shard g runs mof_bm_process_batch_device on its
+ * pairs, and the per-block shifts AND the per-pair histogram modes -- the pair FastSpacedBMMethod returns,
+ * /root/reference/src/FastSpacedBMMethod_OCL.cpp:172-175 -- ride in ONE slab per rank ("BM mode vectors ride in the same slab",
+ * SURVEY section 8(e)), so one all-gather moves everything. A rank's slab, with sp = mof_shard_slab_pairs(n_pairs, n_shards) and
+ * blocks = grid_x * grid_y, is three planes of int8:
+ *     dx[sp][blocks] | dy[sp][blocks] | mode[sp][8]          (mode as in mof_bm_process_batch_device)
+ * padded to a multiple of 16 bytes = mof_shard_bm_slab_bytes(); d_out[g] holds n_shards such slabs, rank i's at byte i * slab.
+ * mof_shard_bm_locate gives the byte offsets of pair k's dx / dy / mode inside such a buffer. Everything else as the FFT group. */
+typedef struct mof_shard_bm mof_shard_bm;
+int mof_shard_bm_create(const mof_bm_config* cfg, const int* devices, int n_devices, mof_shard_bm** out);
+void mof_shard_bm_destroy(mof_shard_bm* g);
+int mof_shard_bm_devices(const mof_shard_bm* g);
+void* mof_shard_bm_stream(const mof_shard_bm* g, int shard);
+int mof_shard_bm_init_gather(mof_shard_bm* g);
+int mof_shard_bm_gather_ready(const mof_shard_bm* g);
+size_t mof_shard_bm_slab_bytes(const mof_shard_bm* g, int n_pairs); /* bytes of one rank's slab (0 for a null group) */
+int mof_shard_bm_locate(const mof_shard_bm* g, int n_pairs, int pair, size_t* dx_off, size_t* dy_off, size_t* mode_off);
+int mof_shard_bm_process_batch_device(mof_shard_bm* g, const uint8_t* const* d_cur, size_t cur_stride,
+                                      const uint8_t* const* d_prev, size_t prev_stride, size_t pitch, int n_pairs,
+                                      int8_t* const* d_out, int gather);
+int mof_shard_bm_sync(mof_shard_bm* g);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Scale / rotation estimator (scaleRotationEstimator, BASELINE config c5)                    */

@@ -171,10 +171,57 @@ class ShardedFftMethod {
                                                      d_out.data(), gather ? 1 : 0), "mof_shard_fft_process_batch_device");
   }
   void sync() { detail::check(mof_shard_fft_sync(group_), "mof_shard_fft_sync"); }
+  // The gather's set-up (RCCL bound, ncclCommInitAll): explicit and blocking, once, BEFORE the first process(.., gather = true) --
+  // the asynchronous batch call never builds communicators itself (it throws with MOF_ERR_NOT_INIT's text instead).
+  void initGather() { detail::check(mof_shard_fft_init_gather(group_), "mof_shard_fft_init_gather"); }
+  bool gatherReady() const { return mof_shard_fft_gather_ready(group_) != 0; }
 
  private:
   mof_fft_config cfg_{};
   mof_shard_fft* group_ = nullptr;
+};
+
+// The same for the block matchers (mof_shard_bm_*): per-block shifts and the per-pair histogram modes -- what
+// FastSpacedBMMethod::processImage returns, FastSpacedBMMethod_OCL.cpp:172-175 -- ride in one slab per device
+// (dx | dy | mode planes, include/mof.h), so one all-gather moves everything.
+class ShardedBlockMatcher {
+ public:
+  struct Where {  // byte offsets of one pair's results inside a device's result buffer
+    size_t dx, dy, mode;
+  };
+  ShardedBlockMatcher(const mof_bm_config& cfg, int n_devices, const std::vector<int>& devices = {}) : cfg_(cfg) {
+    if (!devices.empty() && (int)devices.size() != n_devices) throw std::runtime_error("ShardedBlockMatcher: one device per shard");
+    detail::check(mof_shard_bm_create(&cfg_, devices.empty() ? nullptr : devices.data(), n_devices, &group_), "mof_shard_bm_create");
+  }
+  ~ShardedBlockMatcher() { mof_shard_bm_destroy(group_); }
+  ShardedBlockMatcher(const ShardedBlockMatcher&) = delete;
+  ShardedBlockMatcher& operator=(const ShardedBlockMatcher&) = delete;
+
+  int devices() const { return mof_shard_bm_devices(group_); }
+  void partition(int n_pairs, int shard, int* first, int* count) const {
+    detail::check(mof_shard_partition(n_pairs, devices(), shard, first, count), "mof_shard_partition");
+  }
+  // bytes every device's result buffer must hold: devices * (one rank's slab)
+  size_t resultBytes(int n_pairs) const { return (size_t)devices() * mof_shard_bm_slab_bytes(group_, n_pairs); }
+  Where locate(int n_pairs, int pair) const {
+    Where w{};
+    detail::check(mof_shard_bm_locate(group_, n_pairs, pair, &w.dx, &w.dy, &w.mode), "mof_shard_bm_locate");
+    return w;
+  }
+  void process(const std::vector<const uint8_t*>& d_cur, size_t cur_stride, const std::vector<const uint8_t*>& d_prev, size_t prev_stride,
+               size_t pitch, int n_pairs, const std::vector<int8_t*>& d_out, bool gather = true) {
+    if ((int)d_cur.size() != devices() || (int)d_prev.size() != devices() || (int)d_out.size() != devices())
+      throw std::runtime_error("ShardedBlockMatcher::process: one pointer per shard");
+    detail::check(mof_shard_bm_process_batch_device(group_, d_cur.data(), cur_stride, d_prev.data(), prev_stride, pitch, n_pairs,
+                                                    d_out.data(), gather ? 1 : 0), "mof_shard_bm_process_batch_device");
+  }
+  void sync() { detail::check(mof_shard_bm_sync(group_), "mof_shard_bm_sync"); }
+  void initGather() { detail::check(mof_shard_bm_init_gather(group_), "mof_shard_bm_init_gather"); }
+  bool gatherReady() const { return mof_shard_bm_gather_ready(group_) != 0; }
+
+ private:
+  mof_bm_config cfg_{};
+  mof_shard_bm* group_ = nullptr;
 };
 
 // Integer stage of both block matchers behind one engine.

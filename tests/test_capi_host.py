@@ -104,3 +104,10 @@ def test_shard_partition_is_the_contiguous_ceil_split():
     assert lib.mof_shard_partition(8, 4, 4, C.byref(f), C.byref(c)) == _capi.MOF_ERR_BAD_ARG
     assert lib.mof_shard_partition(-1, 4, 0, C.byref(f), C.byref(c)) == _capi.MOF_ERR_BAD_ARG
     assert lib.mof_shard_fft_devices(None) == 0 and lib.mof_shard_fft_sync(None) == _capi.MOF_ERR_NOT_INIT
+    # r05: the explicit gather set-up and the block-matching group, on null groups (no device needed)
+    assert lib.mof_shard_fft_init_gather(None) == _capi.MOF_ERR_NOT_INIT and lib.mof_shard_fft_gather_ready(None) == 0
+    assert lib.mof_shard_bm_devices(None) == 0 and lib.mof_shard_bm_sync(None) == _capi.MOF_ERR_NOT_INIT
+    assert lib.mof_shard_bm_init_gather(None) == _capi.MOF_ERR_NOT_INIT and lib.mof_shard_bm_slab_bytes(None, 8) == 0
+    assert lib.mof_shard_bm_locate(None, 8, 0, None, None, None) == _capi.MOF_ERR_NOT_INIT
+    h = C.c_void_p()
+    assert lib.mof_shard_bm_create(None, None, 2, C.byref(h)) == _capi.MOF_ERR_BAD_ARG and not h

@@ -77,9 +77,10 @@ def test_release_captured_of_one_engine_leaves_other_graphs_replayable(gpu):
 
 
 def test_native_sharded_entry_from_a_cpp_host(gpu):
-    """tests/cpp/test_shard.cpp: mof_shard_fft_* -- one process, one engine and stream per device, ceil(B / G) contiguous
-    shards, ONE in-place RCCL all-gather (ncclCommInitAll + ncclAllGather through the run-time-bound librccl) -- with the
-    devices this box has; every device's gathered result equals the single-engine result on the whole batch bit for bit."""
+    """tests/cpp/test_shard.cpp: mof_shard_fft_* and (r05) mof_shard_bm_* -- one process, one engine and stream per device,
+    ceil(B / G) contiguous shards, ONE in-place RCCL all-gather (explicit mof_shard_*_init_gather = ncclCommInitAll, then
+    ncclAllGather through the run-time-bound librccl) -- with the devices this box has; every device's gathered result equals the
+    single-engine result on the whole batch bit for bit (FFT vectors; block shifts and modes in one slab)."""
     binp = os.path.join(ROOT, "tests", "cpp", "test_shard")
     assert os.path.exists(binp), "tests/cpp/test_shard missing: run __graft_entry__.build()"
     for pairs in (37, 8):
@@ -107,6 +108,10 @@ def test_native_sharded_entry_through_ctypes(gpu):
             out = torch.full((B, 4, 2), float("nan"), dtype=torch.float64, device=gpu)
             pc, pp, po = (C.c_void_p * 1)(tc.data_ptr()), (C.c_void_p * 1)(tp.data_ptr()), (C.c_void_p * 1)(out.data_ptr())
             torch.cuda.synchronize()
+            if gather:  # r05: the gather's set-up is explicit -- the asynchronous call refuses to build communicators itself
+                assert lib.mof_shard_fft_process_batch_device(grp, pc, tc.stride(0), pp, tp.stride(0), tc.stride(1), B, po, 1) == _capi.MOF_ERR_NOT_INIT
+                _capi.check(lib.mof_shard_fft_init_gather(grp))
+                assert lib.mof_shard_fft_gather_ready(grp) == 1
             _capi.check(lib.mof_shard_fft_process_batch_device(grp, pc, tc.stride(0), pp, tp.stride(0), tc.stride(1), B, po, gather))
             _capi.check(lib.mof_shard_fft_sync(grp))
             assert torch.equal(out, want), gather

@@ -1,0 +1,66 @@
+"""Round-5 GPU tests: the native shard group with G > 1 on the one-GPU box (rehearsal knob), block matching through the shard group
+(dx, dy and mode in one slab), and the round's new kernel forms."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from mrs_optic_flow_amd import FastSpacedBMMethod, FftMethod, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("pairs,G", [(37, 2), (37, 4), (9, 4), (3, 4), (1, 2), (8, 2)])
+def test_shard_group_with_several_shards_on_one_device(gpu, pairs, G):
+    """`mof_shard_*_process_batch_device`'s G > 1 arithmetic -- slab i at i * slab, ragged last shards
+    (37 over 4 -> 10 10 10 7), empty ones (9 over 4 -> 3 3 3 0; 3 over 4 -> 1 1 1 0; 1 over 2) -- executed for real: the rehearsal knob
+    MOF_SHARD_SHARE_DEVICE=1 admits G shards on the one device with gather = 0, and tests/cpp/test_shard.cpp checks that every
+    slab lands at its place bit-equal to the single-engine call and that nothing else of the buffer is written -- FftMethod vectors,
+    and FastSpacedBMMethod's dx | dy | mode planes. The all-gather itself stays a 1-rank run (RCCL: one rank per device) until a
+    multi-GPU node exists; a shared-device group refuses it (checked inside)."""
+    binp = os.path.join(ROOT, "tests", "cpp", "test_shard")
+    assert os.path.exists(binp), "tests/cpp/test_shard missing: run __graft_entry__.build()"
+    r = subprocess.run([binp, "rehearse", str(pairs), str(G)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MOF_SHARD_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and f"rehearse ok {G} {pairs}" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_block_matching_shard_group_through_ctypes(gpu):
+    """mof_shard_bm_* from the ctypes binding on a one-device group, with the (1-rank) RCCL gather: per-block shifts and the
+    per-pair modes come back from ONE slab ("BM mode vectors ride in the same slab"), bit-equal to the engine's
+    own batch call."""
+    from mrs_optic_flow_amd import _capi
+
+    lib = _capi.load()
+    B, h, w = 7, 136, 200
+    cur, prev, _, _ = synth.batch_np(B, h, w, 5, k0=3)
+    bm = FastSpacedBMMethod(16, 8, 8, (h, w))
+    tc, tp = torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)
+    dx, dy, mode = bm.process_batch_device(tc, tp)
+    blocks = dx[0].numel()
+    grp = C.c_void_p()
+    _capi.check(lib.mof_shard_bm_create(C.byref(bm.cfg), None, 1, C.byref(grp)))
+    try:
+        slab = lib.mof_shard_bm_slab_bytes(grp, B)
+        assert slab % 16 == 0 and slab >= B * (2 * blocks + 8)
+        out = torch.full((slab,), -1, dtype=torch.int8, device=gpu)
+        pc, pp, po = (C.c_void_p * 1)(tc.data_ptr()), (C.c_void_p * 1)(tp.data_ptr()), (C.c_void_p * 1)(out.data_ptr())
+        torch.cuda.synchronize()
+        _capi.check(lib.mof_shard_bm_init_gather(grp))
+        _capi.check(lib.mof_shard_bm_process_batch_device(grp, pc, tc.stride(0), pp, tp.stride(0), tc.stride(1), B, po, 1))
+        _capi.check(lib.mof_shard_bm_sync(grp))
+        got = out.cpu().numpy()
+        for k in range(B):
+            ox, oy, om = C.c_size_t(), C.c_size_t(), C.c_size_t()
+            _capi.check(lib.mof_shard_bm_locate(grp, B, k, C.byref(ox), C.byref(oy), C.byref(om)))
+            assert np.array_equal(got[ox.value:ox.value + blocks], dx[k].cpu().numpy().ravel())
+            assert np.array_equal(got[oy.value:oy.value + blocks], dy[k].cpu().numpy().ravel())
+            assert np.array_equal(got[om.value:om.value + 8], mode[k].cpu().numpy().ravel())
+    finally:
+        lib.mof_shard_bm_destroy(grp)
