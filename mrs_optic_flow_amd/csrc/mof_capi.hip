@@ -120,6 +120,8 @@ struct mof_fft_engine {
   bool generic = false;          // patch sizes without a hand-tuned instantiation run the planned kernel (pc_kernel_generic.hip)
   bool large = false;            // ... or, when the padded patch does not fit a CU's LDS, the planned pipeline through HBM
   mof::PcPlan plan{};            //     scratch (pc_large_kernel.hip)
+  int half_m = 0;                // > 0: cv::phaseCorrelate-model batches on full-resolution frames run the fused half-tile kernel of that
+                                 //      transform size instead (pc_half_kernel.hip: even padded sizes in (135, 192]; MOF_FFT_HALF=1: tuned sizes too)
   // scratch of the large-patch pipeline, for `cap` patch pairs per pass: row half-spectra of 2 cap patches, Dt, peak
   // candidates, constant-patch flags, C_dc. Grown by a batch that needs more (never under a graph capture, never while pinned).
   float *d_zh = nullptr, *d_dt = nullptr, *d_cdc = nullptr;
@@ -258,6 +260,10 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
 // every K1 launch of an engine: the hand-tuned instantiation of its patch size, the planned general kernel, or -- for patches
 // too large for a CU -- the planned pipeline through HBM scratch. Returns a MOF status.
 static int launch_field(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hipStream_t stream) {
+  if (e->half_m > 0 && a.downscale == 1 && a.peak_model == 0) {  // (no scratch, nothing engine-owned but the twiddles)
+    HIP_TRY(mof::launch_pc_half(a, e->half_m, e->cfg.patch_size, n_pairs, stream));
+    return MOF_OK;
+  }
   if (e->large) return launch_large(e, a, n_pairs, stream);
   HIP_TRY(e->generic ? mof::launch_pc_generic(a, e->plan, n_pairs, stream) : mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, stream));
   return MOF_OK;
@@ -387,6 +393,14 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     }
   }
   const int n = (e->generic || e->large) ? e->plan.m : cfg->patch_size;  // transform size: the planned kernels work on the padded patch
+  {
+    // the fused half-tile kernel: the default for large patches whose half tile fits a CU (even padded size <= 192); MOF_FFT_HALF=0
+    // keeps them on the pipeline through HBM scratch, MOF_FFT_HALF=1 also routes the tuned / planned sizes it is instantiated for
+    // (64, 96, 120, 128) through it -- A/B and the parity tests of the formulation
+    static const int half_knob = [] { const char* v = getenv("MOF_FFT_HALF"); return v ? atoi(v) : -1; }();
+    if (cfg->peak_model == MOF_PEAK_OPENCV && mof::pc_half_supported(n) && half_knob != 0 && !force_large && (e->large || half_knob == 1))
+      e->half_m = n;
+  }
   // twiddles W_n^k = exp(-2 pi i k / n), double -> float, axis values exact
   std::vector<float> tw(2 * (size_t)n);
   for (int k = 0; k < n; ++k) {
@@ -425,6 +439,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   CREATE_TRY(hipMalloc(&e->d_out, res * sizeof(double)));
   CREATE_TRY(hipHostMalloc(&e->h_out, res * sizeof(double), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
+  if (e->half_m > 0) CREATE_TRY(mof::pc_configure_half());
   if (e->large) {
     CREATE_TRY(hipEventCreateWithFlags(&e->scratch_ev, hipEventDisableTiming));
     CREATE_TRY(large_alloc(e, cfg->grid_x * cfg->grid_y));  // one frame pair; a batch grows it to a whole pass
@@ -443,7 +458,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
 }
 
 const char* mof_fft_kernel_variant(const mof_fft_engine* e) {
-  return !e ? "" : (e->large ? "planned-large" : (e->generic ? "planned" : mof::pc_kernel_variant(e->cfg.patch_size)));
+  return !e ? "" : (e->half_m > 0 ? "planned-half" : (e->large ? "planned-large" : (e->generic ? "planned" : mof::pc_kernel_variant(e->cfg.patch_size))));
 }
 
 static void fft_destroy_now(void* p) {

@@ -89,6 +89,13 @@ hipError_t launch_pcl_peak(const PclFinal& a, const PcPlan& pl, int n_pairs, hip
 // C_dc of every pair from its row spectra (for pipelines whose column kernel does not hand it out)
 hipError_t launch_pcl_cdc(const float* zh_prev, const float* zh_cur, size_t zh_stride, int m, float* cdc, int n_pairs, hipStream_t stream);
 
+// ---- the fused kernel on a HALF-size tile (pc_half_kernel.hip): even padded sizes m in (135, 192] -- and 64 / 96 / 120 / 128 for A/B --,
+// cv::phaseCorrelate's model on full-resolution gray or BGR8 frames. m = padded transform size (a.twiddles: m entries), n = patch size
+bool pc_half_supported(int m);
+int pc_half_workgroups_per_cu(int m);
+hipError_t pc_configure_half();
+hipError_t launch_pc_half(const PcArgs& a, int m, int n, int n_pairs, hipStream_t stream);
+
 bool pc_patch_size_supported(int n);  // the hand-tuned instantiations: 32, 64, 120, 128
 const char* pc_kernel_variant(int patch_size);
 hipError_t pc_configure(int patch_size);  // once per device before the first launch

@@ -1,0 +1,574 @@
+// pc_half_kernel.hip -- K1h: the fused per-patch phase correlation on a HALF-size LDS tile, from compile-time plans.
+//
+// Serves the patch sizes whose padded transform size M = cv::getOptimalDFTSize(samplePointSize) is even and lies in (135, 192]
+// -- FftMethod takes any samplePointSize (/root/reference/src/FftMethod.cpp:1706-1720, :1829-1866) and every patch goes through
+// cv::phaseCorrelate (:1836) -- i.e. the sizes whose M x M COMPLEX tile (pc_kernel_generic.hip's packed z = cur + i prev) no longer
+// fits one CU's 160 KB of LDS but whose HALF tile does. Until r05 those ran the four-kernel pipeline through HBM scratch
+// (pc_large_kernel.hip): 3.5 x slower per pixel than the in-LDS kernels on either side of M = 135.
+//
+// The real formulation (the one pc_seq_half.hip uses for videos and pc_large_kernel.hip streams through HBM) never holds more
+// than M/2 x M complex values: each image is transformed on its own,
+//   rows    two real rows (2j, 2j+1) per complex line j  ->  1-D transforms along x  ->  untangle into the rows' half spectra
+//           u = 0 .. M/2-1 (the real bins u = 0 and u = M/2 of a row share its column 0), DOUBLED (the 1/2 rides in cross_power_ab)
+//   columns M/2 complex columns of length M (column 0 = the two real columns u = 0 | M/2, separated with the partner bin M - v)
+// the previous image's half spectrum waits in REGISTERS (each wave keeps the columns it owns) while the tile is reused for the
+// current image; then, per wave and with no workgroup barrier in between: forward columns of the current image -> normalised
+// cross-power spectrum against the registers, real-only-slot rule and all (pc_common.hpp; mulSpectrums :1494, magSpectrums
+// :70-168, divSpectrums :1086-1251) -> inverse columns; then Hermitian row PAIRS (2j, 2j+1) as one complex transform each, the
+// first maximum of the fft-shifted surface (fftShift :1257-1323, minMaxLoc :1539) riding the last stage's registers, and the
+// 5 x 5 fp64 centroid + gate (:1337-1383, :1838-1856) by one wave. Every 1-D transform is a planned Stockham chain run by ONE
+// wave on lines it owns (pc_plan.hpp: pass_lines_static; compile-time radices, two stages where the size allows).
+//
+// Tile layout (complex elements, P = pitch of a physical line, even):
+//   rows layout   line j, element x          at  j P + x + (x >> 3)                      [load, row passes, result surface]
+//   spec layout   logical row r, column u    at  r (P/2) + u + (u >> 3)                  [half spectra, column passes]
+// logical rows 2j | 2j+1 are the two halves of physical line j, so the untangle (rows -> spec) and the pairing (spec -> rows) are
+// in place per line and wave-local; a column walk is linear in r (stride P/2).
+// Zero padding (M > samplePointSize), constant patches (exact-zero spectra: `box_zeros`, the closed-form degenerate answer) as
+// pc_large_kernel.hip / pc_kernel_generic.hip handle them. cv::phaseCorrelate's peak model on gray or BGR8 frames; the long-range
+// mode and the OpenCL peak model of these sizes stay on the pipeline they had.
+// MOF_FFT_HALF=1 (diagnostics / A-B) also routes the tuned sizes 64, 96, 120, 128 through this kernel: at M = 120 / 128 TWO
+// workgroups fit a CU (the pair kernels' full tiles allow one).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "mof_kernels.h"
+#include "pc_common.hpp"
+#include "pc_plan.hpp"
+#include "pc_plan_build.hpp"
+
+namespace mof {
+
+namespace {
+
+// ---- the compile-time plan ------------------------------------------------------------------------------------------------
+struct HalfPlan {
+  PcPlan P{};    // m, n = m, n_stages, radix[]
+  int lpw = 0;   // lines per wave: row pairs, columns, row pairs again
+  int waves = 0;
+  int pitch = 0;
+  int skew = 0;  // 1: element x of a line sits at x + (x >> 3) (both layouts); 0 where only the unskewed tile fits (M = 192)
+  int lds_bytes = 0;
+  int wgs_per_cu = 0;
+  bool ok = false;
+};
+
+// LDS behind the tile: twiddles (m complex), 16 (value, index) slots, 16 flag words
+constexpr size_t half_extra(int m) { return sizeof(float) * 2 * (size_t)m + 16 * 8 + 64; }
+
+constexpr int half_stage_lines(int m, int R) {  // lines one group of a stage covers (pc_plan.hpp: stage_rt)
+  const int bpl = m / R, nb = 16 / pc_slots(R);
+  return bpl <= 64 ? nb * (64 / bpl) : 1;
+}
+
+#ifndef MOF_HALF_PITCH  // (A/B) force the pitch of every instantiation; 0 = the rule below
+#define MOF_HALF_PITCH 0
+#endif
+constexpr HalfPlan half_plan(int m) {
+  HalfPlan hp{};
+  if (m < 16 || m > 192 || (m & 1)) return hp;
+  PcPlan pl{};
+  if (!pc_line_plan_c(m, pl) || pl.m != m) return hp;  // 5-smooth sizes only (n = m); the generic radix chain as a start
+  int Ra = 0, Rb = 0;
+  if (pc_two_stage_chain(m, Ra, Rb)) {
+    pl.n_stages = 2;
+    pl.radix[0] = Ra;
+    pl.radix[1] = Rb;
+    for (int s = 2; s < 8; ++s) pl.radix[s] = 0;
+  } else {
+    // three stages a b c, c even (the exactness rule of pc_plan_build.hpp), the first split that exists
+    bool found = false;
+    for (int a = 16; a >= 2 && !found; --a) {
+      if (m % a != 0 || !pc_radix_ok(a)) continue;
+      for (int b = 16; b >= 2 && !found; --b) {
+        if ((m / a) % b != 0 || !pc_radix_ok(b)) continue;
+        const int c = m / a / b;
+        if (c < 2 || c > 16 || !pc_radix_ok(c) || (c & 1)) continue;
+        pl.n_stages = 3;
+        pl.radix[0] = a;
+        pl.radix[1] = b;
+        pl.radix[2] = c;
+        for (int s = 3; s < 8; ++s) pl.radix[s] = 0;
+        found = true;
+      }
+    }
+    // (else: the generic chain of pc_line_plan_c stays)
+  }
+  pl.radix_packed = 0;
+  for (int s = 0; s < pl.n_stages; ++s) pl.radix_packed |= (uint32_t)pl.radix[s] << (5 * s);
+  const int H = m / 2;
+  int g = 1 << 20;
+  for (int s = 0; s < pl.n_stages; ++s) {
+    const int gl = half_stage_lines(m, pl.radix[s]);
+    g = gl < g ? gl : g;
+  }
+  g = g > H ? H : g;
+  const int k = (H + g * 16 - 1) / (g * 16);
+  hp.lpw = g * k;
+  hp.waves = (H + hp.lpw - 1) / hp.lpw;
+  // pitch: even, room for both skews; P/2 = 4 (mod 8) spreads the rows of a column walk over the banks (8 rows x 4 columns per
+  // 32-lane read group) -- the first such pitch that still fits, else the smallest; without the skew where nothing else fits
+  const size_t cap = 160u * 1024u;
+  int p = 0, skew = 1;
+  for (; skew >= 0; --skew) {
+    int pmin = m + (skew ? ((m - 1) >> 3) : 0);
+    const int hmin = 2 * (H + (skew ? ((H - 1) >> 3) : 0));
+    pmin = pmin < hmin ? hmin : pmin;
+    pmin += pmin & 1;
+    p = pmin;
+    while ((p / 2) % 8 != 4) p += 2;
+    if ((size_t)H * p * 8 + half_extra(m) > cap) p = pmin;
+    if (MOF_HALF_PITCH > 0 && MOF_HALF_PITCH >= pmin && (MOF_HALF_PITCH & 1) == 0) p = MOF_HALF_PITCH;
+    if ((size_t)H * p * 8 + half_extra(m) <= cap) break;
+  }
+  if (skew < 0) return hp;
+  hp.skew = skew;
+  hp.pitch = p;
+  hp.lds_bytes = (int)((size_t)H * p * 8 + half_extra(m));
+  int wgs = (int)(cap / (size_t)hp.lds_bytes);
+  const int by_waves = 32 / hp.waves;
+  hp.wgs_per_cu = wgs < by_waves ? wgs : by_waves;
+  pl.threads = 64 * hp.waves;
+  pl.pitch = p;
+  pl.skew_mask = skew ? ~0 : 0;
+  pl.hermitian = 1;
+  pl.lds_bytes = hp.lds_bytes;
+  hp.P = pl;
+  hp.ok = true;
+  return hp;
+}
+
+template <int MS>
+struct HalfPlanOf {
+  static constexpr HalfPlan HP = half_plan(MS);
+  static constexpr PcPlan P = HP.P;  // (what pass_lines_static reads)
+  static_assert(HP.ok, "no half-tile plan for this size");
+  static constexpr int T = 64 * HP.waves;
+  // waves per SIMD the registers must allow: what the LDS lets sit on a CU, at most 4 (128 VGPRs)
+  static constexpr int WPE_ = (HP.wgs_per_cu * HP.waves + 3) / 4;
+  static constexpr int WPE = WPE_ < 1 ? 1 : (WPE_ > 4 ? 4 : WPE_);
+};
+
+// arg-max as the sink of the inverse row pass's last stage: line j, element x carries the surface at (2j, x) and (2j + 1, x)
+struct HalfScanSink {
+  static constexpr bool active = true;
+  Best* best;
+  int m, H;
+  __device__ __forceinline__ void operator()(int j, int x, cf v) const {
+    const int xs = x + H >= m ? x + H - m : x + H;
+    const int y1 = 2 * j, ys1 = y1 + H >= m ? y1 + H - m : y1 + H, ys2 = y1 + 1 + H >= m ? y1 + 1 + H - m : y1 + 1 + H;
+    *best = better(*best, Best{v.x, ys1 * m + xs});
+    *best = better(*best, Best{v.y, ys2 * m + xs});
+  }
+};
+
+#ifndef MOF_HABL  // diagnostic builds (results wrong by design): 1 no transform passes, 2 no cross-power, 3 no pixel loads
+#define MOF_HABL 0
+#endif
+
+template <int CH, int MS>
+__global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_half_kernel(PcArgs a, int n) {
+  using SP = HalfPlanOf<MS>;
+  constexpr HalfPlan HP = SP::HP;
+  constexpr int M = MS, H = M / 2, P = HP.pitch, P2 = P / 2, T = SP::T, WAVES = HP.waves, LPW = HP.lpw;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+  cf* z = reinterpret_cast<cf*>(smem_h);
+  cf* tw = z + (size_t)H * P;
+  Best* red = reinterpret_cast<Best*>(tw + M);
+  int* flags = reinterpret_cast<int*>(red + 16);  // [0] cur differs from its first pixel, [1] prev does, [2] C_dc bits, [3] / [4] first pixel of cur / prev
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  constexpr int SKM = HP.skew ? ~0 : 0;
+  auto rows_at = [&](int j, int x) -> int { return j * P + x + ((x >> 3) & SKM); };
+  auto spec_at = [&](int r, int u) -> int { return r * P2 + u + ((u >> 3) & SKM); };
+
+  // ---- patch origin (one workgroup per patch on a 3-D grid: column, row, pair)
+  const int px0 = a.origin_x + (int)blockIdx.x * a.stride_x, py0 = a.origin_y + (int)blockIdx.y * a.stride_y;
+  const size_t poff = (size_t)py0 * a.pitch + (size_t)(CH * px0);
+  const uint8_t* cur = a.cur + (size_t)blockIdx.z * a.cur_stride + poff;
+  const uint8_t* prev = a.prev + (size_t)blockIdx.z * a.prev_stride + poff;
+  const size_t p = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+
+  if (tid < 2) flags[tid] = 0;
+#pragma unroll 1
+  for (int k = tid; k < M; k += T) tw[k] = {a.twiddles[2 * k], a.twiddles[2 * k + 1]};
+  __syncthreads();  // flags zeroed, twiddles in place
+
+  // wave w owns lines [l0, l0 + nl): row pairs in the row passes, columns in the column passes
+  const int l0 = wave * LPW;
+  const int nl = H - l0 < 0 ? 0 : (H - l0 > LPW ? LPW : H - l0);
+  const Walk rows = {P, 1, 0, SKM, 0}, cols = {1, P2, SKM, 0, 1};
+
+  auto px_gray = [&](const uint8_t* q) -> uint32_t {  // four pixels -> four gray bytes
+    if constexpr (CH == 1) {
+      uint32_t w;
+      __builtin_memcpy(&w, q, 4);
+      return w;
+    } else {
+      uint32_t w[3];
+      __builtin_memcpy(w, q, 12);
+      uint32_t g = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = 3 * b;
+        const uint32_t c0 = (w[i >> 2] >> (8 * (i & 3))) & 0xffu, c1 = (w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xffu,
+                       c2 = (w[(i + 2) >> 2] >> (8 * ((i + 2) & 3))) & 0xffu;
+        g |= rgb2gray_fixed(c0, c1, c2) << (8 * b);
+      }
+      return g;
+    }
+  };
+  auto px_one = [&](const uint8_t* q) -> uint32_t {
+    if constexpr (CH == 1) return q[0];
+    else return rgb2gray_fixed(q[0], q[1], q[2]);
+  };
+
+  // ---- one image: pixels of the wave's lines -> LDS (u8 -> f32: convertTo, :1805-1806; zeros beyond n x n: copyMakeBorder of
+  //      cv::phaseCorrelate), row transforms, untangle into the spec layout. Wave-local throughout.
+  auto load_and_rows = [&](const uint8_t* img, int which) {
+    constexpr int CPR = (M + 3) / 4;                     // four-pixel chunks per row of the padded tile
+    constexpr int NCH = (LPW * CPR + 63) / 64;           // chunks per lane: both rows of a line ride one chunk
+    constexpr int SB = CH == 1 ? NCH : (NCH + 1) / 2;    // loads in flight per lane and sub-batch
+    const uint32_t first = px_one(img), pat = first * 0x01010101u;
+    uint32_t diff = 0u;
+#pragma unroll
+    for (int k0 = 0; k0 < NCH; k0 += SB) {
+      uint32_t ra[SB], rb[SB];
+#pragma unroll
+      for (int t = 0; t < SB; ++t) {
+        const int k = k0 + t, q = lane + 64 * k, li = q / CPR, x0 = 4 * (q % CPR), y = 2 * (l0 + li);
+        ra[t] = rb[t] = 0u;
+        if (k < NCH && MOF_HABL != 3 && li < nl && x0 < n) {
+          const uint8_t* qa = img + (size_t)y * a.pitch + (size_t)CH * x0;
+          if (x0 + 3 < n) {
+            if (y < n) ra[t] = px_gray(qa);
+            if (y + 1 < n) rb[t] = px_gray(qa + a.pitch);
+          } else {  // the last chunk of a row whose length is not a multiple of four: the pixels inside the patch
+            for (int b = 0; x0 + b < n; ++b) {
+              if (y < n) ra[t] |= px_one(qa + CH * b) << (8 * b);
+              if (y + 1 < n) rb[t] |= px_one(qa + a.pitch + CH * b) << (8 * b);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < SB; ++t) {
+        const int k = k0 + t, q = lane + 64 * k, li = q / CPR, x0 = 4 * (q % CPR), y = 2 * (l0 + li);
+        if (k < NCH && li < nl) {
+          if (x0 < n) {
+            const uint32_t inside = x0 + 3 < n ? 0xffffffffu : (1u << (8 * (n - x0))) - 1u;
+            if (y < n) diff |= (ra[t] ^ pat) & inside;
+            if (y + 1 < n) diff |= (rb[t] ^ pat) & inside;
+          }
+          cf* line = z + (l0 + li) * P;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int x = x0 + b;
+            if (x < M) line[x + ((x >> 3) & SKM)] = {(float)((ra[t] >> (8 * b)) & 0xffu), (float)((rb[t] >> (8 * b)) & 0xffu)};
+          }
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(diff != 0u) != 0ull && lane == 0) flags[which] = 1;
+    if (tid == 0) flags[3 + which] = (int)first;
+    wave_sync();
+    if (nl > 0 && MOF_HABL != 1) pass_lines_static<SP>(z, tw, rows, l0, nl, lane, false);
+    // untangle: line j = rows 2j + i (2j + 1): R_2j[u] = (Z[u] + conj Z[M-u]) / 2, R_2j+1[u] = (Z[u] - conj Z[M-u]) / 2i, kept
+    // DOUBLED; the real bins u = 0 and u = M/2 of a row share its column 0. Every read of a line before its first write.
+    constexpr int KU = (LPW * H + 63) / 64;
+    cf zk[KU], zm[KU], zh[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int q = lane + 64 * k, li = q / H, u = q % H;
+      zk[k] = zm[k] = zh[k] = cf{0.f, 0.f};
+      if (li < nl) {
+        zk[k] = lds_read(&z[rows_at(l0 + li, u)]);
+        zm[k] = lds_read(&z[rows_at(l0 + li, u == 0 ? 0 : M - u)]);
+        if (u == 0) zh[k] = lds_read(&z[rows_at(l0 + li, H)]);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int q = lane + 64 * k, li = q / H, u = q % H;
+      if (li < nl) {
+        cf A, B;
+        untangle2(zk[k], zm[k], &A, &B);
+        if (u == 0) {
+          A = {A.x, 2.f * zh[k].x};
+          B = {B.x, 2.f * zh[k].y};
+        }
+        z[spec_at(2 * (l0 + li), u)] = A;
+        z[spec_at(2 * (l0 + li) + 1, u)] = B;
+      }
+    }
+  };
+
+  // column 0 after a forward column pass = G[v] = F[v][0] + i F[v][M/2] (two real columns): apart with the partner bin M - v, in
+  // place: slot v <- F0[v], slot M - v <- FH[v] (0 < v < M/2), slot 0 <- (F0[0], F0[M/2]), slot M/2 <- (FH[0], FH[M/2]) -- every
+  // slot then meets its counterpart of the other image element by element. By the wave that owns column 0.
+  auto split_col0 = [&]() {
+    constexpr int KV = (H + 1 + 63) / 64;
+    cf g1[KV], g2[KV];
+#pragma unroll
+    for (int i = 0; i < KV; ++i) {
+      const int v = lane + 64 * i;
+      g1[i] = g2[i] = cf{0.f, 0.f};
+      if (v < H) {
+        g1[i] = lds_read(&z[spec_at(v, 0)]);
+        g2[i] = lds_read(&z[spec_at(v == 0 ? H : M - v, 0)]);  // (the lane of v = 0 takes G[M/2] along)
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < KV; ++i) {
+      const int v = lane + 64 * i;
+      if (v == 0) {
+        // G[0] = (F0[0], FH[0]), G[M/2] = (F0[M/2], FH[M/2]) -> (F0[0], F0[M/2]), (FH[0], FH[M/2])
+        z[spec_at(0, 0)] = {g1[i].x, g2[i].x};
+        z[spec_at(H, 0)] = {g1[i].y, g2[i].y};
+      } else if (v < H) {
+        cf f0, fh;
+        untangle2(g1[i], g2[i], &f0, &fh);
+        z[spec_at(v, 0)] = {0.5f * f0.x, 0.5f * f0.y};
+        z[spec_at(M - v, 0)] = {0.5f * fh.x, 0.5f * fh.y};
+      }
+    }
+    wave_sync();
+  };
+
+  // ---- previous image: rows, barrier, columns; its half spectrum moves into registers
+  constexpr int KE = (LPW * M + 63) / 64;  // elements of the wave's columns per lane: element q = lane + 64 k -> (row q / LPW, column q % LPW)
+  cf pv[KE];
+  load_and_rows(prev, 1);
+  __syncthreads();
+  if (nl > 0 && MOF_HABL != 1) pass_lines_static<SP>(z, tw, cols, l0, nl, lane, false);
+  if (wave == 0) split_col0();
+#pragma unroll
+  for (int k = 0; k < KE; ++k) {
+    const int q = lane + 64 * k, r = q / LPW, c = q % LPW;
+    pv[k] = (r < M && c < nl) ? lds_read(&z[spec_at(r, l0 + c)]) : cf{1.f, 0.f};
+  }
+  __syncthreads();  // every wave has its columns: the tile may take the current image
+
+  // ---- current image: rows, barrier, then per wave forward columns -> cross-power -> inverse columns
+  load_and_rows(cur, 0);
+  __syncthreads();
+  if (nl > 0 && MOF_HABL != 1) pass_lines_static<SP>(z, tw, cols, l0, nl, lane, false);
+  if (wave == 0) split_col0();
+  // A CONSTANT patch that zero padding turned into an n x n box (n, m even): its spectrum is EXACTLY zero on the Nyquist row and
+  // column in the reference's transforms (alternating sums of equal numbers), so C = 0 there; here the rows were transformed in
+  // pairs and the zeros carry rounding noise that the normalisation would blow up to unit magnitude (pc_large_kernel.hip, L6)
+  const bool box_zeros = M > n && (n & 1) == 0 && (flags[0] == 0 || flags[1] == 0);
+  if (MOF_HABL != 2) {
+#pragma unroll
+    for (int k = 0; k < KE; ++k) {
+      const int q = lane + 64 * k, r = q / LPW, c = q % LPW;
+      const bool on = r < M && c < nl;
+      const int rr = on ? r : 0, u = on ? l0 + c : l0;  // (lanes past the wave's elements repeat a bin: cross_power_ab's
+      const cf av = lds_read(&z[spec_at(rr, u)]);       //  wave-uniform branch wants every lane to take part)
+      const cf bv = on ? pv[k] : cf{1.f, 0.f};
+      cf C = cross_power_ab(av, bv, false);
+      if (u == 0 && (rr == 0 || rr == H)) {
+        // the two real-only slots each of the columns u = 0 (slot 0) and u = M/2 (slot M/2): C = P / (P^2 + eps)
+        const float c1 = cross_power_ab(cf{av.x, 0.f}, cf{bv.x, 0.f}, true).x, c2 = cross_power_ab(cf{av.y, 0.f}, cf{bv.y, 0.f}, true).x;
+        C = {c1, c2};
+        if (rr == 0 && on) flags[2] = __float_as_int(c1);  // C_dc: all that is left of a degenerate pair's spectrum
+      }
+      if (box_zeros) {
+        if (u == 0) {
+          if (rr == 0) C.y = 0.f;             // (v = M/2, u = 0)
+          else if (rr == H) C = {0.f, 0.f};   // (v = 0, u = M/2) and (v = M/2, u = M/2)
+          else if (rr > H) C = {0.f, 0.f};    // slots M - v hold the column u = M/2
+        } else if (rr == H) {
+          C = {0.f, 0.f};
+        }
+      }
+      // conjugated for the inverse (a forward transform of conj C); column 0 keeps C itself until it is put together again below
+      if (on) z[spec_at(rr, u)] = u == 0 ? C : cf{C.x, -C.y};
+    }
+  }
+  wave_sync();
+  if (wave == 0) {
+    // column 0 back together: G'[v] = conj C0[v] + i conj CH[v], G'[M - v] = C0[v] + i CH[v] (C0, CH Hermitian in v)
+    constexpr int KV = (H + 1 + 63) / 64;
+    cf c0v[KV], chv[KV];
+#pragma unroll
+    for (int i = 0; i < KV; ++i) {
+      const int v = lane + 64 * i;
+      c0v[i] = chv[i] = cf{0.f, 0.f};
+      if (v <= H) {
+        c0v[i] = lds_read(&z[spec_at(v, 0)]);
+        chv[i] = lds_read(&z[spec_at(v == 0 ? H : M - v, 0)]);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < KV; ++i) {
+      const int v = lane + 64 * i;
+      if (v == 0) {
+        z[spec_at(0, 0)] = {c0v[i].x, chv[i].x};  // (C0[0], CH[0])
+        z[spec_at(H, 0)] = {c0v[i].y, chv[i].y};  // (C0[M/2], CH[M/2])
+      } else if (v < H) {
+        z[spec_at(v, 0)] = {c0v[i].x + chv[i].y, chv[i].x - c0v[i].y};
+        z[spec_at(M - v, 0)] = {c0v[i].x - chv[i].y, chv[i].x + c0v[i].y};
+      }
+    }
+    wave_sync();
+  }
+  if (nl > 0 && MOF_HABL != 1) pass_lines_static<SP>(z, tw, cols, l0, nl, lane, false);
+  __syncthreads();
+
+  // ---- Hermitian row pairs: line j carries rows y1 = 2j, y2 = 2j + 1: E[u] = D[y1][u] + i D[y2][u], D[y][M - u] = conj D[y][u];
+  //      column 0 holds (D[y][0], D[y][M/2]), both real. spec -> rows layout in place per line, every read before the first write.
+  {
+    constexpr int KU = (LPW * H + 63) / 64;
+    cf d1[KU], d2[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int q = lane + 64 * k, li = q / H, u = q % H;
+      d1[k] = d2[k] = cf{0.f, 0.f};
+      if (li < nl) {
+        d1[k] = lds_read(&z[spec_at(2 * (l0 + li), u)]);
+        d2[k] = lds_read(&z[spec_at(2 * (l0 + li) + 1, u)]);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int q = lane + 64 * k, li = q / H, u = q % H;
+      if (li < nl) {
+        if (u == 0) {
+          z[rows_at(l0 + li, 0)] = {d1[k].x, d2[k].x};
+          z[rows_at(l0 + li, H)] = {d1[k].y, d2[k].y};
+        } else {
+          z[rows_at(l0 + li, u)] = {d1[k].x - d2[k].y, d1[k].y + d2[k].x};
+          z[rows_at(l0 + li, M - u)] = {d1[k].x + d2[k].y, d2[k].x - d1[k].y};
+        }
+      }
+    }
+    wave_sync();
+  }
+  Best best = {-__builtin_huge_valf(), 0x7fffffff};
+  if (nl > 0 && MOF_HABL != 1)
+    pass_lines_static<SP, 0, 1, HalfScanSink>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H});
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o = {__shfl_xor(best.v, off, 64), __shfl_xor(best.idx, off, 64)};
+    best = better(best, o);
+  }
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+
+  // ---- weighted centroid in double + validity gate (:1337-1383, :1838-1856), wave 0
+  if (wave == 0) {
+    for (int w = 1; w < WAVES; ++w) best = better(best, red[w]);
+    const bool have = best.idx != 0x7fffffff;
+    const int py = have ? best.idx / M : 0, pxk = have ? best.idx - py * M : 0;
+    const int ys = py - 2 + lane / 5, xs = pxk - 2 + lane % 5;
+    double val = 0.0;
+    if (have && lane < 25 && ys >= 0 && ys <= M - 1 && xs >= 0 && xs <= M - 1) {  // window clamped to the (padded) patch
+      const int y = ys - H < 0 ? ys - H + M : ys - H, x = xs - H < 0 ? xs - H + M : xs - H;  // un-shifted position
+      const cf s = z[rows_at(y >> 1, x)];
+      val = (double)((y & 1) ? s.y : s.x);
+    }
+    double cx = (double)xs * val, cy = (double)ys * val, sum = val;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      cx += __shfl_xor(cx, off, 64);
+      cy += __shfl_xor(cy, off, 64);
+      sum += __shfl_xor(sum, off, 64);
+    }
+    if (lane == 0) {
+      sum += 2.220446049250313e-16;  // DBL_EPSILON :1378
+      // shift = -(center - t) = t - M / 2.0 (:1836): cv::phaseCorrelate's centre is that of the PADDED image
+      const double half_m = (double)M / 2.0, half_n = (double)n / 2.0;
+      double sx = cx / sum - half_m, sy = cy / sum - half_m;
+      // a constant patch: its transform is exactly zero off DC, the surface is flat = C_dc (pc_common.hpp). With padding
+      // (m > n) only the all-zero patch stays constant on the padded image.
+      const bool cconst = flags[0] == 0, pconst = flags[1] == 0;
+      const bool degenerate = M == n ? (cconst || pconst) : ((cconst && flags[3] == 0) || (pconst && flags[4] == 0));
+      if (degenerate) {
+        const double c9 = 9.0 * (double)__int_as_float(flags[2]);
+        sx = sy = (c9 > 0.0 ? c9 / (c9 + 2.220446049250313e-16) : 0.0) - half_m;
+      }
+      // the gate compares with samplePointSize / 2 -- the UNPADDED size (:1841-1842)
+      const bool bad = (sx * sx + sy * sy > a.max_px_speed_sq) || (fabs(sx) > half_n) || (fabs(sy) > half_n) || (sx != sx) ||
+                       (sy != sy) || (!have && !degenerate);
+      if (bad) sx = sy = __builtin_nan("");
+      a.out[2 * p] = sx;
+      a.out[2 * p + 1] = sy;
+    }
+  }
+}
+
+// the transform sizes with an instantiation: the even 5-smooth sizes in (135, 192] -- what this kernel exists for -- and the
+// tuned pair kernels' sizes for A/B and for the parity tests of this formulation (MOF_FFT_HALF=1)
+#define MOF_HALF_SIZES(X) X(64) X(96) X(120) X(128) X(144) X(150) X(160) X(162) X(180) X(192)
+
+template <int CH, int MS>
+hipError_t configure_half_one() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_half_kernel<CH, MS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             HalfPlanOf<MS>::HP.lds_bytes);
+}
+
+}  // namespace
+
+bool pc_half_supported(int m) {
+  switch (m) {
+#define X(M) case M:
+    MOF_HALF_SIZES(X)
+#undef X
+    return true;
+    default: return false;
+  }
+}
+
+int pc_half_workgroups_per_cu(int m) {
+  switch (m) {
+#define X(M) case M: return HalfPlanOf<M>::HP.wgs_per_cu;
+    MOF_HALF_SIZES(X)
+#undef X
+    default: return 0;
+  }
+}
+
+hipError_t pc_configure_half() {
+  hipError_t e;
+#define X(M)                                                              \
+  if ((e = configure_half_one<1, M>()) != hipSuccess) return e;            \
+  if ((e = configure_half_one<3, M>()) != hipSuccess) return e;
+  MOF_HALF_SIZES(X)
+#undef X
+  return hipSuccess;
+}
+
+// a.downscale must be 1 and a.peak_model 0 (the caller keeps the other front ends on their pipelines); m = the padded size, n the patch
+hipError_t launch_pc_half(const PcArgs& a_in, int m, int n, int n_pairs, hipStream_t stream) {
+  if (a_in.downscale != 1 || a_in.peak_model != 0 || (a_in.channels != 1 && a_in.channels != 3) || n > m || n < 2) return hipErrorInvalidValue;
+  const int patches = a_in.grid_x * a_in.grid_y;
+  for (int k0 = 0; k0 < n_pairs; k0 += 65535) {  // the pair index rides gridDim.z
+    const int nk = n_pairs - k0 < 65535 ? n_pairs - k0 : 65535;
+    PcArgs c = a_in;
+    c.cur = a_in.cur + (size_t)k0 * a_in.cur_stride;
+    c.prev = a_in.prev + (size_t)k0 * a_in.prev_stride;
+    c.out = a_in.out + (size_t)k0 * patches * 2;
+    c.total = nk * patches;
+    const dim3 g((unsigned)c.grid_x, (unsigned)c.grid_y, (unsigned)nk);
+    switch (m) {
+#define X(M)                                                                                                                             \
+  case M:                                                                                                                                \
+    if (c.channels == 3) hipLaunchKernelGGL((pc_half_kernel<3, M>), g, dim3((unsigned)HalfPlanOf<M>::T), (size_t)HalfPlanOf<M>::HP.lds_bytes, stream, c, n); \
+    else hipLaunchKernelGGL((pc_half_kernel<1, M>), g, dim3((unsigned)HalfPlanOf<M>::T), (size_t)HalfPlanOf<M>::HP.lds_bytes, stream, c, n);                 \
+    break;
+      MOF_HALF_SIZES(X)
+#undef X
+      default: return hipErrorInvalidValue;
+    }
+  }
+  return hipGetLastError();
+}
+
+}  // namespace mof

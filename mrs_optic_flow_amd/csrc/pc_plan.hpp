@@ -285,6 +285,7 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
             if (p < R) {
               const int o = base + p * np;
               z[loff + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
+              if constexpr (Sink::active) sink(l, o, v[b][p]);
             }
         }
       wave_sync();

@@ -152,7 +152,9 @@ int run_fft(const std::vector<int>& devices, int B, bool gather) {
     }
   }
   // a missing frame pointer of a LATER shard is caught before anything is launched
-  if (G > 1 && B >= G) {
+  int last_first = 0, last_count = 0;
+  CHECK(mof_shard_partition(B, G, G - 1, &last_first, &last_count) == MOF_OK);
+  if (G > 1 && last_count > 0) {  // (an EMPTY last shard carries no frames: a null pointer is legal there)
     std::vector<uint8_t*> dc2 = b.dc;
     dc2[G - 1] = nullptr;
     CHECK(mof_shard_fft_process_batch_device(g, (const uint8_t* const*)dc2.data(), fb, (const uint8_t* const*)b.dp.data(), fb, W, B,
