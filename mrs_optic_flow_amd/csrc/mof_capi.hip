@@ -120,6 +120,8 @@ struct mof_fft_engine {
   bool generic = false;          // patch sizes without a hand-tuned instantiation run the planned kernel (pc_kernel_generic.hip)
   bool large = false;            // ... or, when the padded patch does not fit a CU's LDS, the planned pipeline through HBM
   mof::PcPlan plan{};            //     scratch (pc_large_kernel.hip)
+  float* d_pair_slabs = nullptr; // MOF_FFT_PAIR_HALF=1 (N = 128): slabs of the pair kernel on the half tile (pc_seq_half.hip), two per CU
+  int n_pair_slabs = 0;
   int half_m = 0;                // > 0: cv::phaseCorrelate-model batches on full-resolution frames run the fused half-tile kernel of that
                                  //      transform size instead (pc_half_kernel.hip: even padded sizes in (135, 192]; MOF_FFT_HALF=1: tuned sizes too)
   // scratch of the large-patch pipeline, for `cap` patch pairs per pass: row half-spectra of 2 cap patches, Dt, peak
@@ -265,6 +267,10 @@ static int launch_field(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
     return MOF_OK;
   }
   if (e->large) return launch_large(e, a, n_pairs, stream);
+  if (e->d_pair_slabs && a.downscale == 1) {
+    HIP_TRY(mof::launch_pc_pair_half(a, e->cfg.patch_size, n_pairs, e->d_pair_slabs, e->n_pair_slabs, stream));
+    return MOF_OK;
+  }
   HIP_TRY(e->generic ? mof::launch_pc_generic(a, e->plan, n_pairs, stream) : mof::launch_pc_field(a, e->cfg.patch_size, n_pairs, stream));
   return MOF_OK;
 }
@@ -449,6 +455,17 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     CREATE_TRY(mof::pc_configure(n));
     if (mof::pc_sequence_supported(n)) CREATE_TRY(mof::pc_configure_sequence());
     if (mof::pc_sequence_half_supported(n)) CREATE_TRY(mof::pc_configure_sequence_half(n));
+    // A/B knob (r05): independent pairs of 128 x 128 patches through the pair kernel on the HALF tile, two workgroups per CU
+    static const bool pair_half = [] { const char* v = getenv("MOF_FFT_PAIR_HALF"); return v && atoi(v) != 0; }();
+    if (pair_half && mof::pc_pair_half_supported(n)) {
+      int dev = 0, cus = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      static const int per_cu = [] { const char* v = getenv("MOF_FFT_PAIR_HALF_WGS"); return v ? atoi(v) : 2; }();
+      e->n_pair_slabs = per_cu * cus;
+      CREATE_TRY(mof::pc_configure_pair_half(n));
+      CREATE_TRY(hipMalloc(&e->d_pair_slabs, (size_t)e->n_pair_slabs * mof::pc_pair_half_slab_floats(n) * sizeof(float)));
+    }
   }
 #undef CREATE_TRY
   *out = e;
@@ -470,6 +487,7 @@ static void fft_destroy_now(void* p) {
   large_free(e);
   if (e->scratch_ev) (void)hipEventDestroy(e->scratch_ev);
   if (e->d_twiddles) (void)hipFree(e->d_twiddles);
+  if (e->d_pair_slabs) (void)hipFree(e->d_pair_slabs);
   if (e->d_frames[0]) (void)hipFree(e->d_frames[0]);
   if (e->d_frames[1]) (void)hipFree(e->d_frames[1]);
   if (e->d_out) (void)hipFree(e->d_out);

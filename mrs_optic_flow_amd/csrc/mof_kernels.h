@@ -109,6 +109,12 @@ hipError_t launch_pc_sequence(const PcArgs& a, int n_pairs, int run, hipStream_t
 bool pc_sequence_half_supported(int patch_size);
 hipError_t pc_configure_sequence_half(int patch_size);
 hipError_t launch_pc_sequence_half(const PcArgs& a, int patch_size, int n_pairs, int run, hipStream_t stream);
+// The PAIR form on the half tile (pc_seq_half.hip, r05; 128 x 128 patches): persistent workgroups, two per CU, the previous image's
+// spectrum parked in a per-workgroup slab of device memory (n_slabs slabs of pc_pair_half_slab_floats floats, owned by the engine)
+bool pc_pair_half_supported(int patch_size);
+size_t pc_pair_half_slab_floats(int patch_size);
+hipError_t pc_configure_pair_half(int patch_size);
+hipError_t launch_pc_pair_half(const PcArgs& a, int patch_size, int n_pairs, float* slabs, int n_slabs, hipStream_t stream);
 // N = 64, quad-per-line formulation (pc_kernel_quad.hip)
 hipError_t pc_configure_quad64();
 hipError_t launch_pc_field_quad64(const PcArgs& a, int n_pairs, hipStream_t stream);

@@ -66,6 +66,23 @@ constexpr int half_stage_lines(int m, int R) {  // lines one group of a stage co
 #ifndef MOF_HALF_PITCH  // (A/B) force the pitch of every instantiation; 0 = the rule below
 #define MOF_HALF_PITCH 0
 #endif
+#ifndef MOF_HALF_PITCH_TABLE  // 0: the generic pitch rule for every size (A/B)
+#define MOF_HALF_PITCH_TABLE 1
+#endif
+// (pitch, skew) with the fewest LDS cycles in the bank model of tools/design/half_banks.py (every ds_read_b64 / ds_write_b64 of a
+// patch pair with the lane groups and bank widths of MI355X_MICROARCH.md) among the pitches that keep the workgroups per CU; 0 = the
+// rule below. Where the unskewed tile is within a few per cent of the best it is preferred: its element offsets are immediates.
+constexpr int half_table_pitch(int m, int* skew) {
+  if (!MOF_HALF_PITCH_TABLE) return 0;
+  switch (m) {
+    case 120: *skew = 0; return 136;
+    case 144: *skew = 1; return 202;
+    case 150: *skew = 0; return 180;
+    case 162: *skew = 0; return 186;
+    case 180: *skew = 0; return 184;
+    default: return 0;
+  }
+}
 constexpr HalfPlan half_plan(int m) {
   HalfPlan hp{};
   if (m < 16 || m > 192 || (m & 1)) return hp;
@@ -124,6 +141,14 @@ constexpr HalfPlan half_plan(int m) {
     if ((size_t)H * p * 8 + half_extra(m) <= cap) break;
   }
   if (skew < 0) return hp;
+  {
+    int tsk = 0;
+    const int tp = half_table_pitch(m, &tsk);
+    if (tp > 0 && MOF_HALF_PITCH == 0 && (size_t)H * tp * 8 + half_extra(m) <= cap) {
+      p = tp;
+      skew = tsk;
+    }
+  }
   hp.skew = skew;
   hp.pitch = p;
   hp.lds_bytes = (int)((size_t)H * p * 8 + half_extra(m));

@@ -32,13 +32,20 @@ constexpr int N = 120, H = 60, R1 = 15, R2 = 8, LPW = 8, WAVES = N / LPW, T = WA
 #define MOF_PITCH120 136
 #endif
 constexpr int PITCH = MOF_PITCH120;
-constexpr size_t LDS_BYTES_120 = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best);
+#ifndef MOF_TW120_LDS  // 1: the 120 inter-stage twiddles live in LDS (one copy per persistent workgroup); 0: fetched from the L1-resident table (r01-r04)
+#define MOF_TW120_LDS 1
+#endif
+constexpr size_t LDS_BYTES_120 = sizeof(float) * 2 * (size_t)N * PITCH + 64 * sizeof(Best) + (MOF_TW120_LDS ? sizeof(float) * 2 * N : 0);
 
 __device__ __forceinline__ int za(int r, int c) { return r * PITCH + c; }
 
 __device__ __forceinline__ cf twiddle(const float* __restrict__ table, int idx) {  // W_120^idx, idx < 120
+#if MOF_TW120_LDS
+  return lds_read(reinterpret_cast<const cf*>(table) + idx);  // (`table` points into LDS: the kernel copied the 120 entries there)
+#else
   const float2 t = *reinterpret_cast<const float2*>(table + 2 * idx);
   return {t.x, t.y};
+#endif
 }
 
 // ---- raw pixel staging (as pc_passes.hpp, raw_store): a chunk's 8 + 8 pixels leave as ONE ds_write_b128 of interleaved
@@ -249,7 +256,17 @@ __global__ void __launch_bounds__(T) pc_field_kernel_120(PcArgs a) {
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
   const int patches = a.grid_x * a.grid_y;
+#if MOF_TW120_LDS
+  // r05: the second-stage twiddles W_120^{kx} (14 per lane and pass) were gathers from the L1-resident global table -- 64 lanes, up
+  // to 8 cache lines per instruction through the texture addresser, ~1260 of them per patch and CU; one LDS copy per persistent
+  // workgroup turns them into ds_read_b64
+  cf* tw_lds = reinterpret_cast<cf*>(reinterpret_cast<int*>(red + 32) + 32);
+  for (int k = tid0; k < N; k += T) tw_lds[k] = {a.twiddles[2 * k], a.twiddles[2 * k + 1]};
+  __syncthreads();
+  const float* tw = reinterpret_cast<const float*>(tw_lds);
+#else
   const float* tw = a.twiddles;
+#endif
   auto patch_ptr = [&](int pp, const uint8_t* frames, size_t frame_stride) -> const uint8_t* {
     const int pair = pp / patches, patch = pp % patches;
     const int x0 = a.origin_x + (patch % a.grid_x) * a.stride_x, y0 = a.origin_y + (patch / a.grid_x) * a.stride_y;

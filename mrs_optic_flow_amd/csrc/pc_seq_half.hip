@@ -189,9 +189,29 @@ __device__ __forceinline__ void half_rows(cf* __restrict__ z, int line0, int lan
 }
 
 // ---- the wave's 8 columns: forward along y, cross-power against `prev`, inverse along y ------------------------------
-template <int N, int PK>
+// Where the previous image's column spectra wait between the two images of a PAIR (pc_pair_half_kernel): in the sequence kernel they
+// stay in the registers `prev`; the pair kernel parks them in a per-workgroup slab of global memory (L2 / Infinity Cache resident:
+// written and re-read by the same lanes a few microseconds apart), so that the 32 registers are free while the current image's
+// rows and columns are transformed -- what lets the 128 x 128 form fit 128 VGPRs = two workgroups per CU.
+struct PrevInRegs {
+  static constexpr bool parked = false;
+  __device__ __forceinline__ void store(int, cf) const {}
+  __device__ __forceinline__ cf load(int) const { return cf{0.f, 0.f}; }
+};
+struct PrevInSlab {
+  static constexpr bool parked = true;
+  float2* slab;  // [elements per lane][threads], this lane's column
+  int threads;
+  __device__ __forceinline__ void store(int i, cf v) const { slab[(size_t)i * threads] = make_float2(v.x, v.y); }
+  __device__ __forceinline__ cf load(int i) const {
+    const float2 t = slab[(size_t)i * threads];
+    return cf{t.x, t.y};
+  }
+};
+
+template <int N, int PK, class Park = PrevInRegs>
 __device__ __forceinline__ void half_cols(cf* __restrict__ z, int col0, int lane, const HalfTw<N>& tw, cf (*prev)[8], cf* prev0,
-                                          cf* prevH, bool prime, bool has_col0) {
+                                          cf* prevH, bool prime, bool has_col0, Park park = Park{}) {
   using L = HalfTile<N>;
   constexpr int R1 = L::R1, R2 = L::R2, H = L::H, PER = 8 * R1 / 64, CW = 64 / R1;
   auto stage1 = [&](bool load) {
@@ -267,17 +287,35 @@ __device__ __forceinline__ void half_cols(cf* __restrict__ z, int col0, int lane
 #pragma unroll
     for (int b = 0; b < PER; ++b)
 #pragma unroll
-      for (int k = 0; k < R2; ++k) prev[b][k] = v[b][k];
+      for (int k = 0; k < R2; ++k) {
+        if constexpr (Park::parked) park.store(b * R2 + k, v[b][k]);
+        else prev[b][k] = v[b][k];
+      }
     return;
   }
+  if constexpr (Park::parked) {
+    cf pv[PER][R2];
 #pragma unroll
-  for (int b = 0; b < PER; ++b)
+    for (int b = 0; b < PER; ++b)
 #pragma unroll
-    for (int k = 0; k < R2; ++k) {
-      const cf C = cross_power_ab<PK>(v[b][k], prev[b][k], false);
-      prev[b][k] = v[b][k];
-      v[b][k] = {C.x, -C.y};
-    }
+      for (int k = 0; k < R2; ++k) pv[b][k] = park.load(b * R2 + k);
+#pragma unroll
+    for (int b = 0; b < PER; ++b)
+#pragma unroll
+      for (int k = 0; k < R2; ++k) {
+        const cf C = cross_power_ab<PK>(v[b][k], pv[b][k], false);
+        v[b][k] = {C.x, -C.y};
+      }
+  } else {
+#pragma unroll
+    for (int b = 0; b < PER; ++b)
+#pragma unroll
+      for (int k = 0; k < R2; ++k) {
+        const cf C = cross_power_ab<PK>(v[b][k], prev[b][k], false);
+        prev[b][k] = v[b][k];
+        v[b][k] = {C.x, -C.y};
+      }
+  }
   if constexpr (R1 == R2) {
     // 64 = 8 x 8: the second-stage output distribution IS the first-stage input distribution: registers go straight on
     const int col = col0 + (lane & 7), x = lane >> 3;
@@ -480,6 +518,106 @@ __global__ void __launch_bounds__(HalfTile<N>::T, (N == 64 ? 4 : 2)) pc_seq_half
   }
 }
 
+// ---- the PAIR form on the half tile (r05): independent frame pairs (BASELINE c4), a persistent workgroup per slab walks patch pairs
+// p = blockIdx.x, + gridDim.x, ...: previous image -> rows, columns, spectrum parked in the workgroup's slab; current image -> rows,
+// columns, cross-power against the slab, inverse columns, row pairs + arg-max, centroid. Same passes as the sequence kernel above,
+// 1.5 transform units per pair like the packed pair kernel (pc_kernel.hip), but on HALF its LDS: TWO workgroups per CU, so one
+// covers the other's barriers and latency chains (the packed N = 128 kernel runs 47 % of its wave-cycles parked, r03 counters).
+#ifndef MOF_PAIR_HALF_WPE  // waves per SIMD the pair kernel is compiled for (4 = two workgroups per CU)
+#define MOF_PAIR_HALF_WPE 4
+#endif
+template <int N, int PK, int CH>
+__global__ void __launch_bounds__(HalfTile<N>::T, MOF_PAIR_HALF_WPE) pc_pair_half_kernel(PcArgs a, float2* __restrict__ slabs) {
+  using L = HalfTile<N>;
+  constexpr int H = L::H, R1 = L::R1, W = HalfCfg<N>::WAVES, PPL = N / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cf* z = reinterpret_cast<cf*>(smem);
+  Best* red = reinterpret_cast<Best*>(z + H * HalfCfg<N>::PITCH);
+  const int lane0 = threadIdx.x & 63, wave0 = threadIdx.x >> 6;
+  const int patches = a.grid_x * a.grid_y;
+  HalfTw<N> tw;
+  tw.init(a.twiddles, lane0);
+  constexpr int PER = 8 * R1 / 64, NC0 = (H + 64) / 64;
+  const PrevInSlab park{slabs + (size_t)blockIdx.x * (PER * 8) * L::T + threadIdx.x, L::T};
+  // this lane's 2 x PPL pixels of a patch: rows 2j, 2j + 1 (j = 8 wave + lane / 8), columns PPL (lane % 8) .. + PPL - 1
+  const size_t lane_off = (size_t)(2 * (8 * wave0 + (lane0 >> 3))) * a.pitch + CH * PPL * (lane0 & 7);
+  auto patch_off = [&](int pp, size_t frame_stride) -> size_t {
+    const int pair = pp / patches, patch = pp - pair * patches, by = patch / a.grid_x, bx = patch - by * a.grid_x;
+    return (size_t)pair * frame_stride + (size_t)(a.origin_y + by * a.stride_y) * a.pitch + (size_t)CH * (a.origin_x + bx * a.stride_x) + lane_off;
+  };
+  uint32_t ra[PPL / 4], rb[PPL / 4];
+  auto fetch = [&](const uint8_t* s) {
+    if constexpr (CH == 1) {
+      __builtin_memcpy(ra, s, PPL);
+      __builtin_memcpy(rb, s + a.pitch, PPL);
+    } else if constexpr (PPL == 16) {
+      gray16_from_bgr48(s, ra);
+      gray16_from_bgr48(s + a.pitch, rb);
+    } else {
+      gray8_from_bgr24(s, ra);
+      gray8_from_bgr24(s + a.pitch, rb);
+    }
+  };
+  int p = blockIdx.x;
+  if (p < a.total) fetch(a.prev + patch_off(p, a.prev_stride));
+  for (; p < a.total; p += gridDim.x) {
+    cf prev[PER][8], prev0[NC0], prevH[NC0];  // (prev itself is never live in this form: the slab holds it)
+#pragma unroll
+    for (int i = 0; i < NC0; ++i) prev0[i] = prevH[i] = {0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {  // f = 0: the previous image, f = 1: the current one
+      int lane = lane0, wave = wave0;
+      asm volatile("" : "+v"(lane), "+v"(wave));
+      lane &= 63;
+      wave &= W - 1;
+      constexpr bool RAW = MOF_RAW_STAGE && PPL == 16;
+      if constexpr (RAW) {
+        half_raw_store<N>(z, 8 * wave, lane, ra, rb);
+      } else {
+        const int lr = 8 * wave + (lane >> 3), c0 = PPL * (lane & 7);
+#pragma unroll
+        for (int i = 0; i < PPL; ++i)
+          z[L::line(lr, c0 + i)] = {(float)((ra[i >> 2] >> (8 * (i & 3))) & 0xffu), (float)((rb[i >> 2] >> (8 * (i & 3))) & 0xffu)};
+      }
+      // the next image's pixels are requested before this one is transformed: the current image of this pair, then the previous
+      // image of the workgroup's next pair
+      if (f == 0) fetch(a.cur + patch_off(p, a.cur_stride));
+      else if (p + (int)gridDim.x < a.total) fetch(a.prev + patch_off(p + (int)gridDim.x, a.prev_stride));
+      wave_sync();
+      half_rows<N, RAW>(z, 8 * wave, lane, tw);
+      __syncthreads();
+      half_cols<N, PK, PrevInSlab>(z, 8 * wave, lane, tw, prev, prev0, prevH, f == 0, wave == 0, park);
+      __syncthreads();
+    }
+    int lane = lane0, wave = wave0;
+    asm volatile("" : "+v"(lane), "+v"(wave));
+    lane &= 63;
+    wave &= W - 1;
+    // (no constant-patch rule: the images are transformed separately with power-of-two butterflies, so a constant patch has the exactly
+    //  zero spectrum the reference's transforms give it and the flat surface produces the degenerate answer by itself, as in the
+    //  sequence kernel above)
+    Best best = half_row_pairs<N, PK>(z, 8 * wave, lane, tw, a.search_radius);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      Best o = {__shfl_xor(best.v, off, 64), __shfl_xor(best.idx, off, 64)};
+      best = better(best, o);
+    }
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    float wval = 0.f;
+    if (wave == 0) {
+      for (int w = 1; w < W; ++w) best = better(best, red[w]);
+      wval = centroid_window_value<N, PK>(best, lane, [&](int ys, int xs) {
+        const int y = (ys + H) & (N - 1), x = (xs + H) & (N - 1);
+        const cf s = z[L::out(y & (H - 1), x)];
+        return y < H ? s.x : s.y;
+      });
+    }
+    __syncthreads();
+    if (wave == 0) centroid_gate_store<N, PK>(best, wval, lane, a.max_px_speed_sq, a.out + 2 * (size_t)p);
+  }
+}
+
 size_t half_extra_lds() {
   static const size_t v = [] {
     const char* e = getenv("MOF_PC_EXTRA_LDS");
@@ -515,7 +653,45 @@ hipError_t launch_half(const PcArgs& a, int n_pairs, int run, hipStream_t stream
   return hipGetLastError();
 }
 
+template <int N>
+hipError_t launch_pair_half(const PcArgs& a_in, int n_pairs, float* slabs, int n_slabs, hipStream_t stream) {
+  if ((a_in.channels != 1 && a_in.channels != 3) || a_in.downscale != 1 || !slabs || n_slabs < 1) return hipErrorInvalidValue;
+  PcArgs a = a_in;
+  a.total = n_pairs * a.grid_x * a.grid_y;
+  const unsigned blocks = (unsigned)(a.total < n_slabs ? a.total : n_slabs);
+  const size_t lds = HalfTile<N>::LDS_BYTES + half_extra_lds();
+  float2* sl = reinterpret_cast<float2*>(slabs);
+  if (a.channels == 3) {
+    if (a.peak_model == 1) hipLaunchKernelGGL((pc_pair_half_kernel<N, 1, 3>), dim3(blocks), dim3(HalfTile<N>::T), lds, stream, a, sl);
+    else hipLaunchKernelGGL((pc_pair_half_kernel<N, 0, 3>), dim3(blocks), dim3(HalfTile<N>::T), lds, stream, a, sl);
+  } else if (a.peak_model == 1) {
+    hipLaunchKernelGGL((pc_pair_half_kernel<N, 1, 1>), dim3(blocks), dim3(HalfTile<N>::T), lds, stream, a, sl);
+  } else {
+    hipLaunchKernelGGL((pc_pair_half_kernel<N, 0, 1>), dim3(blocks), dim3(HalfTile<N>::T), lds, stream, a, sl);
+  }
+  return hipGetLastError();
+}
+
+template <int N>
+hipError_t configure_pair_half() {
+  const int lds = (int)(HalfTile<N>::LDS_BYTES + half_extra_lds());
+  hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_pair_half_kernel<N, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_pair_half_kernel<N, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_pair_half_kernel<N, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_pair_half_kernel<N, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
 }  // namespace
+
+// The pair form on the half tile (N = 128): slabs = n_slabs * pc_pair_half_slab_floats() floats of device memory owned by the engine
+bool pc_pair_half_supported(int patch_size) { return patch_size == 128; }
+size_t pc_pair_half_slab_floats(int patch_size) { return patch_size == 128 ? (size_t)2 * (8 * HalfCfg<128>::R1 / 64) * 8 * HalfTile<128>::T : 0; }
+hipError_t pc_configure_pair_half(int patch_size) { return patch_size == 128 ? configure_pair_half<128>() : hipErrorInvalidValue; }
+hipError_t launch_pc_pair_half(const PcArgs& a, int patch_size, int n_pairs, float* slabs, int n_slabs, hipStream_t stream) {
+  if (n_pairs <= 0) return hipSuccess;
+  return patch_size == 128 ? launch_pair_half<128>(a, n_pairs, slabs, n_slabs, stream) : hipErrorInvalidValue;
+}
 
 bool pc_sequence_half_supported(int patch_size) { return patch_size == 64 || patch_size == 128; }
 
