@@ -29,3 +29,24 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible (there is no CPU fallback)")
     return torch.device("cuda:0")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The f32-limited patches this session met (tests/tolerances.py): label, patch, oracle-to-oracle distance, bar used, distances."""
+    try:
+        import json
+
+        import tolerances
+    except Exception:
+        return
+    if not tolerances.RECORDS:
+        return
+    path = os.environ.get("MOF_F32_LIMITED_JSON", os.path.join(ROOT, "gpurun_out", "f32_limited.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump({"tol_px": tolerances.TOL, "factor": tolerances.F32_LIMITED_FACTOR, "ceiling_px": tolerances.CEILING,
+                       "count": len(tolerances.RECORDS), "worst_bar_px": max(r["bar_px"] for r in tolerances.RECORDS),
+                       "patches": tolerances.RECORDS}, f, indent=1)
+    except OSError:
+        pass

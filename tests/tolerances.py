@@ -1,0 +1,57 @@
+"""The ONE statement of the FFT path's parity bars (BASELINE north_star: sub-pixel shifts within 1e-4 px of the reference's CPU path).
+
+Two oracles exist: the f64 restatement ("truth") and the f32 one -- the reference's own arithmetic (cv::phaseCorrelate computes in
+CV_32F, /root/reference/src/FftMethod.cpp:1805-1806, :1836). On well-conditioned patches they agree to ~2e-7 px and a kernel is held
+to 1e-4 px against BOTH. Where they differ by more than 2e-5 px the patch is *f32-limited*: a cross-power bin sits at the f32 rounding
+floor (or the 5 x 5 centroid's denominator nearly cancels) and f32 oracle, f64 oracle and kernel are three roundings of an
+ill-conditioned quantity. There the kernel is compared with the F32 oracle -- what the reference would print --
+at 1e-4 + 2 x (oracle-to-oracle distance), NEVER above 1e-3 px, and every such patch is recorded (label, patch, distance, bar used,
+|kernel - f32 oracle|, |kernel - f64 oracle|); conftest.py writes the record to a JSON file at the end of the session
+(MOF_F32_LIMITED_JSON, default gpurun_out/f32_limited.json; tools/summarize_round.py copies it to profiles/rNN_f32_limited.json).
+A second member of the class does not show in the oracle-to-oracle distance: a spectral bin that is zero in exact arithmetic (both
+oracles cancel it exactly, every other f32 transform leaves 1e-7-relative noise that the normalisation blows up to a unit-magnitude
+bin): `floor_bins_bar`, same ceiling, same record."""
+import numpy as np
+
+TOL = 1e-4                 # px, well-conditioned patches, against both oracles
+F32_LIMITED_FROM = 2e-5    # px of oracle-to-oracle distance above which a patch counts as f32-limited
+F32_LIMITED_FACTOR = 2.0
+CEILING = 1e-3             # px: no relaxed bar ever exceeds this
+RECORDS = []               # dicts, appended by check_patch / floor_bins_bar users; dumped by conftest.py
+
+
+def f32_limited_bar(dd):
+    """The bar against the f32 oracle on a patch whose two oracles are `dd` px apart."""
+    return min(TOL + F32_LIMITED_FACTOR * dd, CEILING)
+
+
+def floor_bins_bar(bins, normalised_peak):
+    """Bar for a patch with `bins` spectral bins below the f32 rounding floor (oracle_lib.f32_floor_bins) and the given peak."""
+    return min(TOL + 4.0 * bins / normalised_peak, CEILING)
+
+
+def check_patch(got, want64, want32, label, patch, what="kernel"):
+    """Assert one patch's (x, y) against the bars above. NaN patterns must agree wherever the two oracles agree on them. Returns True if
+    the patch was pinned (compared), False if the oracles themselves disagree about validity (nothing to pin)."""
+    got, want64, want32 = np.asarray(got, np.float64), np.asarray(want64, np.float64), np.asarray(want32, np.float64)
+    n64, n32 = np.isnan(want64), np.isnan(want32)
+    if n64.any() or n32.any():
+        if np.array_equal(n64, n32):
+            assert np.array_equal(np.isnan(got), n64), (label, patch, got, want64)
+            return True
+        return False
+    dd = float(np.abs(want32 - want64).max())
+    e64, e32 = float(np.abs(got - want64).max()), float(np.abs(got - want32).max())
+    if dd <= F32_LIMITED_FROM:
+        assert e64 <= TOL and e32 <= TOL, (label, patch, what, got, want64, want32)
+        return True
+    bar = f32_limited_bar(dd)
+    RECORDS.append({"label": label, "patch": int(patch), "what": what, "rule": "f32-limited", "oracle_distance_px": dd, "bar_px": bar,
+                    "kernel_minus_f32_oracle_px": e32, "kernel_minus_f64_oracle_px": e64})
+    assert e32 <= bar, (label, patch, what, got, want32, want64, dd, bar)
+    return True
+
+
+def record_floor_bins(label, patch, bins, bar, e32, e64, what="kernel"):
+    RECORDS.append({"label": label, "patch": int(patch), "what": what, "rule": "exact-zero spectral bins", "bins": int(bins), "bar_px": bar,
+                    "kernel_minus_f32_oracle_px": e32, "kernel_minus_f64_oracle_px": e64})

@@ -50,6 +50,12 @@ def factor(kernel):
     return 1.0
 
 
+# the session record of the f32-limited patches (tests/tolerances.py, written by tests/conftest.py) and the round's fuzz summary
+# (tools/fuzz_round.sh), when this round's GPU runs left them
+for src, name in (("f32_limited.json", f"{tag}_f32_limited.json"), (f"{tag}_fuzz.txt", f"{tag}_fuzz.txt")):
+    if os.path.exists(os.path.join(root, "gpurun_out", src)):
+        shutil.copy(os.path.join(root, "gpurun_out", src), os.path.join(dst, name))
+
 for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{tag}_*"))):
     wl = os.path.basename(d)[len(f"prof_{tag}_"):]
     if wl == "mfma":
