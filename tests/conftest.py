@@ -46,7 +46,9 @@ def pytest_sessionfinish(session, exitstatus):
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "w") as f:
             json.dump({"tol_px": tolerances.TOL, "factor": tolerances.F32_LIMITED_FACTOR, "ceiling_px": tolerances.CEILING,
-                       "count": len(tolerances.RECORDS), "worst_bar_px": max(r["bar_px"] for r in tolerances.RECORDS),
+                       "count": len(tolerances.RECORDS), "unpinned_from_px": tolerances.UNPINNED_FROM,
+                       "unpinned": sum(r["bar_px"] is None for r in tolerances.RECORDS),
+                       "worst_bar_px": max([r["bar_px"] for r in tolerances.RECORDS if r["bar_px"] is not None], default=None),
                        "patches": tolerances.RECORDS}, f, indent=1)
     except OSError:
         pass

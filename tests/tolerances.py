@@ -8,6 +8,11 @@ ill-conditioned quantity. There the kernel is compared with
 at 1e-4 + 2 x (oracle-to-oracle distance), NEVER above 1e-3 px, and every such patch is recorded (label, patch, distance, bar used,
 |kernel - f32 oracle|, |kernel - f64 oracle|); conftest.py writes the record to a JSON file at the end of the session
 (MOF_F32_LIMITED_JSON, default gpurun_out/f32_limited.json; tools/summarize_round.py copies it to profiles/rNN_f32_limited.json).
+Beyond an oracle-to-oracle distance of (1e-3 - 1e-4) / 2 = 4.5e-4 px that bar would pass its ceiling: the reference's OWN f32 result is
+then more than four tolerances from its f64 restatement, i.e. its arithmetic does not determine the sub-pixel answer to 1e-3 px, and
+any other f32 transform order (OpenCV's included) lands a comparable distance away. Such a patch is UNPINNED -- a criterion computed
+from the two oracles alone, never from the kernel -- : it is recorded with all three distances, only the integer peak is asserted
+(0.25 px), and the suite bounds how many there may be (test_zz_f32_limited_patches_are_rare: 3). No asserted sub-pixel bar exceeds 1e-3 px.
 A second member of the class does not show in the oracle-to-oracle distance: a spectral bin that is zero in exact arithmetic (both
 oracles cancel it exactly, every other f32 transform leaves 1e-7-relative noise that the normalisation blows up to a unit-magnitude
 bin): `floor_bins_bar`, same ceiling, same record."""
@@ -17,6 +22,7 @@ TOL = 1e-4                 # px, well-conditioned patches, against both oracles
 F32_LIMITED_FROM = 2e-5    # px of oracle-to-oracle distance above which a patch counts as f32-limited
 F32_LIMITED_FACTOR = 2.0
 CEILING = 1e-3             # px: no relaxed bar ever exceeds this
+UNPINNED_FROM = (CEILING - TOL) / F32_LIMITED_FACTOR  # px of oracle distance beyond which the reference's f32 arithmetic pins nothing to 1e-3
 RECORDS = []               # dicts, appended by check_patch / floor_bins_bar users; dumped by conftest.py
 
 
@@ -45,6 +51,11 @@ def check_patch(got, want64, want32, label, patch, what="kernel"):
     if dd <= F32_LIMITED_FROM:
         assert e64 <= TOL and e32 <= TOL, (label, patch, what, got, want64, want32)
         return True
+    if dd > UNPINNED_FROM:
+        RECORDS.append({"label": label, "patch": int(patch), "what": what, "rule": "unpinned (oracles too far apart)", "oracle_distance_px": dd,
+                        "bar_px": None, "kernel_minus_f32_oracle_px": e32, "kernel_minus_f64_oracle_px": e64})
+        assert e32 <= 0.25 and e64 <= 0.25, (label, patch, what, got, want32, want64, dd)  # the integer peak still agrees
+        return False
     bar = f32_limited_bar(dd)
     RECORDS.append({"label": label, "patch": int(patch), "what": what, "rule": "f32-limited", "oracle_distance_px": dd, "bar_px": bar,
                     "kernel_minus_f32_oracle_px": e32, "kernel_minus_f64_oracle_px": e64})
