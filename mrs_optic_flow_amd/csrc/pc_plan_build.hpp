@@ -145,14 +145,37 @@ constexpr int pc_static_pitch(int m) {
     default: return 0;
   }
 }
+// r05: the same model run WITHOUT the column skew (tile column c at c, not c + (c >> 3)). The skew exists for the stride-8 stage writes
+// of power-of-two radices; for most other sizes an unskewed tile with the right pitch has as few or fewer conflict cycles
+// (tools/design/planned_banks.py, kernel_cost(m, pitch, skew=False)) -- and every element offset of a stage (x + j bpl, (x - k) R + k + p np)
+// is then linear in the loop index: an immediate of the LDS instruction instead of a shift and an add per element. Sizes listed here
+// take the unskewed pitch; 0 = keep the skewed plan (16, 32, 64, 96, 128 and what has no two-stage chain).
+#ifndef MOF_PLANNED_UNSKEWED
+#define MOF_PLANNED_UNSKEWED 1
+#endif
+constexpr int pc_static_pitch_unskewed(int m) {
+  if (!MOF_PLANNED_PITCH_TABLE || !MOF_PLANNED_UNSKEWED) return 0;
+  switch (m) {
+    case 18: return 20;  case 20: return 44;  case 24: return 44;  case 25: return 44;  case 27: return 46;  case 30: return 52;
+    case 36: return 41;  case 40: return 44;  case 45: return 52;  case 48: return 55;  case 50: return 69;  case 54: return 58;
+    case 60: return 76;  case 72: return 73;  case 75: return 76;  case 80: return 108; case 81: return 103; case 90: return 116;
+    case 100: return 103; case 108: return 108; case 120: return 120;
+    default: return 0;
+  }
+}
 
 constexpr PcPlan pc_static_plan(int m) {  // for a 5-smooth m (n = m); threads == 0 when there is none
   PcPlan pl{};
   if (!pc_tile_plan_c(m, pl) || pl.m != m) return PcPlan{};
   int Ra = 0, Rb = 0;
   if (pc_two_stage_chain(m, Ra, Rb)) {
+    const int tu = pc_static_pitch_unskewed(m);
     const int tp = pc_static_pitch(m);
-    if (tp > 0 && pl.skew_mask != 0 && tp >= m + ((m - 1) >> 3)) {
+    if (tu >= m && (size_t)m * tu * 8 + pc_tile_extra(m) <= 160u * 1024u) {
+      pl.pitch = tu;
+      pl.skew_mask = 0;
+      pl.lds_bytes = (int)((size_t)m * tu * 8 + pc_tile_extra(m));
+    } else if (tp > 0 && pl.skew_mask != 0 && tp >= m + ((m - 1) >> 3)) {
       const size_t extra = pc_tile_extra(m);
       if ((size_t)m * tp * 8 + extra <= 160u * 1024u) {
         pl.pitch = tp;
