@@ -120,7 +120,7 @@ WORKLOADS = {
                 name="p62: FftMethod 496x496, 8x8 grid of 62x62 patches padded to 64 (planned kernel), batch=1024 per GPU",
                 bytes_per_pair=2 * 496 * 496 + 64 * 8),
     "l160": dict(kind="fft", h=480, w=480, n=160, grid=(3, 3), origin=(0, 0), stride=(160, 160), batch=512, s=15,
-                 name="l160: FftMethod 480x480, 3x3 grid of 160x160 patches (planned pipeline through HBM scratch), batch=512 per GPU",
+                 name="l160: FftMethod 480x480, 3x3 grid of 160x160 patches (fused half-tile kernel; MOF_FFT_HALF=0: the pipeline through HBM scratch), batch=512 per GPU",
                  bytes_per_pair=2 * 480 * 480 + 9 * 8),
     "l480": dict(kind="fft", h=480, w=480, n=480, grid=(1, 1), origin=(0, 0), stride=(480, 480), batch=512, s=15,
                  name="l480: FftMethod 480x480, ONE 480x480 patch (the reference's whole-frame fallback), batch=512 per GPU",
@@ -737,9 +737,9 @@ def main() -> None:
             torch.cuda.empty_cache()
             # driver-visible records of the other BASELINE configurations (same protocol, fewer steps)
             line["other_workloads"] = {tag: measure_other(tag, dev, st, 5)
-                                       for tag, st in (("c3", 50), ("c4", 10), ("c5", 20), ("c2seq", 50), ("c4seq", 10), ("c5seq", 20), ("ref", 50),
+                                       for tag, st in (("c3", 50), ("c4", 20), ("c5", 40), ("c2seq", 50), ("c4seq", 10), ("c5seq", 40), ("ref", 50),
                                                        ("bmref", 50), ("refrt", 50), ("reflr", 50),
-                                                       ("p60", 50), ("l480", 20))}  # r04: the planned kernel and the large-patch pipeline
+                                                       ("p60", 50), ("l160", 40), ("l480", 20))}  # the planned kernel, the half-tile kernel (r05), the large-patch pipeline
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

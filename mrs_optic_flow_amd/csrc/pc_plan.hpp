@@ -137,6 +137,10 @@ __device__ __forceinline__ void bfly_rt(int R, cf* v) {
 // against the tuned kernel's 1412, with 61 % of its LDS cycles bank conflicts (profiles/r04_p62_planned_v1_sq_pmc.csv).
 // Sink: what the LAST stage of a pass hands its outputs to besides the tile (line l, element o of the line, value): the planned
 // kernel's arg-max rides the final stage of the inverse transform that way instead of a sweep of its own over the tile.
+#ifndef MOF_PLANNED_TW8  // 1: radix-8 stages with twiddles use butterfly8_tw (the products ride the first radix-2 layer as FMAs: 8 instructions
+                         // fewer per butterfly, the same value up to rounding -- what the tuned kernels do); 0: cmul + butterfly<8> (r04)
+#define MOF_PLANNED_TW8 1
+#endif
 struct NoSink {
   static constexpr bool active = false;
   __device__ __forceinline__ void operator()(int, int, cf) const {}
@@ -210,10 +214,12 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
               } else {
                 a = lds_read(&z[loff[b] + e * w.es + ((e >> 3) & w.emask)]);
               }
-              if (j > 0 && np > 1) a = cmul(a, t[j - 1]);
+              // (a radix-8 stage behind an earlier one takes its twiddles inside the butterfly: butterfly8_tw, pc_common.hpp)
+              if (j > 0 && np > 1 && !(MOF_PLANNED_TW8 && SLOTS == 8 && R == 8)) a = cmul(a, t[j - 1]);
               v[b][j] = a;
             }
-          bfly_rt<SLOTS>(R, v[b]);
+          if (MOF_PLANNED_TW8 && SLOTS == 8 && R == 8 && np > 1) butterfly8_tw(v[b], t);
+          else bfly_rt<SLOTS>(R, v[b]);
         }
       }
       wave_sync();
