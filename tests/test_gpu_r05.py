@@ -64,3 +64,44 @@ def test_block_matching_shard_group_through_ctypes(gpu):
             assert np.array_equal(got[om.value:om.value + 8], mode[k].cpu().numpy().ravel())
     finally:
         lib.mof_shard_bm_destroy(grp)
+
+
+def test_pair_kernel_on_the_half_tile_at_128(gpu):
+    """MOF_FFT_PAIR_HALF=1: independent pairs of 128 x 128 patches through pc_pair_half_kernel (csrc/pc_seq_half.hip) -- the sequence
+    kernel's passes on the half-size tile, the previous image's column spectra parked in a per-workgroup slab of device memory, two
+    persistent workgroups per CU. Measured slower than the packed pair kernel (48 k against 84 k pairs/s at c4: 58 spilled VGPRs at the
+    128-register limit, profiles/r05_c4_pair_half_ab.txt), so it is opt-in; a child process holds it to the oracle: 150 frame pairs of
+    3 x 2 overlapping patches (more patch pairs than slabs, so every workgroup walks several), 1e-4 px on every clear-peak patch."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_pair_half.py")], env=dict(os.environ, MOF_FFT_PAIR_HALF="1"),
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "bad 0" in r.stdout and "checked" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("n", [160, 150, 137, 186])
+def test_half_tile_kernel_entries(gpu, n):
+    """csrc/pc_half_kernel.hip is what patches of 136 .. 192 pixels run by default (r05): the batch entry on a strided view (pitch >
+    width), one pair alone = the same bits as inside a batch, the video entry = the pair entry's bits. (Stateful entry, BGR8 frames, black
+    frames and constant boxes on these sizes: the large-patch tests of test_gpu_generic.py / test_gpu_r04.py, which now reach this kernel.)"""
+    gx, gy = 2, 1
+    w, h = 2 * n + 11, n + 4
+    B = 4
+    cur, prev, _, kinds = synth.batch_np(B, h, w + 8, min(n // 8, 20), k0=n + 1)
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(3, 2), stride=(n + 6, 1))
+    assert fm.kernel_variant == "planned-half"
+    tc, tp = torch.from_numpy(cur).to(gpu)[:, :, :w], torch.from_numpy(prev).to(gpu)[:, :, :w]  # (views: pitch = w + 8)
+    got = fm.process_batch_device(tc, tp).cpu().numpy()
+    lay = O.fft_layout(w, h, n, gx, gy, (3, 2), (n + 6, 1))
+    import tolerances
+    for k in range(B):
+        c, p = np.ascontiguousarray(cur[k][:, :w]), np.ascontiguousarray(prev[k][:, :w])
+        want64, _, diags = O.fft_process(c, p, lay, 64, want_diag=True)
+        want32, _ = O.fft_process(c, p, lay, 32)
+        for q in range(gx * gy):
+            if diags[q].second_value < 0.5 * diags[q].peak_value:
+                tolerances.check_patch(got[k][q], want64[q], want32[q], f"half{n}/pair{k}/{kinds[k]}", q)
+    one = fm.process_batch_device(tc[2:3], tp[2:3]).cpu().numpy()
+    assert np.array_equal(one[0], got[2], equal_nan=True)
+    video = np.stack([synth.pair_np(9 + n, h, w, 3 * t, -t, blur=True)[0] for t in range(3)])
+    dv = torch.from_numpy(video).to(gpu)
+    assert np.array_equal(fm.process_sequence_device(dv).cpu().numpy(), fm.process_batch_device(dv[1:], dv[:-1]).cpu().numpy(), equal_nan=True)

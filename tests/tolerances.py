@@ -33,7 +33,7 @@ def f32_limited_bar(dd):
 
 def floor_bins_bar(bins, normalised_peak):
     """Bar for a patch with `bins` spectral bins below the f32 rounding floor (oracle_lib.f32_floor_bins) and the given peak."""
-    return min(TOL + 4.0 * bins / normalised_peak, CEILING)
+    return min(TOL + 2.0 * bins / normalised_peak, CEILING)
 
 
 def check_patch(got, want64, want32, label, patch, what="kernel"):
