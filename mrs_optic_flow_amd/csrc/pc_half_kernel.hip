@@ -189,6 +189,42 @@ struct HalfScanSink {
   }
 };
 
+// raw pixel staging (as the tuned kernels, pc_passes.hpp raw_store): a chunk's 4 + 4 pixels (rows 2j, 2j + 1) leave as ONE
+// ds_write_b64 of interleaved bytes (a0 b0 a1 b1 ..) into the first 2 M bytes of the line's own tile span, and the first row stage
+// converts them on its way into the butterfly (u8 -> f32: convertTo, :1805-1806) -- four ds_write_b64 of floats per chunk less
+#ifndef MOF_HALF_RAW
+#define MOF_HALF_RAW 1
+#endif
+struct HalfRawSrc {
+  static constexpr bool active = true;
+  int pitch;  // complex elements per line
+  __device__ __forceinline__ cf operator()(const cf* z, int l, int e) const {
+    typedef const volatile uint16_t __attribute__((address_space(3))) * lds_u16_ptr;
+    const uint32_t ab = *(lds_u16_ptr)(reinterpret_cast<const unsigned char*>(z + l * pitch) + 2 * e);
+    return {(float)(ab & 0xffu), (float)(ab >> 8)};
+  }
+};
+
+// the pairing of the inverse row pass (spec -> rows layout) as the SOURCE of its first stage: element e of line j is built from the two
+// spec rows 2j | 2j + 1 on the way into the butterfly -- the sweep of its own (a read and a write of the half tile) disappears
+#ifndef MOF_HALF_PAIR_SRC
+#define MOF_HALF_PAIR_SRC 1
+#endif
+struct HalfPairSrc {
+  static constexpr bool active = true;
+  int p2, m, skm;
+  __device__ __forceinline__ cf operator()(const cf* z, int l, int e) const {
+    const int H = m >> 1;
+    const int u = e < H ? e : (e == H ? 0 : m - e);
+    const int o = u + ((u >> 3) & skm);
+    const cf d1 = lds_read(&z[(2 * l) * p2 + o]), d2 = lds_read(&z[(2 * l + 1) * p2 + o]);
+    if (e == 0) return {d1.x, d2.x};
+    if (e == H) return {d1.y, d2.y};
+    if (e < H) return {d1.x - d2.y, d1.y + d2.x};
+    return {d1.x + d2.y, d2.x - d1.y};
+  }
+};
+
 #ifndef MOF_HABL  // diagnostic builds (results wrong by design): 1 no transform passes, 2 no cross-power, 3 no pixel loads
 #define MOF_HABL 0
 #endif
@@ -288,10 +324,19 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
             if (y + 1 < n) diff |= (rb[t] ^ pat) & inside;
           }
           cf* line = z + (l0 + li) * P;
+          if constexpr (MOF_HALF_RAW) {
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            typedef u2 __attribute__((address_space(3))) * lds_u2_ptr;
+            u2 d;
+            d.x = __builtin_amdgcn_perm(rb[t], ra[t], 0x05010400u);
+            d.y = __builtin_amdgcn_perm(rb[t], ra[t], 0x07030602u);
+            *(lds_u2_ptr)(reinterpret_cast<unsigned char*>(line) + 2 * x0) = d;  // (a partial last chunk spills past 2 M bytes: inside the line, never read)
+          } else {
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int x = x0 + b;
-            if (x < M) line[x + ((x >> 3) & SKM)] = {(float)((ra[t] >> (8 * b)) & 0xffu), (float)((rb[t] >> (8 * b)) & 0xffu)};
+            for (int b = 0; b < 4; ++b) {
+              const int x = x0 + b;
+              if (x < M) line[x + ((x >> 3) & SKM)] = {(float)((ra[t] >> (8 * b)) & 0xffu), (float)((rb[t] >> (8 * b)) & 0xffu)};
+            }
           }
         }
       }
@@ -299,7 +344,10 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
     if (__builtin_amdgcn_ballot_w64(diff != 0u) != 0ull && lane == 0) flags[which] = 1;
     if (tid == 0) flags[3 + which] = (int)first;
     wave_sync();
-    if (nl > 0 && MOF_HABL != 1) pass_lines_static<SP>(z, tw, rows, l0, nl, lane, false);
+    if (nl > 0 && MOF_HABL != 1) {
+      if constexpr (MOF_HALF_RAW) pass_lines_static<SP, 0, 1, NoSink, HalfRawSrc>(z, tw, rows, l0, nl, lane, false, NoSink{}, HalfRawSrc{P});
+      else pass_lines_static<SP>(z, tw, rows, l0, nl, lane, false);
+    }
     // untangle: line j = rows 2j + i (2j + 1): R_2j[u] = (Z[u] + conj Z[M-u]) / 2, R_2j+1[u] = (Z[u] - conj Z[M-u]) / 2i, kept
     // DOUBLED; the real bins u = 0 and u = M/2 of a row share its column 0. Every read of a line before its first write.
     constexpr int KU = (LPW * H + 63) / 64;
@@ -448,7 +496,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
 
   // ---- Hermitian row pairs: line j carries rows y1 = 2j, y2 = 2j + 1: E[u] = D[y1][u] + i D[y2][u], D[y][M - u] = conj D[y][u];
   //      column 0 holds (D[y][0], D[y][M/2]), both real. spec -> rows layout in place per line, every read before the first write.
-  {
+  if constexpr (!MOF_HALF_PAIR_SRC) {
     constexpr int KU = (LPW * H + 63) / 64;
     cf d1[KU], d2[KU];
 #pragma unroll
@@ -477,8 +525,12 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
     wave_sync();
   }
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
-  if (nl > 0 && MOF_HABL != 1)
-    pass_lines_static<SP, 0, 1, HalfScanSink>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H});
+  if (nl > 0 && MOF_HABL != 1) {
+    if constexpr (MOF_HALF_PAIR_SRC)
+      pass_lines_static<SP, 0, 1, HalfScanSink, HalfPairSrc>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H}, HalfPairSrc{P2, M, SKM});
+    else
+      pass_lines_static<SP, 0, 1, HalfScanSink>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H});
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     Best o = {__shfl_xor(best.v, off, 64), __shfl_xor(best.idx, off, 64)};
