@@ -404,7 +404,12 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     // keeps them on the pipeline through HBM scratch, MOF_FFT_HALF=1 also routes the tuned / planned sizes it is instantiated for
     // (64, 96, 120, 128) through it -- A/B and the parity tests of the formulation
     static const int half_knob = [] { const char* v = getenv("MOF_FFT_HALF"); return v ? atoi(v) : -1; }();
-    if (cfg->peak_model == MOF_PEAK_OPENCV && mof::pc_half_supported(n) && half_knob != 0 && !force_large && (e->large || half_knob == 1))
+    // r05: N = 120 -- the reference's default samplePointSize -- takes it by default too: two workgroups per CU and every phase on all
+    // waves beat the tuned one-workgroup kernel there (1.14 M against 1.10 M pairs/s same-box, profiles/r05_half_raw_pairsrc_ab.txt);
+    // its long-range mode and OpenCL peak model stay on the tuned kernel (launch_field)
+    const bool tuned_size_default = n == 120 && !e->generic && !e->large;
+    if (cfg->peak_model == MOF_PEAK_OPENCV && mof::pc_half_supported(n) && half_knob != 0 && !force_large && !force_planned &&
+        (e->large || half_knob == 1 || tuned_size_default))
       e->half_m = n;
   }
   // twiddles W_n^k = exp(-2 pi i k / n), double -> float, axis values exact

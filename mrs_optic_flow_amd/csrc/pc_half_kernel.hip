@@ -66,6 +66,9 @@ constexpr int half_stage_lines(int m, int R) {  // lines one group of a stage co
 #ifndef MOF_HALF_PITCH  // (A/B) force the pitch of every instantiation; 0 = the rule below
 #define MOF_HALF_PITCH 0
 #endif
+#ifndef MOF_HALF_SKEW  // (A/B, with MOF_HALF_PITCH) 0 / 1: force the unskewed / skewed layout; -1 = the rule
+#define MOF_HALF_SKEW (-1)
+#endif
 #ifndef MOF_HALF_PITCH_TABLE  // 0: the generic pitch rule for every size (A/B)
 #define MOF_HALF_PITCH_TABLE 1
 #endif
@@ -75,7 +78,7 @@ constexpr int half_stage_lines(int m, int R) {  // lines one group of a stage co
 constexpr int half_table_pitch(int m, int* skew) {
   if (!MOF_HALF_PITCH_TABLE) return 0;
   switch (m) {
-    case 120: *skew = 0; return 136;
+    case 120: *skew = 0; return 136;  // (measured too, tools/sweep_half_pitch.sh, profiles/r05_half_pitch120_sweep.txt: 136 unskewed 1.14 M, 120 1.13 M, 152 1.13 M, 128 0.93 M; skewed 136 / 152: 1.05 M)
     case 144: *skew = 1; return 202;
     case 150: *skew = 0; return 180;
     case 162: *skew = 0; return 186;
@@ -138,6 +141,7 @@ constexpr HalfPlan half_plan(int m) {
     while ((p / 2) % 8 != 4) p += 2;
     if ((size_t)H * p * 8 + half_extra(m) > cap) p = pmin;
     if (MOF_HALF_PITCH > 0 && MOF_HALF_PITCH >= pmin && (MOF_HALF_PITCH & 1) == 0) p = MOF_HALF_PITCH;
+    if (MOF_HALF_SKEW >= 0 && skew != MOF_HALF_SKEW) continue;
     if ((size_t)H * p * 8 + half_extra(m) <= cap) break;
   }
   if (skew < 0) return hp;
@@ -583,7 +587,11 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
 
 // the transform sizes with an instantiation: the even 5-smooth sizes in (135, 192] -- what this kernel exists for -- and the
 // tuned pair kernels' sizes for A/B and for the parity tests of this formulation (MOF_FFT_HALF=1)
+#ifdef MOF_HALF_ONLY  // (A/B sweeps: one instantiation compiles in seconds)
+#define MOF_HALF_SIZES(X) X(MOF_HALF_ONLY)
+#else
 #define MOF_HALF_SIZES(X) X(64) X(96) X(120) X(128) X(144) X(150) X(160) X(162) X(180) X(192)
+#endif
 
 template <int CH, int MS>
 hipError_t configure_half_one() {
