@@ -229,6 +229,32 @@ struct HalfPairSrc {
   }
 };
 
+// the untangle (rows -> spec layout) as the SOURCE of the forward column pass's first stage, for the sizes whose wave runs ONE group of
+// that stage (64, 96, 120, 128, 144): row r = 2j + i of column u is formed from Z_j[u] and Z_j[M - u] of the ROWS layout on its way into
+// the butterfly; the stage's outputs land in the spec layout, over rows-layout bins that OTHER waves' columns read -- so a workgroup
+// barrier stands between the stage's reads and its writes (WorkgroupSync). The sweep of its own (17 reads + 16 writes per lane and
+// image) disappears for 15 more reads and one more barrier.
+#ifndef MOF_HALF_UNTANGLE_SRC
+#define MOF_HALF_UNTANGLE_SRC 1
+#endif
+struct HalfUntangleSrc {
+  static constexpr bool active = true;
+  int p, m, skm;
+  __device__ __forceinline__ cf operator()(const cf* z, int l, int e) const {  // column l, row e
+    const cf* line = z + (e >> 1) * p;
+    const int H = m >> 1, um = l == 0 ? H : m - l;
+    const cf zk = lds_read(&line[l + ((l >> 3) & skm)]), zm = lds_read(&line[um + ((um >> 3) & skm)]);
+    cf A, B;
+    if (l == 0) {  // the real bins u = 0 and u = M/2 of a row share column 0
+      A = {2.f * zk.x, 2.f * zm.x};
+      B = {2.f * zk.y, 2.f * zm.y};
+    } else {
+      untangle2(zk, zm, &A, &B);
+    }
+    return (e & 1) ? B : A;
+  }
+};
+
 #ifndef MOF_HABL  // diagnostic builds (results wrong by design): 1 no transform passes, 2 no cross-power, 3 no pixel loads
 #define MOF_HABL 0
 #endif
@@ -261,6 +287,10 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   for (int k = tid; k < M; k += T) tw[k] = {a.twiddles[2 * k], a.twiddles[2 * k + 1]};
   __syncthreads();  // flags zeroed, twiddles in place
 
+  // first stage of a pass (pc_plan.hpp, stage_rt): R0 butterflies ... one group covers GROUP0 lines
+  constexpr int R0 = SP::P.radix[0], BPL0 = M / R0, GROUP0 = (16 / pc_slots(R0)) * (64 / BPL0);
+  constexpr bool UFUSE = MOF_HALF_UNTANGLE_SRC != 0 && LPW <= GROUP0;  // the wave's columns are ONE group of the first column stage
+  static_assert(!UFUSE || (WAVES - 1) * LPW < H, "every wave owns a line: the barrier inside the fused stage is met by all");
   // wave w owns lines [l0, l0 + nl): row pairs in the row passes, columns in the column passes
   const int l0 = wave * LPW;
   const int nl = H - l0 < 0 ? 0 : (H - l0 > LPW ? LPW : H - l0);
@@ -352,6 +382,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
       if constexpr (MOF_HALF_RAW) pass_lines_static<SP, 0, 1, NoSink, HalfRawSrc>(z, tw, rows, l0, nl, lane, false, NoSink{}, HalfRawSrc{P});
       else pass_lines_static<SP>(z, tw, rows, l0, nl, lane, false);
     }
+    if constexpr (UFUSE) return;  // (the untangle rides the forward column pass: HalfUntangleSrc)
     // untangle: line j = rows 2j + i (2j + 1): R_2j[u] = (Z[u] + conj Z[M-u]) / 2, R_2j+1[u] = (Z[u] - conj Z[M-u]) / 2i, kept
     // DOUBLED; the real bins u = 0 and u = M/2 of a row share its column 0. Every read of a line before its first write.
     constexpr int KU = (LPW * H + 63) / 64;
@@ -421,7 +452,15 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   cf pv[KE];
   load_and_rows(prev, 1);
   __syncthreads();
-  if (nl > 0 && MOF_HABL != 1) pass_lines_static<SP>(z, tw, cols, l0, nl, lane, false);
+  // forward column pass of the image in the tile (UFUSE: with the untangle as its source and a workgroup barrier inside its first stage)
+  auto fwd_cols = [&]() {
+    if constexpr (MOF_HABL == 1) return;
+    if constexpr (UFUSE)
+      pass_lines_static<SP, 0, 1, NoSink, HalfUntangleSrc, WorkgroupSync>(z, tw, cols, l0, nl, lane, false, NoSink{}, HalfUntangleSrc{P, M, SKM});
+    else if (nl > 0)
+      pass_lines_static<SP>(z, tw, cols, l0, nl, lane, false);
+  };
+  fwd_cols();
   if (wave == 0) split_col0();
 #pragma unroll
   for (int k = 0; k < KE; ++k) {
@@ -433,7 +472,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   // ---- current image: rows, barrier, then per wave forward columns -> cross-power -> inverse columns
   load_and_rows(cur, 0);
   __syncthreads();
-  if (nl > 0 && MOF_HABL != 1) pass_lines_static<SP>(z, tw, cols, l0, nl, lane, false);
+  fwd_cols();
   if (wave == 0) split_col0();
   // A CONSTANT patch that zero padding turned into an n x n box (n, m even): its spectrum is EXACTLY zero on the Nyquist row and
   // column in the reference's transforms (alternating sums of equal numbers), so C = 0 there; here the rows were transformed in

@@ -153,7 +153,18 @@ struct NoSrc {
   __device__ __forceinline__ cf operator()(const cf*, int, int) const { return cf{0.f, 0.f}; }
 };
 
-template <int SLOTS, class Sink = NoSink, class Src = NoSrc>
+// Sync: what separates a group's reads from its writes. WaveSync (default): the wave's in-order LDS queue -- a stage is in place on lines
+// the wave owns. WorkgroupSync: a workgroup barrier -- for a stage whose SOURCE reads lines of other waves that its own writes would
+// overwrite (pc_half_kernel.hip: the untangle as the source of the forward column pass); every wave must then run the same number of
+// groups (the caller guarantees exactly one).
+struct WaveSync {
+  __device__ __forceinline__ void operator()() const { wave_sync(); }
+};
+struct WorkgroupSync {
+  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+
+template <int SLOTS, class Sink = NoSink, class Src = NoSrc, class Sync = WaveSync>
 __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restrict__ tw, const Walk& w, int m, int R, int np, int bpl,
                                          int tstep, int line0, int nlines, int lane, bool herm_first, Sink sink = Sink{}, Src src = Src{}) {
   constexpr int NB = 16 / SLOTS;  // butterflies per lane and group
@@ -222,7 +233,7 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
           else bfly_rt<SLOTS>(R, v[b]);
         }
       }
-      wave_sync();
+      Sync{}();
 #pragma unroll
       for (int b = 0; b < NB; ++b)
         if (on[b]) {
@@ -353,7 +364,7 @@ __device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl
 // The same for a compile-time plan (SP::P a constexpr PcPlan): the stages are a compile-time recursion, so every radix, stride and
 // count reaches the stage routine as a constant (a `#pragma unroll` on the run-time loop is not honoured once the 16-slot bodies make
 // it large, and the radix dispatch then stays in the code).
-template <class SP, int S = 0, int NP = 1, class Sink = NoSink, class Src = NoSrc>
+template <class SP, int S = 0, int NP = 1, class Sink = NoSink, class Src = NoSrc, class Sync0 = WaveSync>
 __device__ __forceinline__ void pass_lines_static(cf* z, const cf* tw, const Walk& w, int line0, int nlines, int lane, bool herm,
                                                   Sink sink = Sink{}, Src src = Src{}) {
   if constexpr (S < SP::P.n_stages) {
@@ -361,9 +372,9 @@ __device__ __forceinline__ void pass_lines_static(cf* z, const cf* tw, const Wal
     constexpr int SL = R > 8 ? 16 : (R > 4 ? 8 : 4);
     static_assert(SP::P.n_stages >= 2 || !(Sink::active && Src::active), "sink and source ride different stages");
     if constexpr (S + 1 == SP::P.n_stages) stage_rt<SL, Sink>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm && S == 0, sink);
-    else if constexpr (S == 0) stage_rt<SL, NoSink, Src>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm, NoSink{}, src);
+    else if constexpr (S == 0) stage_rt<SL, NoSink, Src, Sync0>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm, NoSink{}, src);
     else stage_rt<SL>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, false);
-    pass_lines_static<SP, S + 1, NP * R, Sink, Src>(z, tw, w, line0, nlines, lane, herm, sink, src);
+    pass_lines_static<SP, S + 1, NP * R, Sink, Src, Sync0>(z, tw, w, line0, nlines, lane, herm, sink, src);
   }
 }
 
