@@ -255,6 +255,39 @@ struct HalfUntangleSrc {
   }
 };
 
+// The spectra never pass through LDS (sizes whose wave runs ONE group of the LAST column stage too -- the same 64, 96, 120, 128, 144):
+// the last stage of the previous image's forward column pass keeps its outputs in registers (HalfSaveSink; only column 0 is written:
+// it still has to be taken apart with its partner bins), and the last stage of the current image's pass meets them there -- same
+// lane, same register slot -- and writes the CONJUGATED CROSS-POWER SPECTRUM instead of the spectrum (HalfXpowSink). Gone: the copy of
+// the previous spectrum into registers, its tile write, and the cross-power sweep's read and write of the wave's columns.
+#ifndef MOF_HALF_XPOW_SINK
+#define MOF_HALF_XPOW_SINK 1
+#endif
+struct HalfSaveSink {
+  static constexpr bool active = true;
+  static constexpr bool transforms = true;
+  cf* pv;
+  int R;
+  __device__ __forceinline__ cf transform(int l, int, cf v, int b, int p, bool* wr) const {
+    pv[b * R + p] = v;
+    *wr = l == 0;
+    return v;
+  }
+};
+struct HalfXpowSink {
+  static constexpr bool active = true;
+  static constexpr bool transforms = true;
+  const cf* pv;
+  int R, H;
+  bool box_zeros;
+  __device__ __forceinline__ cf transform(int l, int o, cf v, int b, int p, bool* wr) const {
+    *wr = true;
+    cf C = cross_power_ab(v, pv[b * R + p], false);
+    if (box_zeros && o == H) C = {0.f, 0.f};
+    return l == 0 ? v : cf{C.x, -C.y};  // (column 0 leaves as it is: taken apart, crossed and put together again by its owner)
+  }
+};
+
 #ifndef MOF_HABL  // diagnostic builds (results wrong by design): 1 no transform passes, 2 no cross-power, 3 no pixel loads
 #define MOF_HABL 0
 #endif
@@ -290,6 +323,8 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   // first stage of a pass (pc_plan.hpp, stage_rt): R0 butterflies ... one group covers GROUP0 lines
   constexpr int R0 = SP::P.radix[0], BPL0 = M / R0, GROUP0 = (16 / pc_slots(R0)) * (64 / BPL0);
   constexpr bool UFUSE = MOF_HALF_UNTANGLE_SRC != 0 && LPW <= GROUP0;  // the wave's columns are ONE group of the first column stage
+  constexpr int RL = SP::P.radix[SP::P.n_stages - 1], BPLL = M / RL, NBL = 16 / pc_slots(RL), GROUPL = BPLL <= 64 ? NBL * (64 / BPLL) : 0;
+  constexpr bool XSINK = MOF_HALF_XPOW_SINK != 0 && UFUSE && LPW <= GROUPL && SP::P.n_stages >= 2;  // ... and ONE group of the last one
   static_assert(!UFUSE || (WAVES - 1) * LPW < H, "every wave owns a line: the barrier inside the fused stage is met by all");
   // wave w owns lines [l0, l0 + nl): row pairs in the row passes, columns in the column passes
   const int l0 = wave * LPW;
@@ -449,35 +484,102 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
 
   // ---- previous image: rows, barrier, columns; its half spectrum moves into registers
   constexpr int KE = (LPW * M + 63) / 64;  // elements of the wave's columns per lane: element q = lane + 64 k -> (row q / LPW, column q % LPW)
-  cf pv[KE];
+  constexpr int NPV = XSINK ? NBL * RL : KE;  // XSINK: the last column stage's own outputs, butterfly b, output p
+  constexpr int KV0 = (H + 1 + 63) / 64;      // XSINK: column 0's slots v and M - v (v <= M/2) of the previous image, lane v
+  cf pv[NPV], pv0a[KV0], pv0b[KV0];
   load_and_rows(prev, 1);
   __syncthreads();
   // forward column pass of the image in the tile (UFUSE: with the untangle as its source and a workgroup barrier inside its first stage)
-  auto fwd_cols = [&]() {
+  auto fwd_cols = [&](auto sink) {
+    using Sink = decltype(sink);
     if constexpr (MOF_HABL == 1) return;
     if constexpr (UFUSE)
-      pass_lines_static<SP, 0, 1, NoSink, HalfUntangleSrc, WorkgroupSync>(z, tw, cols, l0, nl, lane, false, NoSink{}, HalfUntangleSrc{P, M, SKM});
+      pass_lines_static<SP, 0, 1, Sink, HalfUntangleSrc, WorkgroupSync>(z, tw, cols, l0, nl, lane, false, sink, HalfUntangleSrc{P, M, SKM});
     else if (nl > 0)
-      pass_lines_static<SP>(z, tw, cols, l0, nl, lane, false);
+      pass_lines_static<SP, 0, 1, Sink>(z, tw, cols, l0, nl, lane, false, sink);
   };
-  fwd_cols();
-  if (wave == 0) split_col0();
+  if constexpr (XSINK) {
 #pragma unroll
-  for (int k = 0; k < KE; ++k) {
-    const int q = lane + 64 * k, r = q / LPW, c = q % LPW;
-    pv[k] = (r < M && c < nl) ? lds_read(&z[spec_at(r, l0 + c)]) : cf{1.f, 0.f};
+    for (int i = 0; i < NPV; ++i) pv[i] = cf{1.f, 0.f};
+    fwd_cols(HalfSaveSink{pv, RL});
+    if (wave == 0) {
+      split_col0();
+#pragma unroll
+      for (int i = 0; i < KV0; ++i) {
+        const int v = lane + 64 * i;
+        pv0a[i] = pv0b[i] = cf{1.f, 0.f};
+        if (v <= H) {
+          pv0a[i] = lds_read(&z[spec_at(v, 0)]);
+          pv0b[i] = lds_read(&z[spec_at(v == 0 ? H : M - v, 0)]);
+        }
+      }
+    }
+  } else {
+    fwd_cols(NoSink{});
+    if (wave == 0) split_col0();
+#pragma unroll
+    for (int k = 0; k < KE; ++k) {
+      const int q = lane + 64 * k, r = q / LPW, c = q % LPW;
+      pv[k] = (r < M && c < nl) ? lds_read(&z[spec_at(r, l0 + c)]) : cf{1.f, 0.f};
+    }
   }
   __syncthreads();  // every wave has its columns: the tile may take the current image
 
   // ---- current image: rows, barrier, then per wave forward columns -> cross-power -> inverse columns
   load_and_rows(cur, 0);
   __syncthreads();
-  fwd_cols();
-  if (wave == 0) split_col0();
   // A CONSTANT patch that zero padding turned into an n x n box (n, m even): its spectrum is EXACTLY zero on the Nyquist row and
   // column in the reference's transforms (alternating sums of equal numbers), so C = 0 there; here the rows were transformed in
   // pairs and the zeros carry rounding noise that the normalisation would blow up to unit magnitude (pc_large_kernel.hip, L6)
   const bool box_zeros = M > n && (n & 1) == 0 && (flags[0] == 0 || flags[1] == 0);
+  // one bin of column 0 (slot rr): the general rule, or -- slots 0 and M/2 -- the two real-only components (C = P / (P^2 + eps),
+  // SURVEY F8); box_zeros: slot 0 = (C0[0], C0[M/2]), slots M/2 .. M-1 hold the column u = M/2
+  auto col0_bin = [&](cf av, cf bv, int rr, bool on) -> cf {
+    cf C = cross_power_ab(av, bv, false);
+    if (rr == 0 || rr == H) {
+      const float c1 = cross_power_ab(cf{av.x, 0.f}, cf{bv.x, 0.f}, true).x, c2 = cross_power_ab(cf{av.y, 0.f}, cf{bv.y, 0.f}, true).x;
+      C = {c1, c2};
+      if (rr == 0 && on) flags[2] = __float_as_int(c1);  // C_dc: all that is left of a degenerate pair's spectrum
+    }
+    if (box_zeros) {
+      if (rr == 0) C.y = 0.f;
+      else if (rr >= H) C = {0.f, 0.f};
+    }
+    return C;
+  };
+  if constexpr (XSINK) {
+    if constexpr (MOF_HABL == 2) fwd_cols(NoSink{});
+    else fwd_cols(HalfXpowSink{pv, RL, H, box_zeros});
+    if (wave == 0) {
+      // column 0: apart, crossed with the previous image's slots (registers, lane v), together again -- G'[v] = conj C0[v] + i conj CH[v],
+      // G'[M - v] = C0[v] + i CH[v] (C0, CH Hermitian in v) -- straight from the registers
+      split_col0();
+      cf c0v[KV0], chv[KV0];
+#pragma unroll
+      for (int i = 0; i < KV0; ++i) {
+        const int v = lane + 64 * i;
+        const bool on = v <= H;
+        const int ra = on ? v : 1, rb = on ? (v == 0 ? H : M - v) : 1;
+        c0v[i] = col0_bin(lds_read(&z[spec_at(ra, 0)]), pv0a[i], ra, on);
+        chv[i] = col0_bin(lds_read(&z[spec_at(rb, 0)]), pv0b[i], rb, on);
+      }
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < KV0; ++i) {
+        const int v = lane + 64 * i;
+        if (v == 0) {
+          z[spec_at(0, 0)] = {c0v[i].x, chv[i].x};  // (C0[0], CH[0])
+          z[spec_at(H, 0)] = {c0v[i].y, chv[i].y};  // (C0[M/2], CH[M/2])
+        } else if (v < H) {
+          z[spec_at(v, 0)] = {c0v[i].x + chv[i].y, chv[i].x - c0v[i].y};
+          z[spec_at(M - v, 0)] = {c0v[i].x - chv[i].y, chv[i].x + c0v[i].y};
+        }
+      }
+      wave_sync();
+    }
+  } else {
+  fwd_cols(NoSink{});
+  if (wave == 0) split_col0();
   if (MOF_HABL != 2) {
 #pragma unroll
     for (int k = 0; k < KE; ++k) {
@@ -486,22 +588,8 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
       const int rr = on ? r : 0, u = on ? l0 + c : l0;  // (lanes past the wave's elements repeat a bin: cross_power_ab's
       const cf av = lds_read(&z[spec_at(rr, u)]);       //  wave-uniform branch wants every lane to take part)
       const cf bv = on ? pv[k] : cf{1.f, 0.f};
-      cf C = cross_power_ab(av, bv, false);
-      if (u == 0 && (rr == 0 || rr == H)) {
-        // the two real-only slots each of the columns u = 0 (slot 0) and u = M/2 (slot M/2): C = P / (P^2 + eps)
-        const float c1 = cross_power_ab(cf{av.x, 0.f}, cf{bv.x, 0.f}, true).x, c2 = cross_power_ab(cf{av.y, 0.f}, cf{bv.y, 0.f}, true).x;
-        C = {c1, c2};
-        if (rr == 0 && on) flags[2] = __float_as_int(c1);  // C_dc: all that is left of a degenerate pair's spectrum
-      }
-      if (box_zeros) {
-        if (u == 0) {
-          if (rr == 0) C.y = 0.f;             // (v = M/2, u = 0)
-          else if (rr == H) C = {0.f, 0.f};   // (v = 0, u = M/2) and (v = M/2, u = M/2)
-          else if (rr > H) C = {0.f, 0.f};    // slots M - v hold the column u = M/2
-        } else if (rr == H) {
-          C = {0.f, 0.f};
-        }
-      }
+      cf C = u == 0 ? col0_bin(av, bv, rr, on) : cross_power_ab(av, bv, false);
+      if (box_zeros && u != 0 && rr == H) C = {0.f, 0.f};
       // conjugated for the inverse (a forward transform of conj C); column 0 keeps C itself until it is put together again below
       if (on) z[spec_at(rr, u)] = u == 0 ? C : cf{C.x, -C.y};
     }
@@ -534,6 +622,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
     }
     wave_sync();
   }
+  }  // (!XSINK)
   if (nl > 0 && MOF_HABL != 1) pass_lines_static<SP>(z, tw, cols, l0, nl, lane, false);
   __syncthreads();
 

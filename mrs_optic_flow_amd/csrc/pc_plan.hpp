@@ -141,6 +141,14 @@ __device__ __forceinline__ void bfly_rt(int R, cf* v) {
                          // fewer per butterfly, the same value up to rounding -- what the tuned kernels do); 0: cmul + butterfly<8> (r04)
 #define MOF_PLANNED_TW8 1
 #endif
+// A sink may declare `transforms = true`: the last stage then hands it every output BEFORE the tile write, with the stage routine's
+// compile-time loop indices (butterfly b of the lane's group, output p): val = sink.transform(line, o, val, b, p, &write). The sink may
+// keep the value in a per-lane register array laid out in the stage's own lane map, replace it, or suppress the write
+// (pc_half_kernel.hip: the previous image's spectrum never passes through LDS, the cross-power spectrum is formed on the way out).
+template <class S, class = void>
+struct SinkTransforms { static constexpr bool value = false; };
+template <class S>
+struct SinkTransforms<S, decltype((void)S::transforms)> { static constexpr bool value = S::transforms; };
 struct NoSink {
   static constexpr bool active = false;
   __device__ __forceinline__ void operator()(int, int, cf) const {}
@@ -241,8 +249,14 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
           for (int p = 0; p < SLOTS; ++p)
             if (p < R) {
               const int o = obase + p * np;
-              z[loff[b] + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
-              if constexpr (Sink::active) sink(line0 + g0 + b * lpg + sub, o, v[b][p]);
+              if constexpr (SinkTransforms<Sink>::value) {
+                bool wr = true;
+                const cf val = sink.transform(line0 + g0 + b * lpg + sub, o, v[b][p], b, p, &wr);
+                if (wr) z[loff[b] + o * w.es + ((o >> 3) & w.emask)] = val;
+              } else {
+                z[loff[b] + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
+                if constexpr (Sink::active) sink(line0 + g0 + b * lpg + sub, o, v[b][p]);
+              }
             }
         }
       wave_sync();
@@ -301,8 +315,14 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
           for (int p = 0; p < SLOTS; ++p)
             if (p < R) {
               const int o = base + p * np;
-              z[loff + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
-              if constexpr (Sink::active) sink(l, o, v[b][p]);
+              if constexpr (SinkTransforms<Sink>::value) {
+                bool wr = true;
+                const cf val = sink.transform(l, o, v[b][p], b, p, &wr);
+                if (wr) z[loff + o * w.es + ((o >> 3) & w.emask)] = val;
+              } else {
+                z[loff + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
+                if constexpr (Sink::active) sink(l, o, v[b][p]);
+              }
             }
         }
       wave_sync();
