@@ -713,12 +713,14 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   }
 }
 
-// the transform sizes with an instantiation: the even 5-smooth sizes in (135, 192] -- what this kernel exists for -- and the
-// tuned pair kernels' sizes for A/B and for the parity tests of this formulation (MOF_FFT_HALF=1)
+// the transform sizes with an instantiation: the even 5-smooth sizes in (135, 192] -- what this kernel was written for --, the sizes
+// below that where it beats the full-tile kernels on the box (60, 64 padded, 96, 100 against the planned kernel: +10 .. 14 %; 120
+// against the tuned pair kernel: +18 %; profiles/r05_half_vs_planned_rates.txt -- it loses at 40, 48, 50, 54, 80, 108 and ties at 72,
+// 90, which therefore have no instantiation), and 128 / 64 for the A/B against the tuned pair kernels (MOF_FFT_HALF=1)
 #ifdef MOF_HALF_ONLY  // (A/B sweeps: one instantiation compiles in seconds)
 #define MOF_HALF_SIZES(X) X(MOF_HALF_ONLY)
 #else
-#define MOF_HALF_SIZES(X) X(64) X(96) X(120) X(128) X(144) X(150) X(160) X(162) X(180) X(192)
+#define MOF_HALF_SIZES(X) X(60) X(64) X(96) X(100) X(120) X(128) X(144) X(150) X(160) X(162) X(180) X(192)
 #endif
 
 template <int CH, int MS>
