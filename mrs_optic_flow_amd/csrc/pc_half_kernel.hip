@@ -263,6 +263,9 @@ struct HalfUntangleSrc {
 #ifndef MOF_HALF_XPOW_SINK
 #define MOF_HALF_XPOW_SINK 1
 #endif
+#ifndef MOF_HALF_MAX_GROUPS  // groups of a fused stage a wave may hold in registers at once (1: the r05 first form, sizes up to 144 only)
+#define MOF_HALF_MAX_GROUPS 2
+#endif
 struct HalfSaveSink {
   static constexpr bool active = true;
   static constexpr bool transforms = true;
@@ -322,9 +325,13 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
 
   // first stage of a pass (pc_plan.hpp, stage_rt): R0 butterflies ... one group covers GROUP0 lines
   constexpr int R0 = SP::P.radix[0], BPL0 = M / R0, GROUP0 = (16 / pc_slots(R0)) * (64 / BPL0);
-  constexpr bool UFUSE = MOF_HALF_UNTANGLE_SRC != 0 && LPW <= GROUP0;  // the wave's columns are ONE group of the first column stage
+  // the wave's columns as NG0 compile-time groups of the first column stage (stage_rt_ng; r05: one group -- 64 .. 144 -- or two -- the
+  // sizes of 150 .. 192, 32 complex values per lane in flight)
+  constexpr int NG0 = (LPW + GROUP0 - 1) / GROUP0;
+  constexpr bool UFUSE = MOF_HALF_UNTANGLE_SRC != 0 && NG0 <= MOF_HALF_MAX_GROUPS;
   constexpr int RL = SP::P.radix[SP::P.n_stages - 1], BPLL = M / RL, NBL = 16 / pc_slots(RL), GROUPL = BPLL <= 64 ? NBL * (64 / BPLL) : 0;
-  constexpr bool XSINK = MOF_HALF_XPOW_SINK != 0 && UFUSE && LPW <= GROUPL && SP::P.n_stages >= 2;  // ... and ONE group of the last one
+  constexpr int NGL = GROUPL > 0 ? (LPW + GROUPL - 1) / GROUPL : 99;  // ... and of the last one (162's radix-2 stage has long lines: none)
+  constexpr bool XSINK = MOF_HALF_XPOW_SINK != 0 && UFUSE && NGL <= MOF_HALF_MAX_GROUPS && SP::P.n_stages >= 2;
   static_assert(!UFUSE || (WAVES - 1) * LPW < H, "every wave owns a line: the barrier inside the fused stage is met by all");
   // wave w owns lines [l0, l0 + nl): row pairs in the row passes, columns in the column passes
   const int l0 = wave * LPW;
@@ -484,7 +491,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
 
   // ---- previous image: rows, barrier, columns; its half spectrum moves into registers
   constexpr int KE = (LPW * M + 63) / 64;  // elements of the wave's columns per lane: element q = lane + 64 k -> (row q / LPW, column q % LPW)
-  constexpr int NPV = XSINK ? NBL * RL : KE;  // XSINK: the last column stage's own outputs, butterfly b, output p
+  constexpr int NPV = XSINK ? NGL * NBL * RL : KE;  // XSINK: the last column stage's own outputs: (group, butterfly), output p
   constexpr int KV0 = (H + 1 + 63) / 64;      // XSINK: column 0's slots v and M - v (v <= M/2) of the previous image, lane v
   cf pv[NPV], pv0a[KV0], pv0b[KV0];
   load_and_rows(prev, 1);
@@ -494,7 +501,8 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
     using Sink = decltype(sink);
     if constexpr (MOF_HABL == 1) return;
     if constexpr (UFUSE)
-      pass_lines_static<SP, 0, 1, Sink, HalfUntangleSrc, WorkgroupSync>(z, tw, cols, l0, nl, lane, false, sink, HalfUntangleSrc{P, M, SKM});
+      pass_lines_static<SP, 0, 1, Sink, HalfUntangleSrc, WorkgroupSync, NG0, (XSINK ? NGL : 0)>(z, tw, cols, l0, nl, lane, false, sink,
+                                                                                                HalfUntangleSrc{P, M, SKM});
     else if (nl > 0)
       pass_lines_static<SP, 0, 1, Sink>(z, tw, cols, l0, nl, lane, false, sink);
   };

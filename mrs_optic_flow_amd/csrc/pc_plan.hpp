@@ -330,6 +330,89 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
   }
 }
 
+// The same stage with the wave's lines as NG compile-time GROUPS, every group's inputs read (and transformed) before the first output
+// is written: what a stage needs whose source reads lines that ANOTHER wave's writes of the same stage overwrite (Sync = WorkgroupSync
+// between the two phases; each wave runs the stage exactly once, so the barrier is met by all) or whose sink / source addresses a
+// per-lane register array by (group, butterfly, element) -- the indices must be compile-time for the array to stay in registers.
+// NG * (16 / SLOTS) * SLOTS = 16 NG complex values per lane are in flight. Requires bpl <= 64 and nlines <= NG * group.
+template <int SLOTS, int NG, class Sink = NoSink, class Src = NoSrc, class Sync = WaveSync>
+__device__ __forceinline__ void stage_rt_ng(cf* __restrict__ z, const cf* __restrict__ tw, const Walk& w, int m, int R, int np, int bpl,
+                                            int tstep, int line0, int nlines, int lane, Sink sink = Sink{}, Src src = Src{}) {
+  constexpr int NB = 16 / SLOTS;
+  const float inv_np = 1.0f / (float)np, inv_bpl = 1.0f / (float)bpl;
+  int rem64;
+  const int lpg = fdiv(64, bpl, inv_bpl, &rem64);
+  int x, sub;
+  if (w.line_fast) {
+    const float inv_lpg = 1.0f / (float)lpg;
+    x = fdiv(lane, lpg, inv_lpg, &sub);
+  } else {
+    sub = fdiv(lane, bpl, inv_bpl, &x);
+  }
+  const bool lane_on = w.line_fast ? x < bpl : sub < lpg;
+  int k = 0;
+  if (np > 1) (void)fdiv(x, np, inv_np, &k);
+  cf t[SLOTS - 1];
+  if (np > 1) {
+#pragma unroll
+    for (int j = 1; j < SLOTS; ++j)
+      if (j < R) t[j - 1] = lds_read(&tw[j * k * tstep]);
+  }
+  const int obase = (x - k) * R + k;
+  const int group = NB * lpg;
+  cf v[NG][NB][SLOTS];
+  int loff[NG][NB];
+  bool on[NG][NB];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int li = g * group + b * lpg + sub;
+      const int l = line0 + li;
+      on[g][b] = lane_on && li < nlines;
+      loff[g][b] = l * w.ls + ((l >> 3) & w.lmask);
+      if (on[g][b]) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j)
+          if (j < R) {
+            const int e = x + j * bpl;
+            cf a;
+            if constexpr (Src::active) {
+              a = src(z, l, e);
+            } else {
+              a = lds_read(&z[loff[g][b] + e * w.es + ((e >> 3) & w.emask)]);
+            }
+            if (j > 0 && np > 1 && !(MOF_PLANNED_TW8 && SLOTS == 8 && R == 8)) a = cmul(a, t[j - 1]);
+            v[g][b][j] = a;
+          }
+        if (MOF_PLANNED_TW8 && SLOTS == 8 && R == 8 && np > 1) butterfly8_tw(v[g][b], t);
+        else bfly_rt<SLOTS>(R, v[g][b]);
+      }
+    }
+  Sync{}();
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      if (on[g][b]) {
+#pragma unroll
+        for (int p = 0; p < SLOTS; ++p)
+          if (p < R) {
+            const int o = obase + p * np;
+            const int l = line0 + g * group + b * lpg + sub;
+            if constexpr (SinkTransforms<Sink>::value) {
+              bool wr = true;
+              const cf val = sink.transform(l, o, v[g][b][p], g * NB + b, p, &wr);
+              if (wr) z[loff[g][b] + o * w.es + ((o >> 3) & w.emask)] = val;
+            } else {
+              z[loff[g][b] + o * w.es + ((o >> 3) & w.emask)] = v[g][b][p];
+              if constexpr (Sink::active) sink(l, o, v[g][b][p]);
+            }
+          }
+      }
+  wave_sync();
+}
+
 // all stages of one 1-D pass over the wave's lines. EXACT = false: stage bodies with 8 and 4 register slots per butterfly (radix 5
 // and 6 ride in the 8-slot body, 3 and 2 in the 4-slot one; WIDE adds the 16-slot body for the composite radices 9 .. 16 of the
 // compile-time plans) -- enough for every line of a tile that fits a CU (m / R <= 67) and the smallest code; EXACT = true: one body
@@ -384,17 +467,25 @@ __device__ __forceinline__ void pass_lines(cf* z, const cf* tw, const PcPlan& pl
 // The same for a compile-time plan (SP::P a constexpr PcPlan): the stages are a compile-time recursion, so every radix, stride and
 // count reaches the stage routine as a constant (a `#pragma unroll` on the run-time loop is not honoured once the 16-slot bodies make
 // it large, and the radix dispatch then stays in the code).
-template <class SP, int S = 0, int NP = 1, class Sink = NoSink, class Src = NoSrc, class Sync0 = WaveSync>
+// NG0 / NGL > 0: the first / last stage runs as stage_rt_ng with that many compile-time groups (the caller guarantees
+// nlines <= NG * that stage's group and bpl <= 64 there).
+template <class SP, int S = 0, int NP = 1, class Sink = NoSink, class Src = NoSrc, class Sync0 = WaveSync, int NG0 = 0, int NGL = 0>
 __device__ __forceinline__ void pass_lines_static(cf* z, const cf* tw, const Walk& w, int line0, int nlines, int lane, bool herm,
                                                   Sink sink = Sink{}, Src src = Src{}) {
   if constexpr (S < SP::P.n_stages) {
     constexpr int R = SP::P.radix[S], M = SP::P.m, REST = M / (NP * R);
     constexpr int SL = R > 8 ? 16 : (R > 4 ? 8 : 4);
     static_assert(SP::P.n_stages >= 2 || !(Sink::active && Src::active), "sink and source ride different stages");
-    if constexpr (S + 1 == SP::P.n_stages) stage_rt<SL, Sink>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm && S == 0, sink);
-    else if constexpr (S == 0) stage_rt<SL, NoSink, Src, Sync0>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm, NoSink{}, src);
-    else stage_rt<SL>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, false);
-    pass_lines_static<SP, S + 1, NP * R, Sink, Src, Sync0>(z, tw, w, line0, nlines, lane, herm, sink, src);
+    if constexpr (S + 1 == SP::P.n_stages) {
+      if constexpr (NGL > 0) stage_rt_ng<SL, NGL, Sink>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, sink);
+      else stage_rt<SL, Sink>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm && S == 0, sink);
+    } else if constexpr (S == 0) {
+      if constexpr (NG0 > 0) stage_rt_ng<SL, NG0, NoSink, Src, Sync0>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, NoSink{}, src);
+      else stage_rt<SL, NoSink, Src, Sync0>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, herm, NoSink{}, src);
+    } else {
+      stage_rt<SL>(z, tw, w, M, R, NP, REST * NP, REST, line0, nlines, lane, false);
+    }
+    pass_lines_static<SP, S + 1, NP * R, Sink, Src, Sync0, NG0, NGL>(z, tw, w, line0, nlines, lane, herm, sink, src);
   }
 }
 
