@@ -117,7 +117,7 @@ WORKLOADS = {
                 name="p96: FftMethod 480x480, 5x5 grid of 96x96 patches (half-tile kernel since r05; MOF_FFT_HALF=0: the full-tile planned kernel), batch=1024 per GPU",
                 bytes_per_pair=2 * 480 * 480 + 25 * 8),
     "p62": dict(kind="fft", h=496, w=496, n=62, grid=(8, 8), origin=(0, 0), stride=(62, 62), batch=1024, s=7,
-                name="p62: FftMethod 496x496, 8x8 grid of 62x62 patches padded to 64 (half-tile kernel since r05; MOF_FFT_HALF=0: the full-tile planned kernel), batch=1024 per GPU",
+                name="p62: FftMethod 496x496, 8x8 grid of 62x62 patches padded to 64 (planned kernel), batch=1024 per GPU",
                 bytes_per_pair=2 * 496 * 496 + 64 * 8),
     "l160": dict(kind="fft", h=480, w=480, n=160, grid=(3, 3), origin=(0, 0), stride=(160, 160), batch=512, s=15,
                  name="l160: FftMethod 480x480, 3x3 grid of 160x160 patches (fused half-tile kernel; MOF_FFT_HALF=0: the pipeline through HBM scratch), batch=512 per GPU",

@@ -408,9 +408,10 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     // waves beat the tuned one-workgroup kernel there (1.14 M against 1.10 M pairs/s same-box, profiles/r05_half_raw_pairsrc_ab.txt);
     // its long-range mode and OpenCL peak model stay on the tuned kernel (launch_field)
     const bool tuned_size_default = n == 120 && !e->generic && !e->large;
-    // ... and the planned sizes where it beats the full-tile planned kernel on the box (transform sizes 60, 64, 96, 100: +10 .. 14 %,
-    // profiles/r05_half_vs_planned_rates.txt); the tuned N = 64 / 128 pair kernels stay faster than it and keep their sizes
-    const bool planned_size_default = e->generic && !force_planned && (n == 60 || n == 64 || n == 96 || n == 100);
+    // ... and the planned sizes where it beats the full-tile planned kernel on the box (transform sizes 60, 96, 100: p60 1.10 -> 1.38 M,
+    // p96 757 -> 855 k pairs/s, profiles/r05_half_vs_planned_bench_ab.txt, r05_half_vs_planned_rates.txt; on patches padded to 64 it
+    // loses 4 %, p62); the tuned N = 64 / 128 pair kernels stay faster than it and keep their sizes
+    const bool planned_size_default = e->generic && !force_planned && (n == 60 || n == 96 || n == 100);
     if (cfg->peak_model == MOF_PEAK_OPENCV && mof::pc_half_supported(n) && half_knob != 0 && !force_large && !force_planned &&
         (e->large || half_knob == 1 || tuned_size_default || planned_size_default))
       e->half_m = n;

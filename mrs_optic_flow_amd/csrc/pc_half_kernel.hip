@@ -78,6 +78,7 @@ constexpr int half_stage_lines(int m, int R) {  // lines one group of a stage co
 constexpr int half_table_pitch(int m, int* skew) {
   if (!MOF_HALF_PITCH_TABLE) return 0;
   switch (m) {
+    case 60: *skew = 0; return 68;    // (box: 68 / 76 unskewed 1.36 M at p60, the rule's 72 skewed 1.29 M; profiles/r05_half_pitch60_sweep.txt)
     case 120: *skew = 0; return 136;  // (measured too, tools/sweep_half_pitch.sh, profiles/r05_half_pitch120_sweep.txt: 136 unskewed 1.14 M, 120 1.13 M, 152 1.13 M, 128 0.93 M; skewed 136 / 152: 1.05 M)
     case 144: *skew = 1; return 202;
     case 150: *skew = 0; return 180;
@@ -722,9 +723,9 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
 }
 
 // the transform sizes with an instantiation: the even 5-smooth sizes in (135, 192] -- what this kernel was written for --, the sizes
-// below that where it beats the full-tile kernels on the box (60, 64 padded, 96, 100 against the planned kernel: +10 .. 14 %; 120
-// against the tuned pair kernel: +18 %; profiles/r05_half_vs_planned_rates.txt -- it loses at 40, 48, 50, 54, 80, 108 and ties at 72,
-// 90, which therefore have no instantiation), and 128 / 64 for the A/B against the tuned pair kernels (MOF_FFT_HALF=1)
+// below that where it beats the full-tile kernels on the box (60, 96, 100 against the planned kernel: +10 .. 25 %; 120 against the tuned
+// pair kernel: +18 %; profiles/r05_half_vs_planned_rates.txt, r05_half_vs_planned_bench_ab.txt -- it loses at 40, 48, 50, 54, 80, 108
+// and on patches padded to 64, and ties at 72, 90), and 128 / 64 for the A/B against the tuned pair kernels (MOF_FFT_HALF=1)
 #ifdef MOF_HALF_ONLY  // (A/B sweeps: one instantiation compiles in seconds)
 #define MOF_HALF_SIZES(X) X(MOF_HALF_ONLY)
 #else

@@ -34,10 +34,10 @@ def _compare(got, cur, prev, lay, label=""):
 
 
 def _planned_variant(n):
-    """r05: transform sizes 60, 64, 96, 100 run the half-tile kernel by default (it beats the full-tile planned kernel there by 10 - 14 %,
-    profiles/r05_half_vs_planned_rates.txt); MOF_FFT_HALF=0 keeps the planned kernel (a child process below re-runs them that way)."""
+    """r05: transform sizes 60, 96, 100 run the half-tile kernel by default (it beats the full-tile planned kernel there by 10 - 25 %,
+    profiles/r05_half_vs_planned_bench_ab.txt); MOF_FFT_HALF=0 keeps the planned kernel (a child process below re-runs them that way)."""
     import os
-    half = O.optimal_dft_size(n) in (60, 64, 96, 100) and os.environ.get("MOF_FFT_HALF", "") != "0"
+    half = O.optimal_dft_size(n) in (60, 96, 100) and os.environ.get("MOF_FFT_HALF", "") != "0"
     return "planned-half" if half else "planned"
 
 
