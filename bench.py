@@ -53,7 +53,7 @@ def binding_note(name: str, wl) -> str:
     if wl["kind"] == "fftseq":
         if wl["n"] == 64:
             return ("K1 sequence kernel: one real forward transform + one Hermitian inverse per frame and patch (1.0 instead of 1.5 "
-                    "complex-transform units), four barriers per frame. profiles/r04_c2seq_sq_pmc.csv (per launch of 65,536 patch "
+                    "complex-transform units), four barriers per frame. profiles/r04_c2seq_sq_pmc.csv (kernel unchanged in r05) (per launch of 65,536 patch "
                     "frames): VALU issue 47.8 % (272.3 M wave-instructions x 2 cycles over 1024 SIMDs x 1.114 M cycles), LDS active "
                     "56.7 % of the CU cycles (12.6 % of it bank conflicts); the two add to 104 %: the pipes run one after the other, "
                     "not side by side; not HBM")
@@ -63,24 +63,31 @@ def binding_note(name: str, wl) -> str:
         return ("c5 on a video: one Lanczos4 remap and one real row transform per frame (K5s), column pass walking pairs in "
                 "time with the previous spectra in registers (K6s); DESIGN.md section 4 (sequence mode)")
     if wl["kind"] == "fft+sr":
-        return ("scale/rotation pipeline K4-K8 takes 78 % of the step: log-polar gathers (v_dot4c taps on LDS-staged source "
-                "boxes: LDS reads + VALU) 34 %, whole-frame transforms through Zt / Dt (per-frame real row transforms K5s, column "
-                "pass K6s, inverse rows K7: 4.5-4.9 TB/s of HBM traffic each, 70-80 % of the achievable rate) 43 %; "
-                "K1 as in c2; DESIGN.md section 4 (K4-K8)")
+        return ("scale/rotation pipeline K4-K8 takes 76 % of the step (profiles/r05_c5_kernel_stats.csv, r05_c5_sq_pmc.csv): log-polar gathers "
+                "(v_dot4c taps on LDS-staged source boxes; Lanczos4 540 us: LDS 58 % busy, VALU 30 %, waits 45 %; cubic 367 us) 32 %, whole-frame "
+                "transforms through Zh / Dt (K5s 447 us at 5.2 TB/s, K6s 581 us at 4.8 TB/s, K7 202 us at 4.6 TB/s: the minimum bytes of a rows -> "
+                "columns -> rows structure in f32, at 73-83 % of the achievable copy rate) 43 %; K1 as in c2; DESIGN.md section 4 (K4-K8, r05 block)")
     if wl["n"] == 120:
-        return ("one persistent workgroup of 15 waves per CU (the 120 x 136 tile fills the LDS). profiles/r04_ref_sq_pmc.csv (per launch "
-                "of 16,384 patch pairs): VALU issue 38.6 % (435.2 M wave-instructions x 2 cycles over 1024 SIMDs x 2.203 M cycles), LDS "
-                "active 32.4 % of the CU cycles (1.9 % of it bank conflicts), waves parked at a wait 47.8 % of their cycles: with one "
-                "workgroup per CU nothing covers a phase's own read -> butterfly -> write chain; not HBM")
+        return ("half-tile kernel K1h (pc_half_kernel.hip, r05): each image transformed on its own on a 60 x 136 complex tile, TWO workgroups of "
+                "8 waves per CU, every phase on all waves, the untangle / pairing / cross-power fused into the passes, the previous spectrum in "
+                "registers. profiles/r05_ref_sq_pmc.csv (per launch of 16,384 patch pairs): VALU issue 50.7 % (467.8 M wave-instructions x 2 cycles "
+                "over 1024 SIMDs x 1.845 M cycles; 3569 per wave), LDS active 52.1 % of the CU cycles (28 % of it bank conflicts), waves parked at a "
+                "wait 32.0 % of their cycles -- against the tuned one-workgroup kernel's 38.8 % + 37.0 %, waits 45.6 % (r05_ref_tuned_sq_pmc.csv, "
+                "MOF_FFT_HALF=0: 1.10 M pairs/s); VALU + LDS = 103 %: the two pipes in series, as K1; not HBM")
     if wl["n"] >= 128:
         return ("one persistent workgroup per CU (the tile fills the LDS): the LDS store path (ds_write_b64 = 6 cycles per "
                 "wave-instruction, 7.5 tile stores per patch pair) and the 8-wave inverse passes; N = 128: VALU issue ~42 %, "
-                "LDS 46 % busy, 6 % of it bank conflicts (profiles/r03_c4_sq_pmc.csv; the kernel is unchanged since); the two add to "
+                "LDS 46 % busy, 6 % of it bank conflicts (profiles/r05_c4_sq_pmc.csv; the kernel is unchanged since r03); the two add to "
                 "88 %: in series; not HBM -- DESIGN.md section 4 (K1 at N = 128)")
+    if wl["n"] in (60, 96, 100) or 136 <= wl["n"] <= 192:
+        return ("half-tile kernel K1h (pc_half_kernel.hip, r05; planned Stockham stages with compile-time radices, sources / sinks fused into "
+                "the passes). profiles/r05_{p60,p96,l160}_sq_pmc.csv: p60 VALU issue 56 % + LDS 61 % (30 % of it conflicts), waits 28 %; p96 "
+                "36 % + 45 % (40 %), waits 36 %; l160 36 % + 41 % (40 %), waits 36 % at one 10-wave workgroup per CU -- LDS bank conflicts of the "
+                "generic lane maps and the series of the two pipes; not HBM (DESIGN.md section 4, K1h)")
     if wl["n"] != 64:
         return ("planned kernel (run-time radix plan, pc_kernel_generic.hip / pc_large_kernel.hip): the general path, not tuned -- "
                 "DESIGN.md section 4 (size-generic kernels)")
-    return ("four workgroups per CU (LDS capacity). profiles/r04_c2_sq_pmc.csv (per launch of 65,536 patch pairs): VALU issue 53.7 % "
+    return ("four workgroups per CU (LDS capacity). profiles/r05_c2_sq_pmc.csv (per launch of 65,536 patch pairs; the kernel and its counters are unchanged since r04): VALU issue 53.7 % "
             "(370.3 M wave-instructions x 2 cycles over 1024 SIMDs x 1.346 M cycles; 1412 per wave and patch pair), LDS active 52.7 % "
             "of the CU cycles (9.7 % of it bank conflicts; two thirds of it the store path, 6 cycles per ds_write_b64), waves stalled "
             "on LDS issue 14 %; VALU + LDS = 106 %: the two pipes run one after the other, not side by side -- that serialisation, "

@@ -111,18 +111,23 @@ typedef struct mof_fft_engine mof_fft_engine;
 /* Patch sizes (FftMethod.cpp:1680-1720 takes frameSize / samplePointSize from ROS parameters, config/default.yaml:31-32, and
  * falls back to ONE patch = the whole frame when they do not divide): every patch goes through cv::phaseCorrelate (:1836),
  * which zero-pads it to M = cv::getOptimalDFTSize(N), the smallest 2^a 3^b 5^c >= N (possibly odd: 74 -> 75); peak, centroid and
- * centre (M / 2.0) live on the padded image, the gate compares with N / 2 (:1841-1842). Three kernel families serve this
- * (mof_fft_kernel_variant): hand-tuned instantiations for N = 32, 64, 120 (reference default), 128 ("stockham"); a run-time
- * planned kernel for every other N with M <= 135 ("planned", csrc/pc_kernel_generic.hip); a planned pipeline through HBM scratch
- * for larger patches up to M = 960 ("planned-large", csrc/pc_large_kernel.hip; unpadded patches of 240 / 256 / 480 pixels run the
- * scale / rotation estimator's tuned transform kernels inside it). mof_fft_create fails with MOF_ERR_UNSUPPORTED
+ * centre (M / 2.0) live on the padded image, the gate compares with N / 2 (:1841-1842). Four kernel families serve this
+ * (mof_fft_kernel_variant): hand-tuned packed-pair instantiations for N = 32, 64, 128 -- and 120 for the long-range mode and the OpenCL
+ * peak model -- ("stockham"); the fused kernel on a HALF-size tile ("planned-half", csrc/pc_half_kernel.hip, r05: each image
+ * transformed on its own, the previous spectrum waiting in registers) for N = 120 -- the reference's default, two workgroups per CU --,
+ * for every N whose padded size is an even 136 .. 192, and for padded sizes 60 / 96 / 100; a planned kernel on the full M x M tile for
+ * every other N with M <= 135 ("planned", csrc/pc_kernel_generic.hip); a planned pipeline through HBM scratch for larger patches up to
+ * M = 960 ("planned-large", csrc/pc_large_kernel.hip; unpadded patches of 240 / 256 / 480 pixels run the scale / rotation
+ * estimator's tuned transform kernels inside it). mof_fft_create fails with MOF_ERR_UNSUPPORTED
  * only beyond that, and for MOF_PEAK_OCL on sizes the reference's OpenCL branch cannot plan either (odd, not 5-smooth) or M > 135.
  * The large-patch pipeline owns scratch (three half-spectrum planes per patch pair of a pass); it grows with the first batch
  * that needs more -- never inside a HIP graph capture: run the largest batch once before capturing. */
 int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out);
-/* Diagnostics: name of the kernel formulation the engine launches: "stockham" (pc_kernel.hip / pc_kernel_mixed.hip),
- * "planned" or "planned-large" (above) in the product library; "quad" only in the A/B build csrc/ab/libmof_hip_quad.so with MOF_PC_QUAD=1 (pc_kernel_quad.hip,
- * a measured-slower alternative kept for comparison, not shipped). */
+/* Diagnostics: name of the kernel formulation the engine launches for cv::phaseCorrelate-model batches on full-resolution frames:
+ * "stockham" (pc_kernel.hip / pc_kernel_mixed.hip), "planned-half", "planned" or "planned-large" (above) in the product library;
+ * "quad" only in the A/B build csrc/ab/libmof_hip_quad.so with MOF_PC_QUAD=1 (pc_kernel_quad.hip, a measured-slower alternative kept
+ * for comparison, not shipped). MOF_FFT_HALF=0 / 1 (environment, read once) keeps every size off / forces the instantiated sizes
+ * onto the half-tile kernel (A/B and the tests of either family). */
 const char* mof_fft_kernel_variant(const mof_fft_engine* e);
 void mof_fft_destroy(mof_fft_engine* e);
 int mof_fft_release_graphs(mof_fft_engine* e);      /* see "HIP graphs" above */

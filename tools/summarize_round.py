@@ -39,6 +39,12 @@ FACTORS = {
     "sr_cols_fused_kernel": (2.0, "r04, K56: every log-polar image comes from HBM once (TCC_HIT 96 %): 2*480*480 B per pair = 471.9 MB per 1024-pair "
                                   "launch; FETCH_SIZE 234.5 MB = 0.50x (profiles/r04_sr_fused_pmc.csv)"),
     "sr_cols_seq_kernel": (2.0, "reads 17 frames of Zh (925,440 B) per 16-pair run = 503.4 MB per 512-pair launch; FETCH_SIZE 251.5 MB = 0.50x"),
+    # r05: the half-tile kernel reads every pixel of every patch exactly once with one unaligned dword per four pixels. At l160 (160-byte
+    # patch rows) FETCH_SIZE reads BELOW the bytes that must be fetched -- 189.29 MB against 2*480*480*512 B = 235.93 MB per launch
+    # (profiles/r05_l160_pmc.csv): factor 1.247 from its own lower bound, for THAT instantiation only; at ref (120-byte rows: 472.7 MB
+    # against 471.9 MB) and p96 the counter matches the known bytes, at p60 (60-byte rows, neighbouring patches share every line) it
+    # reads 1.54 x -- real re-fetches. The other instantiations are taken at face value.
+    "pc_half_kernel<1, 160": (1.247, "l160: known 235.93 MB per launch (every pixel once), FETCH_SIZE 189.29 MB: factor 1.247 (lower bound from its own algorithmic bytes)"),
     "pc_seq_kernel": (1.0, "8-byte loads; 285.2 MB of patch pixels per launch x the same 1.40 row-gap overhead K1 shows on the c2 layout = 399 MB; FETCH_SIZE 398.7 MB"),
 }
 
