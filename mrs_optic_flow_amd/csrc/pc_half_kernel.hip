@@ -1,34 +1,39 @@
 // pc_half_kernel.hip -- K1h: the fused per-patch phase correlation on a HALF-size LDS tile, from compile-time plans.
 //
-// Serves the patch sizes whose padded transform size M = cv::getOptimalDFTSize(samplePointSize) is even and lies in (135, 192]
+// Written for the patch sizes whose padded transform size M = cv::getOptimalDFTSize(samplePointSize) is even and lies in (135, 192]
 // -- FftMethod takes any samplePointSize (/root/reference/src/FftMethod.cpp:1706-1720, :1829-1866) and every patch goes through
 // cv::phaseCorrelate (:1836) -- i.e. the sizes whose M x M COMPLEX tile (pc_kernel_generic.hip's packed z = cur + i prev) no longer
-// fits one CU's 160 KB of LDS but whose HALF tile does. Until r05 those ran the four-kernel pipeline through HBM scratch
-// (pc_large_kernel.hip): 3.5 x slower per pixel than the in-LDS kernels on either side of M = 135.
+// fits one CU's 160 KB of LDS but whose HALF tile does; until r05 those ran the four-kernel pipeline through HBM scratch
+// (pc_large_kernel.hip), 3.5 x slower per pixel than the in-LDS kernels on either side of M = 135. It then turned out to beat the
+// full-tile kernels where TWO or more of its workgroups fit a CU: it is the default for samplePointSize 120 (the reference's own
+// default, config/default.yaml:31-32: 1.10 -> 1.30 M pairs/s at the reference geometry) and for padded sizes 60 / 96 / 100.
 //
 // The real formulation (the one pc_seq_half.hip uses for videos and pc_large_kernel.hip streams through HBM) never holds more
 // than M/2 x M complex values: each image is transformed on its own,
-//   rows    two real rows (2j, 2j+1) per complex line j  ->  1-D transforms along x  ->  untangle into the rows' half spectra
-//           u = 0 .. M/2-1 (the real bins u = 0 and u = M/2 of a row share its column 0), DOUBLED (the 1/2 rides in cross_power_ab)
-//   columns M/2 complex columns of length M (column 0 = the two real columns u = 0 | M/2, separated with the partner bin M - v)
-// the previous image's half spectrum waits in REGISTERS (each wave keeps the columns it owns) while the tile is reused for the
-// current image; then, per wave and with no workgroup barrier in between: forward columns of the current image -> normalised
-// cross-power spectrum against the registers, real-only-slot rule and all (pc_common.hpp; mulSpectrums :1494, magSpectrums
-// :70-168, divSpectrums :1086-1251) -> inverse columns; then Hermitian row PAIRS (2j, 2j+1) as one complex transform each, the
-// first maximum of the fft-shifted surface (fftShift :1257-1323, minMaxLoc :1539) riding the last stage's registers, and the
-// 5 x 5 fp64 centroid + gate (:1337-1383, :1838-1856) by one wave. Every 1-D transform is a planned Stockham chain run by ONE
-// wave on lines it owns (pc_plan.hpp: pass_lines_static; compile-time radices, two stages where the size allows).
+//   rows    two real rows (2j, 2j+1) per complex line j, staged as raw bytes and converted by the first row stage (HalfRawSrc)
+//           -> 1-D transforms along x
+//   columns M/2 complex columns of length M; the UNTANGLE of the row pairs (R_2j[u] = (Z[u] + conj Z[M-u]) / 2, R_2j+1[u] = (Z[u] -
+//           conj Z[M-u]) / 2i, kept doubled; the real bins u = 0 and u = M/2 of a row share column 0) is the SOURCE of the first column
+//           stage (HalfUntangleSrc, a workgroup barrier between that stage's reads and writes); column 0 = the two real columns
+//           u = 0 | M/2, separated with the partner bin M - v by its owner
+// and the spectra never pass through LDS: the last stage of the previous image's column pass keeps its outputs in REGISTERS
+// (HalfSaveSink), the last stage of the current image's pass meets them there and writes the conjugated normalised cross-power
+// spectrum instead (HalfXpowSink: real-only-slot rule and all, pc_common.hpp; mulSpectrums :1494, magSpectrums :70-168, divSpectrums
+// :1086-1251) -> inverse columns, no workgroup barrier since the forward pass -> Hermitian row PAIRS (2j, 2j+1) as one complex
+// transform each, the pairing as the source of their first stage (HalfPairSrc), the first maximum of the fft-shifted surface
+// (fftShift :1257-1323, minMaxLoc :1539) riding the last stage's registers (HalfScanSink), and the 5 x 5 fp64 centroid + gate
+// (:1337-1383, :1838-1856) by one wave. Every 1-D transform is a planned Stockham chain run by ONE wave on lines it owns
+// (pc_plan.hpp: pass_lines_static, stage_rt / stage_rt_ng; compile-time radices, two stages where the size allows).
 //
-// Tile layout (complex elements, P = pitch of a physical line, even):
-//   rows layout   line j, element x          at  j P + x + (x >> 3)                      [load, row passes, result surface]
+// Tile layout (complex elements, P = pitch of a physical line, even; the skew where the size's plan keeps it):
+//   rows layout   line j, element x          at  j P + x + (x >> 3)                      [raw bytes, row passes, result surface]
 //   spec layout   logical row r, column u    at  r (P/2) + u + (u >> 3)                  [half spectra, column passes]
-// logical rows 2j | 2j+1 are the two halves of physical line j, so the untangle (rows -> spec) and the pairing (spec -> rows) are
-// in place per line and wave-local; a column walk is linear in r (stride P/2).
+// logical rows 2j | 2j+1 are the two halves of physical line j; a column walk is linear in r (stride P/2).
 // Zero padding (M > samplePointSize), constant patches (exact-zero spectra: `box_zeros`, the closed-form degenerate answer) as
 // pc_large_kernel.hip / pc_kernel_generic.hip handle them. cv::phaseCorrelate's peak model on gray or BGR8 frames; the long-range
-// mode and the OpenCL peak model of these sizes stay on the pipeline they had.
-// MOF_FFT_HALF=1 (diagnostics / A-B) also routes the tuned sizes 64, 96, 120, 128 through this kernel: at M = 120 / 128 TWO
-// workgroups fit a CU (the pair kernels' full tiles allow one).
+// mode and the OpenCL peak model of these sizes stay on the kernels they had.
+// MOF_FFT_HALF=0 keeps every size on its r04 kernel, MOF_FFT_HALF=1 also routes 64 and 128 through this one (A/B: the tuned packed
+// kernels win there, DESIGN.md section 4 "K1h").
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
