@@ -94,6 +94,15 @@ def binding_note(name: str, wl) -> str:
             "not either pipe and not HBM, is what binds (DESIGN.md section 4, K1)")
 
 
+def _tile_workload(n: int):
+    """t<n>: a frame of (480 // n * n)^2 pixels tiled by n x n patches -- the reference tiling at another sample_point_size (sweeps)."""
+    g = max(1, 480 // n)
+    fs = g * n
+    return dict(kind="fft", h=fs, w=fs, n=n, grid=(g, g), origin=(0, 0), stride=(n, n), batch=512 if n > 128 else 1024, s=min(n // 8, 15),
+                name=f"t{n}: FftMethod {fs}x{fs}, {g}x{g} grid of {n}x{n} patches (reference tiling), batch per GPU as stated",
+                bytes_per_pair=2 * fs * fs + g * g * 8)
+
+
 def fft_flops_per_pair(n: int, patches: int) -> float:
     """fp32 work of one frame pair on the FFT path, BASELINE.md section 3 convention: per patch pair one complex 2-D
     forward transform (the two real images ride one complex transform) and half of one for the Hermitian inverse,
@@ -132,6 +141,7 @@ WORKLOADS = {
     "l480": dict(kind="fft", h=480, w=480, n=480, grid=(1, 1), origin=(0, 0), stride=(480, 480), batch=512, s=15,
                  name="l480: FftMethod 480x480, ONE 480x480 patch (the reference's whole-frame fallback), batch=512 per GPU",
                  bytes_per_pair=2 * 480 * 480 + 8),
+    # (the t<n> workloads below are generated: one per remaining half-tile size, for the pitch sweeps of tools/sweep_half_pitch.sh)
     # the node's whole per-frame chain on the device: u8 frame pairs -> K1 shifts -> getRT (undistort,
     # RANSAC homography, decomposition, IMU-consistent pick) -> rotation + velocity; nothing but 64 B per pair leaves the GPU
     "refrt": dict(kind="fft+rt", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
@@ -564,6 +574,10 @@ def measure_other(tag: str, dev, steps: int, warmup: int):
     del launch, eng
     torch.cuda.empty_cache()
     return rec
+
+
+for _n in (100, 144, 150, 162, 180, 192):
+    WORKLOADS[f"t{_n}"] = _tile_workload(_n)
 
 
 def self_launch(n_ranks: int) -> int:

@@ -337,6 +337,23 @@ __device__ __forceinline__ cf cross_power(cf zk, cf zm, bool real_only) {
 // complex transform, which leaks ~1e-7 of the textured patch's spectrum into those zeros; the normalisation blows that up
 // to unit magnitude and the result is noise (found by tools/fft_sr_fuzz.py, r03). So constant patches are detected where
 // the pixels are loaded (exact: integer compares) and the exact answer is substituted in the tail.
+// A constant n x n patch that cv::phaseCorrelate pads to m x m is a BOX, and its spectrum -- level D[v] D[u], D the transform of n ones in a
+// line of m -- is EXACTLY zero on every line k != 0 with k n = 0 (mod m), i.e. on the multiples of q = m / gcd(n, m): the Nyquist line
+// alone when n and m share one factor of two only (158 in 160), but 40, 80, 120 for 156 in 160 and every multiple of 20 for 152 in 160.
+// There P = 0 and C = 0; any transform that leaves rounding noise in those bins has it normalised to unit magnitude (0.03 - 0.09 px off on
+// 156 / 152-pixel constant-against-texture pairs, tools/fft_sr_fuzz.py seeds 606 / 608, r05). The kernels know a constant patch exactly
+// (integer compares where the pixels are loaded), so they zero exactly those bins. q = m when there is no such line.
+__device__ __forceinline__ int box_zero_period(int n, int m) {
+  int a = m, b = n;
+  while (b != 0) {
+    const int t = a % b;
+    a = b;
+    b = t;
+  }
+  return m / a;
+}
+__device__ __forceinline__ bool box_zero_line(int k, int q) { return k != 0 && k % q == 0; }
+
 // (1) per lane: `first` = its first pixel, `diff` != 0 iff one of its packed pixels differs from it
 __device__ __forceinline__ void const_track(const uint32_t* words, int n_words, bool reset, uint32_t& first, uint32_t& diff) {
   if (reset) {

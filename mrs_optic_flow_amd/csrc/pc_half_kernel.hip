@@ -289,10 +289,11 @@ struct HalfXpowSink {
   const cf* pv;
   int R, H;
   bool box_zeros;
+  int q;  // box_zeros: the exact-zero lines of the constant box are the multiples of q (pc_common.hpp, box_zero_period)
   __device__ __forceinline__ cf transform(int l, int o, cf v, int b, int p, bool* wr) const {
     *wr = true;
     cf C = cross_power_ab(v, pv[b * R + p], false);
-    if (box_zeros && o == H) C = {0.f, 0.f};
+    if (box_zeros && (box_zero_line(o, q) || box_zero_line(l, q))) C = {0.f, 0.f};
     return l == 0 ? v : cf{C.x, -C.y};  // (column 0 leaves as it is: taken apart, crossed and put together again by its owner)
   }
 };
@@ -545,7 +546,8 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   // A CONSTANT patch that zero padding turned into an n x n box (n, m even): its spectrum is EXACTLY zero on the Nyquist row and
   // column in the reference's transforms (alternating sums of equal numbers), so C = 0 there; here the rows were transformed in
   // pairs and the zeros carry rounding noise that the normalisation would blow up to unit magnitude (pc_large_kernel.hip, L6)
-  const bool box_zeros = M > n && (n & 1) == 0 && (flags[0] == 0 || flags[1] == 0);
+  const bool box_zeros = M > n && (flags[0] == 0 || flags[1] == 0);
+  const int zq = box_zero_period(n, M);  // its exact-zero lines: the multiples of zq (the Nyquist line alone for most sizes)
   // one bin of column 0 (slot rr): the general rule, or -- slots 0 and M/2 -- the two real-only components (C = P / (P^2 + eps),
   // SURVEY F8); box_zeros: slot 0 = (C0[0], C0[M/2]), slots M/2 .. M-1 hold the column u = M/2
   auto col0_bin = [&](cf av, cf bv, int rr, bool on) -> cf {
@@ -555,15 +557,18 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
       C = {c1, c2};
       if (rr == 0 && on) flags[2] = __float_as_int(c1);  // C_dc: all that is left of a degenerate pair's spectrum
     }
-    if (box_zeros) {
-      if (rr == 0) C.y = 0.f;
-      else if (rr >= H) C = {0.f, 0.f};
+    if (box_zeros) {  // slot rr < M/2: bin (v = rr, u = 0); slot 0 also (M/2, 0); slot M/2: (0, M/2), (M/2, M/2); slots rr > M/2: (M - rr, M/2)
+      const bool zh = box_zero_line(H, zq);
+      if (rr == 0) C.y = zh ? 0.f : C.y;
+      else if (rr == H) C = zh ? cf{0.f, 0.f} : C;
+      else if (rr < H) C = box_zero_line(rr, zq) ? cf{0.f, 0.f} : C;
+      else C = (zh || box_zero_line(M - rr, zq)) ? cf{0.f, 0.f} : C;
     }
     return C;
   };
   if constexpr (XSINK) {
     if constexpr (MOF_HABL == 2) fwd_cols(NoSink{});
-    else fwd_cols(HalfXpowSink{pv, RL, H, box_zeros});
+    else fwd_cols(HalfXpowSink{pv, RL, H, box_zeros, zq});
     if (wave == 0) {
       // column 0: apart, crossed with the previous image's slots (registers, lane v), together again -- G'[v] = conj C0[v] + i conj CH[v],
       // G'[M - v] = C0[v] + i CH[v] (C0, CH Hermitian in v) -- straight from the registers
@@ -603,7 +608,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
       const cf av = lds_read(&z[spec_at(rr, u)]);       //  wave-uniform branch wants every lane to take part)
       const cf bv = on ? pv[k] : cf{1.f, 0.f};
       cf C = u == 0 ? col0_bin(av, bv, rr, on) : cross_power_ab(av, bv, false);
-      if (box_zeros && u != 0 && rr == H) C = {0.f, 0.f};
+      if (box_zeros && u != 0 && (box_zero_line(rr, zq) || box_zero_line(u, zq))) C = {0.f, 0.f};
       // conjugated for the inverse (a forward transform of conj C); column 0 keeps C itself until it is put together again below
       if (on) z[spec_at(rr, u)] = u == 0 ? C : cf{C.x, -C.y};
     }

@@ -68,13 +68,14 @@ struct XpowSrc {
   static constexpr bool active = true;
   int m, H, pitch, skew_mask;
   bool box_zeros;
+  int zq;  // box_zeros: the constant box's exact-zero lines are the multiples of zq (pc_common.hpp, box_zero_period)
   __device__ __forceinline__ cf operator()(const cf* z, int v, int u) const {
     const cf zk = lds_read(&z[v * pitch + u + ((u >> 3) & skew_mask)]);
     if (v == 0) return zk;
     const int um = u == 0 ? 0 : m - u;
     const cf zm = lds_read(&z[(m - v) * pitch + um + ((um >> 3) & skew_mask)]);
     cf C = cross_power<0>(zk, zm, false);
-    if (box_zeros && u == H) C = {0.f, 0.f};
+    if (box_zeros && (box_zero_line(u, zq) || box_zero_line(v, zq))) C = {0.f, 0.f};
     return {C.x, -C.y};
   }
 };
@@ -249,6 +250,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   // lines): 1e-3 px on a 118 x 118 constant-against-texture pair (tools/fft_sr_fuzz.py seed 202). So D goes into LDS here (m sums
   // of n table twiddles) and the cross-power below takes the box from it and the textured spectrum as Z -+ i box: no untangle.
   const bool one_box = m > n && ((flags[0] == 0) != (flags[1] == 0));
+  const int zq = box_zero_period(n, m);  // exact-zero lines of a constant n x n box in the m x m tile: the multiples of zq
   if (one_box) {
 #pragma unroll 1
     for (int k = tid; k < m; k += T) {
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
         idx += k;
         idx = idx >= m ? idx - m : idx;
       }
-      dbox[k] = (k == H && herm && (n & 1) == 0) ? cf{0.f, 0.f} : cf{(float)ax, (float)ay};  // (an even number of alternating ones)
+      dbox[k] = box_zero_line(k, zq) ? cf{0.f, 0.f} : cf{(float)ax, (float)ay};  // (the box's exact zeros: whole periods of the twiddle)
     }
   }
   const Walk rows = {pl.pitch, 1, 0, pl.skew_mask, 0}, cols = {1, pl.pitch, pl.skew_mask, 0, 1};
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
   // 4096 bins at n = 62 -- while the packed transform leaks ~1e-7 of the other patch's spectrum into them, which the
   // normalisation blows up to unit magnitude: 0.5 px off on a constant-against-texture pair (found by the seeded fuzzer classes,
   // r04). The constant patch is known exactly (flags), so are its zero bins.
-  const bool box_zeros = herm && m > n && (n & 1) == 0 && (flags[0] == 0 || flags[1] == 0);
+  const bool box_zeros = m > n && (flags[0] == 0 || flags[1] == 0);
   const bool box_is_cur = flags[0] == 0;
   const float box_level = (float)(box_is_cur ? flags[3] : flags[4]);
   // cross-power of bin (v, u): from the packed pair (untangle), or -- one_box -- from the closed-form box and Z(v, u) alone
@@ -334,7 +336,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
           const int v = 1 + divmod_m(i, &u);
           const int um = u == 0 ? 0 : m - u;
           cf C = cross_power<PK>(zat(v, u), zat(m - v, um), false);
-          if (box_zeros && u == H) C = {0.f, 0.f};
+          if (box_zeros && (box_zero_line(u, zq) || box_zero_line(v, zq))) C = {0.f, 0.f};
           zat(v, u) = {C.x, -C.y};
         }
       }
@@ -346,7 +348,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
           int u;
           const int v = 1 + divmod_m(i, &u);
           cf C = xpow(v, u, m - v, u == 0 ? 0 : m - u, false);
-          if (box_zeros && u == H) C = {0.f, 0.f};
+          if (box_zeros && (box_zero_line(u, zq) || box_zero_line(v, zq))) C = {0.f, 0.f};
           zat(v, u) = {C.x, -C.y};
         }
       }
@@ -358,9 +360,9 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
       const bool self = u == um;
       cf C0 = xpow(0, u, 0, um, self);
       cf Ch = xpow(H, u, H, um, self);
-      if (box_zeros) {
-        Ch = {0.f, 0.f};
-        if (u == H) C0 = {0.f, 0.f};
+      if (box_zeros) {  // C0 = bin (0, u), Ch = bin (M/2, u)
+        if (box_zero_line(H, zq) || box_zero_line(u, zq)) Ch = {0.f, 0.f};
+        if (box_zero_line(u, zq)) C0 = {0.f, 0.f};
       }
       if (u == 0) flags[2] = __float_as_int(C0.x);  // C_dc: all that is left of a degenerate pair's spectrum
       zat(0, u) = {C0.x + Ch.y, Ch.x - C0.y};
@@ -375,7 +377,8 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
       const int vm = v == 0 ? 0 : m - v, um = u == 0 ? 0 : m - u;
       const int ip = vm * m + um;
       if (i > ip) continue;
-      const cf C = xpow(v, u, vm, um, i == 0);
+      cf C = xpow(v, u, vm, um, i == 0);
+      if (box_zeros && (box_zero_line(u, zq) || box_zero_line(v, zq))) C = {0.f, 0.f};  // (odd M: e.g. 130 in 135 has zero lines at 27 k)
       if (i == 0) flags[2] = __float_as_int(C.x);
       zat(v, u) = {C.x, -C.y};
       if (i != ip) zat(vm, um) = {C.x, C.y};  // C[-k] = conj C[k]
@@ -396,7 +399,7 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
       if (xpow_fused) {
         if (nl > 0 && MOF_GABL != 1 && MOF_GABL != 7)
           pass_lines_static<StaticPlanOf<MS>, 0, 1, NoSink, XpowSrc>(z, tw, rows, l0, nl, lane, false, NoSink{},
-                                                                     XpowSrc{m, H, pl.pitch, pl.skew_mask, box_zeros});
+                                                                     XpowSrc{m, H, pl.pitch, pl.skew_mask, box_zeros, zq});
       } else if (nl > 0) {
         run_pass(rows, l0, nl, false);
       }

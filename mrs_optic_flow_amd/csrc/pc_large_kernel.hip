@@ -176,12 +176,15 @@ __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict
   // difference instead of 0 -- which the normalisation blows up to unit magnitude (0.04 px on a 158 x 158 constant-against-texture
   // pair: tools/fft_sr_fuzz.py seed 101). The constant patch is known exactly (L5's flags), so are its zero bins -- the rule of
   // the in-LDS planned kernel (pc_kernel_generic.hip, box_zeros).
-  const bool box_zeros = flags && even && m > pl.n && (pl.n & 1) == 0 && (((flags[2 * pair] & 1) == 0) || ((flags[2 * pair + 1] & 1) == 0));
+  // r05: the box's exact zeros are ALL the lines k != 0 with k n = 0 (mod m) -- the multiples of zq (pc_common.hpp, box_zero_period) --, the
+  // Nyquist line alone for most sizes but e.g. every multiple of 50 for 196 in 200
+  const bool box_zeros = flags && m > pl.n && (((flags[2 * pair] & 1) == 0) || ((flags[2 * pair + 1] & 1) == 0));
+  const int zq = box_zero_period(pl.n, m);
   for (int v0 = 0; v0 < m; v0 += 64) {
     const int v = v0 + lane, vv = v < m ? v : m - 1;  // (lanes past the line repeat its last bin: cross_power_ab's wave-uniform
     const cf a = lds_read(&z[sk(vv)]), b = lds_read(&z[line + sk(vv)]);  //  branch wants every lane to take part)
     cf C = cross_power_ab(a, b, u_edge && (vv == 0 || (even && vv == hu)));
-    if (box_zeros && (u == hu || vv == hu)) C = {0.f, 0.f};
+    if (box_zeros && (box_zero_line(u, zq) || box_zero_line(vv, zq))) C = {0.f, 0.f};
     if (v < m) z[sk(v)] = {C.x, -C.y};
     if (cdc && u == 0 && v == 0) cdc[pair] = C.x;  // C_dc: all that is left of a degenerate pair's spectrum (pc_common.hpp)
   }

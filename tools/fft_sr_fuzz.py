@@ -40,6 +40,13 @@ def floor_slack(cur_f, prev_f, lay, p, diag):
     return tolerances.floor_bins_bar(nb, max(diag.peak_value, 1e-30)) - TOL  # (peak_value is the unscaled surface value: M^2 x the normalised peak)
 
 
+def dump_case(tag, cur_f, prev_f, n, grid, origin, stride):
+    """A failing frame pair with its layout -> gpurun_out/fuzz_fail_<tag>.npz (the inputs a seeded regression test needs)."""
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    np.savez_compressed(os.path.join(out, f"fuzz_fail_{tag}.npz"), cur=cur_f, prev=prev_f, n=n, grid=grid, origin=origin, stride=stride)
+
+
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n_fft = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 n_sr = int(sys.argv[3]) if len(sys.argv) > 3 else 12
@@ -78,9 +85,11 @@ for trial in range(n_fft):
                     unpinned += 1
                     continue
                 lim = tolerances.f32_limited_bar(dd)  # three roundings of an ill-conditioned quantity: the reference's own arithmetic is the bar
+                lim = max(lim, TOL + floor_slack(cur[k], prev[k], lay, p, diags[p]))  # (exact-zero spectral bins make a patch f32-limited too)
                 if not np.allclose(got[k, p], want32[p], rtol=0, atol=lim, equal_nan=True):
                     bad += 1
                     print("FFT MISMATCH (f32-limited patch)", trial, n, k, p, got[k, p], want64[p], want32[p])
+                    dump_case(f"fft_{seed}_{trial}_{k}", cur[k], prev[k], n, (gx, gy), (ox, oy), (sx, sy))
                 continue
             checked += 1
             if not np.allclose(got[k, p], want64[p], rtol=0, atol=TOL, equal_nan=True):
@@ -90,6 +99,7 @@ for trial in range(n_fft):
                     print("(exact-zero spectral bins: f32-limited patch)", trial, n, k, p, got[k, p], want64[p], "slack", fs)
                     continue
                 bad += 1
+                dump_case(f"fft_{seed}_{trial}_{k}", cur[k], prev[k], n, (gx, gy), (ox, oy), (sx, sy))
                 print("FFT MISMATCH", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), k, p, got[k, p], want64[p],
                       "f32 oracle", want32[p], "peak", diags[p].peak_value, "second", diags[p].second_value)
 print(f"fft: {checked}/{total} patches with a stable arg-max checked at 1e-4 px (+ {soft} where f32 and f64 oracle differ by more: checked against "
@@ -171,12 +181,14 @@ for trial in range(max(4, n_fft // 4)):
                 if not np.allclose(got[k, p], want32[p], rtol=0, atol=lim, equal_nan=True):
                     seq_bad += 1
                     print("SEQ FFT MISMATCH (f32-limited patch)", trial, n, k, p, got[k, p], want64[p], want32[p])
+                    dump_case(f"seq_{seed}_{trial}_{k}", frames[k + 1], frames[k], n, (gx, gy), (ox, oy), (sx, sy))
                 continue
             seq_checked += 1
             if not (np.allclose(got[k, p], want64[p], rtol=0, atol=TOL, equal_nan=True)
                     and np.allclose(got[k, p], pairs[k, p], rtol=0, atol=TOL, equal_nan=True)):
                 seq_bad += 1
                 print("SEQ FFT MISMATCH", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), nf, k, p, got[k, p], want64[p], pairs[k, p])
+                dump_case(f"seq_{seed}_{trial}_{k}", frames[k + 1], frames[k], n, (gx, gy), (ox, oy), (sx, sy))
 for trial in range(max(2, n_sr // 3)):
     res = int(rng.choice([240, 256, 480])) if rng.integers(0, 2) else 2 * int(rng.integers(32, 200))
     M = float(rng.uniform(28.0, 90.0)) * res / 480.0
