@@ -410,8 +410,9 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     const bool tuned_size_default = n == 120 && !e->generic && !e->large;
     // ... and the planned sizes where it beats the full-tile planned kernel on the box (transform sizes 60, 96, 100: p60 1.10 -> 1.38 M,
     // p96 757 -> 855 k pairs/s, profiles/r05_half_vs_planned_bench_ab.txt, r05_half_vs_planned_rates.txt; on patches padded to 64 it
-    // loses 4 %, p62); the tuned N = 64 / 128 pair kernels stay faster than it and keep their sizes
-    const bool planned_size_default = e->generic && !force_planned && (n == 60 || n == 96 || n == 100);
+    // loses 4 %, p62); the tuned N = 64 / 128 pair kernels stay faster than it and keep their sizes. Patches of 109 .. 119 pixels pad to
+    // 120 and follow N = 120 itself (the planned kernel at 120: 869 k against 1.30 M pairs/s)
+    const bool planned_size_default = e->generic && !force_planned && (n == 60 || n == 96 || n == 100 || n == 120);
     if (cfg->peak_model == MOF_PEAK_OPENCV && mof::pc_half_supported(n) && half_knob != 0 && !force_large && !force_planned &&
         (e->large || half_knob == 1 || tuned_size_default || planned_size_default))
       e->half_m = n;
