@@ -54,7 +54,9 @@ struct HalfPlan {
   int lpw = 0;   // lines per wave: row pairs, columns, row pairs again
   int waves = 0;
   int pitch = 0;
-  int skew = 0;  // 1: element x of a line sits at x + (x >> 3) (both layouts); 0 where only the unskewed tile fits (M = 192)
+  int skew = 0;  // 1: element x of a line sits at x + (x >> shift) (both layouts); 0 where only the unskewed tile fits (M = 192)
+  int shift = 3; // the skew's shift: 4 for the radix-16-first sizes 96 / 128 / 160 (tools/design/half_lanes.py: stage-0 outputs 16 x + p of the
+                 // eight butterflies of a line land in eight different banks mod 16 only with x + (x >> 4))
   int lds_bytes = 0;
   int wgs_per_cu = 0;
   bool ok = false;
@@ -80,12 +82,31 @@ constexpr int half_stage_lines(int m, int R) {  // lines one group of a stage co
 // (pitch, skew) with the fewest LDS cycles in the bank model of tools/design/half_banks.py (every ds_read_b64 / ds_write_b64 of a
 // patch pair with the lane groups and bank widths of MI355X_MICROARCH.md) among the pitches that keep the workgroups per CU; 0 = the
 // rule below. Where the unskewed tile is within a few per cent of the best it is preferred: its element offsets are immediates.
+#ifndef MOF_HALF_SHIFT  // (A/B) force the skew shift of every skewed instantiation; 0 = the table / 3
+#define MOF_HALF_SHIFT 0
+#endif
+constexpr int half_table_shift(int m) {
+  if (MOF_HALF_SHIFT > 0) return MOF_HALF_SHIFT;
+  if (!MOF_HALF_PITCH_TABLE) return 3;
+  switch (m) {
+    case 96: case 128: case 160: case 192: return 4;  // (192: the skewed tile only fits with this shift: 204 x 96 lines)
+    default: return 3;
+  }
+}
 constexpr int half_table_pitch(int m, int* skew) {
   if (!MOF_HALF_PITCH_TABLE) return 0;
   switch (m) {
+    case 96:  // (with shift 4: x1.09 of the conflict-free LDS cycles in the model against x1.40 at the rule's 120 with shift 3)
+      if (half_table_shift(96) != 4) return 0;
+      *skew = 1;
+      return 104;
     case 60: *skew = 0; return 68;    // (box: 68 / 76 unskewed 1.36 M at p60, the rule's 72 skewed 1.29 M; profiles/r05_half_pitch60_sweep.txt)
     case 120: *skew = 0; return 136;  // (measured too, tools/sweep_half_pitch.sh, profiles/r05_half_pitch120_sweep.txt: 136 unskewed 1.14 M, 120 1.13 M, 152 1.13 M, 128 0.93 M; skewed 136 / 152: 1.05 M)
     case 144: *skew = 1; return 202;
+    case 160:  // (box, shift 4: 172 / 170 / 200 729 k at l160, the rule's 184 725 k; shift 3 at 184: 712 k -- profiles/r05_half_pitch160_shift_sweep.txt)
+      if (half_table_shift(160) != 4) return 0;
+      *skew = 1;
+      return 172;
     case 150: *skew = 0; return 180;
     case 162: *skew = 0; return 186;
     case 180: *skew = 0; return 184;
@@ -137,10 +158,12 @@ constexpr HalfPlan half_plan(int m) {
   // pitch: even, room for both skews; P/2 = 4 (mod 8) spreads the rows of a column walk over the banks (8 rows x 4 columns per
   // 32-lane read group) -- the first such pitch that still fits, else the smallest; without the skew where nothing else fits
   const size_t cap = 160u * 1024u;
+  const int sh = half_table_shift(m);
+  hp.shift = sh;
   int p = 0, skew = 1;
   for (; skew >= 0; --skew) {
-    int pmin = m + (skew ? ((m - 1) >> 3) : 0);
-    const int hmin = 2 * (H + (skew ? ((H - 1) >> 3) : 0));
+    int pmin = m + (skew ? ((m - 1) >> sh) : 0);
+    const int hmin = 2 * (H + (skew ? ((H - 1) >> sh) : 0));
     pmin = pmin < hmin ? hmin : pmin;
     pmin += pmin & 1;
     p = pmin;
@@ -222,11 +245,11 @@ struct HalfRawSrc {
 #endif
 struct HalfPairSrc {
   static constexpr bool active = true;
-  int p2, m, skm;
+  int p2, m, skm, sh;
   __device__ __forceinline__ cf operator()(const cf* z, int l, int e) const {
     const int H = m >> 1;
     const int u = e < H ? e : (e == H ? 0 : m - e);
-    const int o = u + ((u >> 3) & skm);
+    const int o = u + ((u >> sh) & skm);
     const cf d1 = lds_read(&z[(2 * l) * p2 + o]), d2 = lds_read(&z[(2 * l + 1) * p2 + o]);
     if (e == 0) return {d1.x, d2.x};
     if (e == H) return {d1.y, d2.y};
@@ -245,11 +268,11 @@ struct HalfPairSrc {
 #endif
 struct HalfUntangleSrc {
   static constexpr bool active = true;
-  int p, m, skm;
+  int p, m, skm, sh;
   __device__ __forceinline__ cf operator()(const cf* z, int l, int e) const {  // column l, row e
     const cf* line = z + (e >> 1) * p;
     const int H = m >> 1, um = l == 0 ? H : m - l;
-    const cf zk = lds_read(&line[l + ((l >> 3) & skm)]), zm = lds_read(&line[um + ((um >> 3) & skm)]);
+    const cf zk = lds_read(&line[l + ((l >> sh) & skm)]), zm = lds_read(&line[um + ((um >> sh) & skm)]);
     cf A, B;
     if (l == 0) {  // the real bins u = 0 and u = M/2 of a row share column 0
       A = {2.f * zk.x, 2.f * zm.x};
@@ -315,8 +338,9 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   constexpr int SKM = HP.skew ? ~0 : 0;
-  auto rows_at = [&](int j, int x) -> int { return j * P + x + ((x >> 3) & SKM); };
-  auto spec_at = [&](int r, int u) -> int { return r * P2 + u + ((u >> 3) & SKM); };
+  constexpr int SH = HP.shift;
+  auto rows_at = [&](int j, int x) -> int { return j * P + x + ((x >> SH) & SKM); };
+  auto spec_at = [&](int r, int u) -> int { return r * P2 + u + ((u >> SH) & SKM); };
 
   // ---- patch origin (one workgroup per patch on a 3-D grid: column, row, pair)
   const int px0 = a.origin_x + (int)blockIdx.x * a.stride_x, py0 = a.origin_y + (int)blockIdx.y * a.stride_y;
@@ -343,7 +367,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   // wave w owns lines [l0, l0 + nl): row pairs in the row passes, columns in the column passes
   const int l0 = wave * LPW;
   const int nl = H - l0 < 0 ? 0 : (H - l0 > LPW ? LPW : H - l0);
-  const Walk rows = {P, 1, 0, SKM, 0}, cols = {1, P2, SKM, 0, 1};
+  const Walk rows = {P, 1, 0, SKM, 0, SH}, cols = {1, P2, SKM, 0, 1, SH};
 
   auto px_gray = [&](const uint8_t* q) -> uint32_t {  // four pixels -> four gray bytes
     if constexpr (CH == 1) {
@@ -418,7 +442,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
               const int x = x0 + b;
-              if (x < M) line[x + ((x >> 3) & SKM)] = {(float)((ra[t] >> (8 * b)) & 0xffu), (float)((rb[t] >> (8 * b)) & 0xffu)};
+              if (x < M) line[x + ((x >> SH) & SKM)] = {(float)((ra[t] >> (8 * b)) & 0xffu), (float)((rb[t] >> (8 * b)) & 0xffu)};
             }
           }
         }
@@ -509,7 +533,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
     if constexpr (MOF_HABL == 1) return;
     if constexpr (UFUSE)
       pass_lines_static<SP, 0, 1, Sink, HalfUntangleSrc, WorkgroupSync, NG0, (XSINK ? NGL : 0)>(z, tw, cols, l0, nl, lane, false, sink,
-                                                                                                HalfUntangleSrc{P, M, SKM});
+                                                                                                HalfUntangleSrc{P, M, SKM, SH});
     else if (nl > 0)
       pass_lines_static<SP, 0, 1, Sink>(z, tw, cols, l0, nl, lane, false, sink);
   };
@@ -678,7 +702,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
   if (nl > 0 && MOF_HABL != 1) {
     if constexpr (MOF_HALF_PAIR_SRC)
-      pass_lines_static<SP, 0, 1, HalfScanSink, HalfPairSrc>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H}, HalfPairSrc{P2, M, SKM});
+      pass_lines_static<SP, 0, 1, HalfScanSink, HalfPairSrc>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H}, HalfPairSrc{P2, M, SKM, SH});
     else
       pass_lines_static<SP, 0, 1, HalfScanSink>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H});
   }

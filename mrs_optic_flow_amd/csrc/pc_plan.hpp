@@ -36,7 +36,8 @@ struct Walk {
   int ls, es;        // strides (complex elements) of the line index / the element index before the skew
   int lmask, emask;  // ~0 where the skew applies to that coordinate
   int line_fast;     // lane map of a stage: 0 = the butterfly index in the fast lane bits (row walks), 1 = the line (column walks)
-  __device__ __forceinline__ int at(int l, int e) const { return l * ls + ((l >> 3) & lmask) + e * es + ((e >> 3) & emask); }
+  int sh = 3;        // the skew's shift: coordinate c sits at c + (c >> sh) (3 everywhere but the half-tile kernel's radix-16-first sizes: 4)
+  __device__ __forceinline__ int at(int l, int e) const { return l * ls + ((l >> sh) & lmask) + e * es + ((e >> sh) & emask); }
 };
 
 // Composite radices for the compile-time plans (two stages per 1-D transform for every 5-smooth size up to 135, as the tuned
@@ -212,9 +213,9 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
         const int li = g0 + b * lpg + sub;
         const int l = line0 + li;
         on[b] = lane_on && li < nlines;
-        loff[b] = l * w.ls + ((l >> 3) & w.lmask);
+        loff[b] = l * w.ls + ((l >> w.sh) & w.lmask);
         if (on[b]) {
-          const int l2off = (l + H) * w.ls + (((l + H) >> 3) & w.lmask);  // (herm_first only)
+          const int l2off = (l + H) * w.ls + (((l + H) >> w.sh) & w.lmask);  // (herm_first only)
 #pragma unroll
           for (int j = 0; j < SLOTS; ++j)
             if (j < R) {
@@ -224,14 +225,14 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
                 a = src(z, l, e);
               } else if (herm_first) {
                 const int r = e < H ? e : (e == H ? 0 : m - e);
-                const int ro = r * w.es + ((r >> 3) & w.emask);
+                const int ro = r * w.es + ((r >> w.sh) & w.emask);
                 const cf pp = lds_read(&z[loff[b] + ro]), c = lds_read(&z[l2off + ro]);  // tile (row r, col l) and (row r, col l + H)
                 if (e == 0) a = {pp.x, c.x};
                 else if (e == H) a = {pp.y, c.y};
                 else if (e < H) a = {pp.x - c.y, pp.y + c.x};
                 else a = {pp.x + c.y, c.x - pp.y};
               } else {
-                a = lds_read(&z[loff[b] + e * w.es + ((e >> 3) & w.emask)]);
+                a = lds_read(&z[loff[b] + e * w.es + ((e >> w.sh) & w.emask)]);
               }
               // (a radix-8 stage behind an earlier one takes its twiddles inside the butterfly: butterfly8_tw, pc_common.hpp)
               if (j > 0 && np > 1 && !(MOF_PLANNED_TW8 && SLOTS == 8 && R == 8)) a = cmul(a, t[j - 1]);
@@ -252,9 +253,9 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
               if constexpr (SinkTransforms<Sink>::value) {
                 bool wr = true;
                 const cf val = sink.transform(line0 + g0 + b * lpg + sub, o, v[b][p], b, p, &wr);
-                if (wr) z[loff[b] + o * w.es + ((o >> 3) & w.emask)] = val;
+                if (wr) z[loff[b] + o * w.es + ((o >> w.sh) & w.emask)] = val;
               } else {
-                z[loff[b] + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
+                z[loff[b] + o * w.es + ((o >> w.sh) & w.emask)] = v[b][p];
                 if constexpr (Sink::active) sink(line0 + g0 + b * lpg + sub, o, v[b][p]);
               }
             }
@@ -266,7 +267,7 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
   // long lines: one line at a time, up to NB * 64 butterflies (the plan guarantees bpl <= 64 * floor(16 / R))
   for (int li = 0; li < nlines; ++li) {
     const int l = line0 + li;
-    const int loff = l * w.ls + ((l >> 3) & w.lmask);
+    const int loff = l * w.ls + ((l >> w.sh) & w.lmask);
     for (int x0 = 0; x0 < bpl; x0 += 64 * NB) {
       cf v[NB][SLOTS];
       int xx[NB], kk[NB];
@@ -294,7 +295,7 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
                 else if (e < H) a = {pp.x - c.y, pp.y + c.x};
                 else a = {pp.x + c.y, c.x - pp.y};
               } else {
-                a = lds_read(&z[loff + e * w.es + ((e >> 3) & w.emask)]);
+                a = lds_read(&z[loff + e * w.es + ((e >> w.sh) & w.emask)]);
               }
               if (j > 0 && np > 1) a = cmul(a, lds_read(&tw[j * k * tstep]));
               v[b][j] = a;
@@ -318,9 +319,9 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
               if constexpr (SinkTransforms<Sink>::value) {
                 bool wr = true;
                 const cf val = sink.transform(l, o, v[b][p], b, p, &wr);
-                if (wr) z[loff + o * w.es + ((o >> 3) & w.emask)] = val;
+                if (wr) z[loff + o * w.es + ((o >> w.sh) & w.emask)] = val;
               } else {
-                z[loff + o * w.es + ((o >> 3) & w.emask)] = v[b][p];
+                z[loff + o * w.es + ((o >> w.sh) & w.emask)] = v[b][p];
                 if constexpr (Sink::active) sink(l, o, v[b][p]);
               }
             }
@@ -370,7 +371,7 @@ __device__ __forceinline__ void stage_rt_ng(cf* __restrict__ z, const cf* __rest
       const int li = g * group + b * lpg + sub;
       const int l = line0 + li;
       on[g][b] = lane_on && li < nlines;
-      loff[g][b] = l * w.ls + ((l >> 3) & w.lmask);
+      loff[g][b] = l * w.ls + ((l >> w.sh) & w.lmask);
       if (on[g][b]) {
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j)
@@ -380,7 +381,7 @@ __device__ __forceinline__ void stage_rt_ng(cf* __restrict__ z, const cf* __rest
             if constexpr (Src::active) {
               a = src(z, l, e);
             } else {
-              a = lds_read(&z[loff[g][b] + e * w.es + ((e >> 3) & w.emask)]);
+              a = lds_read(&z[loff[g][b] + e * w.es + ((e >> w.sh) & w.emask)]);
             }
             if (j > 0 && np > 1 && !(MOF_PLANNED_TW8 && SLOTS == 8 && R == 8)) a = cmul(a, t[j - 1]);
             v[g][b][j] = a;
@@ -403,9 +404,9 @@ __device__ __forceinline__ void stage_rt_ng(cf* __restrict__ z, const cf* __rest
             if constexpr (SinkTransforms<Sink>::value) {
               bool wr = true;
               const cf val = sink.transform(l, o, v[g][b][p], g * NB + b, p, &wr);
-              if (wr) z[loff[g][b] + o * w.es + ((o >> 3) & w.emask)] = val;
+              if (wr) z[loff[g][b] + o * w.es + ((o >> w.sh) & w.emask)] = val;
             } else {
-              z[loff[g][b] + o * w.es + ((o >> 3) & w.emask)] = v[g][b][p];
+              z[loff[g][b] + o * w.es + ((o >> w.sh) & w.emask)] = v[g][b][p];
               if constexpr (Sink::active) sink(l, o, v[g][b][p]);
             }
           }
