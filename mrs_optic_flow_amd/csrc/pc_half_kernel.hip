@@ -41,6 +41,7 @@
 
 #include "mof_kernels.h"
 #include "pc_common.hpp"
+#include <type_traits>
 #include "pc_plan.hpp"
 #include "pc_plan_build.hpp"
 
@@ -321,6 +322,12 @@ struct HalfXpowSink {
   }
 };
 
+#ifndef MOF_HALF_FAST_LOAD  // 0: the general pixel loader for every patch (A/B)
+#define MOF_HALF_FAST_LOAD 1
+#endif
+#ifndef MOF_HALF_PREFETCH  // 0: the current image is loaded after the previous image's column pass (A/B)
+#define MOF_HALF_PREFETCH 1
+#endif
 #ifndef MOF_HABL  // diagnostic builds (results wrong by design): 1 no transform passes, 2 no cross-power, 3 no pixel loads
 #define MOF_HABL 0
 #endif
@@ -394,60 +401,95 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   };
 
   // ---- one image: pixels of the wave's lines -> LDS (u8 -> f32: convertTo, :1805-1806; zeros beyond n x n: copyMakeBorder of
-  //      cv::phaseCorrelate), row transforms, untangle into the spec layout. Wave-local throughout.
-  auto load_and_rows = [&](const uint8_t* img, int which) {
-    constexpr int CPR = (M + 3) / 4;                     // four-pixel chunks per row of the padded tile
-    constexpr int NCH = (LPW * CPR + 63) / 64;           // chunks per lane: both rows of a line ride one chunk
-    constexpr int SB = CH == 1 ? NCH : (NCH + 1) / 2;    // loads in flight per lane and sub-batch
-    const uint32_t first = px_one(img), pat = first * 0x01010101u;
-    uint32_t diff = 0u;
-#pragma unroll
-    for (int k0 = 0; k0 < NCH; k0 += SB) {
-      uint32_t ra[SB], rb[SB];
-#pragma unroll
-      for (int t = 0; t < SB; ++t) {
-        const int k = k0 + t, q = lane + 64 * k, li = q / CPR, x0 = 4 * (q % CPR), y = 2 * (l0 + li);
-        ra[t] = rb[t] = 0u;
-        if (k < NCH && MOF_HABL != 3 && li < nl && x0 < n) {
-          const uint8_t* qa = img + (size_t)y * a.pitch + (size_t)CH * x0;
-          if (x0 + 3 < n) {
-            if (y < n) ra[t] = px_gray(qa);
-            if (y + 1 < n) rb[t] = px_gray(qa + a.pitch);
-          } else {  // the last chunk of a row whose length is not a multiple of four: the pixels inside the patch
-            for (int b = 0; x0 + b < n; ++b) {
-              if (y < n) ra[t] |= px_one(qa + CH * b) << (8 * b);
-              if (y + 1 < n) rb[t] |= px_one(qa + a.pitch + CH * b) << (8 * b);
-            }
-          }
-        }
+  //      cv::phaseCorrelate), row transforms, untangle into the spec layout. Wave-local throughout. Chunk q = lane + 64 k of the wave's
+  //      lines = four pixels of rows 2j and 2j + 1: chunk_load brings them into two registers, chunk_commit stages them in the tile.
+  constexpr int CPR = (M + 3) / 4;                     // four-pixel chunks per row of the padded tile
+  constexpr int NCH = (LPW * CPR + 63) / 64;           // chunks per lane: both rows of a line ride one chunk
+  constexpr int SB = CH == 1 ? NCH : (NCH + 1) / 2;    // loads in flight per lane and sub-batch
+  // The patch fills its tile (n = M, M a multiple of four -- the bench's 60 / 96 / 160): no pixel of a chunk lies outside, and the chunk
+  // coordinates (line, chunk column) of q = lane + 64 k follow from the lane's own by compile-time steps with one wrap -- the general
+  // form spends ~70 instructions per chunk on q / CPR, q % CPR, a 64-bit row offset and four bounds; this one a dozen. A scalar
+  // branch: n is a kernel argument. Same-box (profiles/r05_half_fastload_ab.txt): l160 +2 %, p60 +1.7 %, p96 +-0, ref -0.7 % -- the
+  // loader's arithmetic mostly hides behind its own loads; M = 120 keeps the general form.
+  const bool fills = MOF_HALF_FAST_LOAD != 0 && MOF_HALF_RAW != 0 && (M % 4 == 0) && M != 120 && n == M;
+  const int li0 = lane / CPR, xc0 = lane - li0 * CPR;
+  // (FILLS rides in as a type: the scalar branch on `fills` stands ONCE around a whole loop of chunks -- a branch per chunk puts every
+  // load into a basic block of its own and cost 6 - 8 % at p60 / p96 / l160)
+  auto chunk_load = [&](auto fills_tag, int k, const uint8_t* img, uint32_t* pa, uint32_t* pb) {
+    constexpr bool FILLS = decltype(fills_tag)::value;
+    *pa = *pb = 0u;
+    if (k >= NCH || MOF_HABL == 3) return;
+    if constexpr (FILLS) {
+      const int DL = (64 * k) / CPR, DX = (64 * k) % CPR;
+      const bool wrap = xc0 + DX >= CPR;
+      const int li = li0 + DL + (wrap ? 1 : 0);
+      if (li < nl) {
+        const uint32_t pitch = (uint32_t)a.pitch;
+        const uint32_t off = (uint32_t)(2 * (l0 + li0)) * pitch + (uint32_t)(4 * CH * xc0) + (uint32_t)(2 * DL) * pitch + (uint32_t)(4 * CH * DX) +
+                             (wrap ? 2u * pitch - (uint32_t)(4 * CH * CPR) : 0u);
+        const uint8_t* qa = img + off;
+        *pa = px_gray(qa);
+        *pb = px_gray(qa + pitch);
       }
-#pragma unroll
-      for (int t = 0; t < SB; ++t) {
-        const int k = k0 + t, q = lane + 64 * k, li = q / CPR, x0 = 4 * (q % CPR), y = 2 * (l0 + li);
-        if (k < NCH && li < nl) {
-          if (x0 < n) {
-            const uint32_t inside = x0 + 3 < n ? 0xffffffffu : (1u << (8 * (n - x0))) - 1u;
-            if (y < n) diff |= (ra[t] ^ pat) & inside;
-            if (y + 1 < n) diff |= (rb[t] ^ pat) & inside;
-          }
-          cf* line = z + (l0 + li) * P;
-          if constexpr (MOF_HALF_RAW) {
-            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-            typedef u2 __attribute__((address_space(3))) * lds_u2_ptr;
-            u2 d;
-            d.x = __builtin_amdgcn_perm(rb[t], ra[t], 0x05010400u);
-            d.y = __builtin_amdgcn_perm(rb[t], ra[t], 0x07030602u);
-            *(lds_u2_ptr)(reinterpret_cast<unsigned char*>(line) + 2 * x0) = d;  // (a partial last chunk spills past 2 M bytes: inside the line, never read)
-          } else {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const int x = x0 + b;
-              if (x < M) line[x + ((x >> SH) & SKM)] = {(float)((ra[t] >> (8 * b)) & 0xffu), (float)((rb[t] >> (8 * b)) & 0xffu)};
-            }
+    } else {
+      const int q = lane + 64 * k, li = q / CPR, x0 = 4 * (q % CPR), y = 2 * (l0 + li);
+      if (li < nl && x0 < n) {
+        const uint8_t* qa = img + (size_t)y * a.pitch + (size_t)CH * x0;
+        if (x0 + 3 < n) {
+          if (y < n) *pa = px_gray(qa);
+          if (y + 1 < n) *pb = px_gray(qa + a.pitch);
+        } else {  // the last chunk of a row whose length is not a multiple of four: the pixels inside the patch
+          for (int b = 0; x0 + b < n; ++b) {
+            if (y < n) *pa |= px_one(qa + CH * b) << (8 * b);
+            if (y + 1 < n) *pb |= px_one(qa + a.pitch + CH * b) << (8 * b);
           }
         }
       }
     }
+  };
+  auto chunk_commit = [&](auto fills_tag, int k, uint32_t va, uint32_t vb, uint32_t pat, uint32_t* diff) {
+    constexpr bool FILLS = decltype(fills_tag)::value;
+    if (k >= NCH) return;
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    typedef u2 __attribute__((address_space(3))) * lds_u2_ptr;
+    if constexpr (FILLS) {
+      const int DL = (64 * k) / CPR, DX = (64 * k) % CPR;
+      const bool wrap = xc0 + DX >= CPR;
+      const int li = li0 + DL + (wrap ? 1 : 0);
+      if (li < nl) {
+        *diff |= (va ^ pat) | (vb ^ pat);
+        u2 d;
+        d.x = __builtin_amdgcn_perm(vb, va, 0x05010400u);
+        d.y = __builtin_amdgcn_perm(vb, va, 0x07030602u);
+        const uint32_t lds0 = (uint32_t)((l0 + li0) * (P * 8) + 8 * xc0);
+        *(lds_u2_ptr)(reinterpret_cast<unsigned char*>(z) + (lds0 + (uint32_t)(DL * (P * 8) + 8 * DX) + (wrap ? (uint32_t)(P * 8 - 8 * CPR) : 0u))) = d;
+      }
+    } else {
+      const int q = lane + 64 * k, li = q / CPR, x0 = 4 * (q % CPR), y = 2 * (l0 + li);
+      if (li < nl) {
+        if (x0 < n) {
+          const uint32_t inside = x0 + 3 < n ? 0xffffffffu : (1u << (8 * (n - x0))) - 1u;
+          if (y < n) *diff |= (va ^ pat) & inside;
+          if (y + 1 < n) *diff |= (vb ^ pat) & inside;
+        }
+        cf* line = z + (l0 + li) * P;
+        if constexpr (MOF_HALF_RAW) {
+          u2 d;
+          d.x = __builtin_amdgcn_perm(vb, va, 0x05010400u);
+          d.y = __builtin_amdgcn_perm(vb, va, 0x07030602u);
+          *(lds_u2_ptr)(reinterpret_cast<unsigned char*>(line) + 2 * x0) = d;  // (a partial last chunk spills past 2 M bytes: inside the line, never read)
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int x = x0 + b;
+            if (x < M) line[x + ((x >> SH) & SKM)] = {(float)((va >> (8 * b)) & 0xffu), (float)((vb >> (8 * b)) & 0xffu)};
+          }
+        }
+      }
+    }
+  };
+  // flags of the image whose pixels were just staged, then its row transforms
+  auto rows_of = [&](uint32_t diff, uint32_t first, int which) {
     if (__builtin_amdgcn_ballot_w64(diff != 0u) != 0ull && lane == 0) flags[which] = 1;
     if (tid == 0) flags[3 + which] = (int)first;
     wave_sync();
@@ -485,6 +527,24 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
         z[spec_at(2 * (l0 + li) + 1, u)] = B;
       }
     }
+  };
+  // one image, loads and staging back to back (sub-batches of SB chunks: the loads of a sub-batch in flight together)
+  auto load_and_rows = [&](const uint8_t* img, int which) {
+    const uint32_t first = px_one(img), pat = first * 0x01010101u;
+    uint32_t diff = 0u;
+    auto both = [&](auto tag) {
+#pragma unroll
+      for (int k0 = 0; k0 < NCH; k0 += SB) {
+        uint32_t ra[SB], rb[SB];
+#pragma unroll
+        for (int t = 0; t < SB; ++t) chunk_load(tag, k0 + t, img, &ra[t], &rb[t]);
+#pragma unroll
+        for (int t = 0; t < SB; ++t) chunk_commit(tag, k0 + t, ra[t], rb[t], pat, &diff);
+      }
+    };
+    if (fills) both(std::true_type{});
+    else both(std::false_type{});
+    rows_of(diff, first, which);
   };
 
   // column 0 after a forward column pass = G[v] = F[v][0] + i F[v][M/2] (two real columns): apart with the partner bin M - v, in
@@ -527,6 +587,20 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   cf pv[NPV], pv0a[KV0], pv0b[KV0];
   load_and_rows(prev, 1);
   __syncthreads();
+  // gray frames: the CURRENT image's pixels are requested here, before the previous image's column pass, and wait in 2 NCH registers
+  // (8 - 10) until the tile is free -- their memory latency runs under that pass instead of in front of the row pass (MOF_HALF_PREFETCH)
+  constexpr bool PREFETCH = MOF_HALF_PREFETCH != 0 && CH == 1;
+  uint32_t ca[PREFETCH ? NCH : 1], cb[PREFETCH ? NCH : 1], cfirst = 0u;
+  if constexpr (PREFETCH) {
+    cfirst = px_one(cur);
+    if (fills) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) chunk_load(std::true_type{}, k, cur, &ca[k], &cb[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) chunk_load(std::false_type{}, k, cur, &ca[k], &cb[k]);
+    }
+  }
   // forward column pass of the image in the tile (UFUSE: with the untangle as its source and a workgroup barrier inside its first stage)
   auto fwd_cols = [&](auto sink) {
     using Sink = decltype(sink);
@@ -565,12 +639,25 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   __syncthreads();  // every wave has its columns: the tile may take the current image
 
   // ---- current image: rows, barrier, then per wave forward columns -> cross-power -> inverse columns
-  load_and_rows(cur, 0);
+  if constexpr (PREFETCH) {
+    const uint32_t pat = cfirst * 0x01010101u;
+    uint32_t diff = 0u;
+    if (fills) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) chunk_commit(std::true_type{}, k, ca[k], cb[k], pat, &diff);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) chunk_commit(std::false_type{}, k, ca[k], cb[k], pat, &diff);
+    }
+    rows_of(diff, cfirst, 0);
+  } else {
+    load_and_rows(cur, 0);
+  }
   __syncthreads();
   // A CONSTANT patch that zero padding turned into an n x n box (n, m even): its spectrum is EXACTLY zero on the Nyquist row and
   // column in the reference's transforms (alternating sums of equal numbers), so C = 0 there; here the rows were transformed in
   // pairs and the zeros carry rounding noise that the normalisation would blow up to unit magnitude (pc_large_kernel.hip, L6)
-  const bool box_zeros = M > n && (flags[0] == 0 || flags[1] == 0);
+  const bool box_zeros = __builtin_amdgcn_readfirstlane((int)(M > n && (flags[0] == 0 || flags[1] == 0))) != 0;  // (a scalar: the sinks branch on it per bin)
   const int zq = box_zero_period(n, M);  // its exact-zero lines: the multiples of zq (the Nyquist line alone for most sizes)
   // one bin of column 0 (slot rr): the general rule, or -- slots 0 and M/2 -- the two real-only components (C = P / (P^2 + eps),
   // SURVEY F8); box_zeros: slot 0 = (C0[0], C0[M/2]), slots M/2 .. M-1 hold the column u = M/2
