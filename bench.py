@@ -184,6 +184,13 @@ WORKLOADS = {
     "c4seq": dict(kind="fftseq", h=1080, w=1920, n=128, grid=(16, 16), origin=(0, 0), stride=(119, 63), batch=512, s=16,
                   name="c4seq: c4 on a video -- FftMethod 1920x1080, 16x16 grid of 128x128 patches, 512 consecutive frame pairs",
                   bytes_per_pair=1920 * 1080 + 256 * 8),
+    # the reference's default geometry on a video (r05): the half-tile kernel's sequence form, a frame's spectrum kept in registers
+    "refseq": dict(kind="fftseq", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
+                   name="refseq: ref on a video -- FftMethod 480x480, 4x4 grid of 120x120 patches, 1024 consecutive frame pairs (1025 frames)",
+                   bytes_per_pair=480 * 480 + 16 * 8),
+    "l160seq": dict(kind="fftseq", h=480, w=480, n=160, grid=(3, 3), origin=(0, 0), stride=(160, 160), batch=512, s=20,
+                    name="l160seq: l160 on a video -- 3x3 grid of 160x160 patches, 512 consecutive frame pairs",
+                    bytes_per_pair=480 * 480 + 9 * 8),
     # c5 on a VIDEO (the node's real workload, scaleRotationEstimator.cpp:34-148 steady state): B + 1 consecutive frames,
     # K1 on the B consecutive pairs, the estimator in sequence mode (every frame remapped and row-transformed once)
     "c5seq": dict(kind="fft+srseq", h=480, w=752, n=64, grid=(8, 8), origin=(1, 1), stride=(98, 59), batch=1024, s=8,

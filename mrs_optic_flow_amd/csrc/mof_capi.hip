@@ -712,23 +712,28 @@ static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame
   a.channels = channels;
   if (mof::stream_capturing((hipStream_t)stream)) e->graph_pinned.store(true);
   static const int run = [] { const char* v = getenv("MOF_FFT_SEQ_RUN"); const int r = v ? atoi(v) : 0; return r >= 1 ? r : 16; }();
+  static const bool run_set = [] { const char* v = getenv("MOF_FFT_SEQ_RUN"); return v && atoi(v) >= 1; }();
   static const bool pairs_only = getenv("MOF_FFT_SEQ_PAIRS") != nullptr, half64 = getenv("MOF_FFT_SEQ_HALF64") != nullptr;
   const int n = e->cfg.patch_size;
   const bool half = !e->generic && !e->large && !pairs_only && mof::pc_sequence_half_supported(n) && (n != 64 || half64);
   const bool full = !e->generic && !e->large && !pairs_only && !half && mof::pc_sequence_supported(n);
-  if (!half && !full) {
+  // the half-tile kernel's video form (r05): every size it serves by default but 162; MOF_FFT_HALF_SEQ=0 keeps the pair form on consecutive frames
+  static const bool half_seq_off = [] { const char* v = getenv("MOF_FFT_HALF_SEQ"); return v && atoi(v) == 0; }();
+  const bool khalf = e->half_m > 0 && !pairs_only && !half_seq_off && e->cfg.peak_model == MOF_PEAK_OPENCV && mof::pc_half_sequence_supported(e->half_m);
+  if (!half && !full && !khalf) {
     FIELD_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
     return MOF_OK;
   }
   // the run index rides gridDim.z (at most 65535 per launch): a very long video goes out in several launches
   const size_t per_pair = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
-  const int max_pairs = 65535 * run;
+  const int max_pairs = 65535 * ((khalf && !run_set) ? 4 : run);  // (the half-tile launcher's own run length is at least 4)
   for (int k0 = 0; k0 < n_pairs; k0 += max_pairs) {
     const int nk = n_pairs - k0 < max_pairs ? n_pairs - k0 : max_pairs;
     mof::PcArgs c = a;
     c.cur = d_frames + (size_t)k0 * frame_stride;  // the sequence kernels index frames, not pairs
     c.out = d_out_xy + (size_t)k0 * per_pair;
-    if (half) HIP_TRY(mof::launch_pc_sequence_half(c, n, nk, run, (hipStream_t)stream));
+    if (khalf) HIP_TRY(mof::launch_pc_half_sequence(c, e->half_m, n, nk, run_set ? run : 0, (hipStream_t)stream));  // (0: the launcher picks the run length)
+    else if (half) HIP_TRY(mof::launch_pc_sequence_half(c, n, nk, run, (hipStream_t)stream));
     else HIP_TRY(mof::launch_pc_sequence(c, nk, run, (hipStream_t)stream));
   }
   return MOF_OK;

@@ -95,6 +95,10 @@ bool pc_half_supported(int m);
 int pc_half_workgroups_per_cu(int m);
 hipError_t pc_configure_half();
 hipError_t launch_pc_half(const PcArgs& a, int m, int n, int n_pairs, hipStream_t stream);
+// ... on a video (r05): runs of `run` consecutive pairs per workgroup, a frame's spectrum kept in registers for the next pair; a.cur = the
+// launch's first frame, frame f at a.cur + f * a.cur_stride (as launch_pc_sequence)
+bool pc_half_sequence_supported(int m);
+hipError_t launch_pc_half_sequence(const PcArgs& a, int m, int n, int n_pairs, int run, hipStream_t stream);
 
 bool pc_patch_size_supported(int n);  // the hand-tuned instantiations: 32, 64, 120, 128
 const char* pc_kernel_variant(int patch_size);

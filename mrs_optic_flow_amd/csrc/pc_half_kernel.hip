@@ -307,16 +307,18 @@ struct HalfSaveSink {
     return v;
   }
 };
+template <bool KEEP = false>  // KEEP (the sequence form): this image's spectrum replaces the previous one's in the registers
 struct HalfXpowSink {
   static constexpr bool active = true;
   static constexpr bool transforms = true;
-  const cf* pv;
+  cf* pv;
   int R, H;
   bool box_zeros;
   int q;  // box_zeros: the exact-zero lines of the constant box are the multiples of q (pc_common.hpp, box_zero_period)
   __device__ __forceinline__ cf transform(int l, int o, cf v, int b, int p, bool* wr) const {
     *wr = true;
     cf C = cross_power_ab(v, pv[b * R + p], false);
+    if constexpr (KEEP) pv[b * R + p] = v;
     if (box_zeros && (box_zero_line(o, q) || box_zero_line(l, q))) C = {0.f, 0.f};
     return l == 0 ? v : cf{C.x, -C.y};  // (column 0 leaves as it is: taken apart, crossed and put together again by its owner)
   }
@@ -328,12 +330,18 @@ struct HalfXpowSink {
 #ifndef MOF_HALF_PREFETCH  // 0: the current image is loaded after the previous image's column pass (A/B)
 #define MOF_HALF_PREFETCH 1
 #endif
-#ifndef MOF_HABL  // diagnostic builds (results wrong by design): 1 no transform passes, 2 no cross-power, 3 no pixel loads
+#ifndef MOF_HABL  // diagnostic builds (results wrong by design): 1 no transform passes, 2 no cross-power, 3 no pixel loads, 4 no previous image
+                  // (what a sequence form that keeps a frame's spectrum for the next pair could save at most)
 #define MOF_HABL 0
 #endif
 
-template <int CH, int MS>
-__global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_half_kernel(PcArgs a, int n) {
+// SEQ (the video form, mof_fft_process_sequence_device): blockIdx.z is a RUN of `run` consecutive pairs of one patch position, frame f at
+// a.cur + f * a.cur_stride. The run's first frame is transformed as the previous image of the pair form; after that every frame is the
+// CURRENT image once, and its spectrum -- the forward column pass's last-stage outputs, already in the lanes' registers where the
+// cross-power meets the previous one -- simply stays there for the next pair (HalfXpowSink<true>): one image transform per pair instead of
+// two (a run re-transforms its first frame: 1 / run more).
+template <int CH, int MS, bool SEQ = false>
+__global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_half_kernel(PcArgs a, int n, int n_pairs, int run) {
   using SP = HalfPlanOf<MS>;
   constexpr HalfPlan HP = SP::HP;
   constexpr int M = MS, H = M / 2, P = HP.pitch, P2 = P / 2, T = SP::T, WAVES = HP.waves, LPW = HP.lpw;
@@ -342,7 +350,8 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   cf* tw = z + (size_t)H * P;
   Best* red = reinterpret_cast<Best*>(tw + M);
   int* flags = reinterpret_cast<int*>(red + 16);  // [0] cur differs from its first pixel, [1] prev does, [2] C_dc bits, [3] / [4] first pixel of cur / prev
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tid = threadIdx.x, lane = tid & 63;  // (not const: the sequence form hides them from the optimiser once per pair, below)
+  const int wave = tid >> 6;
 
   constexpr int SKM = HP.skew ? ~0 : 0;
   constexpr int SH = HP.shift;
@@ -352,9 +361,11 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   // ---- patch origin (one workgroup per patch on a 3-D grid: column, row, pair)
   const int px0 = a.origin_x + (int)blockIdx.x * a.stride_x, py0 = a.origin_y + (int)blockIdx.y * a.stride_y;
   const size_t poff = (size_t)py0 * a.pitch + (size_t)(CH * px0);
-  const uint8_t* cur = a.cur + (size_t)blockIdx.z * a.cur_stride + poff;
-  const uint8_t* prev = a.prev + (size_t)blockIdx.z * a.prev_stride + poff;
-  const size_t p = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const size_t pair0 = SEQ ? (size_t)blockIdx.z * (size_t)run : (size_t)blockIdx.z;  // first (only) pair of this workgroup
+  const uint8_t* prev = SEQ ? a.cur + pair0 * a.cur_stride + poff : a.prev + pair0 * a.prev_stride + poff;
+  const uint8_t* cur = SEQ ? prev + a.cur_stride : a.cur + pair0 * a.cur_stride + poff;
+  size_t p = (pair0 * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  int pairs_left = SEQ ? ((size_t)n_pairs - pair0 < (size_t)run ? (int)((size_t)n_pairs - pair0) : run) : 1;
 
   if (tid < 2) flags[tid] = 0;
 #pragma unroll 1
@@ -371,6 +382,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   constexpr int NGL = GROUPL > 0 ? (LPW + GROUPL - 1) / GROUPL : 99;  // ... and of the last one (162's radix-2 stage has long lines: none)
   constexpr bool XSINK = MOF_HALF_XPOW_SINK != 0 && UFUSE && NGL <= MOF_HALF_MAX_GROUPS && SP::P.n_stages >= 2;
   static_assert(!UFUSE || (WAVES - 1) * LPW < H, "every wave owns a line: the barrier inside the fused stage is met by all");
+  static_assert(!SEQ || XSINK, "the sequence form keeps the spectrum in the cross-power sink's registers");
   // wave w owns lines [l0, l0 + nl): row pairs in the row passes, columns in the column passes
   const int l0 = wave * LPW;
   const int nl = H - l0 < 0 ? 0 : (H - l0 > LPW ? LPW : H - l0);
@@ -412,7 +424,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   // branch: n is a kernel argument. Same-box (profiles/r05_half_fastload_ab.txt): l160 +2 %, p60 +1.7 %, p96 +-0, ref -0.7 % -- the
   // loader's arithmetic mostly hides behind its own loads; M = 120 keeps the general form.
   const bool fills = MOF_HALF_FAST_LOAD != 0 && MOF_HALF_RAW != 0 && (M % 4 == 0) && M != 120 && n == M;
-  const int li0 = lane / CPR, xc0 = lane - li0 * CPR;
+  int li0 = lane / CPR, xc0 = lane - li0 * CPR;  // (not const: SEQ, below)
   // (FILLS rides in as a type: the scalar branch on `fills` stands ONCE around a whole loop of chunks -- a branch per chunk puts every
   // load into a basic block of its own and cost 6 - 8 % at p60 / p96 / l160)
   auto chunk_load = [&](auto fills_tag, int k, const uint8_t* img, uint32_t* pa, uint32_t* pb) {
@@ -585,11 +597,11 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   constexpr int NPV = XSINK ? NGL * NBL * RL : KE;  // XSINK: the last column stage's own outputs: (group, butterfly), output p
   constexpr int KV0 = (H + 1 + 63) / 64;      // XSINK: column 0's slots v and M - v (v <= M/2) of the previous image, lane v
   cf pv[NPV], pv0a[KV0], pv0b[KV0];
-  load_and_rows(prev, 1);
+  if constexpr (MOF_HABL != 4) load_and_rows(prev, 1);
   __syncthreads();
   // gray frames: the CURRENT image's pixels are requested here, before the previous image's column pass, and wait in 2 NCH registers
   // (8 - 10) until the tile is free -- their memory latency runs under that pass instead of in front of the row pass (MOF_HALF_PREFETCH)
-  constexpr bool PREFETCH = MOF_HALF_PREFETCH != 0 && CH == 1;
+  constexpr bool PREFETCH = MOF_HALF_PREFETCH != 0 && CH == 1 && !SEQ;  // (SEQ: once per run only, and its registers would be live across the run's loop: 39 spills at M = 120)
   uint32_t ca[PREFETCH ? NCH : 1], cb[PREFETCH ? NCH : 1], cfirst = 0u;
   if constexpr (PREFETCH) {
     cfirst = px_one(cur);
@@ -614,7 +626,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   if constexpr (XSINK) {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) pv[i] = cf{1.f, 0.f};
-    fwd_cols(HalfSaveSink{pv, RL});
+    if constexpr (MOF_HABL != 4) fwd_cols(HalfSaveSink{pv, RL});
     if (wave == 0) {
       split_col0();
 #pragma unroll
@@ -653,6 +665,17 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   } else {
     load_and_rows(cur, 0);
   }
+  if constexpr (SEQ) goto have_current;  // (every `goto` sits inside `if constexpr`: the pair form has no loop in its control flow)
+next_pair:  // SEQ: the run's next frame
+  if constexpr (SEQ) {
+    // every per-lane index below is invariant across the run's pairs and the optimiser would hoist them all out of the loop (the
+    // persistent form of r05: 371 spilled VGPRs); the lane index made opaque once per trip keeps them inside
+    asm volatile("" : "+v"(lane), "+v"(tid));
+    li0 = lane / CPR;
+    xc0 = lane - li0 * CPR;
+    load_and_rows(cur, 0);
+  }
+have_current:
   __syncthreads();
   // A CONSTANT patch that zero padding turned into an n x n box (n, m even): its spectrum is EXACTLY zero on the Nyquist row and
   // column in the reference's transforms (alternating sums of equal numbers), so C = 0 there; here the rows were transformed in
@@ -679,7 +702,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   };
   if constexpr (XSINK) {
     if constexpr (MOF_HABL == 2) fwd_cols(NoSink{});
-    else fwd_cols(HalfXpowSink{pv, RL, H, box_zeros, zq});
+    else fwd_cols(HalfXpowSink<SEQ>{pv, RL, H, box_zeros, zq});
     if (wave == 0) {
       // column 0: apart, crossed with the previous image's slots (registers, lane v), together again -- G'[v] = conj C0[v] + i conj CH[v],
       // G'[M - v] = C0[v] + i CH[v] (C0, CH Hermitian in v) -- straight from the registers
@@ -690,8 +713,13 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
         const int v = lane + 64 * i;
         const bool on = v <= H;
         const int ra = on ? v : 1, rb = on ? (v == 0 ? H : M - v) : 1;
-        c0v[i] = col0_bin(lds_read(&z[spec_at(ra, 0)]), pv0a[i], ra, on);
-        chv[i] = col0_bin(lds_read(&z[spec_at(rb, 0)]), pv0b[i], rb, on);
+        const cf ava = lds_read(&z[spec_at(ra, 0)]), avb = lds_read(&z[spec_at(rb, 0)]);
+        c0v[i] = col0_bin(ava, pv0a[i], ra, on);
+        chv[i] = col0_bin(avb, pv0b[i], rb, on);
+        if constexpr (SEQ) {  // this frame's column 0 is the next pair's previous one
+          pv0a[i] = on ? ava : cf{1.f, 0.f};
+          pv0b[i] = on ? avb : cf{1.f, 0.f};
+        }
       }
       wave_sync();
 #pragma unroll
@@ -839,6 +867,19 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
       if (bad) sx = sy = __builtin_nan("");
       a.out[2 * p] = sx;
       a.out[2 * p + 1] = sy;
+      if constexpr (SEQ) {  // the current frame becomes the previous one (this lane was the flags' last reader)
+        flags[1] = flags[0];
+        flags[4] = flags[3];
+        flags[0] = 0;
+      }
+    }
+  }
+  if constexpr (SEQ) {
+    if (--pairs_left > 0) {
+      cur += a.cur_stride;
+      p += (size_t)gridDim.x * gridDim.y;
+      __syncthreads();  // the centroid window is read, the flags are shifted: the tile may take the next frame
+      goto next_pair;
     }
   }
 }
@@ -853,10 +894,18 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
 #define MOF_HALF_SIZES(X) X(60) X(64) X(96) X(100) X(120) X(128) X(144) X(150) X(160) X(162) X(180) X(192)
 #endif
 
+constexpr bool half_seq_size(int m) { return m != 162; }  // (162's last column stage runs long lines: no register-resident spectrum)
+
 template <int CH, int MS>
 hipError_t configure_half_one() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_half_kernel<CH, MS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             HalfPlanOf<MS>::HP.lds_bytes);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_half_kernel<CH, MS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     HalfPlanOf<MS>::HP.lds_bytes);
+  if constexpr (half_seq_size(MS)) {
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_half_kernel<CH, MS, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              HalfPlanOf<MS>::HP.lds_bytes);
+  }
+  return e;
 }
 
 }  // namespace
@@ -905,13 +954,58 @@ hipError_t launch_pc_half(const PcArgs& a_in, int m, int n, int n_pairs, hipStre
     switch (m) {
 #define X(M)                                                                                                                             \
   case M:                                                                                                                                \
-    if (c.channels == 3) hipLaunchKernelGGL((pc_half_kernel<3, M>), g, dim3((unsigned)HalfPlanOf<M>::T), (size_t)HalfPlanOf<M>::HP.lds_bytes, stream, c, n); \
-    else hipLaunchKernelGGL((pc_half_kernel<1, M>), g, dim3((unsigned)HalfPlanOf<M>::T), (size_t)HalfPlanOf<M>::HP.lds_bytes, stream, c, n);                 \
+    if (c.channels == 3) hipLaunchKernelGGL((pc_half_kernel<3, M>), g, dim3((unsigned)HalfPlanOf<M>::T), (size_t)HalfPlanOf<M>::HP.lds_bytes, stream, c, n, nk, 1); \
+    else hipLaunchKernelGGL((pc_half_kernel<1, M>), g, dim3((unsigned)HalfPlanOf<M>::T), (size_t)HalfPlanOf<M>::HP.lds_bytes, stream, c, n, nk, 1);          \
     break;
       MOF_HALF_SIZES(X)
 #undef X
       default: return hipErrorInvalidValue;
     }
+  }
+  return hipGetLastError();
+}
+
+bool pc_half_sequence_supported(int m) { return pc_half_supported(m) && half_seq_size(m); }
+
+// the video form: a.cur = frame 0 of the launch's first pair, frame f at a.cur + f * a.cur_stride; n_pairs pairs in runs of `run`
+// run = 0: chosen here. Workgroups of one launch all take the same time (run + ~0.45 image transforms: a run's first frame is
+// transformed without an inverse), so the launch lasts ceil(workgroups / resident slots) rounds of that: the run length in 4 .. 64 with
+// the least rounds x (run + 0.45) wins -- 512 pairs of 9 patches at one workgroup per CU: runs of 19 = 243 workgroups in ONE round,
+// where runs of 16 make 288 = a full round and a round that uses 32 of 256 CUs (measured: l160seq 605 k -> see DESIGN)
+hipError_t launch_pc_half_sequence(const PcArgs& a, int m, int n, int n_pairs, int run, hipStream_t stream) {
+  if (a.downscale != 1 || a.peak_model != 0 || (a.channels != 1 && a.channels != 3) || n > m || n < 2 || run < 0 || n_pairs < 1) return hipErrorInvalidValue;
+  if (run == 0) {
+    static const int cus = [] {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }();
+    const long slots = (long)cus * (pc_half_workgroups_per_cu(m) > 0 ? pc_half_workgroups_per_cu(m) : 1), patches = (long)a.grid_x * a.grid_y;
+    double best = 0.0;
+    for (int r = 4; r <= 64; ++r) {
+      const long wgs = patches * ((n_pairs + r - 1) / r), rounds = (wgs + slots - 1) / slots;
+      const double t = (double)rounds * ((double)r + 0.45);
+      if (run == 0 || t <= best) best = t, run = r;
+    }
+  }
+  const int n_runs = (n_pairs + run - 1) / run;
+  if (n_runs > 65535) return hipErrorInvalidValue;
+  PcArgs c = a;
+  c.total = n_pairs * a.grid_x * a.grid_y;
+  const dim3 g((unsigned)c.grid_x, (unsigned)c.grid_y, (unsigned)n_runs);
+  switch (m) {
+#define X(M)                                                                                                                                  \
+  case M:                                                                                                                                     \
+    if constexpr (half_seq_size(M)) {                                                                                                         \
+      if (c.channels == 3) hipLaunchKernelGGL((pc_half_kernel<3, M, true>), g, dim3((unsigned)HalfPlanOf<M>::T), (size_t)HalfPlanOf<M>::HP.lds_bytes, stream, c, n, n_pairs, run); \
+      else hipLaunchKernelGGL((pc_half_kernel<1, M, true>), g, dim3((unsigned)HalfPlanOf<M>::T), (size_t)HalfPlanOf<M>::HP.lds_bytes, stream, c, n, n_pairs, run);                 \
+    } else {                                                                                                                                  \
+      return hipErrorInvalidValue;                                                                                                            \
+    }                                                                                                                                         \
+    break;
+    MOF_HALF_SIZES(X)
+#undef X
+    default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }

@@ -105,3 +105,52 @@ def test_half_tile_kernel_entries(gpu, n):
     video = np.stack([synth.pair_np(9 + n, h, w, 3 * t, -t, blur=True)[0] for t in range(3)])
     dv = torch.from_numpy(video).to(gpu)
     assert np.array_equal(fm.process_sequence_device(dv).cpu().numpy(), fm.process_batch_device(dv[1:], dv[:-1]).cpu().numpy(), equal_nan=True)
+
+
+@pytest.mark.parametrize("n", [120, 146, 60])
+def test_half_tile_kernel_video_form(gpu, n):
+    """r05: on a video the half-tile kernel keeps every frame's spectrum in the registers where the next pair's cross-power meets it
+    (pc_half_kernel<CH, M, SEQ = true>: one image transform per pair instead of two; runs of consecutive pairs per workgroup, the run
+    length chosen by the launcher). 38 frames = 37 pairs (more than one run at any run length the launcher picks for 4 patches), with a
+    constant frame (constant boxes / degenerate pairs on both sides of it, the flags handed from `cur` to `prev`), a black frame and a
+    repeated frame; every pair against the oracle at the bars of tests/tolerances.py, the same BITS as the pair entry on the same
+    frames (the transform code is the same instantiation up to its sinks), and as a forced run length of 5 (runs that end mid-video)."""
+    import tolerances
+    gx, gy = 2, 2
+    stride = (n // 2 + 3, n // 3 + 1)
+    w, h = 5 + stride[0] * (gx - 1) + n + 2, 3 + stride[1] * (gy - 1) + n + 1
+    F = 38
+    video, _ = synth.video_torch(F, h, w, "cpu", k=n)
+    video[7] = 93
+    video[20] = 0
+    video[30] = video[29]
+    frames = video.numpy()
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(5, 3), stride=stride)
+    assert fm.kernel_variant == "planned-half"
+    dv = video.to(gpu)
+    seq = fm.process_sequence_device(dv).cpu().numpy()
+    pair = fm.process_batch_device(dv[1:], dv[:-1]).cpu().numpy()
+    assert np.array_equal(seq, pair, equal_nan=True)
+    lay = O.fft_layout(w, h, n, gx, gy, (5, 3), stride)
+    checked = 0
+    for k in range(F - 1):
+        want64, _, diags = O.fft_process(frames[k + 1], frames[k], lay, 64, want_diag=True)
+        want32, _ = O.fft_process(frames[k + 1], frames[k], lay, 32)
+        for q in range(gx * gy):
+            if np.isnan(want64[q]).any():
+                assert np.isnan(seq[k][q]).all(), (k, q, seq[k][q])
+            elif diags[q].second_value < 0.5 * diags[q].peak_value:
+                checked += bool(tolerances.check_patch(seq[k][q], want64[q], want32[q], f"halfseq{n}/pair{k}", q))
+    assert checked >= 0.8 * (F - 1) * gx * gy, checked
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from mrs_optic_flow_amd import FftMethod, synth;"
+            "v, _ = synth.video_torch(%d, %d, %d, 'cpu', k=%d); v[7] = 93; v[20] = 0; v[30] = v[29];"
+            "fm = FftMethod(sample_point_size=%d, frame_shape=(%d, %d), grid=(2, 2), origin=(5, 3), stride=%r);"
+            "np.save(sys.argv[1], fm.process_sequence_device(v.to('cuda:0')).cpu().numpy())") % (ROOT, F, h, w, n, n, h, w, stride)
+    out = os.path.join(ROOT, "gpurun_out", f"_halfseq_run5_{n}.npy")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, MOF_FFT_SEQ_RUN="5"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(out), seq, equal_nan=True)
+    os.remove(out)
