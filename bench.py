@@ -57,6 +57,11 @@ def binding_note(name: str, wl) -> str:
                     "frames): VALU issue 47.8 % (272.3 M wave-instructions x 2 cycles over 1024 SIMDs x 1.114 M cycles), LDS active "
                     "56.7 % of the CU cycles (12.6 % of it bank conflicts); the two add to 104 %: the pipes run one after the other, "
                     "not side by side; not HBM")
+        if wl["n"] != 128:
+            return ("half-tile kernel K1h in its video form (pc_half_kernel<CH, M, SEQ>, r05): a frame's half spectrum stays in the registers of the "
+                    "forward column pass's last stage, where the next pair's cross-power meets it -- one image transform per pair instead of two; "
+                    "runs of consecutive pairs per workgroup, the run length picked per launch so that the workgroups fill whole rounds of the "
+                    "resident slots; same bits as the pair entry; VALU + LDS in series as K1h; not HBM (DESIGN.md section 4, K1h on a video)")
         return ("K1 sequence kernel on a half-size tile (128 x 128 patches): one real forward transform + one Hermitian inverse per "
                 "frame and patch, one workgroup of 8 waves per CU (192 VGPRs); VALU + LDS in series as K1 at N = 128; not HBM")
     if wl["kind"] == "fft+srseq":
@@ -782,7 +787,7 @@ def main() -> None:
             torch.cuda.empty_cache()
             # driver-visible records of the other BASELINE configurations (same protocol, fewer steps)
             line["other_workloads"] = {tag: measure_other(tag, dev, st, 5)
-                                       for tag, st in (("c3", 50), ("c4", 20), ("c5", 40), ("c2seq", 50), ("c4seq", 10), ("c5seq", 40), ("ref", 50),
+                                       for tag, st in (("c3", 50), ("c4", 20), ("c5", 40), ("c2seq", 50), ("c4seq", 10), ("c5seq", 40), ("ref", 50), ("refseq", 50),
                                                        ("bmref", 50), ("refrt", 50), ("reflr", 50),
                                                        ("p60", 50), ("l160", 40), ("l480", 20))}  # the planned kernel, the half-tile kernel (r05), the large-patch pipeline
         print(json.dumps(line), flush=True)

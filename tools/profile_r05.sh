@@ -5,7 +5,7 @@
 # usage (on the GPU box): bash tools/profile_r05.sh [tag] ; parts: MOF_PROFILE_WORKLOADS / MOF_SQ_WORKLOADS override the lists
 TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for wl in ${MOF_PROFILE_WORKLOADS:-c2 cal c2seq c3 c4 c4seq c5 c5seq ref c1 bmref refrt reflr callr c3bgr p60 p96 l160 l480}; do
+for wl in ${MOF_PROFILE_WORKLOADS:-c2 cal c2seq c3 c4 c4seq c5 c5seq ref refseq c1 bmref refrt reflr callr c3bgr p60 p96 l160 l480}; do
   bash $R/tools/profile.sh ${TAG}_$wl --workload $wl --no-others --sustain-s 0 > $R/gpurun_out/profile_${TAG}_$wl.log 2>&1 || { tail -5 $R/gpurun_out/profile_${TAG}_$wl.log; echo "$wl FAILED"; continue; }
   echo "$wl done: $(head -c 140 $R/gpurun_out/prof_${TAG}_$wl/bench.json)"
 done
