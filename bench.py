@@ -57,13 +57,11 @@ def binding_note(name: str, wl) -> str:
                     "frames): VALU issue 47.8 % (272.3 M wave-instructions x 2 cycles over 1024 SIMDs x 1.114 M cycles), LDS active "
                     "56.7 % of the CU cycles (12.6 % of it bank conflicts); the two add to 104 %: the pipes run one after the other, "
                     "not side by side; not HBM")
-        if wl["n"] != 128:
-            return ("half-tile kernel K1h in its video form (pc_half_kernel<CH, M, SEQ>, r05): a frame's half spectrum stays in the registers of the "
-                    "forward column pass's last stage, where the next pair's cross-power meets it -- one image transform per pair instead of two; "
-                    "runs of consecutive pairs per workgroup, the run length picked per launch so that the workgroups fill whole rounds of the "
-                    "resident slots; same bits as the pair entry; VALU + LDS in series as K1h; not HBM (DESIGN.md section 4, K1h on a video)")
-        return ("K1 sequence kernel on a half-size tile (128 x 128 patches): one real forward transform + one Hermitian inverse per "
-                "frame and patch, one workgroup of 8 waves per CU (192 VGPRs); VALU + LDS in series as K1 at N = 128; not HBM")
+        return ("half-tile kernel K1h in its video form (pc_half_kernel<CH, M, SEQ>, r05; also 128 x 128 since it beat pc_seq_half.hip there: c4seq 93 k -> "
+                "112 k): a frame's half spectrum stays in the registers of the forward column pass's last stage, where the next pair's "
+                "cross-power meets it -- one image transform per pair instead of two; runs of consecutive pairs per workgroup, the run length "
+                "picked per launch so that the workgroups fill whole rounds of the resident slots; same bits as the half-tile pair form; VALU + "
+                "LDS in series as K1h; not HBM (DESIGN.md section 4, K1h on a video)")
     if wl["kind"] == "fft+srseq":
         return ("c5 on a video: one Lanczos4 remap and one real row transform per frame (K5s), column pass walking pairs in "
                 "time with the previous spectra in registers (K6s); DESIGN.md section 4 (sequence mode)")

@@ -465,6 +465,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     CREATE_TRY(mof::pc_configure(n));
     if (mof::pc_sequence_supported(n)) CREATE_TRY(mof::pc_configure_sequence());
     if (mof::pc_sequence_half_supported(n)) CREATE_TRY(mof::pc_configure_sequence_half(n));
+    if (n == 128 && cfg->peak_model == MOF_PEAK_OPENCV && mof::pc_half_sequence_supported(n)) CREATE_TRY(mof::pc_configure_half());  // (its video form serves 128 x 128, fft_sequence)
     // A/B knob (r05): independent pairs of 128 x 128 patches through the pair kernel on the HALF tile, two workgroups per CU
     static const bool pair_half = [] { const char* v = getenv("MOF_FFT_PAIR_HALF"); return v && atoi(v) != 0; }();
     if (pair_half && mof::pc_pair_half_supported(n)) {
@@ -719,7 +720,11 @@ static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame
   const bool full = !e->generic && !e->large && !pairs_only && !half && mof::pc_sequence_supported(n);
   // the half-tile kernel's video form (r05): every size it serves by default but 162; MOF_FFT_HALF_SEQ=0 keeps the pair form on consecutive frames
   static const bool half_seq_off = [] { const char* v = getenv("MOF_FFT_HALF_SEQ"); return v && atoi(v) == 0; }();
-  const bool khalf = e->half_m > 0 && !pairs_only && !half_seq_off && e->cfg.peak_model == MOF_PEAK_OPENCV && mof::pc_half_sequence_supported(e->half_m);
+  // ... and 128 x 128 patches, whose pair form stays on the tuned kernel: on a video the half-tile kernel's sequence form beats the older
+  // half-tile sequence kernel (pc_seq_half.hip: one 8-wave workgroup per CU, 192 VGPRs) -- c4seq 93.3 k -> 112 k pairs/s; MOF_FFT_SEQ_HALF128=1 keeps that one
+  static const bool old128 = getenv("MOF_FFT_SEQ_HALF128") != nullptr;
+  const int kh_m = e->half_m > 0 ? e->half_m : ((!e->generic && !e->large && n == 128 && !old128) ? 128 : 0);
+  const bool khalf = kh_m > 0 && !pairs_only && !half_seq_off && e->cfg.peak_model == MOF_PEAK_OPENCV && mof::pc_half_sequence_supported(kh_m);
   if (!half && !full && !khalf) {
     FIELD_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));
     return MOF_OK;
@@ -732,7 +737,7 @@ static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame
     mof::PcArgs c = a;
     c.cur = d_frames + (size_t)k0 * frame_stride;  // the sequence kernels index frames, not pairs
     c.out = d_out_xy + (size_t)k0 * per_pair;
-    if (khalf) HIP_TRY(mof::launch_pc_half_sequence(c, e->half_m, n, nk, run_set ? run : 0, (hipStream_t)stream));  // (0: the launcher picks the run length)
+    if (khalf) HIP_TRY(mof::launch_pc_half_sequence(c, kh_m, n, nk, run_set ? run : 0, (hipStream_t)stream));  // (0: the launcher picks the run length)
     else if (half) HIP_TRY(mof::launch_pc_sequence_half(c, n, nk, run, (hipStream_t)stream));
     else HIP_TRY(mof::launch_pc_sequence(c, nk, run, (hipStream_t)stream));
   }

@@ -3,6 +3,8 @@ device, pair k = (frame k + 1, frame k) -- what consecutive processImage calls c
 (/root/reference/src/FftMethod.cpp:1872). 64 x 64 patches run the sequence kernel (one real transform per frame, the
 previous spectrum in registers); the bar is the pair kernel's: 1e-4 px against the oracle on well-conditioned patches,
 the same validity (NaN) pattern, and agreement with the pair kernel on (frames[1:], frames[:-1]) within 1e-4 px."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -95,7 +97,9 @@ def test_ocl_peak_model_sequence(gpu):
 
 
 def test_n128_video_matches_oracle_and_pair_kernel(gpu):
-    """128 x 128 patches run the half-tile sequence kernel (pc_seq_half.hip)."""
+    """128 x 128 patches on a video: since r05 the half-tile kernel's video form (pc_half_kernel<CH, 128, SEQ>: c4seq 93 k -> 112 k pairs/s);
+    MOF_FFT_SEQ_HALF128=1 keeps the older half-tile sequence kernel (pc_seq_half.hip), which the child-process test below re-runs this
+    test on."""
     h, w, n, nf = 270, 480, 128, 21
     frames, offs = _video_np(nf, h, w, k=2)
     video = torch.from_numpy(frames).to(gpu)
@@ -126,7 +130,18 @@ def test_n128_video_matches_oracle_and_pair_kernel(gpu):
     assert np.allclose(res[-1], 1 - n / 2, rtol=0, atol=1e-4)
 
 
+def test_older_half_tile_sequence_kernel_at_128_stays_correct(gpu):
+    """pc_seq_half.hip's sequence kernel (r03; the default for 128 x 128 videos until r05) is still in the library behind
+    MOF_FFT_SEQ_HALF128=1: one child process re-runs the 128 x 128 video tests on it."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "n128_video or (bgr_video and 128)",
+                          "-p", "no:cacheprovider"], env=dict(os.environ, MOF_FFT_SEQ_HALF128="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_other_patch_sizes_run_the_pair_kernel_on_the_video(gpu):
+    """(... or, r05, a video form with the pair entry's bits: 120 x 120 runs the half-tile kernel's)"""
     h, w, n = 250, 380, 120
     frames, _ = _video_np(4, h, w, k=2)
     video = torch.from_numpy(frames).to(gpu)
