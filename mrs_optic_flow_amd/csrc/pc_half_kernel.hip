@@ -199,6 +199,16 @@ constexpr HalfPlan half_plan(int m) {
   return hp;
 }
 
+// most waves per SIMD the launch bounds ask the register allocator for: 4 (128 VGPRs), but 5 (96 VGPRs, 26 of them spilled) at M = 96 --
+// its six-wave workgroups sit two per CU at 4 (12 waves; a third would put a fifth wave on two SIMDs), three at 5: p96 893 -> 925 k
+// pairs/s same-box; p60 (two-wave workgroups, already 15.4 waves per CU): -6 % (profiles/r05_half_wpe5_ab.txt). MOF_HALF_WPE_CAP forces one value (A/B).
+constexpr int half_wpe_cap(int m) {
+#ifdef MOF_HALF_WPE_CAP
+  return MOF_HALF_WPE_CAP;
+#else
+  return m == 96 ? 5 : 4;
+#endif
+}
 template <int MS>
 struct HalfPlanOf {
   static constexpr HalfPlan HP = half_plan(MS);
@@ -207,7 +217,7 @@ struct HalfPlanOf {
   static constexpr int T = 64 * HP.waves;
   // waves per SIMD the registers must allow: what the LDS lets sit on a CU, at most 4 (128 VGPRs)
   static constexpr int WPE_ = (HP.wgs_per_cu * HP.waves + 3) / 4;
-  static constexpr int WPE = WPE_ < 1 ? 1 : (WPE_ > 4 ? 4 : WPE_);
+  static constexpr int WPE = WPE_ < 1 ? 1 : (WPE_ > half_wpe_cap(MS) ? half_wpe_cap(MS) : WPE_);
 };
 
 // arg-max as the sink of the inverse row pass's last stage: line j, element x carries the surface at (2j, x) and (2j + 1, x)
