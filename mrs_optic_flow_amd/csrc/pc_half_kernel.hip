@@ -199,14 +199,15 @@ constexpr HalfPlan half_plan(int m) {
   return hp;
 }
 
-// most waves per SIMD the launch bounds ask the register allocator for: 4 (128 VGPRs), but 5 (96 VGPRs, 26 of them spilled) at M = 96 --
-// its six-wave workgroups sit two per CU at 4 (12 waves; a third would put a fifth wave on two SIMDs), three at 5: p96 893 -> 925 k
-// pairs/s same-box; p60 (two-wave workgroups, already 15.4 waves per CU): -6 % (profiles/r05_half_wpe5_ab.txt). MOF_HALF_WPE_CAP forces one value (A/B).
+// most waves per SIMD the launch bounds ask the register allocator for: 4 (128 VGPRs). Measured at 5 (96 VGPRs; profiles/r05_half_wpe5_ab.txt):
+// M = 96 -- six-wave workgroups, two per CU at 4, three at 5 -- gains 3.5 % (p96 893 -> 925 k pairs/s) but spills 26 VGPRs, and the scratch
+// traffic shows as 2.2 x the algorithmic bytes on the fabric counters (1.0 x without); p60 loses 6 %, 100 loses 3 %, 6 waves at 96 lose 21 %.
+// Not adopted: the clean 1.0 x is worth more than 3.5 %. MOF_HALF_WPE_CAP forces a value (A/B).
 constexpr int half_wpe_cap(int m) {
 #ifdef MOF_HALF_WPE_CAP
   return MOF_HALF_WPE_CAP;
 #else
-  return m == 96 ? 5 : 4;
+  return 4;
 #endif
 }
 template <int MS>
