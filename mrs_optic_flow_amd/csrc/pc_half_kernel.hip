@@ -155,6 +155,13 @@ constexpr HalfPlan half_plan(int m) {
   g = g > H ? H : g;
   const int k = (H + g * 16 - 1) / (g * 16);
   hp.lpw = g * k;
+  // M = 96: whole groups (8 lines) make SIX-wave workgroups, and at four waves per SIMD only two of them fit a CU (12 waves: a third
+  // would put a fifth wave on two SIMDs). Six lines per wave = eight emptier waves, two workgroups = 16 waves: p96 892 -> 907 k pairs/s
+  // same-box (profiles/r05_half_lpw96_ab.txt; four lines = 12 waves: 600 k)
+  if (m == 96) hp.lpw = 6;
+#ifdef MOF_HALF_LPW  // (A/B, with MOF_HALF_ONLY) lines per wave: fewer than a whole stage group = more, emptier waves
+  hp.lpw = MOF_HALF_LPW;
+#endif
   hp.waves = (H + hp.lpw - 1) / hp.lpw;
   // pitch: even, room for both skews; P/2 = 4 (mod 8) spreads the rows of a column walk over the banks (8 rows x 4 columns per
   // 32-lane read group) -- the first such pitch that still fits, else the smallest; without the skew where nothing else fits
