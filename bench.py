@@ -67,25 +67,25 @@ def binding_note(name: str, wl) -> str:
                 "time with the previous spectra in registers (K6s); DESIGN.md section 4 (sequence mode)")
     if wl["kind"] == "fft+sr":
         return ("scale/rotation pipeline K4-K8 takes 76 % of the step (profiles/r05_c5_kernel_stats.csv, r05_c5_sq_pmc.csv): log-polar gathers "
-                "(v_dot4c taps on LDS-staged source boxes; Lanczos4 540 us: LDS 58 % busy, VALU 30 %, waits 45 %; cubic 367 us) 32 %, whole-frame "
-                "transforms through Zh / Dt (K5s 447 us at 5.2 TB/s, K6s 581 us at 4.8 TB/s, K7 202 us at 4.6 TB/s: the minimum bytes of a rows -> "
-                "columns -> rows structure in f32, at 73-83 % of the achievable copy rate) 43 %; K1 as in c2; DESIGN.md section 4 (K4-K8, r05 block)")
+                "(v_dot4c taps on LDS-staged source boxes; Lanczos4 515 us: LDS 58 % busy, VALU 30 %, waits 44 %; cubic 382 us) 33 %, whole-frame "
+                "transforms through Zh / Dt (K5s 431 us at 5.4 TB/s, K6s 555 us at 5.0 TB/s, K7 193 us at 4.8 TB/s: the minimum bytes of a rows -> "
+                "columns -> rows structure in f32, at 76-86 % of the achievable copy rate) 43 %; K1 (637 us) as in c2; DESIGN.md section 4 (K4-K8, r05 block)")
     if wl["n"] == 120:
         return ("half-tile kernel K1h (pc_half_kernel.hip, r05): each image transformed on its own on a 60 x 136 complex tile, TWO workgroups of "
                 "8 waves per CU, every phase on all waves, the untangle / pairing / cross-power fused into the passes, the previous spectrum in "
-                "registers. profiles/r05_ref_sq_pmc.csv (per launch of 16,384 patch pairs): VALU issue 50.7 % (467.8 M wave-instructions x 2 cycles "
-                "over 1024 SIMDs x 1.845 M cycles; 3569 per wave), LDS active 52.1 % of the CU cycles (28 % of it bank conflicts), waves parked at a "
-                "wait 32.0 % of their cycles -- against the tuned one-workgroup kernel's 38.8 % + 37.0 %, waits 45.6 % (r05_ref_tuned_sq_pmc.csv, "
-                "MOF_FFT_HALF=0: 1.10 M pairs/s); VALU + LDS = 103 %: the two pipes in series, as K1; not HBM")
-    if wl["n"] >= 128:
+                "registers, the current image's pixels requested under the previous image's column pass. profiles/r05_ref_sq_pmc.csv (per launch of "
+                "16,384 patch pairs): VALU issue 51.7 % (3589 wave-instructions per wave x 2 cycles), LDS active 52.8 % of the CU cycles (28 % of it "
+                "bank conflicts), waves parked at a wait 30.7 % of their cycles -- against the tuned one-workgroup kernel's 38.8 % + 37.0 %, waits 45.6 % (r05_ref_tuned_sq_pmc.csv, "
+                "MOF_FFT_HALF=0: 1.10 M pairs/s); VALU + LDS = 104 %: the two pipes in series, as K1; not HBM")
+    if wl["n"] == 128:
         return ("one persistent workgroup per CU (the tile fills the LDS): the LDS store path (ds_write_b64 = 6 cycles per "
                 "wave-instruction, 7.5 tile stores per patch pair) and the 8-wave inverse passes; N = 128: VALU issue ~42 %, "
                 "LDS 46 % busy, 6 % of it bank conflicts (profiles/r05_c4_sq_pmc.csv; the kernel is unchanged since r03); the two add to "
                 "88 %: in series; not HBM -- DESIGN.md section 4 (K1 at N = 128)")
     if wl["n"] in (60, 96, 100) or 136 <= wl["n"] <= 192:
         return ("half-tile kernel K1h (pc_half_kernel.hip, r05; planned Stockham stages with compile-time radices, sources / sinks fused into "
-                "the passes). profiles/r05_{p60,p96,l160}_sq_pmc.csv: p60 VALU issue 56 % + LDS 61 % (30 % of it conflicts), waits 28 %; p96 "
-                "36 % + 45 % (40 %), waits 36 %; l160 36 % + 41 % (40 %), waits 36 % at one 10-wave workgroup per CU -- LDS bank conflicts of the "
+                "the passes, skew shift per size). profiles/r05_{p60,p96,l160}_sq_pmc.csv: p60 VALU issue 55 % + LDS 61 % (30 % of it conflicts), waits 29 %; p96 "
+                "47 % + 49 % (25 %), waits 33 %; l160 36 % + 41 % (38 %), waits 36 % at one 10-wave workgroup per CU -- LDS bank conflicts of the "
                 "generic lane maps and the series of the two pipes; not HBM (DESIGN.md section 4, K1h)")
     if wl["n"] != 64:
         return ("planned kernel (run-time radix plan, pc_kernel_generic.hip / pc_large_kernel.hip): the general path, not tuned -- "
