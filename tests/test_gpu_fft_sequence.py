@@ -167,10 +167,11 @@ def test_full_size_c2seq_properties(gpu):
     assert ((got - d).abs().amax(dim=-1)[ok] < 0.5).all()
 
 
-@pytest.mark.parametrize("n,fs", [(64, 192), (128, 256), (120, 240)])
+@pytest.mark.parametrize("n,fs", [(64, 192), (128, 256), (120, 240), (160, 320), (93, 186)])
 def test_bgr_video_front_end(gpu, n, fs):
     """SURVEY N2 on the sequence path: a BGR8 video, crop + CV_RGB2GRAY (optic_flow.cpp:1609-1622) fused into the sequence
-    kernels' loads (64 / 128) or the pair kernel's (120): identical bits to the gray entry on the converted crop, oracle bar."""
+    kernels' loads (64: K1s; 128, 120, 160 and 93 -> 96: the half-tile kernel's video form, r05): identical bits to the gray entry on the
+    converted crop, oracle bar."""
     nf, H, W, xi, yi = 5, fs + 9, fs + 24, 11, 5
     gray, _ = _video_np(nf, H, W, k=7)
     rng = np.random.default_rng(5)
