@@ -82,7 +82,7 @@ def binding_note(name: str, wl) -> str:
                 "wave-instruction, 7.5 tile stores per patch pair) and the 8-wave inverse passes; N = 128: VALU issue ~42 %, "
                 "LDS 46 % busy, 6 % of it bank conflicts (profiles/r05_c4_sq_pmc.csv; the kernel is unchanged since r03); the two add to "
                 "88 %: in series; not HBM -- DESIGN.md section 4 (K1 at N = 128)")
-    if wl["n"] in (60, 96, 100) or 136 <= wl["n"] <= 192:
+    if wl["n"] in (60, 72, 90, 96, 100) or 136 <= wl["n"] <= 192:
         return ("half-tile kernel K1h (pc_half_kernel.hip, r05; planned Stockham stages with compile-time radices, sources / sinks fused into "
                 "the passes, skew shift per size). profiles/r05_{p60,p96,l160}_sq_pmc.csv: p60 VALU issue 55 % + LDS 61 % (30 % of it conflicts), waits 29 %; p96 "
                 "47 % + 49 % (25 %), waits 33 %; l160 36 % + 41 % (38 %), waits 36 % at one 10-wave workgroup per CU -- LDS bank conflicts of the "

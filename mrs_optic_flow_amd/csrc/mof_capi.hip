@@ -412,7 +412,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     // p96 757 -> 855 k pairs/s, profiles/r05_half_vs_planned_bench_ab.txt, r05_half_vs_planned_rates.txt; on patches padded to 64 it
     // loses 4 %, p62); the tuned N = 64 / 128 pair kernels stay faster than it and keep their sizes. Patches of 109 .. 119 pixels pad to
     // 120 and follow N = 120 itself (the planned kernel at 120: 869 k against 1.30 M pairs/s)
-    const bool planned_size_default = e->generic && !force_planned && (n == 60 || n == 96 || n == 100 || n == 120);
+    const bool planned_size_default = e->generic && !force_planned && (n == 60 || n == 72 || n == 90 || n == 96 || n == 100 || n == 120);  // (72, 90: +3 % on pairs, and the video form: profiles/r05_half_vs_planned_final.txt)
     if (cfg->peak_model == MOF_PEAK_OPENCV && mof::pc_half_supported(n) && half_knob != 0 && !force_large && !force_planned &&
         (e->large || half_knob == 1 || tuned_size_default || planned_size_default))
       e->half_m = n;

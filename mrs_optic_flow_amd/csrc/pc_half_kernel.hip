@@ -904,12 +904,13 @@ have_current:
 
 // the transform sizes with an instantiation: the even 5-smooth sizes in (135, 192] -- what this kernel was written for --, the sizes
 // below that where it beats the full-tile kernels on the box (60, 96, 100 against the planned kernel: +10 .. 25 %; 120 against the tuned
-// pair kernel: +18 %; profiles/r05_half_vs_planned_rates.txt, r05_half_vs_planned_bench_ab.txt -- it loses at 40, 48, 50, 54, 80, 108
-// and on patches padded to 64, and ties at 72, 90), and 128 / 64 for the A/B against the tuned pair kernels (MOF_FFT_HALF=1)
+// pair kernel: +18 %; profiles/r05_half_vs_planned_rates.txt, r05_half_vs_planned_bench_ab.txt; 72, 90 since the round's second half:
+// +3 %, profiles/r05_half_vs_planned_final.txt -- it loses at 40, 48, 50, 54, 80, 108 and on patches padded to 64), and 128 / 64 for the A/B
+// against the tuned pair kernels (MOF_FFT_HALF=1; 128 also serves the video form)
 #ifdef MOF_HALF_ONLY  // (A/B sweeps: one instantiation compiles in seconds)
 #define MOF_HALF_SIZES(X) X(MOF_HALF_ONLY)
 #else
-#define MOF_HALF_SIZES(X) X(60) X(64) X(96) X(100) X(120) X(128) X(144) X(150) X(160) X(162) X(180) X(192)
+#define MOF_HALF_SIZES(X) X(60) X(64) X(72) X(90) X(96) X(100) X(120) X(128) X(144) X(150) X(160) X(162) X(180) X(192)
 #endif
 
 constexpr bool half_seq_size(int m) { return m != 162; }  // (162's last column stage runs long lines: no register-resident spectrum)

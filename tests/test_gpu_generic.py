@@ -37,7 +37,7 @@ def _planned_variant(n):
     """r05: transform sizes 60, 96, 100 run the half-tile kernel by default (it beats the full-tile planned kernel there by 10 - 25 %,
     profiles/r05_half_vs_planned_bench_ab.txt); MOF_FFT_HALF=0 keeps the planned kernel (a child process below re-runs them that way)."""
     import os
-    half = O.optimal_dft_size(n) in (60, 96, 100, 120) and os.environ.get("MOF_FFT_HALF", "") != "0"
+    half = O.optimal_dft_size(n) in (60, 72, 90, 96, 100, 120) and os.environ.get("MOF_FFT_HALF", "") != "0"
     return "planned-half" if half else "planned"
 
 

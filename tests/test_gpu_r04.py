@@ -313,7 +313,7 @@ def test_constant_frame_against_texture_on_padded_patches(gpu, case):
     frames = video.numpy()
     fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=grid, origin=origin, stride=stride)
     mm, half_on = O.optimal_dft_size(n), os.environ.get("MOF_FFT_HALF", "") != "0"
-    want_variant = ("planned-half" if half_on and mm in (60, 96, 100, 120, 144, 150, 160, 162, 180, 192) else ("planned" if mm <= 135 else "planned-large"))
+    want_variant = ("planned-half" if half_on and mm in (60, 72, 90, 96, 100, 120, 144, 150, 160, 162, 180, 192) else ("planned" if mm <= 135 else "planned-large"))
     assert fm.kernel_variant == want_variant
     dv = video.to(gpu)
     pair = fm.process_batch_device(dv[1:], dv[:-1]).cpu().numpy()[0]
