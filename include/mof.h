@@ -115,7 +115,7 @@ typedef struct mof_fft_engine mof_fft_engine;
  * (mof_fft_kernel_variant): hand-tuned packed-pair instantiations for N = 32, 64, 128 -- and 120 for the long-range mode and the OpenCL
  * peak model -- ("stockham"); the fused kernel on a HALF-size tile ("planned-half", csrc/pc_half_kernel.hip, r05: each image
  * transformed on its own, the previous spectrum waiting in registers) for N = 120 -- the reference's default, two workgroups per CU --,
- * for every N whose padded size is an even 136 .. 192, and for padded sizes 60 / 96 / 100; a planned kernel on the full M x M tile for
+ * for every N whose padded size is an even 136 .. 192, and for padded sizes 60 / 72 / 90 / 96 / 100 / 120; a planned kernel on the full M x M tile for
  * every other N with M <= 135 ("planned", csrc/pc_kernel_generic.hip); a planned pipeline through HBM scratch for larger patches up to
  * M = 960 ("planned-large", csrc/pc_large_kernel.hip; unpadded patches of 240 / 256 / 480 pixels run the scale / rotation
  * estimator's tuned transform kernels inside it). mof_fft_create fails with MOF_ERR_UNSUPPORTED
