@@ -173,7 +173,7 @@ int mof_fft_process_batch_device(mof_fft_engine* e, const uint8_t* d_cur, size_t
  * in registers: one real 2-D transform forward and one Hermitian inverse per frame and patch -- 1.0 instead of the
  * pair kernel's 1.5 complex-transform units (csrc/pc_seq_kernel.hip; csrc/pc_seq_half.hip for 128 x 128, on a half-size
  * LDS tile); r05: the sizes the half-tile kernel serves (120 x 120 -- the reference's default --, patches padded to 60 / 72 / 90 / 96 /
- * 100 / 120, and 136 .. 192 but 162) run its video form the same way (csrc/pc_half_kernel.hip, SEQ: the spectrum stays in the registers of
+ * 100 / 120, and 136 .. 192 but 162; on a video also 50 / 54 / 108, whose pair form stays the planned kernel) run its video form the same way (csrc/pc_half_kernel.hip, SEQ: the spectrum stays in the registers of
  * the forward column pass; identical bits to the pair entry on the two views of the video; MOF_FFT_HALF_SEQ=0 keeps the pair form);
  * every other size runs the pair kernel on the two views. The engine's stateful previous frame is not touched. Asynchronous on
  * `stream`. */

@@ -124,6 +124,7 @@ struct mof_fft_engine {
   int n_pair_slabs = 0;
   int half_m = 0;                // > 0: cv::phaseCorrelate-model batches on full-resolution frames run the fused half-tile kernel of that
                                  //      transform size instead (pc_half_kernel.hip: even padded sizes in (135, 192]; MOF_FFT_HALF=1: tuned sizes too)
+  int seq_half_m = 0;            // > 0: a planned size whose VIDEO entry runs the half-tile kernel's sequence form (its pair entries stay on the planned kernel)
   // scratch of the large-patch pipeline, for `cap` patch pairs per pass: row half-spectra of 2 cap patches, Dt, peak
   // candidates, constant-patch flags, C_dc. Grown by a batch that needs more (never under a graph capture, never while pinned).
   float *d_zh = nullptr, *d_dt = nullptr, *d_cdc = nullptr;
@@ -456,6 +457,16 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   CREATE_TRY(hipHostMalloc(&e->h_out, res * sizeof(double), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
   if (e->half_m > 0) CREATE_TRY(mof::pc_configure_half());
+  {
+    // the planned sizes whose VIDEO form is the half-tile kernel's although their pair form is not (fft_sequence)
+    static const int half_knob2 = [] { const char* v = getenv("MOF_FFT_HALF"); return v ? atoi(v) : -1; }();
+    static const bool force_planned2 = getenv("MOF_FFT_FORCE_PLANNED") != nullptr, force_large2 = getenv("MOF_FFT_FORCE_LARGE") != nullptr;
+    if (e->generic && e->half_m == 0 && half_knob2 != 0 && !force_planned2 && !force_large2 && cfg->peak_model == MOF_PEAK_OPENCV &&
+        !mof::pc_half_supported(n) && mof::pc_half_sequence_supported(n)) {
+      e->seq_half_m = n;
+      CREATE_TRY(mof::pc_configure_half());
+    }
+  }
   if (e->large) {
     CREATE_TRY(hipEventCreateWithFlags(&e->scratch_ev, hipEventDisableTiming));
     CREATE_TRY(large_alloc(e, cfg->grid_x * cfg->grid_y));  // one frame pair; a batch grows it to a whole pass
@@ -723,7 +734,9 @@ static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame
   // ... and 128 x 128 patches, whose pair form stays on the tuned kernel: on a video the half-tile kernel's sequence form beats the older
   // half-tile sequence kernel (pc_seq_half.hip: one 8-wave workgroup per CU, 192 VGPRs) -- c4seq 93.3 k -> 112 k pairs/s; MOF_FFT_SEQ_HALF128=1 keeps that one
   static const bool old128 = getenv("MOF_FFT_SEQ_HALF128") != nullptr;
-  const int kh_m = e->half_m > 0 ? e->half_m : ((!e->generic && !e->large && n == 128 && !old128) ? 128 : 0);
+  // ... and the planned sizes where only the video form wins (50, 54, 108: pc_half_kernel.hip, MOF_HALF_SEQ_SIZES)
+  const int kh_m = e->half_m > 0 ? e->half_m
+                                 : ((!e->generic && !e->large && n == 128 && !old128) ? 128 : ((e->generic && e->seq_half_m > 0) ? e->seq_half_m : 0));
   const bool khalf = kh_m > 0 && !pairs_only && !half_seq_off && e->cfg.peak_model == MOF_PEAK_OPENCV && mof::pc_half_sequence_supported(kh_m);
   if (!half && !full && !khalf) {
     FIELD_TRY(launch_field(e, a, n_pairs, (hipStream_t)stream));

@@ -912,6 +912,13 @@ have_current:
 #else
 #define MOF_HALF_SIZES(X) X(60) X(64) X(72) X(90) X(96) X(100) X(120) X(128) X(144) X(150) X(160) X(162) X(180) X(192)
 #endif
+// ... and the sizes with the VIDEO form only: on pairs the full-tile planned kernel is faster there, on a video one image transform per
+// pair beats it (108: +28 %, 50: +15 %, 54: +11 % -- profiles/r05_half_vs_planned_video.txt; 48 / 40 tie, 80 loses: not listed)
+#ifdef MOF_HALF_ONLY
+#define MOF_HALF_SEQ_SIZES(X)
+#else
+#define MOF_HALF_SEQ_SIZES(X) X(50) X(54) X(108)
+#endif
 
 constexpr bool half_seq_size(int m) { return m != 162; }  // (162's last column stage runs long lines: no register-resident spectrum)
 
@@ -943,9 +950,16 @@ int pc_half_workgroups_per_cu(int m) {
   switch (m) {
 #define X(M) case M: return HalfPlanOf<M>::HP.wgs_per_cu;
     MOF_HALF_SIZES(X)
+    MOF_HALF_SEQ_SIZES(X)
 #undef X
     default: return 0;
   }
+}
+
+template <int CH, int MS>
+hipError_t configure_half_seq_only() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&pc_half_kernel<CH, MS, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             HalfPlanOf<MS>::HP.lds_bytes);
 }
 
 hipError_t pc_configure_half() {
@@ -954,6 +968,11 @@ hipError_t pc_configure_half() {
   if ((e = configure_half_one<1, M>()) != hipSuccess) return e;            \
   if ((e = configure_half_one<3, M>()) != hipSuccess) return e;
   MOF_HALF_SIZES(X)
+#undef X
+#define X(M)                                                              \
+  if ((e = configure_half_seq_only<1, M>()) != hipSuccess) return e;       \
+  if ((e = configure_half_seq_only<3, M>()) != hipSuccess) return e;
+  MOF_HALF_SEQ_SIZES(X)
 #undef X
   return hipSuccess;
 }
@@ -984,7 +1003,15 @@ hipError_t launch_pc_half(const PcArgs& a_in, int m, int n, int n_pairs, hipStre
   return hipGetLastError();
 }
 
-bool pc_half_sequence_supported(int m) { return pc_half_supported(m) && half_seq_size(m); }
+bool pc_half_sequence_supported(int m) {
+  switch (m) {
+#define X(M) case M:
+    MOF_HALF_SEQ_SIZES(X)
+#undef X
+    return true;
+    default: return pc_half_supported(m) && half_seq_size(m);
+  }
+}
 
 // the video form: a.cur = frame 0 of the launch's first pair, frame f at a.cur + f * a.cur_stride; n_pairs pairs in runs of `run`
 // run = 0: chosen here. Workgroups of one launch all take the same time (run + ~0.45 image transforms: a run's first frame is
@@ -1023,6 +1050,7 @@ hipError_t launch_pc_half_sequence(const PcArgs& a, int m, int n, int n_pairs, i
     }                                                                                                                                         \
     break;
     MOF_HALF_SIZES(X)
+    MOF_HALF_SEQ_SIZES(X)
 #undef X
     default: return hipErrorInvalidValue;
   }
