@@ -141,6 +141,13 @@ WORKLOADS = {
     "l160": dict(kind="fft", h=480, w=480, n=160, grid=(3, 3), origin=(0, 0), stride=(160, 160), batch=512, s=15,
                  name="l160: FftMethod 480x480, 3x3 grid of 160x160 patches (fused half-tile kernel; MOF_FFT_HALF=0: the pipeline through HBM scratch), batch=512 per GPU",
                  bytes_per_pair=2 * 480 * 480 + 9 * 8),
+    # the next size cliff: padded sizes 193 .. 256 -- half a tile (M x (M/2 + 8) complex) no longer fits one CU's LDS
+    "l200": dict(kind="fft", h=480, w=480, n=200, grid=(2, 2), origin=(0, 0), stride=(200, 200), batch=512, s=15,
+                 name="l200: FftMethod 480x480, 2x2 grid of 200x200 patches (transform size 200), batch=512 per GPU",
+                 bytes_per_pair=2 * 4 * 200 * 200 + 4 * 8),
+    "l240": dict(kind="fft", h=480, w=480, n=240, grid=(2, 2), origin=(0, 0), stride=(240, 240), batch=512, s=15,
+                 name="l240: FftMethod 480x480, 2x2 grid of 240x240 patches (transform size 240), batch=512 per GPU",
+                 bytes_per_pair=2 * 480 * 480 + 4 * 8),
     "l480": dict(kind="fft", h=480, w=480, n=480, grid=(1, 1), origin=(0, 0), stride=(480, 480), batch=512, s=15,
                  name="l480: FftMethod 480x480, ONE 480x480 patch (the reference's whole-frame fallback), batch=512 per GPU",
                  bytes_per_pair=2 * 480 * 480 + 8),
@@ -601,6 +608,121 @@ for _n in (100, 144, 150, 162, 180, 192):
     WORKLOADS[f"t{_n}"] = _tile_workload(_n)
 
 
+def native_group_run(tag: str, wl, n_dev: int, steps: int, warmup: int, share_gpu: bool, sync_per_step: bool = False, settle_s: float = 0.4):
+    """The batched-frames mode through the NATIVE shard group (mof_shard_fft_* / mof_shard_bm_*, csrc/mof_shard.hip): ONE process, no
+    torch.distributed -- one engine and one HIP stream per device inside the library, ceil(B / G) contiguous shards, one in-place RCCL
+    all-gather per step (ncclCommInitAll by mof_shard_*_init_gather). torch only allocates the per-device buffers and generates the
+    shards. Weak scaling: `batch` pairs per device. --share-gpu: all shards on device 0 under the rehearsal knob
+    MOF_SHARD_SHARE_DEVICE=1 (a one-GPU box; such a group cannot gather). Returns the record for the JSON line."""
+    import ctypes as C
+
+    import torch
+
+    from mrs_optic_flow_amd import BlockMethod, FastSpacedBMMethod, FftMethod, _capi, synth
+
+    if wl["kind"] not in ("fft", "bm") or wl.get("bgr"):
+        raise SystemExit(f"--native serves the gray FftMethod / block-matching workloads (c2, c4, ref, c3, c1, ...), not {tag}")
+    if share_gpu:
+        os.environ["MOF_SHARD_SHARE_DEVICE"] = "1"
+    devices = [0] * n_dev if share_gpu else list(range(n_dev))
+    if not share_gpu and torch.cuda.device_count() < n_dev:
+        raise SystemExit(f"--native --gpus {n_dev}: this process sees {torch.cuda.device_count()} device(s) (use --share-gpu to rehearse on one)")
+    lib = _capi.load()
+    B, G, fft = wl["batch"], n_dev, wl["kind"] == "fft"
+    if fft:
+        proto = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"], origin=wl["origin"], stride=wl["stride"], device=0)
+        per_pair = proto.n_patches * 2
+    elif wl.get("block_method"):
+        proto = BlockMethod(wl["h"], wl["block"], wl["radius"], device=0)
+    else:
+        proto = FastSpacedBMMethod(wl["block"], wl["radius"], wl["step"], (wl["h"], wl["w"]), device=0)
+    grp = C.c_void_p()
+    dev_arr = (C.c_int * G)(*devices)
+    create, destroy = (lib.mof_shard_fft_create, lib.mof_shard_fft_destroy) if fft else (lib.mof_shard_bm_create, lib.mof_shard_bm_destroy)
+    process, sync = (lib.mof_shard_fft_process_batch_device, lib.mof_shard_fft_sync) if fft else (lib.mof_shard_bm_process_batch_device, lib.mof_shard_bm_sync)
+    init_gather, ranks_of, stream_of = ((lib.mof_shard_fft_init_gather, lib.mof_shard_fft_gather_ranks, lib.mof_shard_fft_stream) if fft else
+                                        (lib.mof_shard_bm_init_gather, lib.mof_shard_bm_gather_ranks, lib.mof_shard_bm_stream))
+    _capi.check(create(C.byref(proto.cfg), dev_arr, G, C.byref(grp)))
+    try:
+        gather = 0 if share_gpu else 1
+        if gather:
+            _capi.check(init_gather(grp))
+        rccl_ranks = int(ranks_of(grp))
+        cur, prev, out, ext = [], [], [], []
+        for i, d in enumerate(devices):
+            dv = torch.device("cuda", d)
+            with torch.cuda.device(dv):
+                c, p, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dv, k0=i * B)  # shard i of the global batch, generated on its own GPU
+                cur.append(c)
+                prev.append(p)
+                if fft:
+                    out.append(torch.empty((G * B, per_pair), dtype=torch.float64, device=dv))
+                else:
+                    out.append(torch.empty((G * int(lib.mof_shard_bm_slab_bytes(grp, G * B)),), dtype=torch.int8, device=dv))
+                ext.append(torch.cuda.ExternalStream(int(stream_of(grp, i)), device=dv))
+        pc, pp, po = ((C.c_void_p * G)(*[t.data_ptr() for t in ts]) for ts in (cur, prev, out))
+        cs, ps, pitch = cur[0].stride(0), prev[0].stride(0), cur[0].stride(1)
+
+        def sync_all():
+            _capi.check(sync(grp))
+            for d in set(devices):
+                torch.cuda.synchronize(d)
+
+        def step():
+            _capi.check(process(grp, pc, cs, pp, ps, pitch, G * B, po, gather))
+            if sync_per_step:
+                _capi.check(sync(grp))
+
+        sync_all()
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < settle_s:  # settled clocks, as every other record of this file
+            for _ in range(10):
+                step()
+            sync_all()
+        for _ in range(warmup):
+            step()
+        ev0 = [[torch.cuda.Event(enable_timing=True) for _ in devices] for _ in range(steps)]
+        ev1 = [[torch.cuda.Event(enable_timing=True) for _ in devices] for _ in range(steps)]
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            for i in range(G):
+                ev0[k][i].record(ext[i])
+            step()
+            for i in range(G):
+                ev1[k][i].record(ext[i])
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        per_dev_ms = [sum(ev0[k][i].elapsed_time(ev1[k][i]) for k in range(steps)) / steps for i in range(G)]
+        # the result of the whole batch, as device 0 holds it after the gather, against the plain engine on each shard (bit for bit)
+        verified = True
+        for i, d in enumerate(devices if gather else devices[:1]):
+            with torch.cuda.device(d):
+                if fft:
+                    e = proto if d == 0 else FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"], origin=wl["origin"], stride=wl["stride"], device=d)
+                    want = e.process_batch_device(cur[i], prev[i]).reshape(B, per_pair)
+                    got = (out[0] if gather and d == 0 else out[i])[i * B:(i + 1) * B]
+                    verified = verified and bool(torch.equal(got.to(want.device), want))
+                else:
+                    e = proto if d == 0 else (BlockMethod(wl["h"], wl["block"], wl["radius"], device=d) if wl.get("block_method")
+                                              else FastSpacedBMMethod(wl["block"], wl["radius"], wl["step"], (wl["h"], wl["w"]), device=d))
+                    dx, dy, mode = e.process_batch_device(cur[i], prev[i])
+                    blocks, slab = dx[0].numel(), int(lib.mof_shard_bm_slab_bytes(grp, G * B))
+                    got = (out[0] if gather and d == 0 else out[i])[i * slab:(i + 1) * slab].to(dx.device)  # dx | dy | mode planes of rank i
+                    verified = (verified and bool(torch.equal(got[:B * blocks], dx.reshape(-1))) and bool(torch.equal(got[B * blocks:2 * B * blocks], dy.reshape(-1)))
+                                and bool(torch.equal(got[2 * B * blocks:2 * B * blocks + 8 * B], mode.reshape(-1))))
+        rec = {"value": G * B * steps / elapsed, "unit": "frame-pairs/s", "n_devices": G, "devices": devices, "steps": steps, "warmup": warmup,
+               "ms_per_step": elapsed / steps * 1e3, "per_device_step_ms": per_dev_ms,
+               "per_device_step_ms_note": "HIP events on each shard's own stream around one group call: the shard's kernel(s) + its leg of the all-gather",
+               "rccl_ranks": rccl_ranks, "gather": ("in-place ncclAllGather per step inside one ncclGroupStart/End, %d rank(s) formed by ncclCommInitAll" % rccl_ranks) if gather
+               else "none (shards share a device: RCCL needs one rank per device)",
+               "sync": "per step" if sync_per_step else "end of the timed region (steps are enqueued back to back on the group's streams, as the plain path's)",
+               "batch_per_device": B, "shard_results_equal_plain_engine": verified, "share_gpu": share_gpu}
+        return rec
+    finally:
+        destroy(grp)
+
+
 def self_launch(n_ranks: int) -> int:
     """One process per GPU, started by bench.py itself: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT are set for
     every child BEFORE anything in it touches a GPU (the children are fresh interpreters of this script with the same
@@ -637,6 +759,31 @@ def self_launch(n_ranks: int) -> int:
     return rc
 
 
+def main_native(args) -> None:
+    """`bench.py --native --gpus N`: the contract's JSON line, measured through the native shard group (no torch.distributed)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    rec = native_group_run(args.workload, wl, args.gpus, args.steps, args.warmup, args.share_gpu, args.native_sync_per_step)
+    kern_ms = max(rec["per_device_step_ms"])
+    line = {"metric": "frame_pairs_per_s" + ("_fft_phase_corr" if wl["kind"] == "fft" else ("_block_method" if wl.get("block_method") else "_fast_spaced_bm")),
+            "value": rec["value"], "unit": "frame-pairs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if wl["kind"] == "bm" else "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "batch_per_gpu": wl["batch"], "frame": f'{wl["w"]}x{wl["h"]} u8',
+                       "parallelism": f"native shard group x{args.gpus}" + (" (all shards on GPU 0: rehearsal)" if args.share_gpu else ""),
+                       "gather": rec["gather"], "hip_graph": False},
+            "rccl_ranks": rec["rccl_ranks"], "native_shard_group": rec}
+    if not args.share_gpu:  # (G shards on one device time G batches on one GPU: no roofline of ONE launch to state)
+        line["roofline"] = roofline_block(args.workload, wl, wl["batch"], kern_ms)
+        line["roofline"]["kernel_ms_note"] = "slowest device's step by HIP events on its shard stream (kernel + its leg of the gather)"
+    print(json.dumps(line), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -655,10 +802,16 @@ def main() -> None:
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--blocking-gather", action="store_true",
                     help="--gpus > 1: blocking all_gather_into_tensor per step instead of the double-buffered non-blocking one")
+    ap.add_argument("--native", action="store_true",
+                    help="time the NATIVE shard group (mof_shard_*: one process, one engine + stream per device, RCCL all-gather inside the library) "
+                         "over --gpus devices instead of one torch.distributed rank per GPU; with --share-gpu all shards sit on GPU 0 (no gather)")
+    ap.add_argument("--native-sync-per-step", action="store_true", help="--native: mof_shard_*_sync after every step instead of at the end")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph and replay it (helps the multi-launch c5 pipeline)")
     args = ap.parse_args()
 
+    if args.native:
+        return main_native(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` run bare: this process becomes the launcher. It touches no GPU (nothing below has
         # imported torch or loaded the library yet), starts N fresh rank processes of this same script and relays rank 0's line.
@@ -731,6 +884,20 @@ def main() -> None:
     # W warm-up steps and the K timed steps of the contract. The K-step burst lasts ~13 ms at c2 with the driver's K = 20: measured
     # first, as until r04, it read the clock ramp of a GPU that had just idled (BENCH_r04: 1.54 M in the burst, 1.73 M sustained in the
     # same run); after the sustained leg it reads the settled clocks a streaming job runs at. --sustain-s 0 (the A/B scripts) skips the leg.
+    # (r06) BOTH regimes are reported: `cold_burst` = exactly the W warm-up + K timed steps the command line asks for, started on a GPU
+    # that has idled for a second (what a reader of `--steps 20 --warmup 5` would expect; it reads the clock ramp), then the sustained leg,
+    # then the contract's W + K steps on settled clocks (`value`). No headline moves by protocol alone: both numbers are in every line.
+    cold = None
+    if args.sustain_s > 0:
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        for _ in range(args.warmup):
+            step()
+        step(None, drain=True)
+        cold_elapsed = timed_steps(step, args.steps, world, dev)
+        cold = {"value": B * world * args.steps / cold_elapsed, "ms_per_step": cold_elapsed / args.steps * 1e3,
+                "kernel_ms": sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps, "steps": args.steps, "warmup": args.warmup,
+                "order": "first: after 1 s of idling, before the sustained leg (the r01-r04 protocol)"}
     sustained = None
     if args.sustain_s > 0:
         for _ in range(3):
@@ -776,6 +943,9 @@ def main() -> None:
                        "gather": gather, "hip_graph": bool(args.graph and world == 1)},
             "roofline": roofline_block(args.workload, wl, B, kern_ms),
         }
+        if cold is not None:
+            line["cold_burst"] = cold
+            line["value_regime"] = "settled clocks: the W + K steps run after the sustained leg (cold_burst = the same W + K steps from an idle GPU)"
         if sustained is not None:
             line["sustained"] = sustained
         if world == 1 and not args.no_cpu_baseline:
@@ -784,10 +954,15 @@ def main() -> None:
             del launch, eng, state, step
             torch.cuda.empty_cache()
             # driver-visible records of the other BASELINE configurations (same protocol, fewer steps)
+            # the same workload through the NATIVE shard group (C++ host, RCCL inside the library) on this one device: a 1-rank gather
+            try:
+                line["native_shard_group"] = native_group_run("c2", dict(WORKLOADS["c2"]), 1, 100, 10, False)
+            except BaseException as e:  # (never at the price of the headline line)
+                line["native_shard_group"] = {"error": f"{type(e).__name__}: {e}"}
             line["other_workloads"] = {tag: measure_other(tag, dev, st, 5)
                                        for tag, st in (("c3", 50), ("c4", 20), ("c5", 40), ("c2seq", 50), ("c4seq", 10), ("c5seq", 40), ("ref", 50), ("refseq", 50),
                                                        ("bmref", 50), ("refrt", 50), ("reflr", 50),
-                                                       ("p60", 50), ("l160", 40), ("l480", 20))}  # the planned kernel, the half-tile kernel (r05), the large-patch pipeline
+                                                       ("p60", 50), ("l160", 40), ("l200", 20), ("l240", 20), ("l480", 20))}  # the planned kernel, the half-tile kernel (r05), the large-patch pipeline
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -228,6 +228,7 @@ void* mof_shard_fft_stream(const mof_shard_fft* g, int shard); /* the hipStream_
  * with MOF_ERR_NOT_INIT -- the asynchronous batch call never builds communicators itself. Idempotent. */
 int mof_shard_fft_init_gather(mof_shard_fft* g);
 int mof_shard_fft_gather_ready(const mof_shard_fft* g); /* 1 once init_gather succeeded */
+int mof_shard_fft_gather_ranks(const mof_shard_fft* g); /* ranks RCCL formed: ncclCommCount of communicator 0; 0 before init_gather */
 /* d_cur[g] / d_prev[g]: device g's OWN shard of the batch (its first pair at the pointer; strides and pitch as in
  * mof_fft_process_batch_device) -- frames are generated or loaded directly on the owning GPU. d_out[g]: on device g,
  * n_shards * mof_shard_slab_pairs(n_pairs, n_shards) * grid_x * grid_y * 2 doubles; pair k's vectors land at pair index k
@@ -315,6 +316,7 @@ int mof_shard_bm_devices(const mof_shard_bm* g);
 void* mof_shard_bm_stream(const mof_shard_bm* g, int shard);
 int mof_shard_bm_init_gather(mof_shard_bm* g);
 int mof_shard_bm_gather_ready(const mof_shard_bm* g);
+int mof_shard_bm_gather_ranks(const mof_shard_bm* g);
 size_t mof_shard_bm_slab_bytes(const mof_shard_bm* g, int n_pairs); /* bytes of one rank's slab (0 for a null group) */
 int mof_shard_bm_locate(const mof_shard_bm* g, int n_pairs, int pair, size_t* dx_off, size_t* dy_off, size_t* mode_off);
 int mof_shard_bm_process_batch_device(mof_shard_bm* g, const uint8_t* const* d_cur, size_t cur_stride,

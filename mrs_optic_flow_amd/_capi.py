@@ -92,12 +92,14 @@ SYMBOLS = {
     "mof_shard_fft_sync": (_I, [_VP]),
     "mof_shard_fft_init_gather": (_I, [_VP]),
     "mof_shard_fft_gather_ready": (_I, [_VP]),
+    "mof_shard_fft_gather_ranks": (_I, [_VP]),
     "mof_shard_bm_create": (_I, [C.POINTER(BmConfig), C.POINTER(_I), _I, C.POINTER(_VP)]),
     "mof_shard_bm_destroy": (None, [_VP]),
     "mof_shard_bm_devices": (_I, [_VP]),
     "mof_shard_bm_stream": (_VP, [_VP, _I]),
     "mof_shard_bm_init_gather": (_I, [_VP]),
     "mof_shard_bm_gather_ready": (_I, [_VP]),
+    "mof_shard_bm_gather_ranks": (_I, [_VP]),
     "mof_shard_bm_slab_bytes": (_SZ, [_VP, _I]),
     "mof_shard_bm_locate": (_I, [_VP, _I, _I, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ)]),
     "mof_shard_bm_process_batch_device": (_I, [_VP, C.POINTER(_VP), _SZ, C.POINTER(_VP), _SZ, _SZ, _I, C.POINTER(_VP), _I]),

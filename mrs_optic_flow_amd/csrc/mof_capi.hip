@@ -456,7 +456,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
   CREATE_TRY(hipMalloc(&e->d_out, res * sizeof(double)));
   CREATE_TRY(hipHostMalloc(&e->h_out, res * sizeof(double), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&e->h_stage, e->frame_bytes, hipHostMallocDefault));
-  if (e->half_m > 0) CREATE_TRY(mof::pc_configure_half());
+  if (e->half_m > 0) CREATE_TRY(mof::pc_configure_half(e->half_m));
   {
     // the planned sizes whose VIDEO form is the half-tile kernel's although their pair form is not (fft_sequence)
     static const int half_knob2 = [] { const char* v = getenv("MOF_FFT_HALF"); return v ? atoi(v) : -1; }();
@@ -464,7 +464,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     if (e->generic && e->half_m == 0 && half_knob2 != 0 && !force_planned2 && !force_large2 && cfg->peak_model == MOF_PEAK_OPENCV &&
         !mof::pc_half_supported(n) && mof::pc_half_sequence_supported(n)) {
       e->seq_half_m = n;
-      CREATE_TRY(mof::pc_configure_half());
+      CREATE_TRY(mof::pc_configure_half(n));
     }
   }
   if (e->large) {
@@ -476,7 +476,7 @@ int mof_fft_create(const mof_fft_config* cfg, mof_fft_engine** out) try {
     CREATE_TRY(mof::pc_configure(n));
     if (mof::pc_sequence_supported(n)) CREATE_TRY(mof::pc_configure_sequence());
     if (mof::pc_sequence_half_supported(n)) CREATE_TRY(mof::pc_configure_sequence_half(n));
-    if (n == 128 && cfg->peak_model == MOF_PEAK_OPENCV && mof::pc_half_sequence_supported(n)) CREATE_TRY(mof::pc_configure_half());  // (its video form serves 128 x 128, fft_sequence)
+    if (n == 128 && cfg->peak_model == MOF_PEAK_OPENCV && mof::pc_half_sequence_supported(n)) CREATE_TRY(mof::pc_configure_half(n));  // (its video form serves 128 x 128, fft_sequence)
     // A/B knob (r05): independent pairs of 128 x 128 patches through the pair kernel on the HALF tile, two workgroups per CU
     static const bool pair_half = [] { const char* v = getenv("MOF_FFT_PAIR_HALF"); return v && atoi(v) != 0; }();
     if (pair_half && mof::pc_pair_half_supported(n)) {

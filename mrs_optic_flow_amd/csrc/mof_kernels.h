@@ -93,7 +93,7 @@ hipError_t launch_pcl_cdc(const float* zh_prev, const float* zh_cur, size_t zh_s
 // cv::phaseCorrelate's model on full-resolution gray or BGR8 frames. m = padded transform size (a.twiddles: m entries), n = patch size
 bool pc_half_supported(int m);
 int pc_half_workgroups_per_cu(int m);
-hipError_t pc_configure_half();
+hipError_t pc_configure_half(int m);
 hipError_t launch_pc_half(const PcArgs& a, int m, int n, int n_pairs, hipStream_t stream);
 // ... on a video (r05): runs of `run` consecutive pairs per workgroup, a frame's spectrum kept in registers for the next pair; a.cur = the
 // launch's first frame, frame f at a.cur + f * a.cur_stride (as launch_pc_sequence)

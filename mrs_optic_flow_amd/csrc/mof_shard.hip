@@ -37,6 +37,7 @@ typedef void* rcclComm_t;
 struct Rccl {
   int (*CommInitAll)(rcclComm_t*, int, const int*) = nullptr;
   int (*CommDestroy)(rcclComm_t) = nullptr;
+  int (*CommCount)(const rcclComm_t, int*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int /*ncclDataType_t*/, rcclComm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
@@ -64,6 +65,7 @@ Rccl* rccl() {
     };
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
@@ -123,8 +125,10 @@ struct ShardCore {
     return MOF_OK;
   }
 
-  // waits for the streams of shards [0, upto): the error path of a batch whose later shard failed to launch -- nothing of this
-  // call is still running when the caller sees the error
+  // waits for the streams of shards [0, upto): the error path of a batch one of whose shards failed to launch. The failing shard's OWN
+  // stream is included by the callers (drain(i + 1)): a batch entry may have enqueued part of its work before it failed (the large-patch
+  // pipeline runs several kernels per pass, the half-tile launcher loops over 65535-pair chunks) -- nothing of this call is still running
+  // when the caller sees the error, so it may free its buffers
   void drain(int upto) {
     for (int i = 0; i < upto && i < (int)streams.size(); ++i)
       if (streams[i]) {
@@ -155,6 +159,16 @@ struct ShardCore {
       return mof::capi_fail(MOF_ERR_HIP, "ncclCommInitAll(%d devices): %s", n_dev, r->GetErrorString(nc));
     }
     return MOF_OK;
+  }
+
+  // what RCCL actually formed: ncclCommCount of communicator 0 (0 before init_gather, < 0 on an RCCL error) -- the one fact a
+  // reader of a scaling line wants next to the device count
+  int gather_ranks() const {
+    if (comms.empty()) return 0;
+    Rccl* r = rccl();
+    int n = 0;
+    if (!r || r->CommCount(comms[0], &n) != 0) return mof::capi_fail(MOF_ERR_HIP, "ncclCommCount failed");
+    return n;
   }
 
   // ONE in-place all-gather of `slab_bytes` per rank: rank i's slab already sits at base[i] + i * slab_bytes (the NCCL in-place
@@ -278,6 +292,8 @@ int mof_shard_fft_init_gather(mof_shard_fft* g) {
 
 int mof_shard_fft_gather_ready(const mof_shard_fft* g) { return (g && !g->core.comms.empty()) ? 1 : 0; }
 
+int mof_shard_fft_gather_ranks(const mof_shard_fft* g) { return g ? g->core.gather_ranks() : 0; }
+
 int mof_shard_fft_process_batch_device(mof_shard_fft* g, const uint8_t* const* d_cur, size_t cur_stride,
                                        const uint8_t* const* d_prev, size_t prev_stride, size_t pitch, int n_pairs,
                                        double* const* d_out, int gather) {
@@ -304,7 +320,7 @@ int mof_shard_fft_process_batch_device(mof_shard_fft* g, const uint8_t* const* d
     const int rc = mof_fft_process_batch_device(g->engines[i], d_cur[i], cur_stride, d_prev[i], prev_stride, pitch, count,
                                                 d_out[i] + (size_t)i * slab, g->core.streams[i]);
     if (rc != MOF_OK) {
-      g->core.drain(i);  // (the failing call's message stays the thread's last error)
+      g->core.drain(i + 1);  // (the failing call's message stays the thread's last error)
       return rc;
     }
   }
@@ -373,6 +389,8 @@ int mof_shard_bm_init_gather(mof_shard_bm* g) {
 
 int mof_shard_bm_gather_ready(const mof_shard_bm* g) { return (g && !g->core.comms.empty()) ? 1 : 0; }
 
+int mof_shard_bm_gather_ranks(const mof_shard_bm* g) { return g ? g->core.gather_ranks() : 0; }
+
 size_t mof_shard_bm_slab_bytes(const mof_shard_bm* g, int n_pairs) {
   if (!g || n_pairs < 0) return 0;
   return bm_slab_bytes(g->blocks, (size_t)mof_shard_slab_pairs(n_pairs, g->core.n_dev));
@@ -414,7 +432,7 @@ int mof_shard_bm_process_batch_device(mof_shard_bm* g, const uint8_t* const* d_c
     const int rc = mof_bm_process_batch_device(g->engines[i], d_cur[i], cur_stride, d_prev[i], prev_stride, pitch, count, s,
                                                s + sp * g->blocks, s + 2 * sp * g->blocks, g->core.streams[i]);
     if (rc != MOF_OK) {
-      g->core.drain(i);
+      g->core.drain(i + 1);
       return rc;
     }
   }

@@ -962,19 +962,26 @@ hipError_t configure_half_seq_only() {
                              HalfPlanOf<MS>::HP.lds_bytes);
 }
 
-hipError_t pc_configure_half() {
+// raises the dynamic-LDS limit of the ONE padded size `m` an engine will launch (pair form and, where it exists, video form; both
+// channel counts) on the calling thread's current device -- not of all ~60 instantiations: that loaded every code object at every
+// engine create, on every device of a shard group
+hipError_t pc_configure_half(int m) {
   hipError_t e;
-#define X(M)                                                              \
-  if ((e = configure_half_one<1, M>()) != hipSuccess) return e;            \
-  if ((e = configure_half_one<3, M>()) != hipSuccess) return e;
-  MOF_HALF_SIZES(X)
+  switch (m) {
+#define X(M)                                                               \
+  case M:                                                                  \
+    if ((e = configure_half_one<1, M>()) != hipSuccess) return e;          \
+    return configure_half_one<3, M>();
+    MOF_HALF_SIZES(X)
 #undef X
-#define X(M)                                                              \
-  if ((e = configure_half_seq_only<1, M>()) != hipSuccess) return e;       \
-  if ((e = configure_half_seq_only<3, M>()) != hipSuccess) return e;
-  MOF_HALF_SEQ_SIZES(X)
+#define X(M)                                                               \
+  case M:                                                                  \
+    if ((e = configure_half_seq_only<1, M>()) != hipSuccess) return e;     \
+    return configure_half_seq_only<3, M>();
+    MOF_HALF_SEQ_SIZES(X)
 #undef X
-  return hipSuccess;
+    default: return hipErrorInvalidValue;
+  }
 }
 
 // a.downscale must be 1 and a.peak_model 0 (the caller keeps the other front ends on their pipelines); m = the padded size, n the patch
@@ -1021,11 +1028,8 @@ bool pc_half_sequence_supported(int m) {
 hipError_t launch_pc_half_sequence(const PcArgs& a, int m, int n, int n_pairs, int run, hipStream_t stream) {
   if (a.downscale != 1 || a.peak_model != 0 || (a.channels != 1 && a.channels != 3) || n > m || n < 2 || run < 0 || n_pairs < 1) return hipErrorInvalidValue;
   if (run == 0) {
-    static const int cus = [] {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }();
+    int dev = 0, cus = 0;  // per call: the devices of a shard group need not be alike (an attribute query, no synchronisation)
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const long slots = (long)cus * (pc_half_workgroups_per_cu(m) > 0 ? pc_half_workgroups_per_cu(m) : 1), patches = (long)a.grid_x * a.grid_y;
     double best = 0.0;
     for (int r = 4; r <= 64; ++r) {

@@ -40,7 +40,15 @@ def _mix32_np(seed: int, k: np.ndarray, y: np.ndarray, x: np.ndarray) -> np.ndar
     return h
 
 
-def canvas_np(k: int, height: int, width: int, blur: bool = True, seed: int = SEED) -> np.ndarray:
+def _blur_taps(blur):
+    """3-tap separable integer blur: True = the 3 x 3 box of SURVEY 8(d), (sum + 4) / 9; "mild" = (1 6 1) x (1 6 1), (sum + 32) / 64.
+    The box has spectral zeros (at 1/3 of the sampling rate) and leaves small alternating-sign pixel sums, which makes patches with a
+    spectral bin that is EXACTLY zero -- three equal integer residue-class sums -- an every-few-hundred-patches event (tests/
+    conditioning.py: no f32 arithmetic pins such a patch); "mild" has no zero (response 0.25 .. 1) and keeps them to ~1 in 2000."""
+    return ((1, 6, 1), 64) if blur == "mild" else ((1, 1, 1), 9)
+
+
+def canvas_np(k: int, height: int, width: int, blur=True, seed: int = SEED) -> np.ndarray:
     """uint8 texture canvas ``(height + 2*MARGIN) x (width + 2*MARGIN)`` for pair ``k``."""
     hh, ww = height + 2 * MARGIN, width + 2 * MARGIN
     pad = 1 if blur else 0
@@ -49,14 +57,15 @@ def canvas_np(k: int, height: int, width: int, blur: bool = True, seed: int = SE
     t = (_mix32_np(seed, np.uint64(k) + np.zeros((1, 1), np.uint64), y, x) >> np.uint64(24)).astype(np.int32)
     if not blur:
         return t.astype(np.uint8)
+    taps, div = _blur_taps(blur)
     acc = np.zeros((hh, ww), np.int32)
     for oy in range(3):
         for ox in range(3):
-            acc += t[oy:oy + hh, ox:ox + ww]
-    return ((acc + 4) // 9).astype(np.uint8)
+            acc += taps[oy] * taps[ox] * t[oy:oy + hh, ox:ox + ww]
+    return ((acc + div // 2) // div).astype(np.uint8)
 
 
-def pair_np(k: int, height: int, width: int, dx: int, dy: int, blur: bool = True, seed: int = SEED,
+def pair_np(k: int, height: int, width: int, dx: int, dy: int, blur=True, seed: int = SEED,
             kind: str = "shift", noise: int = 3) -> tuple[np.ndarray, np.ndarray]:
     """(cur, prev) uint8 frames of pair ``k``.
 
@@ -84,7 +93,7 @@ def pair_np(k: int, height: int, width: int, dx: int, dy: int, blur: bool = True
     return cur, prev.copy()
 
 
-def batch_np(n_pairs: int, height: int, width: int, s: int, blur: bool = True, seed: int = SEED,
+def batch_np(n_pairs: int, height: int, width: int, s: int, blur=True, seed: int = SEED,
              k0: int = 0, classes: bool = True):
     """Batch ``[n, H, W]`` uint8 cur/prev plus the planted shifts and class names.
 
@@ -126,7 +135,7 @@ def _mix32_t(seed: int, k, y, x):
     return h
 
 
-def batch_torch(n_pairs: int, height: int, width: int, s: int, device, blur: bool = True, seed: int = SEED,
+def batch_torch(n_pairs: int, height: int, width: int, s: int, device, blur=True, seed: int = SEED,
                 k0: int = 0, classes: bool = True, chunk: int = 32):
     """torch version of :func:`batch_np`; returns (cur, prev, shifts[n,2] int32 cpu tensor, kinds)."""
     import torch
@@ -147,11 +156,12 @@ def batch_torch(n_pairs: int, height: int, width: int, s: int, device, blur: boo
         ks = torch.arange(k0 + c0, k0 + c1, dtype=torch.int64, device=device)[:, None, None]
         t = _mix32_t(seed, ks, y, x) >> 24
         if blur:
+            taps, div = _blur_taps(blur)
             acc = torch.zeros((c1 - c0, hh, ww), dtype=torch.int64, device=device)
             for oy in range(3):
                 for ox in range(3):
-                    acc += t[:, oy:oy + hh, ox:ox + ww]
-            canvas = ((acc + 4) // 9).to(torch.uint8)
+                    acc += taps[oy] * taps[ox] * t[:, oy:oy + hh, ox:ox + ww]
+            canvas = ((acc + div // 2) // div).to(torch.uint8)
         else:
             canvas = t.to(torch.uint8)
         for i in range(c0, c1):
@@ -179,7 +189,7 @@ def batch_torch(n_pairs: int, height: int, width: int, s: int, device, blur: boo
     return cur, prev, shifts, kinds
 
 
-def video_torch(n_frames: int, height: int, width: int, device, k: int = 0, blur: bool = True, seed: int = SEED):
+def video_torch(n_frames: int, height: int, width: int, device, k: int = 0, blur=True, seed: int = SEED):
     """A synthetic VIDEO on `device`: frame t is the height x width window of one canvas (texture index k) at an offset that
     follows a closed Lissajous path inside the canvas margin, so consecutive frames are translated copies of each other
     (what the sequence entry points -- K1 on frames[1:] / frames[:-1], the estimator's sequence mode -- are meant for).
@@ -195,11 +205,12 @@ def video_torch(n_frames: int, height: int, width: int, device, k: int = 0, blur
     x = torch.arange(ww + 2 * pad, dtype=torch.int64, device=device)[None, :]
     t = _mix32_t(seed, k, y, x) >> 24
     if blur:
+        taps, div = _blur_taps(blur)
         acc = torch.zeros((hh, ww), dtype=torch.int64, device=device)
         for oy in range(3):
             for ox in range(3):
-                acc += t[oy:oy + hh, ox:ox + ww]
-        canvas = ((acc + 4) // 9).to(torch.uint8)
+                acc += taps[oy] * taps[ox] * t[oy:oy + hh, ox:ox + ww]
+        canvas = ((acc + div // 2) // div).to(torch.uint8)
     else:
         canvas = t.to(torch.uint8)
     frames = torch.empty((n_frames, height, width), dtype=torch.uint8, device=device)

@@ -1,0 +1,135 @@
+"""CPU tests of tests/conditioning.py + tests/tolerances.py: the inputs-only classification of the patches on which f32 arithmetic does not
+determine -cv::phaseCorrelate's sub-pixel answer (/root/reference/src/FftMethod.cpp:1836), on the committed one-per-mechanism fixtures
+(tests/golden/f32_mechanism_*.npz, made by tests/golden/make_mechanism_fixtures.py), and the oracle against those fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import conditioning
+import oracle_lib as O
+import tolerances
+from mrs_optic_flow_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    g = np.load(os.path.join(GOLDEN, name))
+    n, p = int(g["n"]), int(g["patch"])
+    gx, gy = (int(v) for v in g["grid"])
+    lay = O.fft_layout(g["cur"].shape[1], g["cur"].shape[0], n, gx, gy, tuple(int(v) for v in g["origin"]), tuple(int(v) for v in g["stride"]))
+    return g, lay, p, tolerances.patch_pixels(g["cur"], g["prev"], lay, p)()
+
+
+@pytest.mark.parametrize("name", ["f32_mechanism_cancellation_const_vs_texture_n142.npz", "f32_mechanism_exact_zero_bin_n48.npz",
+                                  "f32_mechanism_exact_zero_bin_n60.npz", "f32_mechanism_cancellation_smooth_n62.npz"])
+def test_oracle_reproduces_the_fixture(name):
+    g, lay, p, _ = _load(name)
+    for prec, key in ((64, "oracle64"), (32, "oracle32")):
+        got, _ = O.fft_process(g["cur"], g["prev"], lay, prec)
+        assert np.array_equal(got, g[key], equal_nan=True), (name, prec)
+
+
+def test_exact_zero_bin_patches_split_the_f32_libraries():
+    """on fs480/n48 #89 pocketfft-f32 cancels both bins (6e-8 px from f64) where the f32 oracle is 8.3e-4 away; on fs480/n60 #22
+    it does not. So 'any f32 order lands a comparable distance away' is false, and the patch is unpinned precisely BECAUSE the libraries
+    split: some orders are exact there and some are not."""
+    for name, bins in (("f32_mechanism_exact_zero_bin_n48.npz", ["B[16,24]", "B[32,24]"]), ("f32_mechanism_exact_zero_bin_n60.npz", ["A[20,40]", "A[40,20]"])):
+        g, lay, p, (a, b) = _load(name)
+        info = conditioning.analyse(a, b)
+        assert info["mechanism"] == "exact-zero bin" and info["zero_bins"] == 2 and info["zero_bin_list"] == bins, info
+        assert info["cancellation"] < 1.5 and info["floor_bins"] == 0
+        libs = info["independent_f32_minus_f64_px"]
+        assert min(libs.values()) < 2e-6 and max(libs.values()) > 3e-4, libs  # one library exact, another 3e-4 .. 1e-3 px off
+        assert np.abs(np.array(info["f64_pipeline_xy"]) - g["oracle64"][p]).max() < 1e-9  # pocketfft f64 == the C oracle's f64
+        dd = float(np.abs(g["oracle32"][p] - g["oracle64"][p]).max())
+        allow, unpinned = tolerances.allowance(info, dd)
+        assert unpinned  # 1e-4 + 2 x spread + 2 bins x 2 sqrt 2 / |S| > 1e-3 px: decided without the oracles' distance and without a kernel
+    # the neighbouring patch of the same frame pair is an ordinary one
+    g, lay, p, _ = _load("f32_mechanism_exact_zero_bin_n48.npz")
+    a, b = tolerances.patch_pixels(g["cur"], g["prev"], lay, 1 - p)()
+    info = conditioning.analyse(a, b)
+    assert info["zero_bins"] == 0 and info["spread_px"] < 1e-6 and info["mechanism"].startswith("f32 rounding")
+
+
+def test_constant_frame_against_texture_is_centroid_cancellation():
+    """The r05 fuzz exceedance (seed 605): the correlation surface of a constant box against texture is noise, its 5 x 5 window sums to
+    1 / 230 of its absolute sum, and even two FLOAT64 transforms (pocketfft and the C oracle's) are 0.15 px apart on it."""
+    g, lay, p, (a, b) = _load("f32_mechanism_cancellation_const_vs_texture_n142.npz")
+    assert int(a.min()) == int(a.max()) == 81
+    info = conditioning.analyse(a, b)
+    assert info["mechanism"] == "centroid cancellation + exact-zero bin", info["mechanism"]
+    assert info["cancellation"] > 200 and info["zero_bins"] == 287  # the box's Nyquist row and column: 2 x 144 - 1
+    assert info["spread_px"] > 0.05
+    assert np.abs(np.array(info["f64_pipeline_xy"]) - g["oracle64"][p]).max() > 0.1
+    assert tolerances.allowance(info, 0.0)[1]  # unpinned by the inputs alone
+    # the other patch of the pair has the same 287 zero bins, a window that cancels 7-fold, and is pinned (relaxed bar below the ceiling)
+    a1, b1 = tolerances.patch_pixels(g["cur"], g["prev"], lay, 1)()
+    i1 = conditioning.analyse(a1, b1)
+    assert i1["zero_bins"] == 287 and 4 < i1["cancellation"] < 10 and i1["spread_px"] < 2e-4
+    assert not tolerances.allowance(i1, 0.0)[1]
+
+
+def test_smooth_content_on_a_padded_size_is_centroid_cancellation():
+    g, lay, p, (a, b) = _load("f32_mechanism_cancellation_smooth_n62.npz")
+    info = conditioning.analyse(a, b)
+    assert info["mechanism"] == "centroid cancellation" and info["zero_bins"] == 0 and info["cancellation"] > 40
+    assert 1e-5 < info["spread_px"] < 2e-4 and not tolerances.allowance(info, 0.0)[1]
+
+
+def test_check_patch_rules():
+    g, lay, p, px = _load("f32_mechanism_exact_zero_bin_n48.npz")
+    w64, w32 = g["oracle64"], g["oracle32"]
+    del tolerances.RECORDS[:]
+    # ordinary patch: fast path, nothing recorded; 2e-4 px off fails (the inputs allow nothing)
+    q = 1 - p
+    assert tolerances.check_patch(w64[q] + 5e-5, w64[q], w32[q], "t", q, pixels=tolerances.patch_pixels(g["cur"], g["prev"], lay, q))
+    assert not tolerances.RECORDS
+    with pytest.raises(AssertionError):
+        tolerances.check_patch(w64[q] + 2e-4, w64[q], w32[q], "t", q, pixels=tolerances.patch_pixels(g["cur"], g["prev"], lay, q))
+    del tolerances.RECORDS[:]
+    # exact-zero-bin patch: unpinned by the inputs, integer peak still asserted, recorded with the library columns
+    assert tolerances.check_patch(w32[p] + 1e-3, w64[p], w32[p], "mechanism/t", p, pixels=px) is False
+    r = tolerances.RECORDS[-1]
+    assert r["bar_px"] is None and r["mechanism"] == "exact-zero bin" and "torch" in r["independent_f32_minus_f64_px"] or "np" in r["independent_f32_minus_f64_px"]
+    with pytest.raises(AssertionError):
+        tolerances.check_patch(w32[p] + 0.3, w64[p], w32[p], "mechanism/t", p, pixels=px)
+    # off the fast path without pixels: refused
+    with pytest.raises(AssertionError):
+        tolerances.check_patch(w64[p], w64[p], w32[p], "t", p)
+    # the session bounds: one unpinned patch outside the mechanism tests is tolerated, two are not
+    del tolerances.RECORDS[:]
+    tolerances.check_patch(w32[p], w64[p], w32[p], "somewhere/a", p, pixels=px)
+    assert not tolerances.violations()
+    tolerances.check_patch(w32[p], w64[p], w32[p], "elsewhere/b", p + 100, pixels=px)
+    assert tolerances.violations()
+    del tolerances.RECORDS[:]
+
+
+REFERENCE_TILINGS = [(480, 60), (480, 80), (480, 96), (400, 100), (480, 40), (480, 48), (296, 74), (480, 30)]  # test_gpu_generic.py
+TILING_SEED = 45
+
+
+def tiling_frames(fs, n, blur="mild", seed=TILING_SEED):
+    """The three frames test_reference_tiling_stateful_entry feeds the stateful entry."""
+    return [synth.pair_np(seed + n, fs, fs, 2 * t, -t, blur=blur)[0] for t in range(3)]
+
+
+def test_reference_tiling_frames_hold_no_exact_zero_bin():
+    """Integer images make spectral bins that are EXACTLY zero by coincidence (equal residue-class sums): with the 3 x 3 box blur of
+    SURVEY 8(d) -- small alternating-sign pixel sums -- on 6 of the 1971 patches of the reference-tiling tests (the two VERDICT r05 cited
+    among them), with a (1 2 1) binomial on 44 (its response is zero at Nyquist), with the (1 6 1) blur or none on 1 - 4 depending on
+    the texture seed. The class has its own seeded tests (test_gpu_f32_mechanisms.py); the tiling tests use (1 6 1) and a seed under
+    which NO patch has one (seeds 40 .. 44 have 1 - 3), so what they measure is the kernels."""
+    def zeros(frames, n):
+        m = conditioning.optimal_dft_size(n)
+        z = 0
+        for fr in frames:
+            for j in range(fr.shape[0] // n):
+                for i in range(fr.shape[1] // n):
+                    x = fr[j * n:(j + 1) * n, i * n:(i + 1) * n].astype(np.float64)
+                    z += bool((np.abs(np.fft.fft2(x, s=(m, m))) < conditioning.ZERO_REL * np.sqrt((x * x).sum())).any())
+        return z
+    assert sum(zeros(tiling_frames(fs, n), n) for fs, n in REFERENCE_TILINGS) == 0
+    assert sum(zeros(tiling_frames(fs, n, blur=True, seed=40), n) for fs, n in [(480, 60), (480, 48), (480, 40)]) >= 3

@@ -1,0 +1,174 @@
+"""GPU tests of the degenerate / ill-conditioned input classes the random fuzzers found worth pinning (synth.fuzz_classes_np), seeded,
+through EVERY entry point (pair batch, BGR front end, video, stateful processImage, long-range mode), and a constant frame against
+texture on padded patch sizes (the kernels take the constant box from its closed form)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import tolerances
+from mrs_optic_flow_amd import FftMethod, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# ---- the fuzzers' input classes, seeded, through EVERY entry point ----------------------------------------
+_DBL_EPS, _FLT_EPS = float(np.finfo(np.float64).eps), float(np.finfo(np.float32).eps)
+TOL = 1e-4
+
+
+def _expected(cur, prev, lay, max_speed=80.0):
+    """Per patch: (want [2] or None, tolerance). Constant patches: the closed form of cv::phaseCorrelate's flat surface (first
+    index, clamped 3 x 3 centroid of equal values: 9c / (9c + DBL_EPSILON) - M/2 with c = C_dc = P / (P^2 + FLT_EPSILON), P the
+    product of the two pixel sums) -- the oracle's own radix-3/5 transform of a constant is not exactly zero off DC, OpenCV's
+    neither, so the closed form (what exact arithmetic gives) is the bar there. With zero padding (M > N) only an all-zero patch
+    stays constant. Everything else: the oracle, where its arg-max is stable (tests/test_gpu_fft.py::_compare)."""
+    n, gx, gy = lay.patch, lay.grid_x, lay.grid_y
+    m = O.optimal_dft_size(n)
+    want64, _, diags = O.fft_process(cur, prev, lay, 64, want_diag=True)
+    want32, _ = O.fft_process(cur, prev, lay, 32)
+    out = []
+    for j in range(gy):
+        for i in range(gx):
+            p = i + j * gx
+            x0, y0 = lay.origin_x + i * lay.stride_x, lay.origin_y + j * lay.stride_y
+            a, b = cur[y0:y0 + n, x0:x0 + n], prev[y0:y0 + n, x0:x0 + n]
+            ca, cb = int(a.max()) == int(a.min()), int(b.max()) == int(b.min())
+            deg = (ca or cb) if m == n else ((ca and a.max() == 0) or (cb and b.max() == 0))
+            if deg:
+                P = float(a.astype(np.float64).sum()) * float(b.astype(np.float64).sum())
+                c9 = 9.0 * P / (P * P + _FLT_EPS) if P > 0 else 0.0
+                s = (c9 / (c9 + _DBL_EPS) if c9 > 0 else 0.0) - m / 2.0
+                bad = 2 * s * s > max_speed ** 2 or abs(s) > n / 2.0
+                out.append((np.array([np.nan, np.nan]) if bad else np.array([s, s]), 1e-4))
+                continue
+            # only a CLEAR peak pins the answer: on unrelated or flat-against-texture content (a constant patch that zero padding
+            # turned into a box; a frame next to an unrelated one in the video below) the surface is noise, its arg-max and its
+            # near-cancelling centroid are decided by rounding, and the two oracle precisions agreeing with each other (same
+            # algorithm, same order of operations) says nothing about a third arithmetic
+            if not diags[p].second_value < 0.5 * diags[p].peak_value:
+                out.append((None, 0.0))
+                continue
+            out.append(((want64[p], want32[p]), TOL))  # (both oracles: the bars of tests/tolerances.py, f32-limited patches included)
+    return out
+
+
+def _check(got, cur, prev, lay, label):
+    n_checked = 0
+    for p, (want, tol) in enumerate(_expected(cur, prev, lay)):
+        if want is None:
+            continue
+        if isinstance(want, tuple):
+            n_checked += bool(tolerances.check_patch(got[p], want[0], want[1], label, p, pixels=tolerances.patch_pixels(cur, prev, lay, p)))
+            continue
+        assert np.allclose(got[p], want, rtol=0, atol=tol, equal_nan=True), (label, p, got[p], want)
+        n_checked += 1
+    return n_checked
+
+
+@pytest.mark.parametrize("n", [32, 64, 120, 128, 60, 62, 160])
+def test_fuzzer_classes_through_every_entry_point(gpu, n):
+    """one-sided constant frames, black frames, a constant rectangle inside a frame, a saturated region, strongly low-passed
+    content and exactly-cancelling alternating sums -- through the pair batch, the BGR front end, the sequence entry, the
+    stateful processImage and the long-range mode, at tuned (32 / 64 / 120 / 128), planned (60, 62 -> 64) and large (160) sizes."""
+    fs = 2 * n  # 2 x 2 patches, reference tiling
+    classes = synth.fuzz_classes_np(100 + n, fs, fs, 3, -2)
+    lay = O.fft_layout(fs, fs, n, 2, 2)
+    fm = FftMethod(fs, n, 80.0)
+    names = sorted(classes)
+    cur = np.stack([classes[k][0] for k in names])
+    prev = np.stack([classes[k][1] for k in names])
+    tc, tp = torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)
+    # (1) independent pairs
+    got = fm.process_batch_device(tc, tp).cpu().numpy()
+    total = 0
+    for k, name in enumerate(names):
+        total += _check(got[k], cur[k], prev[k], lay, f"n{n}/pair/{name}")
+    assert total >= 0.6 * 4 * len(names), total
+    # (2) the same frames as interleaved BGR8 with B = G = R (CV_RGB2GRAY then returns the value itself): same bits
+    bgr_c, bgr_p = tc[..., None].expand(-1, -1, -1, 3).contiguous(), tp[..., None].expand(-1, -1, -1, 3).contiguous()
+    assert np.array_equal(fm.process_batch_device_bgr(bgr_c, bgr_p).cpu().numpy(), got, equal_nan=True)
+    # (3) a video that walks through the classes: texture, constant, texture, black, texture with a constant rectangle, smooth ...
+    tex_c, tex_p = synth.pair_np(7 + n, fs, fs, 2, 1)
+    video = np.stack([tex_p, tex_c, classes["const_cur"][0], tex_c, classes["black_both"][0], classes["const_rect"][0], tex_p,
+                      classes["smooth"][1], classes["smooth"][0], classes["saturated"][0], classes["checker"][1], classes["checker"][0]])
+    seq = fm.process_sequence_device(torch.from_numpy(video).to(gpu)).cpu().numpy()
+    for k in range(len(video) - 1):
+        _check(seq[k], video[k + 1], video[k], lay, f"n{n}/seq/{k}")
+    # (4) the stateful entry, frame by frame (first frame against itself)
+    fm.reset()
+    for k in range(len(video)):
+        out = fm.processImage(video[k])
+        _check(out, video[k], video[k - 1] if k else video[k], lay, f"n{n}/stateful/{k}")
+    # (5) long-range mode: frames whose quarter-resolution reduction IS the class frame (every 4 x 4 cell constant), one patch
+    if n <= 128:
+        flr = FftMethod(4 * n, n, 80.0)
+        lay1 = O.fft_layout(n, n, n, 1, 1)
+        sel = [k for k, name in enumerate(names)]
+        small_c = np.stack([cur[k][:n, :n] for k in sel])
+        small_p = np.stack([prev[k][:n, :n] for k in sel])
+        up = lambda a: np.repeat(np.repeat(a, 4, axis=1), 4, axis=2)
+        lr = flr.process_long_range_batch_device(torch.from_numpy(up(small_c)).to(gpu), torch.from_numpy(up(small_p)).to(gpu)).cpu().numpy()
+        for k in sel:
+            _check(lr[k], small_c[k], small_p[k], lay1, f"n{n}/longrange/{names[k]}")
+
+
+@pytest.mark.parametrize("case", ["in_lds_118", "in_lds_124_odd", "large_158", "large_146", "half_156", "half_152", "half_56", "large_232", "in_lds_130_odd"])
+def test_constant_frame_against_texture_on_padded_patches(gpu, case):
+    """Found by tools/fft_sr_fuzz.py's sequence trials (seeds 101 / 202): ONE frame of the pair constant, patch size below its
+    transform size. cv::phaseCorrelate pads the constant patch to an n x n box whose spectrum is level x D[v] D[u], exactly zero on
+    the Nyquist lines. (a) large-patch pipeline: rows are transformed in pairs, the spectra of rows 2j and 2j + 1 of a constant
+    image differ by rounding and their alternating column sum is 79 x that instead of 0 -- 0.04 px off; L6 now zeroes those
+    bins from L5's flags (box_zeros). (b) in-LDS planned kernel: the packed transform delivers the box with the textured
+    patch's rounding noise on top -- 1e-3 px off; the kernel now takes the box from its closed form (D in LDS) and the textured
+    spectrum as Z -+ i box (D summed in f64: 124 f32 additions lose 4e-4 of it, 1e-3 px on the 124 -> 125 case). Both the pair entry
+    and the sequence entry, against the bars of tests/tolerances.py. (r05: 146 and 158 pad to 150 / 160 and run the fused half-tile kernel, which applies the same box_zeros rule.)"""
+    n, grid, origin, stride, (h, w), k, const = {
+        "in_lds_118": (118, (3, 3), (4, 5), (76, 84), (294, 281), 68, (0, 120)),
+        "in_lds_124_odd": (124, (1, 2), (7, 8), (136, 123), (256, 136), 988, (0, 39)),  # pads to 125: no Nyquist lines, |box bin| = level everywhere
+        "large_158": (158, (1, 2), (3, 2), (154, 169), (331, 166), 777, (1, 169)),
+        "large_146": (146, (1, 2), (4, 2), (53, 156), (308, 156), 634, (0, 84)),
+        # r05 (tools/fft_sr_fuzz.py seeds 606 / 608 at 160 trials): the box's EXACT zeros are all the lines k != 0 with k n = 0 (mod M) -- the
+        # multiples of M / gcd(n, M) --, not the Nyquist line alone: 156 in 160 -> 40, 80, 120; 152 in 160 -> every multiple of 20; 56 in 60 ->
+        # 15, 30, 45; 232 in 240 -> multiples of 30; 130 in 135 (odd M) -> multiples of 27. 0.03 - 0.09 px off before the rule was generalised
+        # (csrc/pc_common.hpp: box_zero_period) in all three kernel families.
+        "half_156": (156, (1, 2), (1, 3), (53, 79), (249, 167), 611, (1, 160)),
+        "half_152": (152, (1, 1), (7, 0), (83, 150), (158, 167), 612, (0, 212)),
+        "half_56": (56, (2, 2), (3, 4), (60, 58), (125, 127), 613, (0, 97)),
+        "large_232": (232, (1, 1), (2, 3), (1, 1), (240, 238), 614, (1, 55)),
+        "in_lds_130_odd": (130, (1, 1), (2, 2), (1, 1), (136, 134), 615, (0, 201)),
+    }[case]
+    video, _ = synth.video_torch(2, h, w, "cpu", k=k)
+    video[const[0]] = const[1]
+    frames = video.numpy()
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=grid, origin=origin, stride=stride)
+    mm, half_on = O.optimal_dft_size(n), os.environ.get("MOF_FFT_HALF", "") != "0"
+    want_variant = ("planned-half" if half_on and mm in (60, 72, 90, 96, 100, 120, 144, 150, 160, 162, 180, 192) else ("planned" if mm <= 135 else "planned-large"))
+    assert fm.kernel_variant == want_variant
+    dv = video.to(gpu)
+    pair = fm.process_batch_device(dv[1:], dv[:-1]).cpu().numpy()[0]
+    seq = fm.process_sequence_device(dv).cpu().numpy()[0]
+    lay = O.fft_layout(w, h, n, grid[0], grid[1], origin, stride)
+    want64, _, diags = O.fft_process(frames[1], frames[0], lay, 64, want_diag=True)
+    want32, _ = O.fft_process(frames[1], frames[0], lay, 32)
+    checked = 0
+    for p in range(want64.shape[0]):
+        if not diags[p].second_value < 0.5 * diags[p].peak_value:
+            continue
+        dd = float(np.abs(want64[p] - want32[p]).max())
+        if case == "in_lds_130_odd":
+            # an ODD zero period (27): the f64 oracle gets ~1e-13 in the box's zero bins (C = 0, the exact-arithmetic answer), the f32 oracle's
+            # radix-3/5 sums leave 1e-7-relative noise there that the normalisation turns into eight lines of unit-magnitude bins: the two
+            # oracles are 0.065 px apart. The kernel knows the box exactly and zeroes those lines: it must give the exact-arithmetic answer.
+            assert dd > 1e-3, (case, p, dd)
+            assert np.abs(pair[p] - want64[p]).max() <= 1e-4 and np.abs(seq[p] - want64[p]).max() <= 1e-4, (case, p, pair[p], seq[p], want64[p])
+            checked += 1
+            continue
+        assert dd < 2e-4, (case, p, dd)
+        checked += 1
+        # (the STRICT rule of tests/tolerances.py: independent f32 libraries scatter by 1e-3 .. 1e-1 px on these inputs -- they do not cancel the
+        #  box's zero lines --, the kernel is built to give the exact-arithmetic answer and is held to it)
+        tolerances.check_patch_strict(pair[p], want64[p], want32[p], case + "/pair", p)
+        tolerances.check_patch_strict(seq[p], want64[p], want32[p], case + "/seq", p)
+    assert checked >= want64.shape[0] - 1, (case, checked)

@@ -20,17 +20,10 @@ pytestmark = pytest.mark.gpu
 
 def _compare(got, cur, prev, lay, label=""):
     """Every clear-peak patch (second-highest surface value outside the 5 x 5 window < half the peak) against the bars of
-    tests/tolerances.py: 1e-4 px against both oracle precisions; on f32-limited patches (oracles more than 2e-5 px apart) against the
-    f32 oracle -- the reference's arithmetic -- at 1e-4 + 2 x that distance, never above 1e-3 px, each one recorded. Returns the number
-    of patches pinned."""
-    want64, _, diags = O.fft_process(cur, prev, lay, 64, want_diag=True)
-    want32, _ = O.fft_process(cur, prev, lay, 32)
-    n_checked = 0
-    for p in range(want64.shape[0]):
-        if not diags[p].second_value < 0.5 * diags[p].peak_value:
-            continue
-        n_checked += bool(tolerances.check_patch(got[p], want64[p], want32[p], label, p))
-    return n_checked
+    tests/tolerances.py: 1e-4 px against both oracle precisions; a patch that misses that is classified from its input pixels
+    (tests/conditioning.py) and held to 1e-4 + 2 x the measured scatter of independent f32 transforms on it, never above 1e-3 px, each one
+    recorded. Returns the number of patches pinned."""
+    return tolerances.check_frame(got, cur, prev, lay, label)
 
 
 def _planned_variant(n):
@@ -75,7 +68,9 @@ def test_reference_tiling_stateful_entry(gpu, fs, n):
     fm = FftMethod(fs, n, 80.0)
     sq = fs // n
     assert fm.sqNum == sq
-    seq = [synth.pair_np(40 + n, fs, fs, 2 * t, -t, blur=True)[0] for t in range(3)]
+    # (1 6 1)-blurred texture under a seed with no exactly-zero spectral bin on any patch: tests/test_conditioning.py::tiling_frames)
+    from test_conditioning import tiling_frames
+    seq = tiling_frames(fs, n)
     lay = O.fft_layout(fs, fs, n, sq, sq)
     out0 = fm.processImage(seq[0])
     assert np.allclose(out0, O.fft_process(seq[0], seq[0], lay, 64)[0], rtol=0, atol=TOL, equal_nan=True)
@@ -169,16 +164,6 @@ def test_ocl_peak_model_on_planned_sizes(gpu):
         with pytest.raises(MofError) as exc:
             FftMethod(bad, bad, 80.0, peak_model=PEAK_OCL)
         assert exc.value.code == -5
-
-
-def test_zz_f32_limited_patches_are_rare(gpu):
-    """The relaxed bar of tests/tolerances.py applies to a handful of patches only (it runs after the size sweep above; the record --
-    label, patch, oracle-to-oracle distance, bar used, distances -- goes to the session's JSON), and never exceeds its ceiling."""
-    lim = [r for r in tolerances.RECORDS if r["rule"] == "f32-limited"]
-    unpinned = [r for r in tolerances.RECORDS if r["bar_px"] is None]
-    assert len(lim) <= 12, lim
-    assert len(unpinned) <= 3, unpinned
-    assert all(r["bar_px"] is None or r["bar_px"] <= tolerances.CEILING for r in tolerances.RECORDS)
 
 
 # ---- patches too large for one CU's full tile (padded side > 135): the fused half-tile kernel (csrc/pc_half_kernel.hip, r05) where
@@ -341,7 +326,7 @@ def test_large_patches_of_the_estimators_sizes_front_ends(gpu, n):
     assert np.array_equal(got, same, equal_nan=True)
     lay = O.fft_layout(w, h, n, gx, gy, (1, 3), (n + 5, 1))
     # (random BGR frames against their rolled copy: patch 0 of pair 1 holds a constant previous patch -- its closed form is pinned in
-    #  test_gpu_r04.py; every clear-peak patch goes through the common bars)
+    #  test_gpu_fft_classes.py; every clear-peak patch goes through the common bars)
     assert sum(_compare(got[k], gray_c[k], gray_p[k], lay, f"tuned-large{n}/bgr{k}") for k in range(B)) >= B * gx * gy - 2
     video = np.stack([synth.pair_np(5 + n, h, w, 2 * t, -t, blur=True)[0] for t in range(4)])
     seq = fm.process_sequence_device(torch.from_numpy(video).to(gpu)).cpu().numpy()

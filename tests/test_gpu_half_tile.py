@@ -1,6 +1,5 @@
-"""Round-5 GPU tests: the native shard group with G > 1 on the one-GPU box (rehearsal knob), block matching through the shard group
-(dx, dy and mode in one slab), and the round's new kernel forms."""
-import ctypes as C
+"""GPU parity tests of the half-tile kernel K1h (csrc/pc_half_kernel.hip): pair entries, the video form (a frame's spectrum kept in
+registers), and the planned sizes whose video form it serves -- against both oracles under the bars of tests/tolerances.py."""
 import os
 import subprocess
 
@@ -9,80 +8,18 @@ import pytest
 import torch
 
 import oracle_lib as O
-from mrs_optic_flow_amd import FastSpacedBMMethod, FftMethod, synth
+from mrs_optic_flow_amd import FftMethod, synth
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-4
-
-
-@pytest.mark.parametrize("pairs,G", [(37, 2), (37, 4), (9, 4), (3, 4), (1, 2), (8, 2)])
-def test_shard_group_with_several_shards_on_one_device(gpu, pairs, G):
-    """`mof_shard_*_process_batch_device`'s G > 1 arithmetic -- slab i at i * slab, ragged last shards
-    (37 over 4 -> 10 10 10 7), empty ones (9 over 4 -> 3 3 3 0; 3 over 4 -> 1 1 1 0; 1 over 2) -- executed for real: the rehearsal knob
-    MOF_SHARD_SHARE_DEVICE=1 admits G shards on the one device with gather = 0, and tests/cpp/test_shard.cpp checks that every
-    slab lands at its place bit-equal to the single-engine call and that nothing else of the buffer is written -- FftMethod vectors,
-    and FastSpacedBMMethod's dx | dy | mode planes. The all-gather itself stays a 1-rank run (RCCL: one rank per device) until a
-    multi-GPU node exists; a shared-device group refuses it (checked inside)."""
-    binp = os.path.join(ROOT, "tests", "cpp", "test_shard")
-    assert os.path.exists(binp), "tests/cpp/test_shard missing: run __graft_entry__.build()"
-    r = subprocess.run([binp, "rehearse", str(pairs), str(G)], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, MOF_SHARD_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert r.returncode == 0 and f"rehearse ok {G} {pairs}" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
-
-
-def test_block_matching_shard_group_through_ctypes(gpu):
-    """mof_shard_bm_* from the ctypes binding on a one-device group, with the (1-rank) RCCL gather: per-block shifts and the
-    per-pair modes come back from ONE slab ("BM mode vectors ride in the same slab"), bit-equal to the engine's
-    own batch call."""
-    from mrs_optic_flow_amd import _capi
-
-    lib = _capi.load()
-    B, h, w = 7, 136, 200
-    cur, prev, _, _ = synth.batch_np(B, h, w, 5, k0=3)
-    bm = FastSpacedBMMethod(16, 8, 8, (h, w))
-    tc, tp = torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)
-    dx, dy, mode = bm.process_batch_device(tc, tp)
-    blocks = dx[0].numel()
-    grp = C.c_void_p()
-    _capi.check(lib.mof_shard_bm_create(C.byref(bm.cfg), None, 1, C.byref(grp)))
-    try:
-        slab = lib.mof_shard_bm_slab_bytes(grp, B)
-        assert slab % 16 == 0 and slab >= B * (2 * blocks + 8)
-        out = torch.full((slab,), -1, dtype=torch.int8, device=gpu)
-        pc, pp, po = (C.c_void_p * 1)(tc.data_ptr()), (C.c_void_p * 1)(tp.data_ptr()), (C.c_void_p * 1)(out.data_ptr())
-        torch.cuda.synchronize()
-        _capi.check(lib.mof_shard_bm_init_gather(grp))
-        _capi.check(lib.mof_shard_bm_process_batch_device(grp, pc, tc.stride(0), pp, tp.stride(0), tc.stride(1), B, po, 1))
-        _capi.check(lib.mof_shard_bm_sync(grp))
-        got = out.cpu().numpy()
-        for k in range(B):
-            ox, oy, om = C.c_size_t(), C.c_size_t(), C.c_size_t()
-            _capi.check(lib.mof_shard_bm_locate(grp, B, k, C.byref(ox), C.byref(oy), C.byref(om)))
-            assert np.array_equal(got[ox.value:ox.value + blocks], dx[k].cpu().numpy().ravel())
-            assert np.array_equal(got[oy.value:oy.value + blocks], dy[k].cpu().numpy().ravel())
-            assert np.array_equal(got[om.value:om.value + 8], mode[k].cpu().numpy().ravel())
-    finally:
-        lib.mof_shard_bm_destroy(grp)
-
-
-def test_pair_kernel_on_the_half_tile_at_128(gpu):
-    """MOF_FFT_PAIR_HALF=1: independent pairs of 128 x 128 patches through pc_pair_half_kernel (csrc/pc_seq_half.hip) -- the sequence
-    kernel's passes on the half-size tile, the previous image's column spectra parked in a per-workgroup slab of device memory, two
-    persistent workgroups per CU. Measured slower than the packed pair kernel (48 k against 84 k pairs/s at c4: 58 spilled VGPRs at the
-    128-register limit, profiles/r05_c4_pair_half_ab.txt), so it is opt-in; a child process holds it to the oracle: 150 frame pairs of
-    3 x 2 overlapping patches (more patch pairs than slabs, so every workgroup walks several), 1e-4 px on every clear-peak patch."""
-    import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_pair_half.py")], env=dict(os.environ, MOF_FFT_PAIR_HALF="1"),
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0 and "bad 0" in r.stdout and "checked" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("n", [160, 150, 137, 186])
 def test_half_tile_kernel_entries(gpu, n):
     """csrc/pc_half_kernel.hip is what patches of 136 .. 192 pixels run by default (r05): the batch entry on a strided view (pitch >
     width), one pair alone = the same bits as inside a batch, the video entry = the pair entry's bits. (Stateful entry, BGR8 frames, black
-    frames and constant boxes on these sizes: the large-patch tests of test_gpu_generic.py / test_gpu_r04.py, which now reach this kernel.)"""
+    frames and constant boxes on these sizes: the large-patch tests of test_gpu_generic.py / test_gpu_fft_classes.py, which now reach this kernel.)"""
     gx, gy = 2, 1
     w, h = 2 * n + 11, n + 4
     B = 4
@@ -99,7 +36,7 @@ def test_half_tile_kernel_entries(gpu, n):
         want32, _ = O.fft_process(c, p, lay, 32)
         for q in range(gx * gy):
             if diags[q].second_value < 0.5 * diags[q].peak_value:
-                tolerances.check_patch(got[k][q], want64[q], want32[q], f"half{n}/pair{k}/{kinds[k]}", q)
+                tolerances.check_patch(got[k][q], want64[q], want32[q], f"half{n}/pair{k}/{kinds[k]}", q, pixels=tolerances.patch_pixels(c, p, lay, q))
     one = fm.process_batch_device(tc[2:3], tp[2:3]).cpu().numpy()
     assert np.array_equal(one[0], got[2], equal_nan=True)
     video = np.stack([synth.pair_np(9 + n, h, w, 3 * t, -t, blur=True)[0] for t in range(3)])
@@ -140,7 +77,8 @@ def test_half_tile_kernel_video_form(gpu, n):
             if np.isnan(want64[q]).any():
                 assert np.isnan(seq[k][q]).all(), (k, q, seq[k][q])
             elif diags[q].second_value < 0.5 * diags[q].peak_value:
-                checked += bool(tolerances.check_patch(seq[k][q], want64[q], want32[q], f"halfseq{n}/pair{k}", q))
+                checked += bool(tolerances.check_patch(seq[k][q], want64[q], want32[q], f"halfseq{n}/pair{k}", q,
+                                                       pixels=tolerances.patch_pixels(frames[k + 1], frames[k], lay, q)))
     assert checked >= 0.8 * (F - 1) * gx * gy, checked
     import subprocess
     import sys
@@ -187,6 +125,6 @@ def test_planned_sizes_whose_video_form_is_the_half_tile_kernels(gpu, n):
             if np.isnan(want64[q]).any():
                 assert np.isnan(seq[k][q]).all(), (k, q, seq[k][q])
             elif diags[q].second_value < 0.5 * diags[q].peak_value:
-                if tolerances.check_patch(seq[k][q], want64[q], want32[q], f"seqonly{n}/pair{k}", q):
+                if tolerances.check_patch(seq[k][q], want64[q], want32[q], f"seqonly{n}/pair{k}", q, pixels=tolerances.patch_pixels(frames[k + 1], frames[k], lay, q)):
                     checked += 1
     assert checked >= 0.8 * (F - 1) * gx * gy, checked

@@ -1,5 +1,5 @@
 """Quick on-box parity sweep of the fused half-tile kernel (csrc/pc_half_kernel.hip) against the oracle -- the development check behind
-tests/test_gpu_r05.py. usage: MOF_FFT_HALF=1 python tools/check_half.py [sizes...]"""
+tests/test_gpu_half_tile.py. usage: MOF_FFT_HALF=1 python tools/check_half.py [sizes...]"""
 import os
 import sys
 

@@ -46,7 +46,7 @@ for n in sizes:
             if not diags[p].second_value < 0.5 * diags[p].peak_value:
                 continue
             try:
-                tolerances.check_patch(seq[k][p], want64[p], want32[p], f"halfseq{n}/pair{k}", p)
+                tolerances.check_patch(seq[k][p], want64[p], want32[p], f"halfseq{n}/pair{k}", p, pixels=tolerances.patch_pixels(frames[k + 1], frames[k], lay, p))
             except AssertionError as e:
                 print("  off", n, k, p, seq[k][p], pair[k][p], want64[p], str(e)[:120]); bad += 1
             worst = max(worst, float(np.abs(seq[k][p] - want64[p]).max())); nchk += 1
