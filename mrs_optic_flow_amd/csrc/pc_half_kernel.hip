@@ -114,6 +114,16 @@ constexpr int half_table_pitch(int m, int* skew) {
     default: return 0;
   }
 }
+#ifndef MOF_HALF_SWAP160  // the product's choice for M = 160 (0 until the A/B says otherwise)
+#define MOF_HALF_SWAP160 0
+#endif
+#ifndef MOF_HALF_SWAP  // (A/B) 1: a two-stage chain's radices in the other order (the last one must stay even: pc_plan_build.hpp's exactness rule)
+#define MOF_HALF_SWAP 0
+#endif
+// sizes whose two-stage chain runs the SMALLER radix first (r06, tools/design/half_lanes.py in counter terms + same-box A/B): 160 = 10 x 16 --
+// with 16 first the stage-0 outputs 16 x + p of neighbouring butterflies of a column sit 16 rows = 16 P/2 complex = 0 (mod 32 dwords) apart
+// for ANY pitch, a 3-way conflict on every first-stage column write
+constexpr bool half_swapped(int m) { return MOF_HALF_SWAP != 0 ? true : (m == 160 && MOF_HALF_SWAP160); }
 constexpr HalfPlan half_plan(int m) {
   HalfPlan hp{};
   if (m < 16 || m > 192 || (m & 1)) return hp;
@@ -121,6 +131,11 @@ constexpr HalfPlan half_plan(int m) {
   if (!pc_line_plan_c(m, pl) || pl.m != m) return hp;  // 5-smooth sizes only (n = m); the generic radix chain as a start
   int Ra = 0, Rb = 0;
   if (pc_two_stage_chain(m, Ra, Rb)) {
+    if (half_swapped(m) && (Ra & 1) == 0) {
+      const int t = Ra;
+      Ra = Rb;
+      Rb = t;
+    }
     pl.n_stages = 2;
     pl.radix[0] = Ra;
     pl.radix[1] = Rb;
@@ -373,6 +388,9 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
 
   constexpr int SKM = HP.skew ? ~0 : 0;
   constexpr int SH = HP.shift;
+  // lines 0 2 1 3 in the later row stages where two lines of a 32-lane read half overlap in the banks: neighbouring lines P complex = 2 P
+  // dwords apart, a line's 16 complex = 32 dwords -- conflict-free iff 2 P = 32 (mod 64); lines two apart: 4 P = 32 (mod 64) iff P = 8 (mod 16)
+  constexpr int HALF_LINE_PERM = ((2 * P) % 64 != 32 && (4 * P) % 64 == 32) ? 1 : 0;
   auto rows_at = [&](int j, int x) -> int { return j * P + x + ((x >> SH) & SKM); };
   auto spec_at = [&](int r, int u) -> int { return r * P2 + u + ((u >> SH) & SKM); };
 
@@ -404,7 +422,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   // wave w owns lines [l0, l0 + nl): row pairs in the row passes, columns in the column passes
   const int l0 = wave * LPW;
   const int nl = H - l0 < 0 ? 0 : (H - l0 > LPW ? LPW : H - l0);
-  const Walk rows = {P, 1, 0, SKM, 0, SH}, cols = {1, P2, SKM, 0, 1, SH};
+  const Walk rows = {P, 1, 0, SKM, 0, HALF_LINE_PERM, SH}, cols = {1, P2, SKM, 0, 1, 0, SH};
 
   auto px_gray = [&](const uint8_t* q) -> uint32_t {  // four pixels -> four gray bytes
     if constexpr (CH == 1) {

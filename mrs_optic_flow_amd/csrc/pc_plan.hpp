@@ -36,6 +36,7 @@ struct Walk {
   int ls, es;        // strides (complex elements) of the line index / the element index before the skew
   int lmask, emask;  // ~0 where the skew applies to that coordinate
   int line_fast;     // lane map of a stage: 0 = the butterfly index in the fast lane bits (row walks), 1 = the line (column walks)
+  int line_perm = 0; // 1: later stages of a row walk take the lines of a four-line group in the order 0 2 1 3 (stage_rt; the half-tile kernel's pitches)
   int sh = 3;        // the skew's shift: coordinate c sits at c + (c >> sh) (3 everywhere but the half-tile kernel's radix-16-first sizes: 4)
   __device__ __forceinline__ int at(int l, int e) const { return l * ls + ((l >> sh) & lmask) + e * es + ((e >> sh) & emask); }
 };
@@ -173,6 +174,21 @@ struct WorkgroupSync {
   __device__ __forceinline__ void operator()() const { __syncthreads(); }
 };
 
+// MOF_SITE_ABL (diagnostic builds, results wrong by design; tools/half_site_counters.sh): ONE class of a stage's LDS accesses is removed,
+// so that SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the build, subtracted from the product's, give that class's share. Site =
+// 1 + (column walk ? 4 : 0) + (later stage, np > 1 ? 2 : 0) + (write ? 1 : 0); 0 = the product. A removed read hands the butterfly a
+// lane-dependent constant; a removed write keeps its value alive in a register (nothing upstream is dead code).
+#ifndef MOF_SITE_ABL
+#define MOF_SITE_ABL 0
+#endif
+#ifndef MOF_PLAN_LINE_PERM  // 0: every stage takes a group's lines in order (A/B)
+#define MOF_PLAN_LINE_PERM 1
+#endif
+__device__ __forceinline__ constexpr bool site_off(int line_fast, int np, int rw) {
+  return MOF_SITE_ABL != 0 && (MOF_SITE_ABL - 1) == (line_fast ? 4 : 0) + (np > 1 ? 2 : 0) + rw;
+}
+__device__ __forceinline__ void site_keep(cf v) { asm volatile("" ::"v"(v.x), "v"(v.y)); }
+
 template <int SLOTS, class Sink = NoSink, class Src = NoSrc, class Sync = WaveSync>
 __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restrict__ tw, const Walk& w, int m, int R, int np, int bpl,
                                          int tstep, int line0, int nlines, int lane, bool herm_first, Sink sink = Sink{}, Src src = Src{}) {
@@ -191,6 +207,12 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
       sub = fdiv(lane, bpl, inv_bpl, &x);
     }
     const bool lane_on = w.line_fast ? x < bpl : sub < lpg;
+    // Line order inside a group (r06; measured per access class with tools/half_site_counters.sh: the later-stage reads of the row walks were
+    // 2-way conflicts, 50 % of their LDS cycles, at every K1h size with four lines side by side): a later stage of a row walk reads 16
+    // consecutive complex values per line, two lines per 32-lane half; with the pitches in use neighbouring lines start 48 or 16 banks
+    // apart (mod 64) and overlap in 16 banks, lines TWO apart start 32 banks apart and do not. Which line a lane group takes is free
+    // (a stage is in place per line): sub-groups 0 1 2 3 take lines 0 2 1 3.
+    if (MOF_PLAN_LINE_PERM && !w.line_fast && np > 1 && lpg == 4 && w.line_perm) sub = ((sub & 1) << 1) | (sub >> 1);
     int k = 0;
     if (np > 1) (void)fdiv(x, np, inv_np, &k);
     cf t[SLOTS - 1];
@@ -221,7 +243,9 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
             if (j < R) {
               const int e = x + j * bpl;
               cf a;
-              if constexpr (Src::active) {
+              if (site_off(w.line_fast, np, 0)) {
+                a = cf{(float)(lane + j), 1.f};
+              } else if constexpr (Src::active) {
                 a = src(z, l, e);
               } else if (herm_first) {
                 const int r = e < H ? e : (e == H ? 0 : m - e);
@@ -253,9 +277,11 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
               if constexpr (SinkTransforms<Sink>::value) {
                 bool wr = true;
                 const cf val = sink.transform(line0 + g0 + b * lpg + sub, o, v[b][p], b, p, &wr);
-                if (wr) z[loff[b] + o * w.es + ((o >> w.sh) & w.emask)] = val;
+                if (site_off(w.line_fast, np, 1)) site_keep(val);
+                else if (wr) z[loff[b] + o * w.es + ((o >> w.sh) & w.emask)] = val;
               } else {
-                z[loff[b] + o * w.es + ((o >> w.sh) & w.emask)] = v[b][p];
+                if (site_off(w.line_fast, np, 1)) site_keep(v[b][p]);
+                else z[loff[b] + o * w.es + ((o >> w.sh) & w.emask)] = v[b][p];
                 if constexpr (Sink::active) sink(line0 + g0 + b * lpg + sub, o, v[b][p]);
               }
             }
@@ -378,7 +404,9 @@ __device__ __forceinline__ void stage_rt_ng(cf* __restrict__ z, const cf* __rest
           if (j < R) {
             const int e = x + j * bpl;
             cf a;
-            if constexpr (Src::active) {
+            if (site_off(w.line_fast, np, 0)) {
+              a = cf{(float)(lane + j), 1.f};
+            } else if constexpr (Src::active) {
               a = src(z, l, e);
             } else {
               a = lds_read(&z[loff[g][b] + e * w.es + ((e >> w.sh) & w.emask)]);
@@ -404,9 +432,11 @@ __device__ __forceinline__ void stage_rt_ng(cf* __restrict__ z, const cf* __rest
             if constexpr (SinkTransforms<Sink>::value) {
               bool wr = true;
               const cf val = sink.transform(l, o, v[g][b][p], g * NB + b, p, &wr);
-              if (wr) z[loff[g][b] + o * w.es + ((o >> w.sh) & w.emask)] = val;
+              if (site_off(w.line_fast, np, 1)) site_keep(val);
+              else if (wr) z[loff[g][b] + o * w.es + ((o >> w.sh) & w.emask)] = val;
             } else {
-              z[loff[g][b] + o * w.es + ((o >> w.sh) & w.emask)] = v[g][b][p];
+              if (site_off(w.line_fast, np, 1)) site_keep(v[g][b][p]);
+              else z[loff[g][b] + o * w.es + ((o >> w.sh) & w.emask)] = v[g][b][p];
               if constexpr (Sink::active) sink(l, o, v[g][b][p]);
             }
           }

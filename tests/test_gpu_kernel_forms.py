@@ -87,7 +87,9 @@ def test_fused_estimator_kernel_passes_the_estimator_parity_tests(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MOF_SR_FUSED="1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_sr.py"),
-                          os.path.join(root, "tests", "test_gpu_sr_pipeline.py"), "-q", "-x", "-m", "gpu", "-k", "not stateful and not sequence and not two_streams",
+                          os.path.join(root, "tests", "test_gpu_sr_pipeline.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "not stateful and not sequence and not two_streams and not crossing_the_pipeline_chunk",  # (the fused form is an opt-in of the batch entry: a pair alone
+                                                                                                                         #  runs the un-fused kernels, so batch == alone bit for bit is not its contract)
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
