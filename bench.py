@@ -44,6 +44,9 @@ def binding_note(name: str, wl) -> str:
                     "92 % of its issue time, 75-77 % of the instruction's ceiling; not HBM (DESIGN.md section 4, K2)")
         return ("integer VALU: generic block scan 97 % VALU-busy, 81 % of those cycles in v_qsad_pk_u16_u8 (the rest: one "
                 "v_pk_mov per odd window pair, widening); small geometries (c1) are staging-latency-bound; not HBM")
+    if wl["kind"] == "fftlr":
+        return ("planned kernel (run-time plan), long-range front end: the quarter-resolution pixels of four columns from two 16-byte runs per tapped row (r06); "
+                "one patch per pair: launch- and latency-bound, not HBM")
     if wl["kind"] == "fft+2dt":
         return (f"1/4-scale resize fused into K1's load (half of the frame rows are fetched) + one {wl['n']} x {wl['n']} patch per pair: "
                 "0.10 ms per 1024 pairs, the one path here whose time is mostly frame fetch (FETCH_SIZE factor of this load path "
@@ -138,6 +141,21 @@ WORKLOADS = {
     "p62": dict(kind="fft", h=496, w=496, n=62, grid=(8, 8), origin=(0, 0), stride=(62, 62), batch=1024, s=7,
                 name="p62: FftMethod 496x496, 8x8 grid of 62x62 patches padded to 64 (planned kernel), batch=1024 per GPU",
                 bytes_per_pair=2 * 496 * 496 + 64 * 8),
+    # front ends of the planned kernel (r06: four pixels per load on every one of them): the long-range mode on ONE quarter-resolution patch of
+    # 60 / 96 pixels (frames of 240 / 384 pixels) against the gray compile-time-plan kernel on one patch of the same size, and p60 on BGR8
+    "lr60": dict(kind="fftlr", h=240, w=240, n=60, grid=(4, 4), origin=(0, 0), stride=(60, 60), batch=4096, s=7,
+                 name="lr60: processImageLongRange on 240x240 frames (one quarter-resolution 60x60 patch), batch=4096", bytes_per_pair=2 * 240 * 120 + 8),
+    "lr96": dict(kind="fftlr", h=384, w=384, n=96, grid=(4, 4), origin=(0, 0), stride=(96, 96), batch=4096, s=12,
+                 name="lr96: processImageLongRange on 384x384 frames (one quarter-resolution 96x96 patch), batch=4096", bytes_per_pair=2 * 384 * 192 + 8),
+    "g60": dict(kind="fft", h=60, w=60, n=60, grid=(1, 1), origin=(0, 0), stride=(60, 60), batch=4096, s=7,
+                name="g60: FftMethod on 60x60 gray frames, ONE 60x60 patch (MOF_FFT_HALF=0: the planned kernel lr60 compares with), batch=4096", bytes_per_pair=2 * 60 * 60 + 8),
+    "g96": dict(kind="fft", h=96, w=96, n=96, grid=(1, 1), origin=(0, 0), stride=(96, 96), batch=4096, s=12,
+                name="g96: FftMethod on 96x96 gray frames, ONE 96x96 patch (MOF_FFT_HALF=0: the planned kernel lr96 compares with), batch=4096", bytes_per_pair=2 * 96 * 96 + 8),
+    "p54": dict(kind="fft", h=486, w=486, n=54, grid=(9, 9), origin=(0, 0), stride=(54, 54), batch=1024, s=6,
+                name="p54: FftMethod 486x486, 9x9 grid of 54x54 patches (full-tile planned kernel), batch=1024 per GPU", bytes_per_pair=2 * 486 * 486 + 81 * 8),
+    "p54bgr": dict(kind="fft", bgr=True, h=486, w=486, n=54, grid=(9, 9), origin=(0, 0), stride=(54, 54), batch=512, s=6,
+                   name="p54bgr: p54 on interleaved BGR8 frames (CV_RGB2GRAY fused into the planned kernel's four-pixel loads), batch=512 per GPU",
+                   bytes_per_pair=3 * 2 * 486 * 486 + 81 * 8),
     "l160": dict(kind="fft", h=480, w=480, n=160, grid=(3, 3), origin=(0, 0), stride=(160, 160), batch=512, s=15,
                  name="l160: FftMethod 480x480, 3x3 grid of 160x160 patches (fused half-tile kernel; MOF_FFT_HALF=0: the pipeline through HBM scratch), batch=512 per GPU",
                  bytes_per_pair=2 * 480 * 480 + 9 * 8),
@@ -394,7 +412,7 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
     else:
         # every rank owns its own shard of the global batch: pairs [rank*B, (rank+1)*B)
         cur, prev, _, _ = synth.batch_torch(B, wl["h"], wl["w"], wl["s"], dev, k0=rank * B)
-    if wl["kind"] in ("fft", "fftseq", "fft+sr", "fft+srseq", "fft+rt", "fft+2dt"):
+    if wl["kind"] in ("fft", "fftlr", "fftseq", "fft+sr", "fft+srseq", "fft+rt", "fft+2dt"):
         eng = FftMethod(sample_point_size=wl["n"], frame_shape=(wl["h"], wl["w"]), grid=wl["grid"],
                         origin=wl["origin"], stride=wl["stride"], device=local_rank)
         state["out"] = torch.empty((B, eng.n_patches, 2), dtype=torch.float64, device=dev)
@@ -435,6 +453,9 @@ def build_workload(wl, dev, local_rank: int, rank: int, graph: bool = False):
                 if side is not None:
                     cs.wait_stream(side)
                 return torch.cat([state["out"].reshape(B, -1), srout], dim=1)
+        elif wl["kind"] == "fftlr":
+            def launch():
+                return eng.process_long_range_batch_device(cur, prev)
         elif wl["kind"] == "fft+2dt":
             import numpy as np
 
@@ -921,7 +942,7 @@ def main() -> None:
     if rank == 0:
         pairs = B * world * args.steps
         line = {
-            "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fftseq": "_fft_phase_corr_sequence",
+            "metric": "frame_pairs_per_s" + {"fft": "_fft_phase_corr", "fftlr": "_long_range", "fftseq": "_fft_phase_corr_sequence",
                                              "fft+sr": "_fft_phase_corr_plus_scale_rotation",
                                              "fft+srseq": "_fft_phase_corr_plus_scale_rotation_sequence",
                                              "fft+rt": "_fft_phase_corr_plus_get_rt",

@@ -47,6 +47,40 @@ __device__ __forceinline__ uint32_t fetch_px(const uint8_t* __restrict__ base, s
   }
 }
 
+// four consecutive pixels x0 .. x0 + 3 of row y, one byte each (x0 + 3 inside the patch): ONE unaligned dword of a gray frame, three dwords
+// of a BGR8 frame (12 bytes -> four CV_RGB2GRAY values, as K1h's px_gray), or -- the long-range mode -- the 2 x 2 taps of four quarter-resolution
+// pixels from two 16-byte runs of the frame rows 4 y + 1 and 4 y + 2 (cv::resize(1/4, INTER_LINEAR): columns 4 x + 1 and 4 x + 2)
+template <int DS, int CH>
+__device__ __forceinline__ uint32_t fetch_px4(const uint8_t* __restrict__ base, size_t pitch, int y, int x0) {
+  if constexpr (DS == 4) {
+    const uint8_t* r1 = base + (size_t)(4 * y + 1) * pitch + 4 * (size_t)x0;
+    uint32_t w1[4], w2[4];
+    __builtin_memcpy(w1, r1, 16);
+    __builtin_memcpy(w2, r1 + pitch, 16);
+    uint32_t g = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      g |= ((((w1[b] >> 8) & 0xffu) + ((w1[b] >> 16) & 0xffu) + ((w2[b] >> 8) & 0xffu) + ((w2[b] >> 16) & 0xffu) + 2u) >> 2) << (8 * b);
+    return g;
+  } else if constexpr (CH == 3) {
+    uint32_t w[3];
+    __builtin_memcpy(w, base + (size_t)y * pitch + 3 * (size_t)x0, 12);
+    uint32_t g = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = 3 * b;
+      const uint32_t c0 = (w[i >> 2] >> (8 * (i & 3))) & 0xffu, c1 = (w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xffu,
+                     c2 = (w[(i + 2) >> 2] >> (8 * ((i + 2) & 3))) & 0xffu;
+      g |= rgb2gray_fixed(c0, c1, c2) << (8 * b);
+    }
+    return g;
+  } else {
+    uint32_t w;
+    __builtin_memcpy(&w, base + (size_t)y * pitch + x0, 4);
+    return w;
+  }
+}
+
 }  // namespace
 
 // the planned kernel's arg-max as a sink of the inverse transform's last stage (pc_plan.hpp: stage_rt): line c, element y of the
@@ -162,77 +196,67 @@ __global__ void __launch_bounds__(StaticPlanOf<MS>::T, StaticPlanOf<MS>::WPE) pc
     // loop pays the memory latency once per trip -- 16 trips per patch in the first form of this kernel; one batch of 18 held
     // 36 pixel registers plus their addresses and spilled 646 VGPRs). Element i = tid + t T of the padded tile sits at
     // (y, x) = divmod(i, m); the pair advances by divmod(T, m) per step -- one division per lane instead of one per element.
-    if constexpr (DS == 1 && CH == 1 && MS > 0) {
-      // Compile-time plan on gray frames: FOUR pixels per load (an unaligned dword; the byte form issued 36 loads per lane and
-      // was 8 % of the kernel), chunk q = tid + k T of the padded tile's rows of ceil(M / 4) chunks; every division is by a constant.
-      constexpr int M_ = StaticPlanOf<MS>::P.m, T_ = StaticPlanOf<MS>::T, CPR = (M_ + 3) / 4, NCHK = (M_ * CPR + T_ - 1) / T_;
-      uint32_t cw[NCHK], pw[NCHK];
-#pragma unroll
-      for (int k = 0; k < NCHK; ++k) {
-        const int q = tid + k * T_, y = q / CPR, x0 = 4 * (q % CPR);
-        cw[k] = pw[k] = 0u;
-        if (MOF_GABL != 4 && MOF_GABL != 6 && MOF_GABL != 7 && q < M_ * CPR && y < n && x0 < n) {
-          const uint8_t* pc = cur + (size_t)y * a.pitch + x0;
-          const uint8_t* pp = prev + (size_t)y * a.pitch + x0;
-          if (x0 + 3 < n) {
-            __builtin_memcpy(&cw[k], pc, 4);
-            __builtin_memcpy(&pw[k], pp, 4);
-          } else {  // the last chunk of a row whose length is not a multiple of four: the bytes inside the patch
-            for (int b = 0; x0 + b < n; ++b) {
-              cw[k] |= (uint32_t)pc[b] << (8 * b);
-              pw[k] |= (uint32_t)pp[b] << (8 * b);
-            }
-          }
-        }
-      }
+    // FOUR pixels per load on every front end (r06; until then only gray frames under a compile-time plan -- BGR8, the long-range mode
+    // and the OpenCL peak model's run-time-plan kernels issued up to 18 x 2 byte loads per lane, 4 x that at DS = 4): chunk q = tid + k T
+    // of the padded tile's rows of ceil(m / 4) chunks (fetch_px4: one dword, three dwords of BGR8, or two 16-byte runs of the tapped
+    // quarter-resolution rows). Compile-time plan: every division is by a constant and all of a lane's chunks are in flight together;
+    // run-time plan: sub-batches of CMAX chunks (the plan sizes the workgroup so that a lane owns at most 18 elements = 5 chunks).
+    {
+      constexpr int M_ = MS > 0 ? StaticPlanOf<MS>::P.m : 0, T_ = MS > 0 ? StaticPlanOf<MS>::T : 1;
+      constexpr int CMAX = MS > 0 ? (M_ * ((M_ + 3) / 4) + T_ - 1) / T_ : 6;
+      const int cpr = (m + 3) >> 2, nchunks = m * cpr;
+      const float inv_cpr = 1.0f / (float)cpr;
       const uint32_t c4 = c00 * 0x01010101u, p4 = p00 * 0x01010101u;
+      auto coords = [&](int q, int* x0) -> int {  // chunk q -> (row, first column)
+        int r;
+        int y;
+        if constexpr (MS > 0) {
+          constexpr int CPR_ = (M_ + 3) / 4;
+          y = q / CPR_;
+          r = q % CPR_;
+        } else {
+          y = fdiv(q, cpr, inv_cpr, &r);
+        }
+        *x0 = 4 * r;
+        return y;
+      };
+#pragma unroll 1
+      for (int q0 = tid; q0 < ((MOF_GABL == 6 || MOF_GABL == 7) ? 0 : nchunks); q0 += CMAX * T) {
+        uint32_t cw[CMAX], pw[CMAX];
 #pragma unroll
-      for (int k = 0; k < NCHK; ++k) {
-        const int q = tid + k * T_, y = q / CPR, x0 = 4 * (q % CPR);
-        if ((MOF_GABL == 6 || MOF_GABL == 7) || q >= M_ * CPR) continue;
-        if (y < n && x0 < n) {
-          const uint32_t inside = x0 + 3 < n ? 0xffffffffu : (1u << (8 * (n - x0))) - 1u;
-          dc |= (cw[k] ^ c4) & inside;
-          dp |= (pw[k] ^ p4) & inside;
-        }
-        cf* row = z + y * pl.pitch;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int x = x0 + b;
-          if (x < M_) row[x + ((x >> 3) & pl.skew_mask)] = {(float)((cw[k] >> (8 * b)) & 0xffu), (float)((pw[k] >> (8 * b)) & 0xffu)};
-        }
-      }
-    } else {
-      constexpr int SB = 6, NSB = 3;  // the plan sizes the workgroup so that a lane owns at most SB * NSB = 18 elements
-      int sx;
-      const int sy = fdiv(T, m, inv_m, &sx);
-      int x;
-      int y = fdiv(tid, m, inv_m, &x);
-  #pragma unroll 1
-      for (int sb = 0; sb < ((MOF_GABL == 6 || MOF_GABL == 7) ? 0 : NSB); ++sb) {
-        uint32_t cpx[SB], ppx[SB];
-        int ys[SB], xs[SB];
-  #pragma unroll
-        for (int t = 0; t < SB; ++t) {
-          ys[t] = y;
-          xs[t] = x;
-          cpx[t] = ppx[t] = 0u;
-          if (MOF_GABL != 4 && MOF_GABL != 7 && y < n && x < n) {  // (y < n <= m also bounds the tile)
-            cpx[t] = fetch_px<DS, CH>(cur, a.pitch, y, x);
-            ppx[t] = fetch_px<DS, CH>(prev, a.pitch, y, x);
-          }
-          x += sx;
-          y += sy;
-          if (x >= m) { x -= m; ++y; }
-        }
-  #pragma unroll
-        for (int t = 0; t < SB; ++t) {
-          if (ys[t] < m) {
-            if (ys[t] < n && xs[t] < n) {
-              dc |= cpx[t] ^ c00;
-              dp |= ppx[t] ^ p00;
+        for (int k = 0; k < CMAX; ++k) {
+          const int q = q0 + k * T;
+          int x0;
+          const int y = coords(q, &x0);
+          cw[k] = pw[k] = 0u;
+          if (MOF_GABL != 4 && q < nchunks && y < n && x0 < n) {
+            if (x0 + 3 < n) {
+              cw[k] = fetch_px4<DS, CH>(cur, a.pitch, y, x0);
+              pw[k] = fetch_px4<DS, CH>(prev, a.pitch, y, x0);
+            } else {  // the last chunk of a row whose length is not a multiple of four: the pixels inside the patch
+              for (int b = 0; x0 + b < n; ++b) {
+                cw[k] |= fetch_px<DS, CH>(cur, a.pitch, y, x0 + b) << (8 * b);
+                pw[k] |= fetch_px<DS, CH>(prev, a.pitch, y, x0 + b) << (8 * b);
+              }
             }
-            z[ys[t] * pl.pitch + xs[t] + ((xs[t] >> 3) & pl.skew_mask)] = {(float)cpx[t], (float)ppx[t]};
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < CMAX; ++k) {
+          const int q = q0 + k * T;
+          int x0;
+          const int y = coords(q, &x0);
+          if (q >= nchunks) continue;
+          if (y < n && x0 < n) {
+            const uint32_t inside = x0 + 3 < n ? 0xffffffffu : (1u << (8 * (n - x0))) - 1u;
+            dc |= (cw[k] ^ c4) & inside;
+            dp |= (pw[k] ^ p4) & inside;
+          }
+          cf* row = z + y * pl.pitch;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int x = x0 + b;
+            if (x < m) row[x + ((x >> 3) & pl.skew_mask)] = {(float)((cw[k] >> (8 * b)) & 0xffu), (float)((pw[k] >> (8 * b)) & 0xffu)};
           }
         }
       }
@@ -536,7 +560,8 @@ hipError_t pc_configure_generic() {
   if ((e = configure_generic_one<4, 1, 1, 0>()) != hipSuccess) return e;
 #define X(M)                                                                    \
   if ((e = configure_generic_one<1, 1, 0, M>()) != hipSuccess) return e;          \
-  if ((e = configure_generic_one<1, 3, 0, M>()) != hipSuccess) return e;
+  if ((e = configure_generic_one<1, 3, 0, M>()) != hipSuccess) return e;          \
+  if ((e = configure_generic_one<4, 1, 0, M>()) != hipSuccess) return e;
   MOF_STATIC_SIZES(X)
 #undef X
   return hipSuccess;
@@ -562,7 +587,22 @@ hipError_t launch_pc_generic(const PcArgs& a_in, const PcPlan& pl, int n_pairs, 
       else if (c.channels == 3) hipLaunchKernelGGL((pc_generic_kernel<1, 3, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
       else hipLaunchKernelGGL((pc_generic_kernel<1, 1, 1, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
     } else if (c.downscale == 4) {
-      hipLaunchKernelGGL((pc_generic_kernel<4, 1, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
+      // the long-range mode (FftMethod.cpp:1905-2007) under the transform size's compile-time plan too (r06: lr60 / lr96 ran the run-time-plan
+      // kernel at a third of the gray compile-time-plan rate)
+      bool done = false;
+      if (use_static) {
+        switch (pl.m) {
+#define X(M)                                                                                                                                                    \
+  case M:                                                                                                                                                       \
+    hipLaunchKernelGGL((pc_generic_kernel<4, 1, 0, M>), g, dim3((unsigned)StaticPlanOf<M>::T), (size_t)StaticPlanOf<M>::P.lds_bytes, stream, c, pl);           \
+    done = true;                                                                                                                                                \
+    break;
+          MOF_STATIC_SIZES(X)
+#undef X
+          default: break;
+        }
+      }
+      if (!done) hipLaunchKernelGGL((pc_generic_kernel<4, 1, 0, 0>), g, b, (size_t)pl.lds_bytes, stream, c, pl);
     } else {
       // gray and BGR8 frames (the latter promise the gray path's bits, include/mof.h): the compile-time instantiation of the
       // transform size where there is one

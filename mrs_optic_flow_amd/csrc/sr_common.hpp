@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "pc_common.hpp"
+#include "pc_plan.hpp"  // butterfly_ct, butterfly10: the composite radices of the compile-time plans
 
 namespace mof {
 namespace {
@@ -31,12 +32,24 @@ template <>
 struct SrPlan<256> {
   static constexpr int R1 = 16, R2 = 16, Y2 = 17, LINE = 273;
 };
+// r06: FftMethod patches of 200 x 200 pixels (the first 5-smooth size past the half-tile kernel's 192) on the same
+// tuned transforms -- 200 = 10 x 20: three lines per stage-1 pass (60 of 64 lanes), ten of sixteen lanes per line in stage 2
+template <>
+struct SrPlan<200> {
+  static constexpr int R1 = 10, R2 = 20, Y2 = 21, LINE = 211;
+};
 
 // Zt / Zh / Dt (and the log-polar images) are STREAMS: written once by one kernel, read once by the next, hundreds of MB per
 // pass. Marking those accesses non-temporal keeps them from displacing each other's lines on their way through the caches:
 // same-box A/B (r03) c5seq 492 k -> 516 k pairs/s with K5s / K6s alone. MOF_SR_NT=0 builds the plain form.
 #ifndef MOF_SR_NT
 #define MOF_SR_NT 1
+#endif
+// MOF_SR_L2_ABLATE=1 (diagnostic build, results wrong by design): every frame's Zh and every pair's Dt live in slot 0 --
+// K5s writes, K6s reads and writes, K7 reads the SAME 0.9 MB over and over, so the intermediates stay in the L2s instead of going through
+// HBM. What that build gains over the product is the most ANY decomposition that keeps Zh / Dt on chip can return (it pays no hand-off).
+#ifndef MOF_SR_L2_ABLATE
+#define MOF_SR_L2_ABLATE 0
 #endif
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 stream_load(const float4* p) {
@@ -63,10 +76,16 @@ __device__ __forceinline__ uint32_t stream_load(const uint32_t* p) {
 #endif
 }
 
+__device__ __forceinline__ void butterfly20(cf* v) {  // 5 x 4 (pc_plan.hpp: butterfly_ct), twiddles W_20^j = (cos(pi j / 10), -sin(pi j / 10))
+  const cf w[13] = {{1.00000000000000000000f, -0.00000000000000000000f}, {0.95105651629515353118f, -0.30901699437494739575f}, {0.80901699437494745126f, -0.58778525229247313710f}, {0.58778525229247313710f, -0.80901699437494745126f}, {0.30901699437494745126f, -0.95105651629515353118f}, {0.00000000000000006123f, -1.00000000000000000000f}, {-0.30901699437494734024f, -0.95105651629515364220f}, {-0.58778525229247302608f, -0.80901699437494745126f}, {-0.80901699437494734024f, -0.58778525229247324813f}, {-0.95105651629515353118f, -0.30901699437494750677f}, {-1.00000000000000000000f, -0.00000000000000012246f}, {-0.95105651629515375323f, 0.30901699437494689615f}, {-0.80901699437494756229f, 0.58778525229247302608f}};
+  butterfly_ct<5, 4>(v, w);
+}
 template <int R>
 __device__ __forceinline__ void bfly(cf* v) {
   if constexpr (R == 15) butterfly15(v);
   else if constexpr (R == 32) butterfly32(v);
+  else if constexpr (R == 20) butterfly20(v);
+  else if constexpr (R == 10) butterfly10(v);
   else butterfly<R>(v);
 }
 
@@ -100,7 +119,7 @@ __device__ __forceinline__ void wave_fft(cf* __restrict__ z, int nl, int lane, c
   constexpr int LP1 = 64 / P::R2;  // lines per stage-1 pass
   for (int l0 = 0; l0 < nl; l0 += LP1) {
     const int l = l0 + lane / P::R2, n2 = lane % P::R2;
-    if (l < nl) {  // (R2 = 16 packs four lines into a pass; a two-line call leaves half the wave idle)
+    if (l < nl && lane < LP1 * P::R2) {  // (R2 = 16 packs four lines into a pass; a two-line call leaves half the wave idle; R2 = 20: lanes 60 .. 63 idle)
       cf* line = z + l * P::LINE;
       cf v[P::R1];
 #pragma unroll

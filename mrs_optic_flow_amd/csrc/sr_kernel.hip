@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = blockIdx.y, p0 = blockIdx.x * SR_LINES;
   SrTw<N> tw;
   tw.load(a.twiddles, lane);
-  const cf* Dt = reinterpret_cast<const cf*>(a.Dt) + (size_t)pair * (H + 1) * N;
+  const cf* Dt = reinterpret_cast<const cf*>(a.Dt) + (size_t)(MOF_SR_L2_ABLATE ? 0 : pair) * (H + 1) * N;
   // line l carries rows y1 = 2 (p0 + l), y2 = y1 + 1: E[u] = F[y1][u] + i F[y2][u], F[y][N-u] = conj F[y][u].
   // Dt[u][y1], Dt[u][y2] are neighbours: one 16-byte load; 8 lanes fetch the 16 rows of the workgroup (128 bytes).
   {
@@ -626,7 +626,8 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int i = tid + SR_T * k;
-      if (i < SR_LINES * (H + 1)) t[k] = stream_load(reinterpret_cast<const float4*>(Dt + (size_t)(i / SR_LINES) * N + 2 * (p0 + i % SR_LINES)));
+      t[k] = make_float4(0.f, 0.f, 0.f, 0.f);  // (a line past the last row pair -- H = 100 is not a multiple of 8 -- transforms zeros and is left out of the arg-max)
+      if (i < SR_LINES * (H + 1) && p0 + i % SR_LINES < H) t[k] = stream_load(reinterpret_cast<const float4*>(Dt + (size_t)(i / SR_LINES) * N + 2 * (p0 + i % SR_LINES)));
     }
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
@@ -641,6 +642,7 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
   __syncthreads();
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
   wave_fft<N>(z + 4 * wave * P::LINE, 4, lane, tw, [&](cf*, int l, int k1, const cf* v) {
+    if (H % SR_LINES != 0 && p0 + 4 * wave + l >= H) return;
     const int y1 = 2 * (p0 + 4 * wave + l), y2 = y1 + 1;
     const int r1 = ((y1 + H) % N) * N, r2 = ((y2 + H) % N) * N;  // fftShift + first maximum (minMaxLoc)
 #pragma unroll
@@ -840,12 +842,12 @@ static hipError_t launch_sr_pc_n(const SrPcArgs& a, int n_pairs, hipStream_t str
   return hipGetLastError();
 }
 
-int sr_candidates(int res) { return (res / 2) / SR_LINES; }
+int sr_candidates(int res) { return (res / 2 + SR_LINES - 1) / SR_LINES; }
 
 // K7 + K8 alone: from a Dt that somebody else produced (the sequence pipeline, sr_seq_kernel.hip) to (scale, rot, pt)
 template <int N>
 static hipError_t launch_sr_peak_n(const SrPcArgs& a, int n_pairs, hipStream_t stream) {
-  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3((N / 2) / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
+  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3((N / 2 + SR_LINES - 1) / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
   hipLaunchKernelGGL(sr_final_kernel<N>, dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
@@ -868,7 +870,7 @@ static hipError_t launch_sr_rows_inv_n(const SrPcArgs& a, int n_pairs, hipStream
     SrPcArgs b = a;
     b.Dt = a.Dt + (size_t)p0 * (N / 2 + 1) * N * 2;
     b.cand = a.cand + (size_t)p0 * a.n_cand;
-    hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3((N / 2) / SR_LINES, (unsigned)np), dim3(SR_T), 0, stream, b);
+    hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3((N / 2 + SR_LINES - 1) / SR_LINES, (unsigned)np), dim3(SR_T), 0, stream, b);
   }
   return hipGetLastError();
 }
@@ -880,6 +882,7 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
   a.cand = cand;
   a.n_cand = sr_candidates(res);
   switch (res) {
+    case 200: return launch_sr_rows_inv_n<200>(a, n_pairs, stream);
     case 240: return launch_sr_rows_inv_n<240>(a, n_pairs, stream);
     case 256: return launch_sr_rows_inv_n<256>(a, n_pairs, stream);
     case 480: return launch_sr_rows_inv_n<480>(a, n_pairs, stream);

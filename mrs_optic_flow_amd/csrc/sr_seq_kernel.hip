@@ -39,7 +39,8 @@ namespace {
 #endif
 template <int N>
 struct RowsReal {
-  static constexpr int ROWS = (N % 32 == 0 && MOF_K5S_ROWS32) ? 32 : 16;
+  static constexpr int ROWS = (N % 32 == 0 && MOF_K5S_ROWS32) ? 32 : (N % 16 == 0 ? 16 : 8);  // (200: 25 one-wave workgroups of 8 rows per image)
+  static_assert(N % ROWS == 0 && ROWS % 8 == 0, "whole workgroups of four-line waves");
   static constexpr int LINES = ROWS / 2;
   static constexpr int T = LINES * 16;
 };
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint
   wave_fft<N>(mine, 4, lane, tw, StoreNatural<N>{});
   __syncthreads();
   // untangle the two rows of every line and store transposed: Zh[u][row0 + 2j], Zh[u][row0 + 2j + 1] are neighbours
-  cf* out = reinterpret_cast<cf*>(zh + (size_t)frame * zh_stride) + row0;
+  cf* out = reinterpret_cast<cf*>(zh + (size_t)(MOF_SR_L2_ABLATE ? 0 : frame) * zh_stride) + row0;
   for (int i = tid; i < R::LINES * (H + 1); i += R::T) {
     const int u = i / R::LINES, j = i % R::LINES;
     const cf zk = z[j * P::LINE + u], zm = z[j * P::LINE + (N - u) % N];
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
 #define MOF_K6S_ABLATE 0
 #endif
   cf ap[CW][MV];  // column spectra of the previous frame (doubled): 2 B[v][u]
-  load_cols(zh_prev + (size_t)(MOF_K6S_ABLATE ? 0 : p0) * zh_stride);
+  load_cols(zh_prev + (size_t)((MOF_K6S_ABLATE != 0 || MOF_SR_L2_ABLATE != 0) ? 0 : p0) * zh_stride);
 #pragma unroll
   for (int s = 0; s < CW; ++s)
 #pragma unroll
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
     }
   wave_sync();
   for (int j = 0; j < np; ++j) {
-    load_cols(zh_cur + (size_t)(MOF_K6S_ABLATE ? 0 : p0 + j) * zh_stride);
+    load_cols(zh_cur + (size_t)((MOF_K6S_ABLATE != 0 || MOF_SR_L2_ABLATE != 0) ? 0 : p0 + j) * zh_stride);
     // normalised cross-power spectrum of bins (v, u), conjugated in place; the current spectra move into the registers
 #pragma unroll
     for (int s = 0; s < CW; ++s) {
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
     }
     wave_sync();
     wave_fft<N>(z, CW, lane, tw, StoreNatural<N>{});
-    cf* D = reinterpret_cast<cf*>(Dt) + (size_t)(p0 + j) * (H + 1) * N;
+    cf* D = reinterpret_cast<cf*>(Dt) + (size_t)(MOF_SR_L2_ABLATE ? 0 : p0 + j) * (H + 1) * N;
 #pragma unroll
     for (int s = 0; s < CW; ++s) {
       const int u = u0 + s;
@@ -265,7 +266,10 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
         const int q = lane + 64 * m;
         if (q < N / 2 && u <= H) {
           const cf a0 = z[s * P::LINE + 2 * q], a1 = z[s * P::LINE + 2 * q + 1];
-          stream_store(reinterpret_cast<float4*>(D + (size_t)u * N + 2 * q), make_float4(a0.x, a0.y, a1.x, a1.y));
+          // (MOF_SR_L2_ABLATE = 2: Dt is not stored at all -- thousands of waves storing to the SAME aliased lines serialise in the L2 and
+          //  made the aliased build's K6s 44 % slower; dropping the store bounds the write side from above instead)
+          if (MOF_SR_L2_ABLATE == 2) asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y));
+          else stream_store(reinterpret_cast<float4*>(D + (size_t)u * N + 2 * q), make_float4(a0.x, a0.y, a1.x, a1.y));
         }
       }
     }
@@ -493,6 +497,7 @@ hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, flo
   if (n_images <= 0) return hipSuccess;
   if (!src.paired || (channels != 1 && channels != 3)) return hipErrorInvalidValue;
   switch (res) {
+    case 200: return launch_rows_real_src_n<200>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
     case 240: return launch_rows_real_src_n<240>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
     case 256: return launch_rows_real_src_n<256>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
     case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
@@ -507,6 +512,7 @@ hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t 
   // a run longer than one pair walks cur(p) as prev(p + 1): only valid for a contiguous sequence
   if (run > 1 && zh_cur != zh_prev + zh_stride) return hipErrorInvalidValue;
   switch (res) {
+    case 200: return launch_cols_seq_n<200>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
     case 240: return launch_cols_seq_n<240>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
     case 256: return launch_cols_seq_n<256>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
     case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);

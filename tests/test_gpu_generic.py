@@ -198,7 +198,7 @@ def test_large_patches_match_oracle(gpu, n):
     assert np.array_equal(one[0], got[1], equal_nan=True)
 
 
-@pytest.mark.parametrize("fs,n", [(480, 160), (480, 240), (480, 480), (450, 150), (470, 100)])
+@pytest.mark.parametrize("fs,n", [(480, 160), (480, 240), (480, 480), (450, 150), (470, 100), (400, 200)])
 def test_large_patches_reference_constructor_and_stateful_entry(gpu, fs, n):
     """FftMethod(frame_size, sample_point_size) as the node constructs it, incl. the reference's fallback to ONE patch = the whole
     frame when frameSize is not a multiple of samplePointSize (FftMethod.cpp:1709-1716: 470 / 100 -> one 470 x 470 patch)."""
@@ -249,6 +249,48 @@ def test_large_patches_front_ends_and_passes(gpu):
     out = flr.process_long_range_batch_device(torch.from_numpy(cur[None]).to(gpu), torch.from_numpy(prev[None]).to(gpu)).cpu().numpy()[0]
     want, _ = O.fft_process_long_range(cur, prev, O.fft_layout(fs, fs, n, 4, 4), 64)
     assert np.allclose(out, want, rtol=0, atol=TOL, equal_nan=True), (out, want)
+
+
+def test_patches_of_200_pixels_on_the_tuned_transforms(gpu):
+    """r06 (VERDICT r05 item 5): unpadded 200 x 200 patches run the estimator's tuned transforms (csrc/sr_common.hpp: SrPlan<200> = 10 x 20;
+    25 one-wave row workgroups per image, a thirteenth candidate workgroup for the 100 row pairs) -- gray and BGR8 frames give the same
+    bits, a batch and its pairs one at a time too, every clear-peak patch within the bars of both oracles; 198-pixel patches pad to 200
+    and keep the planned pipeline."""
+    n, gx, gy = 200, 2, 1
+    w, h = 2 * n + 9, n + 6
+    rng = np.random.default_rng(200)
+    B = 3
+    bgr_c = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+    bgr_p = np.roll(bgr_c, (4, -7), axis=(1, 2))
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(3, 2), stride=(n + 4, 1))
+    assert fm.kernel_variant == "planned-large"
+    got = fm.process_batch_device_bgr(torch.from_numpy(bgr_c).to(gpu), torch.from_numpy(bgr_p).to(gpu)).cpu().numpy()
+    gray_c = np.stack([O.rgb2gray(f) for f in bgr_c])
+    gray_p = np.stack([O.rgb2gray(f) for f in bgr_p])
+    same = fm.process_batch_device(torch.from_numpy(gray_c).to(gpu), torch.from_numpy(gray_p).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, same, equal_nan=True)
+    lay = O.fft_layout(w, h, n, gx, gy, (3, 2), (n + 4, 1))
+    assert sum(_compare(got[k], gray_c[k], gray_p[k], lay, f"t200/bgr{k}") for k in range(B)) >= B * gx * gy - 1
+    for k in range(B):
+        one = fm.process_batch_device(torch.from_numpy(gray_c[k:k + 1]).to(gpu), torch.from_numpy(gray_p[k:k + 1]).to(gpu)).cpu().numpy()
+        assert np.array_equal(one[0], same[k], equal_nan=True)
+    # circular shifts of a 200 x 200 texture: exact integers while the 5 x 5 window lies inside the surface; at +-99 the window is clamped
+    # at the border (weightedCentroid, FftMethod.cpp:1337-1383) and the answer is the oracle's -- the peak then sits in the LAST candidate
+    # workgroup of K7 (100 row pairs = 12 workgroups of 8 and one of 4)
+    tex = synth.canvas_np(9, n, n, False)[:n, :n].copy()
+    f1 = FftMethod(n, n, 200.0)
+    lay1 = O.fft_layout(n, n, n, 1, 1, (0, 0), (n, n), 200.0)
+    for dx, dy in ((0, 0), (37, -61), (-99, 99), (5, 99), (-98, -99)):
+        cur = np.roll(tex, (dy, dx), axis=(0, 1))
+        out = f1.process_batch_host(cur[None], tex[None])[0]
+        want, _ = O.fft_process(cur, tex, lay1, 64)
+        assert np.allclose(out, want, rtol=0, atol=1e-4, equal_nan=True), (dx, dy, out, want)
+        if max(abs(dx), abs(dy)) <= 97:
+            assert np.allclose(out, [[dx, dy]], rtol=0, atol=1e-4), (dx, dy, out)
+    video = np.stack([synth.pair_np(21, h, w, 2 * t, -t, blur=True)[0] for t in range(3)])
+    seq = fm.process_sequence_device(torch.from_numpy(video).to(gpu)).cpu().numpy()
+    for k in range(2):
+        assert _compare(seq[k], video[k + 1], video[k], lay, f"t200/seq{k}") >= gx * gy - 1
 
 
 # ---- scaleRotationEstimator at any even resolution (scaleRotationEstimator.cpp:3-32) ----
@@ -337,14 +379,14 @@ def test_large_patches_of_the_estimators_sizes_front_ends(gpu, n):
 
 
 def test_large_patches_planned_kernels_at_the_estimators_sizes(gpu):
-    """MOF_FFT_LARGE_TUNED=0 keeps the planned L5 / L6 / L7 for 240 / 256 / 480 (the A/B form): a child process re-runs the large-patch
+    """MOF_FFT_LARGE_TUNED=0 keeps the planned L5 / L6 / L7 for 200 / 240 / 256 / 480 (the A/B form): a child process re-runs the large-patch
     parity cases of those sizes with the knob."""
     import os
     import subprocess
     import sys
     env = dict(os.environ, MOF_FFT_LARGE_TUNED="0")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                          "large_patches_match_oracle and (240 or 256 or 480)", "-p", "no:cacheprovider"], env=env, capture_output=True,
+                          "large_patches_match_oracle and (200 or 240 or 256 or 480)", "-p", "no:cacheprovider"], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
