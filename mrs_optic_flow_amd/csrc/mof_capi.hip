@@ -202,7 +202,7 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
   // L5 / L6 / L7 -- same Zh / Dt / candidate formats, 2.5 x faster; L8 (the FftMethod tail) stays. Gray and BGR8 frames alike (the
   // latter promise the gray path's bits); the long-range mode keeps the planned kernels. MOF_FFT_LARGE_TUNED=0: planned kernels (A/B).
   static const bool tuned_on = [] { const char* v = getenv("MOF_FFT_LARGE_TUNED"); return !v || atoi(v) != 0; }();
-  const bool tuned = tuned_on && a.downscale == 1 && e->plan.m == e->plan.n && (e->plan.m == 200 || e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 480);  // (200: r06)
+  const bool tuned = tuned_on && a.downscale == 1 && e->plan.m == e->plan.n && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 480);  // (200, 216: r06)
   const int per_pass = e->cap / patches;
   for (int k0 = 0; k0 < n_pairs; k0 += per_pass) {
     const int np = n_pairs - k0 < per_pass ? n_pairs - k0 : per_pass, nq = np * patches;

@@ -883,6 +883,7 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
   a.n_cand = sr_candidates(res);
   switch (res) {
     case 200: return launch_sr_rows_inv_n<200>(a, n_pairs, stream);
+    case 216: return launch_sr_rows_inv_n<216>(a, n_pairs, stream);
     case 240: return launch_sr_rows_inv_n<240>(a, n_pairs, stream);
     case 256: return launch_sr_rows_inv_n<256>(a, n_pairs, stream);
     case 480: return launch_sr_rows_inv_n<480>(a, n_pairs, stream);

@@ -498,6 +498,7 @@ hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, flo
   if (!src.paired || (channels != 1 && channels != 3)) return hipErrorInvalidValue;
   switch (res) {
     case 200: return launch_rows_real_src_n<200>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
+    case 216: return launch_rows_real_src_n<216>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
     case 240: return launch_rows_real_src_n<240>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
     case 256: return launch_rows_real_src_n<256>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
     case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
@@ -513,6 +514,7 @@ hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t 
   if (run > 1 && zh_cur != zh_prev + zh_stride) return hipErrorInvalidValue;
   switch (res) {
     case 200: return launch_cols_seq_n<200>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
+    case 216: return launch_cols_seq_n<216>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
     case 240: return launch_cols_seq_n<240>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
     case 256: return launch_cols_seq_n<256>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
     case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
