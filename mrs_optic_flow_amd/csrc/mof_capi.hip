@@ -202,7 +202,9 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
   // L5 / L6 / L7 -- same Zh / Dt / candidate formats, 2.5 x faster; L8 (the FftMethod tail) stays. Gray and BGR8 frames alike (the
   // latter promise the gray path's bits); the long-range mode keeps the planned kernels. MOF_FFT_LARGE_TUNED=0: planned kernels (A/B).
   static const bool tuned_on = [] { const char* v = getenv("MOF_FFT_LARGE_TUNED"); return !v || atoi(v) != 0; }();
-  const bool tuned = tuned_on && a.downscale == 1 && e->plan.m == e->plan.n && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 480);  // (200, 216: r06)
+  // r06: 200 and 216 too, and patches that PAD to one of these sizes (193 .. 200, 201 .. 216, 226 .. 240, 251 .. 256, 451 .. 480): the row kernel
+  // zero-pads, the column kernel applies the box-zero rule of padded constant patches from the row kernel's flags
+  const bool tuned = tuned_on && a.downscale == 1 && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 480);
   const int per_pass = e->cap / patches;
   for (int k0 = 0; k0 < n_pairs; k0 += per_pass) {
     const int np = n_pairs - k0 < per_pass ? n_pairs - k0 : per_pass, nq = np * patches;
@@ -229,13 +231,13 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
       sj.base[1] += (size_t)j0 * a.prev_stride;
       if (tuned)
         HIP_TRY(mof::launch_sr_rows_real_src(sj, e->d_twiddles, e->d_zh + (size_t)2 * j0 * patches * zhf, zhf,
-                                             e->d_flags + (size_t)2 * j0 * patches, e->plan.m, 2 * nj * patches, a.channels, s));
+                                             e->d_flags + (size_t)2 * j0 * patches, e->plan.m, 2 * nj * patches, a.channels, e->plan.n, s));
       else
         HIP_TRY(mof::launch_pcl_rows(sj, e->plan, e->d_twiddles, e->d_zh + (size_t)2 * j0 * patches * zhf, zhf,
                                      e->d_flags + (size_t)2 * j0 * patches, 2 * nj * patches, a.channels, a.downscale, s));
     }
     if (tuned) {
-      HIP_TRY(mof::launch_sr_cols_seq(e->d_zh + zhf, e->d_zh, 2 * zhf, e->d_twiddles, e->d_dt, e->plan.m, nq, 1, s));
+      HIP_TRY(mof::launch_sr_cols_seq(e->d_zh + zhf, e->d_zh, 2 * zhf, e->d_twiddles, e->d_dt, e->plan.m, nq, 1, s, e->d_flags, e->plan.n));
       HIP_TRY(mof::launch_pcl_cdc(e->d_zh + zhf, e->d_zh, 2 * zhf, e->plan.m, e->d_cdc, nq, s));
       HIP_TRY(mof::launch_sr_rows_inv(e->d_dt, e->d_twiddles, e->d_cand, e->plan.m, nq, s));
     } else {

@@ -84,21 +84,22 @@ __device__ __forceinline__ void butterfly20(cf* v) {  // 5 x 4 (pc_plan.hpp: but
   const cf w[13] = {{1.00000000000000000000f, -0.00000000000000000000f}, {0.95105651629515353118f, -0.30901699437494739575f}, {0.80901699437494745126f, -0.58778525229247313710f}, {0.58778525229247313710f, -0.80901699437494745126f}, {0.30901699437494745126f, -0.95105651629515353118f}, {0.00000000000000006123f, -1.00000000000000000000f}, {-0.30901699437494734024f, -0.95105651629515364220f}, {-0.58778525229247302608f, -0.80901699437494745126f}, {-0.80901699437494734024f, -0.58778525229247324813f}, {-0.95105651629515353118f, -0.30901699437494750677f}, {-1.00000000000000000000f, -0.00000000000000012246f}, {-0.95105651629515375323f, 0.30901699437494689615f}, {-0.80901699437494756229f, 0.58778525229247302608f}};
   butterfly_ct<5, 4>(v, w);
 }
-__device__ __forceinline__ void butterfly18(cf* v) {  // 2 x 9, decimation in frequency: X[2k] = DFT9(x[n] + x[n + 9]), X[2k + 1] = DFT9((x[n] - x[n + 9]) W_18^n)
+__device__ __forceinline__ void butterfly18(cf* v) {  // 9 x 2, decimation in time: X[k1 + 9 k2] = DFT9(even)[k1] +- W_18^k1 DFT9(odd)[k1]. Bin 9 (the
+  // Nyquist bin of a line) = sum(even) - sum(odd) passes no twiddle: exact on integers, as the real-only CCS slots need (pc_plan_build.hpp)
   const cf w[9] = {{1.00000000000000000000f, -0.00000000000000000000f}, {0.93969262078590842791f, -0.34202014332566871291f}, {0.76604444311897801345f, -0.64278760968653925190f}, {0.50000000000000011102f, -0.86602540378443859659f}, {0.17364817766693041445f, -0.98480775301220802032f}, {-0.17364817766693030343f, -0.98480775301220802032f}, {-0.49999999999999977796f, -0.86602540378443870761f}, {-0.76604444311897790243f, -0.64278760968653947394f}, {-0.93969262078590831688f, -0.34202014332566887944f}};
   cf a[9], b[9];
 #pragma unroll
-  for (int n = 0; n < 9; ++n) {
-    a[n] = {v[n].x + v[n + 9].x, v[n].y + v[n + 9].y};
-    const cf d = {v[n].x - v[n + 9].x, v[n].y - v[n + 9].y};
-    b[n] = n == 0 ? d : cmul(d, w[n]);
+  for (int n1 = 0; n1 < 9; ++n1) {
+    a[n1] = v[2 * n1];
+    b[n1] = v[2 * n1 + 1];
   }
   butterfly9(a);
   butterfly9(b);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    v[2 * k] = a[k];
-    v[2 * k + 1] = b[k];
+  for (int k1 = 0; k1 < 9; ++k1) {
+    const cf t = k1 == 0 ? b[0] : cmul(b[k1], w[k1]);
+    v[k1] = {a[k1].x + t.x, a[k1].y + t.y};
+    v[k1 + 9] = {a[k1].x - t.x, a[k1].y - t.y};
   }
 }
 template <int R>

@@ -626,8 +626,9 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int i = tid + SR_T * k;
-      t[k] = make_float4(0.f, 0.f, 0.f, 0.f);  // (a line past the last row pair -- H = 100 is not a multiple of 8 -- transforms zeros and is left out of the arg-max)
-      if (i < SR_LINES * (H + 1) && p0 + i % SR_LINES < H) t[k] = stream_load(reinterpret_cast<const float4*>(Dt + (size_t)(i / SR_LINES) * N + 2 * (p0 + i % SR_LINES)));
+      constexpr bool TAIL = H % SR_LINES != 0;  // (200, 216: a line past the last row pair transforms zeros and is left out of the arg-max)
+      if constexpr (TAIL) t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < SR_LINES * (H + 1) && (!TAIL || p0 + i % SR_LINES < H)) t[k] = stream_load(reinterpret_cast<const float4*>(Dt + (size_t)(i / SR_LINES) * N + 2 * (p0 + i % SR_LINES)));
     }
 #pragma unroll
     for (int k = 0; k < NL; ++k) {

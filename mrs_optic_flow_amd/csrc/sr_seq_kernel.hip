@@ -106,9 +106,9 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint
 // engine (pc_large_kernel.hip) hands them to the tuned K5s / K6s / K7 instead of its planned L5 / L6 / L7. The only difference
 // to sr_rows_real_kernel is where the pixels come from (image f = 2 (pair * patches + patch) + (0 cur | 1 prev), any row pitch,
 // gray or BGR8 through the node's CV_RGB2GRAY) and the constant-image flags the FFT tail wants (as pcl_rows_kernel sets them).
-template <int N, int CH>
+template <int N, int CH, bool PAD>  // PAD: n < N, the patch is zero-padded to the transform size (the unpadded form pays nothing for it)
 __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc src, const float* __restrict__ twiddles,
-                                                                           float* __restrict__ zh, size_t zh_stride, int* __restrict__ flags) {
+                                                                           float* __restrict__ zh, size_t zh_stride, int* __restrict__ flags, int n) {
   using P = SrPlan<N>;
   using R = RowsReal<N>;
   constexpr int H = N / 2;
@@ -121,18 +121,31 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
                         (size_t)(CH * (src.origin_x + bx * src.stride_x));
   SrTw<N> tw;
   tw.load(twiddles, lane);
+  // r06: n < N -- a patch that cv::phaseCorrelate zero-pads to this transform size (copyMakeBorder): rows and columns beyond n are zeros
+  // and take no part in the constant-image test (`inside`)
   auto px4 = [&](int y, int d) -> uint32_t {  // pixels 4d .. 4d+3 of patch row y, one byte each
+    if (PAD && (y >= n || 4 * d >= n)) return 0u;
     const uint8_t* r = base + (size_t)y * src.pitch + (size_t)CH * 4 * d;
-    if constexpr (CH == 1) {
-      uint32_t v;
-      __builtin_memcpy(&v, r, 4);  // (any alignment: the patch origin and the pitch are the caller's)
-      return v;
-    } else {
-      uint32_t v = 0;
+    if (!PAD || 4 * d + 3 < n) {
+      if constexpr (CH == 1) {
+        uint32_t v;
+        __builtin_memcpy(&v, r, 4);  // (any alignment: the patch origin and the pitch are the caller's)
+        return v;
+      } else {
+        uint32_t v = 0;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) v |= rgb2gray_fixed(r[3 * b], r[3 * b + 1], r[3 * b + 2]) << (8 * b);
-      return v;
+        for (int b = 0; b < 4; ++b) v |= rgb2gray_fixed(r[3 * b], r[3 * b + 1], r[3 * b + 2]) << (8 * b);
+        return v;
+      }
     }
+    uint32_t v = 0;  // the last chunk of a row whose length is not a multiple of four
+    for (int b = 0; 4 * d + b < n; ++b) v |= (CH == 1 ? (uint32_t)r[b] : rgb2gray_fixed(r[3 * b], r[3 * b + 1], r[3 * b + 2])) << (8 * b);
+    return v;
+  };
+  auto inside = [&](int y, int d) -> uint32_t {  // byte mask of the chunk's pixels that lie inside the n x n patch
+    if (!PAD) return 0xffffffffu;
+    if (y >= n || 4 * d >= n) return 0u;
+    return 4 * d + 3 < n ? 0xffffffffu : (1u << (8 * (n - 4 * d))) - 1u;
   };
   const uint32_t p00 = px4(0, 0) & 0xffu, pat = p00 * 0x01010101u;
   uint32_t diff = 0u;
@@ -153,8 +166,8 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
     for (int k = 0; k < NL; ++k) {
       const int i = lane + 64 * k;
       if (i < 4 * ND) {
-        const int l = i / ND, d = i % ND;
-        diff |= (c[k] ^ pat) | (p[k] ^ pat);
+        const int l = i / ND, d = i % ND, y = row0 + 8 * wave + 2 * l;
+        diff |= ((c[k] ^ pat) & inside(y, d)) | ((p[k] ^ pat) & inside(y + 1, d));
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           mine[l * P::LINE + 4 * d + b] = {(float)((c[k] >> (8 * b)) & 0xffu), (float)((p[k] >> (8 * b)) & 0xffu)};
@@ -184,10 +197,10 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
 #endif
 constexpr int SEQ_CW = MOF_SEQ_CW;  // columns per wave
 
-template <int N>
+template <int N, bool BOX = false>  // BOX: patches zero-padded to N -- the box-zero rule of padded CONSTANT patches (the plain form pays nothing for it)
 __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur,
                                                          size_t zh_stride, const float* __restrict__ twiddles,
-                                                         float* __restrict__ Dt, int n_pairs, int run) {
+                                                         float* __restrict__ Dt, int n_pairs, int run, const int* __restrict__ flags, int n) {
   using P = SrPlan<N>;
   constexpr int H = N / 2, CW = SEQ_CW;
   constexpr int MV = (N + 63) / 64;       // bins per lane and line (v = lane + 64 m)
@@ -238,8 +251,15 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
       ap[s][m] = v < N ? lds_read(&z[s * P::LINE + v]) : cf{0.f, 0.f};
     }
   wave_sync();
+  // r06, FftMethod patches zero-padded to this transform size (n < N; `flags` as pcl_rows_kernel sets them, image 2 p = cur, 2 p + 1 = prev): a
+  // CONSTANT patch became an n x n box whose spectrum is exactly zero on the multiples of box_zero_period(n, N) -- the rows were transformed
+  // in pairs, their alternating sums carry rounding, and the normalisation would blow those bins up to unit magnitude: C = 0 there, the
+  // rule of pcl_cols_kernel (pc_large_kernel.hip) and of the in-LDS kernels (pc_common.hpp)
+  const int zq = BOX ? box_zero_period(n, N) : N + 1;
   for (int j = 0; j < np; ++j) {
     load_cols(zh_cur + (size_t)((MOF_K6S_ABLATE != 0 || MOF_SR_L2_ABLATE != 0) ? 0 : p0 + j) * zh_stride);
+    bool box_zeros = false;
+    if constexpr (BOX) box_zeros = __builtin_amdgcn_readfirstlane((int)(((flags[2 * (p0 + j)] & 1) == 0) || ((flags[2 * (p0 + j) + 1] & 1) == 0))) != 0;
     // normalised cross-power spectrum of bins (v, u), conjugated in place; the current spectra move into the registers
 #pragma unroll
     for (int s = 0; s < CW; ++s) {
@@ -250,7 +270,10 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
         const int v = lane + 64 * m;
         const int vv = v < N ? v : N - 1;  // (lanes past the line repeat its last bin: the wave-uniform branch inside
         const cf a = lds_read(&z[s * P::LINE + vv]);  //  cross_power_ab wants every lane to take part)
-        const cf C = cross_power_ab(a, ap[s][m], u_edge && (vv == 0 || vv == H));
+        cf C = cross_power_ab(a, ap[s][m], u_edge && (vv == 0 || vv == H));
+        if constexpr (BOX) {
+          if (box_zeros && (box_zero_line(u, zq) || box_zero_line(vv, zq))) C = {0.f, 0.f};
+        }
         ap[s][m] = a;
         if (v < N) z[s * P::LINE + v] = {C.x, -C.y};
       }
@@ -430,11 +453,13 @@ hipError_t launch_rows_real_n(const uint8_t* lp, size_t lp_stride, const float* 
 
 template <int N>
 hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh, size_t zh_stride, int* flags, int n_images, int channels,
-                                  hipStream_t stream) {
+                                  int n, hipStream_t stream) {
   using R = RowsReal<N>;
   constexpr size_t lds = sizeof(cf) * R::LINES * SrPlan<N>::LINE;
-  const void* f = channels == 3 ? reinterpret_cast<const void*>(&sr_rows_real_src_kernel<N, 3>) : reinterpret_cast<const void*>(&sr_rows_real_src_kernel<N, 1>);
+  const bool pad = n < N;
   if (lds > 48 * 1024) {
+    const void* f = channels == 3 ? (pad ? reinterpret_cast<const void*>(&sr_rows_real_src_kernel<N, 3, true>) : reinterpret_cast<const void*>(&sr_rows_real_src_kernel<N, 3, false>))
+                                  : (pad ? reinterpret_cast<const void*>(&sr_rows_real_src_kernel<N, 1, true>) : reinterpret_cast<const void*>(&sr_rows_real_src_kernel<N, 1, false>));
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
@@ -445,30 +470,35 @@ hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh,
     if (f0 % (2 * patches) != 0) return hipErrorInvalidValue;  // (the caller splits at whole frame pairs: mof_capi.hip)
     s.base[0] += (size_t)(f0 / (2 * patches)) * src.stride[0];
     s.base[1] += (size_t)(f0 / (2 * patches)) * src.stride[1];
-    if (channels == 3)
-      hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3>), dim3(N / R::ROWS, (unsigned)nf), dim3(R::T), lds, stream, s, tw,
-                         zh + (size_t)f0 * zh_stride, zh_stride, flags ? flags + f0 : nullptr);
-    else
-      hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 1>), dim3(N / R::ROWS, (unsigned)nf), dim3(R::T), lds, stream, s, tw,
-                         zh + (size_t)f0 * zh_stride, zh_stride, flags ? flags + f0 : nullptr);
+    const dim3 g(N / R::ROWS, (unsigned)nf), b(R::T);
+    float* zo = zh + (size_t)f0 * zh_stride;
+    int* fl = flags ? flags + f0 : nullptr;
+    if (channels == 3) {
+      if (pad) hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3, true>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n);
+      else hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3, false>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n);
+    } else {
+      if (pad) hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 1, true>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n);
+      else hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 1, false>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n);
+    }
   }
   return hipGetLastError();
 }
 
 template <int N>
 hipError_t launch_cols_seq_n(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* tw, float* Dt, int n_pairs,
-                             int run, hipStream_t stream) {
+                             int run, const int* flags, int n, hipStream_t stream) {
   constexpr int H = N / 2;
   const unsigned groups = (H + 1 + SEQ_CW - 1) / SEQ_CW, runs = (unsigned)((n_pairs + run - 1) / run);
   if constexpr (N == 480) {
     // MOF_SR_COLS_SPLIT=1: K6p, two columns per wave and the radix-32 stage on lane pairs
     static const bool split = [] { const char* v = getenv("MOF_SR_COLS_SPLIT"); return v && atoi(v) != 0; }();
-    if (split) {
+    if (split && !(flags && n < N)) {
       hipLaunchKernelGGL(sr_cols_split_kernel<N>, dim3((H + 2) / 2, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run);
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL(sr_cols_seq_kernel<N>, dim3(groups, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run);
+  if (flags && n < N) hipLaunchKernelGGL((sr_cols_seq_kernel<N, true>), dim3(groups, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run, flags, n);
+  else hipLaunchKernelGGL((sr_cols_seq_kernel<N, false>), dim3(groups, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run, flags, n);
   return hipGetLastError();
 }
 
@@ -493,31 +523,33 @@ hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float*
 }
 
 hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, float* zh, size_t zh_stride, int* flags, int res, int n_images,
-                                   int channels, hipStream_t stream) {
+                                   int channels, int n, hipStream_t stream) {
   if (n_images <= 0) return hipSuccess;
-  if (!src.paired || (channels != 1 && channels != 3)) return hipErrorInvalidValue;
+  if (!src.paired || (channels != 1 && channels != 3) || n < 2 || n > res) return hipErrorInvalidValue;
   switch (res) {
-    case 200: return launch_rows_real_src_n<200>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
-    case 216: return launch_rows_real_src_n<216>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
-    case 240: return launch_rows_real_src_n<240>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
-    case 256: return launch_rows_real_src_n<256>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
-    case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, stream);
+    case 200: return launch_rows_real_src_n<200>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
+    case 216: return launch_rows_real_src_n<216>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
+    case 240: return launch_rows_real_src_n<240>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
+    case 256: return launch_rows_real_src_n<256>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
+    case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
 hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* twiddles, float* Dt, int res,
-                              int n_pairs, int run, hipStream_t stream) {
+                              int n_pairs, int run, hipStream_t stream, const int* flags, int n) {
   if (n_pairs <= 0) return hipSuccess;
   if (run < 1) run = 1;
+  if (flags && run != 1) return hipErrorInvalidValue;  // (the box-zero flags are per independent pair: image 2 p = cur, 2 p + 1 = prev)
+  if (n <= 0) n = res;
   // a run longer than one pair walks cur(p) as prev(p + 1): only valid for a contiguous sequence
   if (run > 1 && zh_cur != zh_prev + zh_stride) return hipErrorInvalidValue;
   switch (res) {
-    case 200: return launch_cols_seq_n<200>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
-    case 216: return launch_cols_seq_n<216>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
-    case 240: return launch_cols_seq_n<240>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
-    case 256: return launch_cols_seq_n<256>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
-    case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, stream);
+    case 200: return launch_cols_seq_n<200>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
+    case 216: return launch_cols_seq_n<216>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
+    case 240: return launch_cols_seq_n<240>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
+    case 256: return launch_cols_seq_n<256>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
+    case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
     default: return hipErrorInvalidValue;
   }
 }

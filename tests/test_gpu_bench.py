@@ -30,13 +30,14 @@ def test_bench_two_rank_rehearsal(gpu):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
                                        "--share-gpu", "--workload", "c4", "--batch", "8", "--steps", "3", "--warmup", "1",
-                                       "--sustain-s", "0", "--no-cpu-baseline"],
+                                       "--sustain-s", "0.2", "--no-cpu-baseline"],  # (> 0: the cold-burst and sustained legs run with two ranks too)
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
     line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
     assert "gloo" in line["config"]["gather"] and line["config"]["batch_per_gpu"] == 8
+    assert line["cold_burst"]["value"] > 0 and line["sustained"]["value"] > 0 and "native_shard_group" not in line
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]  # only rank 0 prints
 
 

@@ -114,7 +114,8 @@ def test_fuzzer_classes_through_every_entry_point(gpu, n):
             _check(lr[k], small_c[k], small_p[k], lay1, f"n{n}/longrange/{names[k]}")
 
 
-@pytest.mark.parametrize("case", ["in_lds_118", "in_lds_124_odd", "large_158", "large_146", "half_156", "half_152", "half_56", "large_232", "in_lds_130_odd"])
+@pytest.mark.parametrize("case", ["in_lds_118", "in_lds_124_odd", "large_158", "large_146", "half_156", "half_152", "half_56", "large_232", "in_lds_130_odd",
+                                  "tuned_196", "tuned_252"])
 def test_constant_frame_against_texture_on_padded_patches(gpu, case):
     """Found by tools/fft_sr_fuzz.py's sequence trials (seeds 101 / 202): ONE frame of the pair constant, patch size below its
     transform size. cv::phaseCorrelate pads the constant patch to an n x n box whose spectrum is level x D[v] D[u], exactly zero on
@@ -138,6 +139,11 @@ def test_constant_frame_against_texture_on_padded_patches(gpu, case):
         "half_56": (56, (2, 2), (3, 4), (60, 58), (125, 127), 613, (0, 97)),
         "large_232": (232, (1, 1), (2, 3), (1, 1), (240, 238), 614, (1, 55)),
         "in_lds_130_odd": (130, (1, 1), (2, 2), (1, 1), (136, 134), 615, (0, 201)),
+        # r06: patches that pad to 200 / 240 / 256 run the estimator's tuned transforms, whose column kernel got the box-zero rule (sr_seq_kernel.hip:
+        # sr_cols_seq_kernel, flags from the row kernel): 196 in 200 -> zero lines at the multiples of 50; 252 in 256 -> multiples of 64; large_232
+        # above (232 in 240 -> multiples of 30) now takes this path too
+        "tuned_196": (196, (1, 1), (2, 3), (1, 1), (204, 202), 616, (1, 77)),
+        "tuned_252": (252, (1, 1), (1, 1), (1, 1), (256, 258), 617, (0, 140)),
     }[case]
     video, _ = synth.video_torch(2, h, w, "cpu", k=k)
     video[const[0]] = const[1]

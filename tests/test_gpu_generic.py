@@ -175,7 +175,7 @@ def _large_variant(n):
     return "planned-half" if half else "planned-large"
 
 
-@pytest.mark.parametrize("n", [160, 136, 144, 150, 180, 192, 162, 158, 170, 186, 200, 216, 240, 250, 256, 148, 225, 243, 202, 480, 750, 810])  # (750, 810: one stage body per radix;
+@pytest.mark.parametrize("n", [160, 136, 144, 150, 180, 192, 162, 158, 170, 186, 200, 216, 240, 250, 256, 148, 225, 243, 202, 196, 230, 252, 480, 750, 810])  # (750, 810: one stage body per radix;
                                                                                                                #  240 / 256 / 480: the estimator's tuned transforms)
 def test_large_patches_match_oracle(gpu, n):
     gx, gy = (2, 2) if n <= 256 else (1, 1)
@@ -291,6 +291,19 @@ def test_patches_of_200_pixels_on_the_tuned_transforms(gpu):
     seq = fm.process_sequence_device(torch.from_numpy(video).to(gpu)).cpu().numpy()
     for k in range(2):
         assert _compare(seq[k], video[k + 1], video[k], lay, f"t200/seq{k}") >= gx * gy - 1
+    # the input classes whose alternating-sign pixel sums cancel exactly (synth.fuzz_classes_np "checker": the real-only CCS slots must come
+    # out of the tuned two-stage transforms exactly -- bin N/2 of butterfly20 / butterfly18 passes no twiddle), saturated and smooth content
+    for m in (200, 216):
+        fc = FftMethod(m, m, 80.0)
+        cls = synth.fuzz_classes_np(300 + m, m, m, 3, -2)
+        lay_m = O.fft_layout(m, m, m, 1, 1)
+        for name in ("checker", "saturated", "const_rect", "smooth"):
+            c, p = cls[name]
+            out = fc.process_batch_host(c[None], p[None])[0]
+            tolerances.check_frame(out, c, p, lay_m, f"t{m}/{name}")
+        c, p = cls["checker"]
+        want, _ = O.fft_process(c, p, lay_m, 64)
+        assert np.allclose(fc.process_batch_host(c[None], p[None])[0], want, rtol=0, atol=1e-4, equal_nan=True)
 
 
 # ---- scaleRotationEstimator at any even resolution (scaleRotationEstimator.cpp:3-32) ----
@@ -386,7 +399,7 @@ def test_large_patches_planned_kernels_at_the_estimators_sizes(gpu):
     import sys
     env = dict(os.environ, MOF_FFT_LARGE_TUNED="0")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                          "large_patches_match_oracle and (200 or 216 or 240 or 256 or 480)", "-p", "no:cacheprovider"], env=env, capture_output=True,
+                          "large_patches_match_oracle and (200 or 216 or 240 or 256 or 480 or 202 or 196 or 230 or 252)", "-p", "no:cacheprovider"], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
