@@ -60,6 +60,10 @@ def binding_note(name: str, wl) -> str:
                     "frames): VALU issue 47.8 % (272.3 M wave-instructions x 2 cycles over 1024 SIMDs x 1.114 M cycles), LDS active "
                     "56.7 % of the CU cycles (12.6 % of it bank conflicts); the two add to 104 %: the pipes run one after the other, "
                     "not side by side; not HBM")
+        if wl["n"] > 192:
+            return ("large-patch pipeline on a video (r06): the tuned row transforms once per FRAME (Zh slot = frame x patches + patch), the column "
+                    "kernel on slots q | q + patches, inverse rows, tail; through Zh / Dt in HBM scratch; the transforms are bound by their own LDS / "
+                    "VALU work at two waves per SIMD (DESIGN.md section 4, large patches / K4-K8)")
         return ("half-tile kernel K1h in its video form (pc_half_kernel<CH, M, SEQ>, r05; also 128 x 128 since it beat pc_seq_half.hip there: c4seq 93 k -> "
                 "112 k): a frame's half spectrum stays in the registers of the forward column pass's last stage, where the next pair's "
                 "cross-power meets it -- one image transform per pair instead of two; runs of consecutive pairs per workgroup, the run length "
@@ -69,31 +73,31 @@ def binding_note(name: str, wl) -> str:
         return ("c5 on a video: one Lanczos4 remap and one real row transform per frame (K5s), column pass walking pairs in "
                 "time with the previous spectra in registers (K6s); DESIGN.md section 4 (sequence mode)")
     if wl["kind"] == "fft+sr":
-        return ("scale/rotation pipeline K4-K8 takes 76 % of the step (profiles/r05_c5_kernel_stats.csv, r05_c5_sq_pmc.csv): log-polar gathers "
+        return ("scale/rotation pipeline K4-K8 takes 76 % of the step (profiles/r06_c5_kernel_stats.csv, r06_c5_sq_pmc.csv): log-polar gathers "
                 "(v_dot4c taps on LDS-staged source boxes; Lanczos4 515 us: LDS 58 % busy, VALU 30 %, waits 44 %; cubic 382 us) 33 %, whole-frame "
                 "transforms through Zh / Dt (K5s 431 us at 5.4 TB/s, K6s 555 us at 5.0 TB/s, K7 193 us at 4.8 TB/s: the minimum bytes of a rows -> "
                 "columns -> rows structure in f32, at 76-86 % of the achievable copy rate) 43 %; K1 (637 us) as in c2; DESIGN.md section 4 (K4-K8, r05 block)")
     if wl["n"] == 120:
         return ("half-tile kernel K1h (pc_half_kernel.hip, r05): each image transformed on its own on a 60 x 136 complex tile, TWO workgroups of "
                 "8 waves per CU, every phase on all waves, the untangle / pairing / cross-power fused into the passes, the previous spectrum in "
-                "registers, the current image's pixels requested under the previous image's column pass. profiles/r05_ref_sq_pmc.csv (per launch of "
-                "16,384 patch pairs): VALU issue 51.7 % (3589 wave-instructions per wave x 2 cycles), LDS active 52.8 % of the CU cycles (28 % of it "
-                "bank conflicts), waves parked at a wait 30.7 % of their cycles -- against the tuned one-workgroup kernel's 38.8 % + 37.0 %, waits 45.6 % (r05_ref_tuned_sq_pmc.csv, "
+                "registers, the current image's pixels requested under the previous image's column pass. profiles/r06_ref_sq_pmc.csv (per launch of "
+                "16,384 patch pairs): VALU issue 51.7 % (3589 wave-instructions per wave x 2 cycles), LDS active 51.5 % of the CU cycles (26 % of it "
+                "bank conflicts; r06: line order 0 2 1 3 in the later row stages), waves parked at a wait 30.9 % of their cycles -- against the tuned one-workgroup kernel's 38.8 % + 37.0 %, waits 45.6 % (r05_ref_tuned_sq_pmc.csv, "
                 "MOF_FFT_HALF=0: 1.10 M pairs/s); VALU + LDS = 104 %: the two pipes in series, as K1; not HBM")
     if wl["n"] == 128:
         return ("one persistent workgroup per CU (the tile fills the LDS): the LDS store path (ds_write_b64 = 6 cycles per "
                 "wave-instruction, 7.5 tile stores per patch pair) and the 8-wave inverse passes; N = 128: VALU issue ~42 %, "
-                "LDS 46 % busy, 6 % of it bank conflicts (profiles/r05_c4_sq_pmc.csv; the kernel is unchanged since r03); the two add to "
+                "LDS 46 % busy, 6 % of it bank conflicts (profiles/r06_c4_sq_pmc.csv; the kernel is unchanged since r03); the two add to "
                 "88 %: in series; not HBM -- DESIGN.md section 4 (K1 at N = 128)")
     if wl["n"] in (60, 72, 90, 96, 100) or 136 <= wl["n"] <= 192:
         return ("half-tile kernel K1h (pc_half_kernel.hip, r05; planned Stockham stages with compile-time radices, sources / sinks fused into "
-                "the passes, skew shift per size). profiles/r05_{p60,p96,l160}_sq_pmc.csv: p60 VALU issue 55 % + LDS 61 % (30 % of it conflicts), waits 29 %; p96 "
+                "the passes, skew shift per size). profiles/r06_{p60,l160}_sq_pmc.csv, r05_p96_sq_pmc.csv: p60 VALU issue 55 % + LDS 61 % (30 % of it conflicts), waits 29 %; p96 "
                 "47 % + 49 % (25 %), waits 33 %; l160 36 % + 41 % (38 %), waits 36 % at one 10-wave workgroup per CU -- LDS bank conflicts of the "
                 "generic lane maps and the series of the two pipes; not HBM (DESIGN.md section 4, K1h)")
     if wl["n"] != 64:
         return ("planned kernel (run-time radix plan, pc_kernel_generic.hip / pc_large_kernel.hip): the general path, not tuned -- "
                 "DESIGN.md section 4 (size-generic kernels)")
-    return ("four workgroups per CU (LDS capacity). profiles/r05_c2_sq_pmc.csv (per launch of 65,536 patch pairs; the kernel and its counters are unchanged since r04): VALU issue 53.7 % "
+    return ("four workgroups per CU (LDS capacity). profiles/r06_c2_sq_pmc.csv (per launch of 65,536 patch pairs; the kernel and its counters are unchanged since r04): VALU issue 53.7 % "
             "(370.3 M wave-instructions x 2 cycles over 1024 SIMDs x 1.346 M cycles; 1412 per wave and patch pair), LDS active 52.7 % "
             "of the CU cycles (9.7 % of it bank conflicts; two thirds of it the store path, 6 cycles per ds_write_b64), waves stalled "
             "on LDS issue 14 %; VALU + LDS = 106 %: the two pipes run one after the other, not side by side -- that serialisation, "
@@ -219,6 +223,12 @@ WORKLOADS = {
     "refseq": dict(kind="fftseq", h=480, w=480, n=120, grid=(4, 4), origin=(0, 0), stride=(120, 120), batch=1024, s=15,
                    name="refseq: ref on a video -- FftMethod 480x480, 4x4 grid of 120x120 patches, 1024 consecutive frame pairs (1025 frames)",
                    bytes_per_pair=480 * 480 + 16 * 8),
+    "l200seq": dict(kind="fftseq", h=480, w=480, n=200, grid=(2, 2), origin=(0, 0), stride=(200, 200), batch=512, s=20,
+                    name="l200seq: l200 on a video -- 2x2 grid of 200x200 patches, 512 consecutive frame pairs (r06: every frame's row spectra formed once)",
+                    bytes_per_pair=4 * 200 * 200 + 4 * 8),
+    "l480seq": dict(kind="fftseq", h=480, w=480, n=480, grid=(1, 1), origin=(0, 0), stride=(480, 480), batch=512, s=20,
+                    name="l480seq: l480 on a video -- ONE 480x480 patch, 512 consecutive frame pairs",
+                    bytes_per_pair=480 * 480 + 8),
     "l160seq": dict(kind="fftseq", h=480, w=480, n=160, grid=(3, 3), origin=(0, 0), stride=(160, 160), batch=512, s=20,
                     name="l160seq: l160 on a video -- 3x3 grid of 160x160 patches, 512 consecutive frame pairs",
                     bytes_per_pair=480 * 480 + 9 * 8),

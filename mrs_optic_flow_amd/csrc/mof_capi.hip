@@ -156,7 +156,7 @@ static hipError_t large_alloc(mof_fft_engine* e, int cap) {
   if ((err = hipMalloc(&e->d_zh, (size_t)2 * cap * zhf * sizeof(float))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_dt, (size_t)cap * zhf * sizeof(float))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_cand, (size_t)cap * mof::pcl_candidates(e->plan) * sizeof(float2))) != hipSuccess) return err;
-  if ((err = hipMalloc(&e->d_flags, (size_t)2 * cap * sizeof(int))) != hipSuccess) return err;
+  if ((err = hipMalloc(&e->d_flags, (size_t)4 * cap * sizeof(int))) != hipSuccess) return err;  // [0, 2 cap): per pair (cur | prev); [2 cap, 4 cap): per image of a video pass
   if ((err = hipMalloc(&e->d_cdc, (size_t)cap * sizeof(float))) != hipSuccess) return err;
   e->cap = cap;
   return hipSuccess;
@@ -205,9 +205,55 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
   // r06: 200 and 216 too, and patches that PAD to one of these sizes (193 .. 200, 201 .. 216, 226 .. 240, 251 .. 256, 451 .. 480): the row kernel
   // zero-pads, the column kernel applies the box-zero rule of padded constant patches from the row kernel's flags
   const bool tuned = tuned_on && a.downscale == 1 && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 480);
+  // r06, a VIDEO on the tuned transforms (pair k = (frame k + 1, frame k): mof_fft_process_sequence_device, or any caller whose cur = prev + one frame):
+  // every frame's row spectra are formed ONCE per pass -- Zh slot = frame * patches + patch, so pair q = k * patches + patch finds its previous
+  // image at slot q and its current one at slot q + patches, which is exactly what the column kernel's (zh_prev, zh_cur, stride) takes; the
+  // kernels and their arithmetic are the pair form's, so are the bits. MOF_FFT_LARGE_VIDEO=0 keeps the pair form (A/B and its tests).
+  static const bool video_on = [] { const char* v = getenv("MOF_FFT_LARGE_VIDEO"); return !v || atoi(v) != 0; }();
+  const bool video = video_on && tuned && n_pairs >= 2 && a.cur == a.prev + a.prev_stride && a.cur_stride == a.prev_stride;
   const int per_pass = e->cap / patches;
   for (int k0 = 0; k0 < n_pairs; k0 += per_pass) {
     const int np = n_pairs - k0 < per_pass ? n_pairs - k0 : per_pass, nq = np * patches;
+    if (video) {
+      mof::PclSrc src{};
+      src.base[0] = a.prev + (size_t)k0 * a.prev_stride;  // frame k0 of the video
+      src.stride[0] = a.prev_stride;
+      src.pitch = a.pitch;
+      src.paired = 2;
+      src.grid_x = a.grid_x;
+      src.grid_y = a.grid_y;
+      src.origin_x = a.origin_x;
+      src.origin_y = a.origin_y;
+      src.stride_x = a.stride_x;
+      src.stride_y = a.stride_y;
+      int* fs = e->d_flags + (size_t)2 * e->cap;  // per image of this pass: (np + 1) * patches <= 2 cap
+      HIP_TRY(hipMemsetAsync(fs, 0, (size_t)(nq + patches) * sizeof(int), s));
+      const int frames_per_launch = 65534 / patches > 0 ? 65534 / patches : 1;
+      for (int j0 = 0; j0 < np + 1; j0 += frames_per_launch) {
+        const int nj = np + 1 - j0 < frames_per_launch ? np + 1 - j0 : frames_per_launch;
+        mof::PclSrc sj = src;
+        sj.base[0] += (size_t)j0 * a.prev_stride;
+        HIP_TRY(mof::launch_sr_rows_real_src(sj, e->d_twiddles, e->d_zh + (size_t)j0 * patches * zhf, zhf, fs + (size_t)j0 * patches, e->plan.m,
+                                             nj * patches, a.channels, e->plan.n, s));
+      }
+      HIP_TRY(mof::launch_pcl_seq_flags(fs, e->d_flags, patches, nq, s));
+      const float* zp = e->d_zh;
+      const float* zc = e->d_zh + (size_t)patches * zhf;
+      HIP_TRY(mof::launch_sr_cols_seq(zp, zc, zhf, e->d_twiddles, e->d_dt, e->plan.m, nq, 1, s, e->d_flags, e->plan.n));
+      HIP_TRY(mof::launch_pcl_cdc(zp, zc, zhf, e->plan.m, e->d_cdc, nq, s));
+      HIP_TRY(mof::launch_sr_rows_inv(e->d_dt, e->d_twiddles, e->d_cand, e->plan.m, nq, s));
+      mof::PclFinal f{};
+      f.Dt = e->d_dt;
+      f.cand = e->d_cand;
+      f.twiddles = e->d_twiddles;
+      f.mode = 1;
+      f.max_px_speed_sq = a.max_px_speed_sq;
+      f.out = a.out + (size_t)k0 * patches * 2;
+      f.flags = e->d_flags;
+      f.cdc = e->d_cdc;
+      HIP_TRY(mof::launch_pcl_peak(f, e->plan, nq, s, true));
+      continue;
+    }
     mof::PclSrc src{};
     src.base[0] = a.cur + (size_t)k0 * a.cur_stride;
     src.base[1] = a.prev + (size_t)k0 * a.prev_stride;

@@ -60,7 +60,8 @@ struct PclSrc {
   const uint8_t* base[2];  // paired: [0] = cur frames, [1] = prev frames; else base[0] alone
   size_t stride[2];        // bytes between consecutive frame pairs (paired) / images (not paired)
   size_t pitch;            // bytes per frame row
-  int paired;              // 1: image f = 2 (pair * patches + patch) + which (0 cur, 1 prev); 0: image f = base[0] + f * stride[0]
+  int paired;              // 1: image f = 2 (pair * patches + patch) + which (0 cur, 1 prev); 0: image f = base[0] + f * stride[0];
+                           // 2 (r06, a VIDEO): image f = frame * patches + patch of base[0] + frame * stride[0] -- every frame transformed once
   int grid_x, grid_y, origin_x, origin_y, stride_x, stride_y;  // patch grid inside a frame (paired)
 };
 struct PclFinal {
@@ -223,6 +224,9 @@ hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float*
 hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, float* zh, size_t zh_stride, int* flags, int res, int n_images,
                                    int channels, int n, hipStream_t stream);  // n <= res: the unpadded patch size (zeros beyond n x n)
 hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* cand, int res, int n_pairs, hipStream_t stream);
+// a video's per-image flags fs[frame * patches + patch] -> the per-pair layout the column kernel and the tail read: f2[2 q] = cur = fs[q + patches],
+// f2[2 q + 1] = prev = fs[q] (pair q = k * patches + patch of frames k + 1, k)
+hipError_t launch_pcl_seq_flags(const int* fs, int* f2, int patches, int n_pairs, hipStream_t stream);
 hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* twiddles, float* Dt, int res,
                               int n_pairs, int run, hipStream_t stream, const int* flags = nullptr, int n = 0);  // flags + n < res: the box-zero rule of padded constant patches (run = 1)
 // K56 (sr_fused_kernel.hip): K5s + K6s in one kernel, the row transforms as a dense product on the matrix cores -- reads the u8

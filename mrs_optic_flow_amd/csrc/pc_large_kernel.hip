@@ -413,6 +413,21 @@ bool pc_build_line_plan(int n, PcPlan* out) {
   return true;
 }
 
+namespace {
+__global__ void __launch_bounds__(256) pcl_seq_flags_kernel(const int* __restrict__ fs, int* __restrict__ f2, int patches, int n_pairs) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q < n_pairs) {
+    f2[2 * q] = fs[q + patches];
+    f2[2 * q + 1] = fs[q];
+  }
+}
+}  // namespace
+hipError_t launch_pcl_seq_flags(const int* fs, int* f2, int patches, int n_pairs, hipStream_t stream) {
+  if (n_pairs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pcl_seq_flags_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, fs, f2, patches, n_pairs);
+  return hipGetLastError();
+}
+
 size_t pcl_zh_floats(const PcPlan& pl) { return (size_t)((pl.m >> 1) + 1) * pl.m * 2; }
 int pcl_candidates(const PcPlan& pl) { return (((pl.m + 1) >> 1) + PCL_LINES - 1) / PCL_LINES; }
 

@@ -34,9 +34,13 @@ struct SrPlan<256> {
 };
 // r06: FftMethod patches of 200 x 200 pixels (the first 5-smooth size past the half-tile kernel's 192) on the same
 // tuned transforms -- 200 = 10 x 20: three lines per stage-1 pass (60 of 64 lanes), ten of sixteen lanes per line in stage 2
+#ifndef MOF_SR_LINE200  // (A/B: LDS line pitch of the 200-point kernels)
+#define MOF_SR_LINE200 211
+#endif
 template <>
 struct SrPlan<200> {
-  static constexpr int R1 = 10, R2 = 20, Y2 = 21, LINE = 211;
+  static constexpr int R1 = 10, R2 = 20, Y2 = 21, LINE = MOF_SR_LINE200;
+  static_assert(LINE >= R1 * Y2, "the padded stage-1 output fits a line");
 };
 template <>
 struct SrPlan<216> {  // 12 x 18: three lines per stage-1 pass (54 of 64 lanes), twelve of sixteen lanes per line in stage 2

@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
   extern __shared__ __attribute__((aligned(16))) unsigned char rr_lds[];
   cf* z = reinterpret_cast<cf*>(rr_lds);  // [LINES][LINE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, img = blockIdx.y, row0 = blockIdx.x * R::ROWS;
-  const int which = img & 1, q = img >> 1, patches = src.grid_x * src.grid_y;
+  const int patches = src.grid_x * src.grid_y;
+  const int which = src.paired == 2 ? 0 : (img & 1), q = src.paired == 2 ? img : (img >> 1);  // (a video: image = frame * patches + patch, `pair` = the frame)
   const int pair = q / patches, pt = q - pair * patches, by = pt / src.grid_x, bx = pt - by * src.grid_x;
   const uint8_t* base = src.base[which] + (size_t)pair * src.stride[which] + (size_t)(src.origin_y + by * src.stride_y) * src.pitch +
                         (size_t)(CH * (src.origin_x + bx * src.stride_x));
@@ -467,9 +468,10 @@ hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh,
     const int nf = n_images - f0 < 65534 ? n_images - f0 : 65534;
     PclSrc s = src;
     const int patches = src.grid_x * src.grid_y;
-    if (f0 % (2 * patches) != 0) return hipErrorInvalidValue;  // (the caller splits at whole frame pairs: mof_capi.hip)
-    s.base[0] += (size_t)(f0 / (2 * patches)) * src.stride[0];
-    s.base[1] += (size_t)(f0 / (2 * patches)) * src.stride[1];
+    const int per_unit = src.paired == 2 ? patches : 2 * patches;  // images per frame (a video) / per frame pair
+    if (f0 % per_unit != 0) return hipErrorInvalidValue;  // (the caller splits at whole frames / frame pairs: mof_capi.hip)
+    s.base[0] += (size_t)(f0 / per_unit) * src.stride[0];
+    if (src.paired != 2) s.base[1] += (size_t)(f0 / per_unit) * src.stride[1];
     const dim3 g(N / R::ROWS, (unsigned)nf), b(R::T);
     float* zo = zh + (size_t)f0 * zh_stride;
     int* fl = flags ? flags + f0 : nullptr;
@@ -525,7 +527,7 @@ hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float*
 hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, float* zh, size_t zh_stride, int* flags, int res, int n_images,
                                    int channels, int n, hipStream_t stream) {
   if (n_images <= 0) return hipSuccess;
-  if (!src.paired || (channels != 1 && channels != 3) || n < 2 || n > res) return hipErrorInvalidValue;
+  if ((src.paired != 1 && src.paired != 2) || (channels != 1 && channels != 3) || n < 2 || n > res) return hipErrorInvalidValue;
   switch (res) {
     case 200: return launch_rows_real_src_n<200>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     case 216: return launch_rows_real_src_n<216>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);

@@ -5,6 +5,8 @@ config/default.yaml:31-32) and hands each patch to cv::phaseCorrelate, which zer
 ODD size (74 -> 75). Sizes without a hand-tuned kernel run the planned kernel (csrc/pc_kernel_generic.hip). Same bars as
 tests/test_gpu_fft.py: 1e-4 px against both oracle precisions on well-conditioned patches.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -304,6 +306,51 @@ def test_patches_of_200_pixels_on_the_tuned_transforms(gpu):
         c, p = cls["checker"]
         want, _ = O.fft_process(c, p, lay_m, 64)
         assert np.allclose(fc.process_batch_host(c[None], p[None])[0], want, rtol=0, atol=1e-4, equal_nan=True)
+
+
+_LARGE_VIDEO_SCRIPT = r"""
+import sys
+sys.path[:0] = [{root!r}, {tests!r}]
+import numpy as np, torch
+from mrs_optic_flow_amd import FftMethod, synth
+dev = torch.device("cuda", 0)
+checked = 0
+for n, gx in ((200, 2), (196, 2), (252, 1), (216, 1)):
+    w, h = gx * (n + 4) + 5, n + 6
+    F = 11
+    video, _ = synth.video_torch(F, h, w, "cpu", k=n)
+    video[4] = 93          # a constant frame in the stream (padded sizes: the box-zero rule through the video form's flags)
+    video[8] = video[7]    # a repeated frame
+    for ch in (1, 3):
+        fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, 1), origin=(2, 3), stride=(n + 4, 1))
+        if ch == 1:
+            dv = video.to(dev)
+            seq = fm.process_sequence_device(dv)
+            pair = fm.process_batch_device(dv[1:].clone(), dv[:-1].clone())   # (separate allocations: the pair form)
+        else:
+            dv = video.to(dev)[..., None].expand(-1, -1, -1, 3).contiguous()
+            seq = fm.process_sequence_device_bgr(dv)
+            pair = fm.process_batch_device_bgr(dv[1:].clone(), dv[:-1].clone())
+        assert torch.equal(torch.nan_to_num(seq, nan=-1e9), torch.nan_to_num(pair, nan=-1e9)), (n, ch)
+        assert torch.equal(torch.isnan(seq), torch.isnan(pair))
+        checked += 1
+print("large video ok", checked)
+"""
+
+
+def test_video_form_of_the_tuned_large_patch_path(gpu):
+    """r06: a video on patches of 193 .. 256 / 451 .. 480 pixels forms every frame's row spectra ONCE per pass (Zh slot = frame x patches +
+    patch; the column kernel finds pair q's images at slots q and q + patches; the per-image flags are re-laid per pair for the box-zero
+    rule and the tail). Same kernels, same arithmetic: the video entry must return the pair entry's BITS -- gray and BGR8, unpadded and
+    padded sizes, a constant and a repeated frame in the stream, passes of 3 pairs (MOF_FFT_LARGE_PASS) so that the 10 pairs take four
+    passes of the scratch; and MOF_FFT_LARGE_VIDEO=0 keeps the pair form."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _LARGE_VIDEO_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
+    for env in ({"MOF_FFT_LARGE_PASS": "3"}, {}, {"MOF_FFT_LARGE_VIDEO": "0"}):
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "large video ok 8" in r.stdout, (env, r.stdout[-1500:], r.stderr[-2500:])
 
 
 # ---- scaleRotationEstimator at any even resolution (scaleRotationEstimator.cpp:3-32) ----

@@ -84,6 +84,53 @@ for trial in range(n_fft):
                 dump_case(f"fft_{seed}_{trial}_{k}", cur[k], prev[k], n, (gx, gy), (ox, oy), (sx, sy))
                 print("FFT MISMATCH", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), k, p, got[k, p], want64[p],
                       "f32 oracle", want32[p], "peak", diags[p].peak_value, "second", diags[p].second_value)
+# ---- front ends (r06): the BGR8 entry on RANDOM colour frames must give the gray entry's bits on the CV_RGB2GRAY frames (every kernel family
+#      loads four pixels per instruction now), and the long-range mode (quarter-resolution pixels formed in the load, compile-time plans
+#      since r06) the oracle's long-range answer, at random patch sizes
+fe_bad = fe_checked = 0
+rfe = np.random.default_rng(seed + 7919)  # (a generator of its own: the trials of the other sections stay what they were for every seed of the earlier rounds)
+for trial in range(max(6, n_fft // 5)):
+    r = rfe.integers(0, 10)
+    n = int(rfe.choice([32, 64, 120, 128])) if r < 2 else (int(rfe.integers(8, 193)) if r < 8 else int(rfe.integers(193, 260)))
+    gx, gy = (int(rfe.integers(1, 4)), int(rfe.integers(1, 3))) if n <= 135 else (int(rfe.integers(1, 3)), 1)
+    sx, sy = int(rfe.integers(max(1, n // 2), n + 20)), int(rfe.integers(max(1, n // 2), n + 20))
+    ox, oy = int(rfe.integers(0, 7)), int(rfe.integers(0, 7))
+    w = ox + (gx - 1) * sx + n + int(rfe.integers(0, 9))
+    h = oy + (gy - 1) * sy + n + int(rfe.integers(0, 9))
+    bgr_c = rfe.integers(0, 256, (2, h, w + 3, 3), dtype=np.uint8)
+    bgr_p = np.roll(bgr_c, (int(rfe.integers(-4, 5)), int(rfe.integers(-4, 5))), axis=(1, 2))
+    if rfe.integers(0, 4) == 0:
+        bgr_p[1] = (17, 140, 201)  # a constant colour frame against texture
+    fm = FftMethod(sample_point_size=n, frame_shape=(h, w), grid=(gx, gy), origin=(ox, oy), stride=(sx, sy))
+    tc, tp = torch.from_numpy(bgr_c).to(dev)[:, :, :w], torch.from_numpy(bgr_p).to(dev)[:, :, :w]  # (views: a row pitch of 3 (w + 3))
+    got = fm.process_batch_device_bgr(tc, tp).cpu().numpy()
+    gray_c = np.stack([O.rgb2gray(f[:, :w]) for f in bgr_c])
+    gray_p = np.stack([O.rgb2gray(f[:, :w]) for f in bgr_p])
+    same = fm.process_batch_device(torch.from_numpy(gray_c).to(dev), torch.from_numpy(gray_p).to(dev)).cpu().numpy()
+    fe_checked += 1
+    if not np.array_equal(got, same, equal_nan=True):
+        fe_bad += 1
+        print("BGR != GRAY BITS", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), fm.kernel_variant, np.nanmax(np.abs(got - same)))
+for trial in range(max(6, n_fft // 5)):
+    n = int(rfe.choice([32, 64, 120, 128])) if rfe.integers(0, 3) == 0 else int(rfe.integers(8, 161))
+    fs = 4 * n
+    try:
+        flr = FftMethod(fs, n, 80.0)
+    except Exception as e:  # (sizes the long-range mode does not serve are refused at create)
+        print("long-range create refused", n, str(e)[:80])
+        continue
+    k = int(rfe.integers(0, 1000))
+    cur, prev = synth.pair_np(k, fs, fs, int(rfe.integers(-12, 13)), int(rfe.integers(-12, 13)), blur=bool(rfe.integers(0, 2)))
+    out = flr.process_long_range_batch_device(torch.from_numpy(cur[None]).to(dev), torch.from_numpy(prev[None]).to(dev)).cpu().numpy()[0]
+    lay_lr = O.fft_layout(fs, fs, n, 4, 4)
+    want, _ = O.fft_process_long_range(cur, prev, lay_lr, 64)
+    want32, _ = O.fft_process_long_range(cur, prev, lay_lr, 32)
+    fe_checked += 1
+    agree = np.array_equal(np.isnan(want), np.isnan(want32)) and np.allclose(want, want32, rtol=0, atol=PIN, equal_nan=True)
+    if agree and not np.allclose(out, want, rtol=0, atol=TOL, equal_nan=True):
+        fe_bad += 1
+        print("LONG-RANGE MISMATCH", trial, n, out, want, want32)
+print(f"front ends: {fe_checked} trials (BGR8 = gray bits on random colour frames; long-range mode against the oracle), mismatches {fe_bad}")
 print(f"fft: {checked}/{total} patches with a stable arg-max within 1e-4 px of both oracles (+ {soft} held to a bar relaxed by their inputs, "
       f"{unpinned} unpinned by their inputs: integer peak only), mismatches {bad}")
 sr_bad = 0
@@ -188,4 +235,4 @@ if os.environ.get("MOF_FUZZ_RECORDS"):
     import json
     with open(os.environ["MOF_FUZZ_RECORDS"], "w") as f:
         json.dump(rel, f, indent=1)
-sys.exit(1 if bad or sr_bad or seq_bad else 0)
+sys.exit(1 if bad or sr_bad or seq_bad or fe_bad else 0)

@@ -18,7 +18,7 @@ mkdir -p $LOGS
 rc=0
 for s in $SEEDS; do
   MOF_FUZZ_RECORDS=$LOGS/records_$s.json python3 $R/tools/fft_sr_fuzz.py $s $TRIALS 12 > $LOGS/fft_sr_$s.log 2>&1; r1=$?
-  echo "seed $s  fft_sr rc=$r1 | $(grep -E '^fft:' $LOGS/fft_sr_$s.log | head -1) | $(grep -E '^sr:|estimator' $LOGS/fft_sr_$s.log | head -1) | $(grep -E '^sequence modes' $LOGS/fft_sr_$s.log | head -1)" >> $OUT
+  echo "seed $s  fft_sr rc=$r1 | $(grep -E '^fft:' $LOGS/fft_sr_$s.log | head -1) | $(grep -E '^sr:|estimator' $LOGS/fft_sr_$s.log | head -1) | $(grep -E '^sequence modes' $LOGS/fft_sr_$s.log | head -1) | $(grep -E '^front ends' $LOGS/fft_sr_$s.log | head -1)" >> $OUT
   grep -E "MISMATCH" $LOGS/fft_sr_$s.log | head -5 | sed 's/^/    /' >> $OUT
   grep -E "^off the plain bar" $LOGS/fft_sr_$s.log | sed 's/^/    /' >> $OUT
   [ $r1 -ne 0 ] && rc=1
