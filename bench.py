@@ -170,6 +170,9 @@ WORKLOADS = {
     "l196": dict(kind="fft", h=480, w=480, n=196, grid=(2, 2), origin=(0, 0), stride=(200, 200), batch=512, s=15,
                  name="l196: FftMethod 480x480, 2x2 grid of 196x196 patches zero-padded to 200 (r06: the tuned transforms with the row kernel padding and the box-zero rule), batch=512 per GPU",
                  bytes_per_pair=2 * 4 * 196 * 196 + 4 * 8),
+    "l320": dict(kind="fft", h=640, w=640, n=320, grid=(2, 2), origin=(0, 0), stride=(320, 320), batch=256, s=15,
+                 name="l320: FftMethod 640x640, 2x2 grid of 320x320 patches (r06: tuned transforms 16 x 20), batch=256 per GPU",
+                 bytes_per_pair=2 * 640 * 640 + 4 * 8),
     "l240": dict(kind="fft", h=480, w=480, n=240, grid=(2, 2), origin=(0, 0), stride=(240, 240), batch=512, s=15,
                  name="l240: FftMethod 480x480, 2x2 grid of 240x240 patches (transform size 240), batch=512 per GPU",
                  bytes_per_pair=2 * 480 * 480 + 4 * 8),

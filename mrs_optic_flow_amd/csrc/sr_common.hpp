@@ -42,6 +42,20 @@ struct SrPlan<200> {
   static constexpr int R1 = 10, R2 = 20, Y2 = 21, LINE = MOF_SR_LINE200;
   static_assert(LINE >= R1 * Y2, "the padded stage-1 output fits a line");
 };
+// ... and 288 = 16 x 18, 320 = 16 x 20, 384 = 12 x 32 (r06): with the zero padding of the row kernel these serve patches of 271 .. 288, 301 .. 320 and
+// 376 .. 384 pixels as well (every radix pair keeps the Nyquist bin of a line free of twiddles: k1 = 0, k2 = R2 / 2)
+template <>
+struct SrPlan<288> {
+  static constexpr int R1 = 16, R2 = 18, Y2 = 19, LINE = 305;
+};
+template <>
+struct SrPlan<320> {
+  static constexpr int R1 = 16, R2 = 20, Y2 = 21, LINE = 337;
+};
+template <>
+struct SrPlan<384> {
+  static constexpr int R1 = 12, R2 = 32, Y2 = 33, LINE = 397;
+};
 template <>
 struct SrPlan<216> {  // 12 x 18: three lines per stage-1 pass (54 of 64 lanes), twelve of sixteen lanes per line in stage 2
   static constexpr int R1 = 12, R2 = 18, Y2 = 19, LINE = 229;
