@@ -53,6 +53,10 @@ struct SrPlan<320> {
   static constexpr int R1 = 16, R2 = 20, Y2 = 21, LINE = 337;
 };
 template <>
+struct SrPlan<360> {  // 15 x 24 (patches of 325 .. 360 pixels): 45 one-wave row workgroups per image, 180 row pairs = 22 candidate workgroups of 8 lines and one of 4
+  static constexpr int R1 = 15, R2 = 24, Y2 = 25, LINE = 377;
+};
+template <>
 struct SrPlan<384> {
   static constexpr int R1 = 12, R2 = 32, Y2 = 33, LINE = 397;
 };
@@ -120,10 +124,15 @@ __device__ __forceinline__ void butterfly18(cf* v) {  // 9 x 2, decimation in ti
     v[k1 + 9] = {a[k1].x - t.x, a[k1].y - t.y};
   }
 }
+__device__ __forceinline__ void butterfly24(cf* v) {  // 3 x 8 (pc_plan.hpp: butterfly_ct), twiddles W_24^j; bin 12 = (k1 = 0, k2 = 4) passes no twiddle
+  const cf w[15] = {{1.00000000000000000000f, -0.00000000000000000000f}, {0.96592582628906831221f, -0.25881904510252073948f}, {0.86602540378443870761f, -0.49999999999999994449f}, {0.70710678118654757274f, -0.70710678118654746172f}, {0.50000000000000011102f, -0.86602540378443859659f}, {0.25881904510252073948f, -0.96592582628906831221f}, {0.00000000000000006123f, -1.00000000000000000000f}, {-0.25881904510252062845f, -0.96592582628906831221f}, {-0.49999999999999977796f, -0.86602540378443870761f}, {-0.70710678118654746172f, -0.70710678118654757274f}, {-0.86602540378443870761f, -0.49999999999999994449f}, {-0.96592582628906820119f, -0.25881904510252101703f}, {-1.00000000000000000000f, -0.00000000000000012246f}, {-0.96592582628906831221f, 0.25881904510252079499f}, {-0.86602540378443881863f, 0.49999999999999972244f}};
+  butterfly_ct<3, 8>(v, w);
+}
 template <int R>
 __device__ __forceinline__ void bfly(cf* v) {
   if constexpr (R == 15) butterfly15(v);
   else if constexpr (R == 32) butterfly32(v);
+  else if constexpr (R == 24) butterfly24(v);
   else if constexpr (R == 20) butterfly20(v);
   else if constexpr (R == 18) butterfly18(v);
   else if constexpr (R == 12) butterfly12(v);

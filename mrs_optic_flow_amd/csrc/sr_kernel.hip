@@ -889,6 +889,7 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
     case 256: return launch_sr_rows_inv_n<256>(a, n_pairs, stream);
     case 288: return launch_sr_rows_inv_n<288>(a, n_pairs, stream);
     case 320: return launch_sr_rows_inv_n<320>(a, n_pairs, stream);
+    case 360: return launch_sr_rows_inv_n<360>(a, n_pairs, stream);
     case 384: return launch_sr_rows_inv_n<384>(a, n_pairs, stream);
     case 480: return launch_sr_rows_inv_n<480>(a, n_pairs, stream);
     default: return hipErrorInvalidValue;
