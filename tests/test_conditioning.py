@@ -98,6 +98,14 @@ def test_check_patch_rules():
     # off the fast path without pixels: refused
     with pytest.raises(AssertionError):
         tolerances.check_patch(w64[p], w64[p], w32[p], "t", p)
+    # the two oracles further apart than the ceiling on a patch whose libraries do not scatter (simulated: the analysis of the ordinary neighbour):
+    # the kernel is held to EITHER restatement -- next to the f64 one passes, between the two fails
+    del tolerances.RECORDS[:]
+    far = w64[q] + 5e-3
+    assert tolerances.check_patch(w64[q] + 2e-6, w64[q], far, "t", q, pixels=tolerances.patch_pixels(g["cur"], g["prev"], lay, q)) is True
+    assert tolerances.RECORDS[-1]["rule"] == "oracles apart: held to either" and tolerances.RECORDS[-1]["bar_px"] <= 2e-4
+    with pytest.raises(AssertionError):
+        tolerances.check_patch(w64[q] + 2.5e-3, w64[q], far, "t", q, pixels=tolerances.patch_pixels(g["cur"], g["prev"], lay, q))
     # the session bounds: one unpinned patch outside the mechanism tests is tolerated, two are not
     del tolerances.RECORDS[:]
     tolerances.check_patch(w32[p], w64[p], w32[p], "somewhere/a", p, pixels=px)

@@ -20,7 +20,9 @@ oracle). The rule:
 i.e. a kernel may be as far from either oracle as correct f32 transforms demonstrably are from the truth on that input (x 2: six samples
 under-estimate a tail), and no further than 1e-3 px; where independent f32 libraries themselves scatter beyond that, the reference's
 arithmetic pins nothing (which f32 answer OpenCV's radix order gives cannot be known here: OpenCV is absent) and only the integer peak
-is asserted. What the table of records shows (profiles/r06_f32_limited.json): the exact-zero-bin patches split the libraries -- on
+is asserted. One more case exists: the two ORACLES themselves further apart than the ceiling allows (1e-4 + 2 dd > 1e-3) on a patch whose
+libraries do not scatter that far -- then no answer satisfies both, and the kernel is held to EITHER restatement at the bar of its inputs
+(rule "oracles apart: held to either"; it never occurred in the test suite, the large-band fuzz met it twice). What the table of records shows (profiles/r06_f32_limited.json): the exact-zero-bin patches split the libraries -- on
 fs480/n48 #89 pocketfft cancels both bins and lands 2e-8 px from f64 while torch.fft and the f32 oracle land 1e-3 / 8e-4 px away, on
 fs480/n60 #22 pocketfft 9e-7, torch 3e-4 .. 7e-4 -- so "any f32 order is that far off" (the r05 text) was wrong: SOME orders are exact there and
 some are not, and that is precisely why the patch is unpinned. Every patch that leaves the fast path is recorded with all columns;
@@ -75,6 +77,16 @@ def check_patch(got, want64, want32, label, patch, pixels=None, what="kernel"):
     if unpinned:
         assert e32 <= 0.25 and e64 <= 0.25, (label, patch, what, got, want32, want64, info)  # the integer peak still agrees
         return False
+    if TOL + SPREAD_FACTOR * dd > CEILING:
+        # The two ORACLES are further apart than the ceiling lets a kernel be from both (found by the large-band fuzz, seed 901: a constant
+        # frame against texture at 363 -> 375; f32 oracle 5.3e-3 px from the f64 one, kernel 2e-6 px from the f64 one, the libraries of
+        # that box within 4.5e-4): no answer can satisfy both. The kernel must agree with ONE of the two restatements at the bar its
+        # inputs give, and with both on the integer peak.
+        bar_in = min(TOL + max(SPREAD_FACTOR * info["spread_px"], info["zero_bin_px"] if 0 < info["zero_bins"] <= ZERO_BINS_FEW else 0.0), CEILING)
+        RECORDS[-1]["rule"] = "oracles apart: held to either"
+        RECORDS[-1]["bar_px"] = bar_in
+        assert min(e32, e64) <= bar_in and e32 <= 0.25 and e64 <= 0.25, (label, patch, what, got, want32, want64, dd, bar_in, info)
+        return True
     assert e32 <= bar and e64 <= bar, (label, patch, what, got, want32, want64, dd, bar, info)
     return True
 

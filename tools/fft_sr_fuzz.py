@@ -47,6 +47,7 @@ def dump_case(tag, cur_f, prev_f, n, grid, origin, stride):
     np.savez_compressed(os.path.join(out, f"fuzz_fail_{tag}.npz"), cur=cur_f, prev=prev_f, n=n, grid=grid, origin=origin, stride=stride)
 
 
+LARGE_BAND = os.environ.get("MOF_FUZZ_LARGE", "") not in ("", "0")
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n_fft = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 n_sr = int(sys.argv[3]) if len(sys.argv) > 3 else 12
@@ -56,6 +57,8 @@ bad = checked = total = soft = unpinned = 0
 for trial in range(n_fft):
     r = rng.integers(0, 10)
     n = int(rng.choice([32, 64, 64, 120, 128, 240, 256])) if r < 4 else (int(rng.integers(8, 201)) if r < 9 else int(rng.integers(136, 301)))
+    if LARGE_BAND:  # MOF_FUZZ_LARGE=1: the band the tuned large-patch kernels serve since r06 (padded sides 200 .. 384 and what lies between them)
+        n = int(rng.integers(193, 401))
     gx, gy = (int(rng.integers(1, 6)), int(rng.integers(1, 5))) if n <= 135 else (int(rng.integers(1, 3)), int(rng.integers(1, 3)))
     sx, sy = int(rng.integers(max(1, n // 3), n + 40)), int(rng.integers(max(1, n // 3), n + 40))
     ox, oy = int(rng.integers(0, 9)), int(rng.integers(0, 9))
@@ -170,6 +173,8 @@ print(f"sr: {n_sr} settings, mismatches {sr_bad}")
 seq_bad = seq_checked = 0
 for trial in range(max(4, n_fft // 4)):
     n = int(rng.choice([32, 64, 64, 120, 128, 128, 240, 256])) if rng.integers(0, 2) else int(rng.integers(8, 180))
+    if LARGE_BAND:
+        n = int(rng.integers(193, 391))
     gx, gy = (int(rng.integers(1, 4)), int(rng.integers(1, 4))) if n <= 135 else (1, int(rng.integers(1, 3)))
     sx, sy = int(rng.integers(max(1, n // 3), n + 30)), int(rng.integers(max(1, n // 3), n + 30))
     ox, oy = int(rng.integers(0, 9)), int(rng.integers(0, 9))
