@@ -796,8 +796,32 @@ def self_launch(n_ranks: int) -> int:
     return rc
 
 
+_JSON_FD = None
+
+
+def quiet_stdout() -> None:
+    """From here on file descriptor 1 is stderr for everybody (RCCL prints a five-line version banner to stdout when a communicator is
+    built -- ncclCommInitAll of the native group, the first collective of torch.distributed); the ONE JSON line of the contract goes to the
+    saved descriptor (emit)."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line) -> None:
+    data = (json.dumps(line) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def main_native(args) -> None:
     """`bench.py --native --gpus N`: the contract's JSON line, measured through the native shard group (no torch.distributed)."""
+    quiet_stdout()
     import torch
 
     if not torch.cuda.is_available():
@@ -818,7 +842,7 @@ def main_native(args) -> None:
     if not args.share_gpu:  # (G shards on one device time G batches on one GPU: no roofline of ONE launch to state)
         line["roofline"] = roofline_block(args.workload, wl, wl["batch"], kern_ms)
         line["roofline"]["kernel_ms_note"] = "slowest device's step by HIP events on its shard stream (kernel + its leg of the gather)"
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 def main() -> None:
@@ -854,6 +878,7 @@ def main() -> None:
         # imported torch or loaded the library yet), starts N fresh rank processes of this same script and relays rank 0's line.
         raise SystemExit(self_launch(args.gpus))
 
+    quiet_stdout()
     import torch
     import torch.distributed as dist
 
@@ -1000,7 +1025,7 @@ def main() -> None:
                                        for tag, st in (("c3", 50), ("c4", 20), ("c5", 40), ("c2seq", 50), ("c4seq", 10), ("c5seq", 40), ("ref", 50), ("refseq", 50),
                                                        ("bmref", 50), ("refrt", 50), ("reflr", 50),
                                                        ("p60", 50), ("l160", 40), ("l200", 20), ("l240", 20), ("l480", 20))}  # the planned kernel, the half-tile kernel (r05), the large-patch pipeline
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

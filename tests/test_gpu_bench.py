@@ -67,6 +67,8 @@ def _bench(*argv, env=None, timeout=900):
     assert r.returncode == 0, (argv, r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    # the contract's stdout is ONE JSON line: RCCL's version banner (printed to stdout when a communicator is built) must not be on it
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout[:1500]
     return json.loads(lines[0])
 
 
