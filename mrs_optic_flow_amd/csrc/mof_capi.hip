@@ -202,11 +202,11 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
   // L5 / L6 / L7 -- same Zh / Dt / candidate formats, 2.5 x faster; L8 (the FftMethod tail) stays. Gray and BGR8 frames alike (the
   // latter promise the gray path's bits); the long-range mode keeps the planned kernels. MOF_FFT_LARGE_TUNED=0: planned kernels (A/B).
   static const bool tuned_on = [] { const char* v = getenv("MOF_FFT_LARGE_TUNED"); return !v || atoi(v) != 0; }();
-  // r06: 200, 216, 288, 320, 384 too, and patches that PAD to one of these sizes (193 .. 216, 226 .. 240, 251 .. 256, 271 .. 288, 301 .. 320, 325 .. 360, 376 .. 384,
+  // r06: 200, 216, 270, 288, 300, 320, 360, 384, 450 too, and patches that PAD to one of these sizes (193 .. 216, 226 .. 240, 251 .. 256, 271 .. 288, 301 .. 320, 325 .. 360, 376 .. 384,
   // 451 .. 480): the row kernel
   // zero-pads, the column kernel applies the box-zero rule of padded constant patches from the row kernel's flags
-  const bool tuned = tuned_on && a.downscale == 1 && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 288 || e->plan.m == 320 || e->plan.m == 360 ||
-                                                            e->plan.m == 384 || e->plan.m == 480);
+  const bool tuned = tuned_on && a.downscale == 1 && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 270 || e->plan.m == 288 || e->plan.m == 300 || e->plan.m == 320 || e->plan.m == 360 ||
+                                                            e->plan.m == 384 || e->plan.m == 450 || e->plan.m == 480);
   // r06, a VIDEO on the tuned transforms (pair k = (frame k + 1, frame k): mof_fft_process_sequence_device, or any caller whose cur = prev + one frame):
   // every frame's row spectra are formed ONCE per pass -- Zh slot = frame * patches + patch, so pair q = k * patches + patch finds its previous
   // image at slot q and its current one at slot q + patches, which is exactly what the column kernel's (zh_prev, zh_cur, stride) takes; the

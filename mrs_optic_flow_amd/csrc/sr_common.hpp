@@ -52,6 +52,20 @@ template <>
 struct SrPlan<320> {
   static constexpr int R1 = 16, R2 = 20, Y2 = 21, LINE = 337;
 };
+// ... and the sizes whose rows are not whole 8-row waves (RowsReal<N>::TAIL; K7 has its own tail): 270 = 15 x 18, 300 = 15 x 20, 450 = 15 x 30
+// (patches of 257 .. 270, 289 .. 300, 433 .. 450 with the padding)
+template <>
+struct SrPlan<270> {
+  static constexpr int R1 = 15, R2 = 18, Y2 = 19, LINE = 285;
+};
+template <>
+struct SrPlan<300> {
+  static constexpr int R1 = 15, R2 = 20, Y2 = 21, LINE = 315;
+};
+template <>
+struct SrPlan<450> {
+  static constexpr int R1 = 15, R2 = 30, Y2 = 31, LINE = 465;
+};
 template <>
 struct SrPlan<360> {  // 15 x 24 (patches of 325 .. 360 pixels): 45 one-wave row workgroups per image, 180 row pairs = 22 candidate workgroups of 8 lines and one of 4
   static constexpr int R1 = 15, R2 = 24, Y2 = 25, LINE = 377;
@@ -124,6 +138,23 @@ __device__ __forceinline__ void butterfly18(cf* v) {  // 9 x 2, decimation in ti
     v[k1 + 9] = {a[k1].x - t.x, a[k1].y - t.y};
   }
 }
+__device__ __forceinline__ void butterfly30(cf* v) {  // 15 x 2, decimation in time (as butterfly18): bin 15 = sum(even) - sum(odd), no twiddle
+  const cf w[15] = {{1.00000000000000000000f, -0.00000000000000000000f}, {0.97814760073380568883f, -0.20791169081775931482f}, {0.91354545764260086660f, -0.40673664307580015276f}, {0.80901699437494745126f, -0.58778525229247313710f}, {0.66913060635885823757f, -0.74314482547739413310f}, {0.50000000000000011102f, -0.86602540378443859659f}, {0.30901699437494745126f, -0.95105651629515353118f}, {0.10452846326765345697f, -0.99452189536827328986f}, {-0.10452846326765333207f, -0.99452189536827340088f}, {-0.30901699437494734024f, -0.95105651629515364220f}, {-0.49999999999999977796f, -0.86602540378443870761f}, {-0.66913060635885790450f, -0.74314482547739446616f}, {-0.80901699437494734024f, -0.58778525229247324813f}, {-0.91354545764260097762f, -0.40673664307580004174f}, {-0.97814760073380568883f, -0.20791169081775931482f}};
+  cf a[15], b[15];
+#pragma unroll
+  for (int n1 = 0; n1 < 15; ++n1) {
+    a[n1] = v[2 * n1];
+    b[n1] = v[2 * n1 + 1];
+  }
+  butterfly15(a);
+  butterfly15(b);
+#pragma unroll
+  for (int k1 = 0; k1 < 15; ++k1) {
+    const cf t = k1 == 0 ? b[0] : cmul(b[k1], w[k1]);
+    v[k1] = {a[k1].x + t.x, a[k1].y + t.y};
+    v[k1 + 15] = {a[k1].x - t.x, a[k1].y - t.y};
+  }
+}
 __device__ __forceinline__ void butterfly24(cf* v) {  // 3 x 8 (pc_plan.hpp: butterfly_ct), twiddles W_24^j; bin 12 = (k1 = 0, k2 = 4) passes no twiddle
   const cf w[15] = {{1.00000000000000000000f, -0.00000000000000000000f}, {0.96592582628906831221f, -0.25881904510252073948f}, {0.86602540378443870761f, -0.49999999999999994449f}, {0.70710678118654757274f, -0.70710678118654746172f}, {0.50000000000000011102f, -0.86602540378443859659f}, {0.25881904510252073948f, -0.96592582628906831221f}, {0.00000000000000006123f, -1.00000000000000000000f}, {-0.25881904510252062845f, -0.96592582628906831221f}, {-0.49999999999999977796f, -0.86602540378443870761f}, {-0.70710678118654746172f, -0.70710678118654757274f}, {-0.86602540378443870761f, -0.49999999999999994449f}, {-0.96592582628906820119f, -0.25881904510252101703f}, {-1.00000000000000000000f, -0.00000000000000012246f}, {-0.96592582628906831221f, 0.25881904510252079499f}, {-0.86602540378443881863f, 0.49999999999999972244f}};
   butterfly_ct<3, 8>(v, w);
@@ -132,6 +163,7 @@ template <int R>
 __device__ __forceinline__ void bfly(cf* v) {
   if constexpr (R == 15) butterfly15(v);
   else if constexpr (R == 32) butterfly32(v);
+  else if constexpr (R == 30) butterfly30(v);
   else if constexpr (R == 24) butterfly24(v);
   else if constexpr (R == 20) butterfly20(v);
   else if constexpr (R == 18) butterfly18(v);

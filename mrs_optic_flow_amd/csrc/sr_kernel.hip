@@ -887,6 +887,9 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
     case 216: return launch_sr_rows_inv_n<216>(a, n_pairs, stream);
     case 240: return launch_sr_rows_inv_n<240>(a, n_pairs, stream);
     case 256: return launch_sr_rows_inv_n<256>(a, n_pairs, stream);
+    case 270: return launch_sr_rows_inv_n<270>(a, n_pairs, stream);
+    case 300: return launch_sr_rows_inv_n<300>(a, n_pairs, stream);
+    case 450: return launch_sr_rows_inv_n<450>(a, n_pairs, stream);
     case 288: return launch_sr_rows_inv_n<288>(a, n_pairs, stream);
     case 320: return launch_sr_rows_inv_n<320>(a, n_pairs, stream);
     case 360: return launch_sr_rows_inv_n<360>(a, n_pairs, stream);

@@ -40,7 +40,9 @@ namespace {
 template <int N>
 struct RowsReal {
   static constexpr int ROWS = (N % 32 == 0 && MOF_K5S_ROWS32) ? 32 : (N % 16 == 0 ? 16 : 8);  // (200: 25 one-wave workgroups of 8 rows per image)
-  static_assert(N % ROWS == 0 && ROWS % 8 == 0, "whole workgroups of four-line waves");
+  static constexpr bool TAIL = N % ROWS != 0;  // (270, 300, 450: the last one-wave workgroup holds 3, 2 or 1 row pairs; the rest of its lines are zeros and are not stored)
+  static_assert((N % ROWS == 0 || ROWS == 8) && ROWS % 8 == 0 && N % 2 == 0, "whole workgroups of four-line waves, a tail only behind one-wave workgroups");
+  static constexpr int GROUPS = (N + ROWS - 1) / ROWS;
   static constexpr int LINES = ROWS / 2;
   static constexpr int T = LINES * 16;
 };
@@ -124,10 +126,14 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
   tw.load(twiddles, lane);
   // r06: n < N -- a patch that cv::phaseCorrelate zero-pads to this transform size (copyMakeBorder): rows and columns beyond n are zeros
   // and take no part in the constant-image test (`inside`)
+  // EDGE: some chunk of some line may lie (partly) outside the pixels to read -- a padded patch, a row length that is not a multiple of
+  // four (270, 450: the last chunk of a row holds two pixels), or the zero lines behind the image in the last workgroup (RowsReal::TAIL)
+  constexpr bool EDGE = PAD || (N % 4 != 0) || R::TAIL;
+  const int ne = PAD ? n : N;
   auto px4 = [&](int y, int d) -> uint32_t {  // pixels 4d .. 4d+3 of patch row y, one byte each
-    if (PAD && (y >= n || 4 * d >= n)) return 0u;
+    if (EDGE && (y >= ne || 4 * d >= ne)) return 0u;
     const uint8_t* r = base + (size_t)y * src.pitch + (size_t)CH * 4 * d;
-    if (!PAD || 4 * d + 3 < n) {
+    if (!EDGE || 4 * d + 3 < ne) {
       if constexpr (CH == 1) {
         uint32_t v;
         __builtin_memcpy(&v, r, 4);  // (any alignment: the patch origin and the pitch are the caller's)
@@ -140,19 +146,19 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
       }
     }
     uint32_t v = 0;  // the last chunk of a row whose length is not a multiple of four
-    for (int b = 0; 4 * d + b < n; ++b) v |= (CH == 1 ? (uint32_t)r[b] : rgb2gray_fixed(r[3 * b], r[3 * b + 1], r[3 * b + 2])) << (8 * b);
+    for (int b = 0; 4 * d + b < ne; ++b) v |= (CH == 1 ? (uint32_t)r[b] : rgb2gray_fixed(r[3 * b], r[3 * b + 1], r[3 * b + 2])) << (8 * b);
     return v;
   };
   auto inside = [&](int y, int d) -> uint32_t {  // byte mask of the chunk's pixels that lie inside the n x n patch
-    if (!PAD) return 0xffffffffu;
-    if (y >= n || 4 * d >= n) return 0u;
-    return 4 * d + 3 < n ? 0xffffffffu : (1u << (8 * (n - 4 * d))) - 1u;
+    if (!EDGE) return 0xffffffffu;
+    if (y >= ne || 4 * d >= ne) return 0u;
+    return 4 * d + 3 < ne ? 0xffffffffu : (1u << (8 * (ne - 4 * d))) - 1u;
   };
   const uint32_t p00 = px4(0, 0) & 0xffu, pat = p00 * 0x01010101u;
   uint32_t diff = 0u;
   cf* mine = z + 4 * wave * P::LINE;
   {
-    constexpr int ND = N / 4, NL = (4 * ND + 63) / 64;
+    constexpr int ND = (N + 3) / 4, NL = (4 * ND + 63) / 64;  // (N = 270, 450: the last chunk of a row is half full)
     uint32_t c[NL], p[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
@@ -185,6 +191,7 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
   cf* out = reinterpret_cast<cf*>(zh + (size_t)img * zh_stride) + row0;
   for (int i = tid; i < R::LINES * (H + 1); i += R::T) {
     const int u = i / R::LINES, j = i % R::LINES;
+    if (R::TAIL && row0 + 2 * j >= N) continue;
     const cf zk = z[j * P::LINE + u], zm = z[j * P::LINE + (N - u) % N];
     cf a2, b2;
     untangle2(zk, zm, &a2, &b2);
@@ -472,7 +479,7 @@ hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh,
     if (f0 % per_unit != 0) return hipErrorInvalidValue;  // (the caller splits at whole frames / frame pairs: mof_capi.hip)
     s.base[0] += (size_t)(f0 / per_unit) * src.stride[0];
     if (src.paired != 2) s.base[1] += (size_t)(f0 / per_unit) * src.stride[1];
-    const dim3 g(N / R::ROWS, (unsigned)nf), b(R::T);
+    const dim3 g(R::GROUPS, (unsigned)nf), b(R::T);
     float* zo = zh + (size_t)f0 * zh_stride;
     int* fl = flags ? flags + f0 : nullptr;
     if (channels == 3) {
@@ -533,6 +540,9 @@ hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, flo
     case 216: return launch_rows_real_src_n<216>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     case 240: return launch_rows_real_src_n<240>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     case 256: return launch_rows_real_src_n<256>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
+    case 270: return launch_rows_real_src_n<270>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
+    case 300: return launch_rows_real_src_n<300>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
+    case 450: return launch_rows_real_src_n<450>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     case 288: return launch_rows_real_src_n<288>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     case 320: return launch_rows_real_src_n<320>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     case 360: return launch_rows_real_src_n<360>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
@@ -555,6 +565,9 @@ hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t 
     case 216: return launch_cols_seq_n<216>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
     case 240: return launch_cols_seq_n<240>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
     case 256: return launch_cols_seq_n<256>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
+    case 270: return launch_cols_seq_n<270>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
+    case 300: return launch_cols_seq_n<300>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
+    case 450: return launch_cols_seq_n<450>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
     case 288: return launch_cols_seq_n<288>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
     case 320: return launch_cols_seq_n<320>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
     case 360: return launch_cols_seq_n<360>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
