@@ -9,13 +9,16 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for L in srbase srl2b; do
   i=0
-  for G in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE WRITE_SIZE"; do
-    MOF_LIB_PATH=$R/tmp_ab/libmof_$L.so rocprofv3 --pmc $G --kernel-include-regex "sr_rows_real_kernel|sr_cols_seq_kernel|sr_rows_inv_kernel" --output-format csv -d $OUT/${L}_g$i -- python3 $R/bench.py --no-cpu-baseline --no-others --sustain-s 0 --workload c5seq --steps 6 --warmup 2 > $OUT/${L}_g$i.log 2>&1 || { tail -5 $OUT/${L}_g$i.log; exit 1; }
+  # (FETCH_SIZE and WRITE_SIZE each in a pass of their own, as MI355X_MICROARCH.md prescribes: together they exceed the hardware's counters,
+  #  rocprofv3 aborts and then waits for a dispatch that never completes; every pass under its own timeout)
+  for G in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+    echo "pass $L: $G"
+    MOF_LIB_PATH=$R/tmp_ab/libmof_$L.so timeout -k 10 240 rocprofv3 --pmc $G --kernel-include-regex "sr_rows_real_kernel|sr_cols_seq_kernel|sr_rows_inv_kernel" --output-format csv -d $OUT/${L}_g$i -- python3 $R/bench.py --no-cpu-baseline --no-others --sustain-s 0 --workload c5seq --steps 6 --warmup 2 > $OUT/${L}_g$i.log 2>&1 || { tail -5 $OUT/${L}_g$i.log; exit 1; }
     i=$((i+1))
   done
 done
 python3 - $OUT > $R/gpurun_out/c5_l2_ablation_tcc.txt <<'PY'
-import csv, glob, sys
+import csv, glob, re, sys
 out = sys.argv[1]
 print("# c5seq, per launch (1024 frames / pairs): product (srbase) against MOF_SR_L2_ABLATE=2 (srl2b: Zh / Dt slots aliased to slot 0, K6s stores no Dt)")
 print(f"{'library':8s} {'kernel':22s} {'TCC_REQ':>12s} {'TCC_HIT':>12s} {'TCC_MISS':>12s} {'hit %':>7s} {'FETCH_SIZE MB':>14s} {'WRITE_SIZE MB':>14s}")
@@ -23,7 +26,8 @@ for L in ("srbase", "srl2b"):
     acc = {}
     for f in glob.glob(f"{out}/{L}_g*/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
+            mk = re.search(r"(sr_\w+_kernel)", row["Kernel_Name"])
+            k = mk.group(1) if mk else row["Kernel_Name"][:40]
             a = acc.setdefault(k, {})
             c = row["Counter_Name"]
             s, n = a.get(c, (0.0, 0))
