@@ -129,8 +129,12 @@ for trial in range(max(6, n_fft // 5)):
     want, _ = O.fft_process_long_range(cur, prev, lay_lr, 64)
     want32, _ = O.fft_process_long_range(cur, prev, lay_lr, 32)
     fe_checked += 1
-    agree = np.array_equal(np.isnan(want), np.isnan(want32)) and np.allclose(want, want32, rtol=0, atol=PIN, equal_nan=True)
-    if agree and not np.allclose(out, want, rtol=0, atol=TOL, equal_nan=True):
+    # the same one rule as everywhere (tests/tolerances.py): the patch the mode correlates is the quarter-resolution image pair (the oracle's
+    # cv::resize restatement), so that is what a patch off the plain bar is classified from (r06 seed 707: n = 50, unblurred texture -- an aliased,
+    # f32-limited surface: oracles 1.9e-5 px apart, kernel 1.03e-4 px from the f64 one)
+    qc, qp = O.resize_quarter(cur), O.resize_quarter(prev)
+    v = judge(out[0], want[0], want32[0], f"fuzz{seed}/longrange{trial}", 0, qc, qp, O.fft_layout(n, n, n, 1, 1))
+    if v == "BAD":
         fe_bad += 1
         print("LONG-RANGE MISMATCH", trial, n, out, want, want32)
 print(f"front ends: {fe_checked} trials (BGR8 = gray bits on random colour frames; long-range mode against the oracle), mismatches {fe_bad}")
