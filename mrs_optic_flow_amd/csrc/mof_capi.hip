@@ -206,7 +206,7 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
   // 451 .. 480): the row kernel
   // zero-pads, the column kernel applies the box-zero rule of padded constant patches from the row kernel's flags
   const bool tuned = tuned_on && a.downscale == 1 && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 270 || e->plan.m == 288 || e->plan.m == 300 || e->plan.m == 320 || e->plan.m == 360 ||
-                                                            e->plan.m == 384 || e->plan.m == 450 || e->plan.m == 480);
+                                                            e->plan.m == 384 || e->plan.m == 450 || e->plan.m == 480 || e->plan.m == 512);
   // r06, a VIDEO on the tuned transforms (pair k = (frame k + 1, frame k): mof_fft_process_sequence_device, or any caller whose cur = prev + one frame):
   // every frame's row spectra are formed ONCE per pass -- Zh slot = frame * patches + patch, so pair q = k * patches + patch finds its previous
   // image at slot q and its current one at slot q + patches, which is exactly what the column kernel's (zh_prev, zh_cur, stride) takes; the

@@ -56,6 +56,7 @@ struct HalfPlan {
   int waves = 0;
   int pitch = 0;
   int skew = 0;  // 1: element x of a line sits at x + (x >> shift) (both layouts); 0 where only the unskewed tile fits (M = 192)
+  int rskew = 0; // r06 (A/B): row skew -- tile row r starts rskew * (r >> 4) complex elements later (pc_plan.hpp: Walk::lrs / ers)
   int shift = 3; // the skew's shift: 4 for the radix-16-first sizes 96 / 128 / 160 (tools/design/half_lanes.py: stage-0 outputs 16 x + p of the
                  // eight butterflies of a line land in eight different banks mod 16 only with x + (x >> 4))
   int lds_bytes = 0;
@@ -63,8 +64,14 @@ struct HalfPlan {
   bool ok = false;
 };
 
-// LDS behind the tile: twiddles (m complex), 16 (value, index) slots, 16 flag words
-constexpr size_t half_extra(int m) { return sizeof(float) * 2 * (size_t)m + 16 * 8 + 64; }
+#ifndef MOF_HALF_RSKEW  // (A/B) the row skew of every instantiation, complex elements per 16 rows; 0 = none (the product)
+#define MOF_HALF_RSKEW 0
+#endif
+constexpr int half_rskew(int m) { return MOF_HALF_RSKEW; }
+// complex elements the row skew adds behind the tile: rskew * ((M - 1) >> 4) for the last row, rounded up
+constexpr int half_rskew_room(int m) { return half_rskew(m) * ((m >> 4) + 1); }
+// LDS behind the tile: the row skew's room, twiddles (m complex), 16 (value, index) slots, 16 flag words
+constexpr size_t half_extra(int m) { return sizeof(float) * 2 * ((size_t)m + half_rskew_room(m)) + 16 * 8 + 64; }
 
 constexpr int half_stage_lines(int m, int R) {  // lines one group of a stage covers (pc_plan.hpp: stage_rt)
   const int bpl = m / R, nb = 16 / pc_slots(R);
@@ -206,6 +213,7 @@ constexpr HalfPlan half_plan(int m) {
     }
   }
   hp.skew = skew;
+  hp.rskew = half_rskew(m);
   hp.pitch = p;
   hp.lds_bytes = (int)((size_t)H * p * 8 + half_extra(m));
   int wgs = (int)(cap / (size_t)hp.lds_bytes);
@@ -265,9 +273,10 @@ struct HalfScanSink {
 struct HalfRawSrc {
   static constexpr bool active = true;
   int pitch;  // complex elements per line
+  int rs;     // row skew (complex elements per 8 lines)
   __device__ __forceinline__ cf operator()(const cf* z, int l, int e) const {
     typedef const volatile uint16_t __attribute__((address_space(3))) * lds_u16_ptr;
-    const uint32_t ab = *(lds_u16_ptr)(reinterpret_cast<const unsigned char*>(z + l * pitch) + 2 * e);
+    const uint32_t ab = *(lds_u16_ptr)(reinterpret_cast<const unsigned char*>(z + l * pitch + rs * (l >> 3)) + 2 * e);
     return {(float)(ab & 0xffu), (float)(ab >> 8)};
   }
 };
@@ -279,11 +288,11 @@ struct HalfRawSrc {
 #endif
 struct HalfPairSrc {
   static constexpr bool active = true;
-  int p2, m, skm, sh;
+  int p2, m, skm, sh, rs;
   __device__ __forceinline__ cf operator()(const cf* z, int l, int e) const {
     const int H = m >> 1;
     const int u = e < H ? e : (e == H ? 0 : m - e);
-    const int o = u + ((u >> sh) & skm);
+    const int o = u + ((u >> sh) & skm) + rs * (l >> 3);  // (rows 2l and 2l + 1 share (2l) >> 4 = l >> 3)
     const cf d1 = lds_read(&z[(2 * l) * p2 + o]), d2 = lds_read(&z[(2 * l + 1) * p2 + o]);
     if (e == 0) return {d1.x, d2.x};
     if (e == H) return {d1.y, d2.y};
@@ -302,9 +311,9 @@ struct HalfPairSrc {
 #endif
 struct HalfUntangleSrc {
   static constexpr bool active = true;
-  int p, m, skm, sh;
+  int p, m, skm, sh, rs;
   __device__ __forceinline__ cf operator()(const cf* z, int l, int e) const {  // column l, row e
-    const cf* line = z + (e >> 1) * p;
+    const cf* line = z + (e >> 1) * p + rs * (e >> 4);
     const int H = m >> 1, um = l == 0 ? H : m - l;
     const cf zk = lds_read(&line[l + ((l >> sh) & skm)]), zm = lds_read(&line[um + ((um >> sh) & skm)]);
     cf A, B;
@@ -380,7 +389,8 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   constexpr int M = MS, H = M / 2, P = HP.pitch, P2 = P / 2, T = SP::T, WAVES = HP.waves, LPW = HP.lpw;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   cf* z = reinterpret_cast<cf*>(smem_h);
-  cf* tw = z + (size_t)H * P;
+  constexpr int RSK = HP.rskew;
+  cf* tw = z + (size_t)H * P + half_rskew_room(M);
   Best* red = reinterpret_cast<Best*>(tw + M);
   int* flags = reinterpret_cast<int*>(red + 16);  // [0] cur differs from its first pixel, [1] prev does, [2] C_dc bits, [3] / [4] first pixel of cur / prev
   int tid = threadIdx.x, lane = tid & 63;  // (not const: the sequence form hides them from the optimiser once per pair, below)
@@ -391,8 +401,8 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   // lines 0 2 1 3 in the later row stages where two lines of a 32-lane read half overlap in the banks: neighbouring lines P complex = 2 P
   // dwords apart, a line's 16 complex = 32 dwords -- conflict-free iff 2 P = 32 (mod 64); lines two apart: 4 P = 32 (mod 64) iff P = 8 (mod 16)
   constexpr int HALF_LINE_PERM = ((2 * P) % 64 != 32 && (4 * P) % 64 == 32) ? 1 : 0;
-  auto rows_at = [&](int j, int x) -> int { return j * P + x + ((x >> SH) & SKM); };
-  auto spec_at = [&](int r, int u) -> int { return r * P2 + u + ((u >> SH) & SKM); };
+  auto rows_at = [&](int j, int x) -> int { return j * P + RSK * (j >> 3) + x + ((x >> SH) & SKM); };
+  auto spec_at = [&](int r, int u) -> int { return r * P2 + RSK * (r >> 4) + u + ((u >> SH) & SKM); };
 
   // ---- patch origin (one workgroup per patch on a 3-D grid: column, row, pair)
   const int px0 = a.origin_x + (int)blockIdx.x * a.stride_x, py0 = a.origin_y + (int)blockIdx.y * a.stride_y;
@@ -422,7 +432,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
   // wave w owns lines [l0, l0 + nl): row pairs in the row passes, columns in the column passes
   const int l0 = wave * LPW;
   const int nl = H - l0 < 0 ? 0 : (H - l0 > LPW ? LPW : H - l0);
-  const Walk rows = {P, 1, 0, SKM, 0, HALF_LINE_PERM, SH}, cols = {1, P2, SKM, 0, 1, 0, SH};
+  const Walk rows = {P, 1, 0, SKM, 0, HALF_LINE_PERM, SH, RSK, 0}, cols = {1, P2, SKM, 0, 1, 0, SH, 0, RSK};
 
   auto px_gray = [&](const uint8_t* q) -> uint32_t {  // four pixels -> four gray bytes
     if constexpr (CH == 1) {
@@ -510,7 +520,8 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
         d.x = __builtin_amdgcn_perm(vb, va, 0x05010400u);
         d.y = __builtin_amdgcn_perm(vb, va, 0x07030602u);
         const uint32_t lds0 = (uint32_t)((l0 + li0) * (P * 8) + 8 * xc0);
-        *(lds_u2_ptr)(reinterpret_cast<unsigned char*>(z) + (lds0 + (uint32_t)(DL * (P * 8) + 8 * DX) + (wrap ? (uint32_t)(P * 8 - 8 * CPR) : 0u))) = d;
+        const uint32_t rsb = RSK != 0 ? (uint32_t)(8 * RSK * ((l0 + li) >> 3)) : 0u;  // (the row skew of line l0 + li)
+        *(lds_u2_ptr)(reinterpret_cast<unsigned char*>(z) + (lds0 + rsb + (uint32_t)(DL * (P * 8) + 8 * DX) + (wrap ? (uint32_t)(P * 8 - 8 * CPR) : 0u))) = d;
       }
     } else {
       const int q = lane + 64 * k, li = q / CPR, x0 = 4 * (q % CPR), y = 2 * (l0 + li);
@@ -520,7 +531,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
           if (y < n) *diff |= (va ^ pat) & inside;
           if (y + 1 < n) *diff |= (vb ^ pat) & inside;
         }
-        cf* line = z + (l0 + li) * P;
+        cf* line = z + (l0 + li) * P + RSK * ((l0 + li) >> 3);
         if constexpr (MOF_HALF_RAW) {
           u2 d;
           d.x = __builtin_amdgcn_perm(vb, va, 0x05010400u);
@@ -542,7 +553,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
     if (tid == 0) flags[3 + which] = (int)first;
     wave_sync();
     if (nl > 0 && MOF_HABL != 1) {
-      if constexpr (MOF_HALF_RAW) pass_lines_static<SP, 0, 1, NoSink, HalfRawSrc>(z, tw, rows, l0, nl, lane, false, NoSink{}, HalfRawSrc{P});
+      if constexpr (MOF_HALF_RAW) pass_lines_static<SP, 0, 1, NoSink, HalfRawSrc>(z, tw, rows, l0, nl, lane, false, NoSink{}, HalfRawSrc{P, RSK});
       else pass_lines_static<SP>(z, tw, rows, l0, nl, lane, false);
     }
     if constexpr (UFUSE) return;  // (the untangle rides the forward column pass: HalfUntangleSrc)
@@ -655,7 +666,7 @@ __global__ void __launch_bounds__(HalfPlanOf<MS>::T, HalfPlanOf<MS>::WPE) pc_hal
     if constexpr (MOF_HABL == 1) return;
     if constexpr (UFUSE)
       pass_lines_static<SP, 0, 1, Sink, HalfUntangleSrc, WorkgroupSync, NG0, (XSINK ? NGL : 0)>(z, tw, cols, l0, nl, lane, false, sink,
-                                                                                                HalfUntangleSrc{P, M, SKM, SH});
+                                                                                                HalfUntangleSrc{P, M, SKM, SH, RSK});
     else if (nl > 0)
       pass_lines_static<SP, 0, 1, Sink>(z, tw, cols, l0, nl, lane, false, sink);
   };
@@ -853,7 +864,7 @@ have_current:
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
   if (nl > 0 && MOF_HABL != 1) {
     if constexpr (MOF_HALF_PAIR_SRC)
-      pass_lines_static<SP, 0, 1, HalfScanSink, HalfPairSrc>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H}, HalfPairSrc{P2, M, SKM, SH});
+      pass_lines_static<SP, 0, 1, HalfScanSink, HalfPairSrc>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H}, HalfPairSrc{P2, M, SKM, SH, RSK});
     else
       pass_lines_static<SP, 0, 1, HalfScanSink>(z, tw, rows, l0, nl, lane, false, HalfScanSink{&best, M, H});
   }

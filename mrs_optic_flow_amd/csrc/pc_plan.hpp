@@ -38,7 +38,13 @@ struct Walk {
   int line_fast;     // lane map of a stage: 0 = the butterfly index in the fast lane bits (row walks), 1 = the line (column walks)
   int line_perm = 0; // 1: later stages of a row walk take the lines of a four-line group in the order 0 2 1 3 (stage_rt; the half-tile kernel's pitches)
   int sh = 3;        // the skew's shift: coordinate c sits at c + (c >> sh) (3 everywhere but the half-tile kernel's radix-16-first sizes: 4)
-  __device__ __forceinline__ int at(int l, int e) const { return l * ls + ((l >> sh) & lmask) + e * es + ((e >> sh) & emask); }
+  // r06 (A/B, the half-tile kernel): a ROW skew -- tile row r (a line of the row walks = rows 2j | 2j + 1; an element of the column walks)
+  // starts rs * (r >> 4) complex elements later, so that the first-stage column writes of a radix-16-first size, 16 rows apart = 0 (mod 32
+  // banks) for any pitch, land in different banks. lrs / ers = rs for the walk whose line / element is the row; 0 everywhere else.
+  int lrs = 0, ers = 0;
+  __device__ __forceinline__ int loffs(int l) const { return l * ls + ((l >> sh) & lmask) + lrs * (l >> 3); }  // (line j = rows 2j, 2j + 1: (2j) >> 4 = j >> 3)
+  __device__ __forceinline__ int eoff(int e) const { return e * es + ((e >> sh) & emask) + ers * (e >> 4); }
+  __device__ __forceinline__ int at(int l, int e) const { return loffs(l) + eoff(e); }
 };
 
 // Composite radices for the compile-time plans (two stages per 1-D transform for every 5-smooth size up to 135, as the tuned
@@ -235,9 +241,9 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
         const int li = g0 + b * lpg + sub;
         const int l = line0 + li;
         on[b] = lane_on && li < nlines;
-        loff[b] = l * w.ls + ((l >> w.sh) & w.lmask);
+        loff[b] = w.loffs(l);
         if (on[b]) {
-          const int l2off = (l + H) * w.ls + (((l + H) >> w.sh) & w.lmask);  // (herm_first only)
+          const int l2off = w.loffs(l + H);  // (herm_first only)
 #pragma unroll
           for (int j = 0; j < SLOTS; ++j)
             if (j < R) {
@@ -249,14 +255,14 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
                 a = src(z, l, e);
               } else if (herm_first) {
                 const int r = e < H ? e : (e == H ? 0 : m - e);
-                const int ro = r * w.es + ((r >> w.sh) & w.emask);
+                const int ro = w.eoff(r);
                 const cf pp = lds_read(&z[loff[b] + ro]), c = lds_read(&z[l2off + ro]);  // tile (row r, col l) and (row r, col l + H)
                 if (e == 0) a = {pp.x, c.x};
                 else if (e == H) a = {pp.y, c.y};
                 else if (e < H) a = {pp.x - c.y, pp.y + c.x};
                 else a = {pp.x + c.y, c.x - pp.y};
               } else {
-                a = lds_read(&z[loff[b] + e * w.es + ((e >> w.sh) & w.emask)]);
+                a = lds_read(&z[loff[b] + w.eoff(e)]);
               }
               // (a radix-8 stage behind an earlier one takes its twiddles inside the butterfly: butterfly8_tw, pc_common.hpp)
               if (j > 0 && np > 1 && !(MOF_PLANNED_TW8 && SLOTS == 8 && R == 8)) a = cmul(a, t[j - 1]);
@@ -278,10 +284,10 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
                 bool wr = true;
                 const cf val = sink.transform(line0 + g0 + b * lpg + sub, o, v[b][p], b, p, &wr);
                 if (site_off(w.line_fast, np, 1)) site_keep(val);
-                else if (wr) z[loff[b] + o * w.es + ((o >> w.sh) & w.emask)] = val;
+                else if (wr) z[loff[b] + w.eoff(o)] = val;
               } else {
                 if (site_off(w.line_fast, np, 1)) site_keep(v[b][p]);
-                else z[loff[b] + o * w.es + ((o >> w.sh) & w.emask)] = v[b][p];
+                else z[loff[b] + w.eoff(o)] = v[b][p];
                 if constexpr (Sink::active) sink(line0 + g0 + b * lpg + sub, o, v[b][p]);
               }
             }
@@ -293,7 +299,7 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
   // long lines: one line at a time, up to NB * 64 butterflies (the plan guarantees bpl <= 64 * floor(16 / R))
   for (int li = 0; li < nlines; ++li) {
     const int l = line0 + li;
-    const int loff = l * w.ls + ((l >> w.sh) & w.lmask);
+    const int loff = w.loffs(l);
     for (int x0 = 0; x0 < bpl; x0 += 64 * NB) {
       cf v[NB][SLOTS];
       int xx[NB], kk[NB];
@@ -321,7 +327,7 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
                 else if (e < H) a = {pp.x - c.y, pp.y + c.x};
                 else a = {pp.x + c.y, c.x - pp.y};
               } else {
-                a = lds_read(&z[loff + e * w.es + ((e >> w.sh) & w.emask)]);
+                a = lds_read(&z[loff + w.eoff(e)]);
               }
               if (j > 0 && np > 1) a = cmul(a, lds_read(&tw[j * k * tstep]));
               v[b][j] = a;
@@ -345,9 +351,9 @@ __device__ __forceinline__ void stage_rt(cf* __restrict__ z, const cf* __restric
               if constexpr (SinkTransforms<Sink>::value) {
                 bool wr = true;
                 const cf val = sink.transform(l, o, v[b][p], b, p, &wr);
-                if (wr) z[loff + o * w.es + ((o >> w.sh) & w.emask)] = val;
+                if (wr) z[loff + w.eoff(o)] = val;
               } else {
-                z[loff + o * w.es + ((o >> w.sh) & w.emask)] = v[b][p];
+                z[loff + w.eoff(o)] = v[b][p];
                 if constexpr (Sink::active) sink(l, o, v[b][p]);
               }
             }
@@ -397,7 +403,7 @@ __device__ __forceinline__ void stage_rt_ng(cf* __restrict__ z, const cf* __rest
       const int li = g * group + b * lpg + sub;
       const int l = line0 + li;
       on[g][b] = lane_on && li < nlines;
-      loff[g][b] = l * w.ls + ((l >> w.sh) & w.lmask);
+      loff[g][b] = w.loffs(l);
       if (on[g][b]) {
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j)
@@ -409,7 +415,7 @@ __device__ __forceinline__ void stage_rt_ng(cf* __restrict__ z, const cf* __rest
             } else if constexpr (Src::active) {
               a = src(z, l, e);
             } else {
-              a = lds_read(&z[loff[g][b] + e * w.es + ((e >> w.sh) & w.emask)]);
+              a = lds_read(&z[loff[g][b] + w.eoff(e)]);
             }
             if (j > 0 && np > 1 && !(MOF_PLANNED_TW8 && SLOTS == 8 && R == 8)) a = cmul(a, t[j - 1]);
             v[g][b][j] = a;
@@ -433,10 +439,10 @@ __device__ __forceinline__ void stage_rt_ng(cf* __restrict__ z, const cf* __rest
               bool wr = true;
               const cf val = sink.transform(l, o, v[g][b][p], g * NB + b, p, &wr);
               if (site_off(w.line_fast, np, 1)) site_keep(val);
-              else if (wr) z[loff[g][b] + o * w.es + ((o >> w.sh) & w.emask)] = val;
+              else if (wr) z[loff[g][b] + w.eoff(o)] = val;
             } else {
               if (site_off(w.line_fast, np, 1)) site_keep(v[g][b][p]);
-              else z[loff[g][b] + o * w.es + ((o >> w.sh) & w.emask)] = v[g][b][p];
+              else z[loff[g][b] + w.eoff(o)] = v[g][b][p];
               if constexpr (Sink::active) sink(l, o, v[g][b][p]);
             }
           }

@@ -67,6 +67,10 @@ struct SrPlan<450> {
   static constexpr int R1 = 15, R2 = 30, Y2 = 31, LINE = 465;
 };
 template <>
+struct SrPlan<512> {  // 16 x 32 (patches of 501 .. 512 pixels)
+  static constexpr int R1 = 16, R2 = 32, Y2 = 33, LINE = 529;
+};
+template <>
 struct SrPlan<360> {  // 15 x 24 (patches of 325 .. 360 pixels): 45 one-wave row workgroups per image, 180 row pairs = 22 candidate workgroups of 8 lines and one of 4
   static constexpr int R1 = 15, R2 = 24, Y2 = 25, LINE = 377;
 };

@@ -895,6 +895,7 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
     case 360: return launch_sr_rows_inv_n<360>(a, n_pairs, stream);
     case 384: return launch_sr_rows_inv_n<384>(a, n_pairs, stream);
     case 480: return launch_sr_rows_inv_n<480>(a, n_pairs, stream);
+    case 512: return launch_sr_rows_inv_n<512>(a, n_pairs, stream);
     default: return hipErrorInvalidValue;
   }
 }

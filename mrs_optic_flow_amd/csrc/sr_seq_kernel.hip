@@ -548,6 +548,7 @@ hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, flo
     case 360: return launch_rows_real_src_n<360>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     case 384: return launch_rows_real_src_n<384>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
+    case 512: return launch_rows_real_src_n<512>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -573,6 +574,7 @@ hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t 
     case 360: return launch_cols_seq_n<360>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
     case 384: return launch_cols_seq_n<384>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
     case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
+    case 512: return launch_cols_seq_n<512>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -177,7 +177,7 @@ def _large_variant(n):
     return "planned-half" if half else "planned-large"
 
 
-@pytest.mark.parametrize("n", [160, 136, 144, 150, 180, 192, 162, 158, 170, 186, 200, 216, 240, 250, 256, 148, 225, 243, 202, 196, 230, 252, 288, 320, 360, 384, 280, 310, 340, 380, 300, 270, 450, 262, 296, 440, 480, 750, 810])  # (750, 810: one stage body per radix;
+@pytest.mark.parametrize("n", [160, 136, 144, 150, 180, 192, 162, 158, 170, 186, 200, 216, 240, 250, 256, 148, 225, 243, 202, 196, 230, 252, 288, 320, 360, 384, 280, 310, 340, 380, 300, 270, 450, 262, 296, 440, 480, 512, 505, 750, 810])  # (750, 810: one stage body per radix;
                                                                                                                #  240 / 256 / 480: the estimator's tuned transforms)
 def test_large_patches_match_oracle(gpu, n):
     gx, gy = (2, 2) if n <= 256 else (1, 1)
@@ -446,7 +446,7 @@ def test_large_patches_planned_kernels_at_the_estimators_sizes(gpu):
     import sys
     env = dict(os.environ, MOF_FFT_LARGE_TUNED="0")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                          "large_patches_match_oracle and (200 or 216 or 240 or 256 or 480 or 202 or 196 or 230 or 252 or 288 or 320 or 360 or 384 or 280 or 310 or 340 or 380 or 300 or 270 or 450 or 262 or 296 or 440)", "-p", "no:cacheprovider"], env=env, capture_output=True,
+                          "large_patches_match_oracle and (200 or 216 or 240 or 256 or 480 or 202 or 196 or 230 or 252 or 288 or 320 or 360 or 384 or 280 or 310 or 340 or 380 or 300 or 270 or 450 or 262 or 296 or 440 or 512 or 505)", "-p", "no:cacheprovider"], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
