@@ -51,6 +51,38 @@ __device__ __forceinline__ uint32_t fetch_px_l(const uint8_t* __restrict__ base,
   }
 }
 
+// four consecutive pixels x0 .. x0 + 3 of row y, one byte each (x0 + 3 inside the patch): as pc_kernel_generic.hip's fetch_px4 (r06)
+template <int DS, int CH>
+__device__ __forceinline__ uint32_t fetch_px4_l(const uint8_t* __restrict__ base, size_t pitch, int y, int x0) {
+  if constexpr (DS == 4) {
+    const uint8_t* r1 = base + (size_t)(4 * y + 1) * pitch + 4 * (size_t)x0;
+    uint32_t w1[4], w2[4];
+    __builtin_memcpy(w1, r1, 16);
+    __builtin_memcpy(w2, r1 + pitch, 16);
+    uint32_t g = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      g |= ((((w1[b] >> 8) & 0xffu) + ((w1[b] >> 16) & 0xffu) + ((w2[b] >> 8) & 0xffu) + ((w2[b] >> 16) & 0xffu) + 2u) >> 2) << (8 * b);
+    return g;
+  } else if constexpr (CH == 3) {
+    uint32_t w[3];
+    __builtin_memcpy(w, base + (size_t)y * pitch + 3 * (size_t)x0, 12);
+    uint32_t g = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = 3 * b;
+      const uint32_t c0 = (w[i >> 2] >> (8 * (i & 3))) & 0xffu, c1 = (w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xffu,
+                     c2 = (w[(i + 2) >> 2] >> (8 * ((i + 2) & 3))) & 0xffu;
+      g |= rgb2gray_fixed(c0, c1, c2) << (8 * b);
+    }
+    return g;
+  } else {
+    uint32_t w;
+    __builtin_memcpy(&w, base + (size_t)y * pitch + x0, 4);
+    return w;
+  }
+}
+
 // ---- L5 ------------------------------------------------------------------------------------------------------------------
 template <int DS, int CH, bool EXACT>
 __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, const float* __restrict__ twiddles,
@@ -75,33 +107,47 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, 
   const uint32_t p00 = fetch_px_l<DS, CH>(base, src.pitch, 0, 0);
   uint32_t diff = 0u;
   {
-    // all of the lane's pixel loads go out before the first is used (a load-use loop pays the memory latency once per trip)
-    constexpr int NX = 15;  // ceil(960 / 64)
-    uint32_t px[2][2][NX];
+    // all of the lane's pixel loads go out before the first is used (a load-use loop pays the memory latency once per trip); r06: FOUR pixels
+    // per load (chunk c = lane + 64 t of a row: a dword, three dwords of BGR8, or two 16-byte runs of the tapped quarter-resolution rows)
+    constexpr int NC = 4;  // ceil(960 / 4 / 64)
+    uint32_t px[2][2][NC];
+    const uint32_t pat = p00 * 0x01010101u;
+    auto load4 = [&](int y, int x0) -> uint32_t {
+      if (y >= n || x0 >= n) return 0u;
+      if (x0 + 3 < n) return fetch_px4_l<DS, CH>(base, src.pitch, y, x0);
+      uint32_t v = 0u;  // the last chunk of a row whose length is not a multiple of four
+      for (int b = 0; x0 + b < n; ++b) v |= fetch_px_l<DS, CH>(base, src.pitch, y, x0 + b) << (8 * b);
+      return v;
+    };
+    auto inside = [&](int y, int x0) -> uint32_t {
+      if (y >= n || x0 >= n) return 0u;
+      return x0 + 3 < n ? 0xffffffffu : (1u << (8 * (n - x0))) - 1u;
+    };
 #pragma unroll
     for (int ll = 0; ll < 2; ++ll) {
       const int y0 = row0 + 2 * (2 * wave + ll), y1 = y0 + 1;
 #pragma unroll
-      for (int t = 0; t < NX; ++t) {
-        const int x = lane + 64 * t;
-        px[ll][0][t] = px[ll][1][t] = 0x100u;  // 0x100: "no pixel" (zero padding)
-        if (x < n) {
-          if (y0 < n) px[ll][0][t] = fetch_px_l<DS, CH>(base, src.pitch, y0, x);
-          if (y1 < n) px[ll][1][t] = fetch_px_l<DS, CH>(base, src.pitch, y1, x);
+      for (int t = 0; t < NC; ++t) {
+        const int x0 = 4 * (lane + 64 * t);
+        px[ll][0][t] = px[ll][1][t] = 0u;
+        if (x0 < m) {
+          px[ll][0][t] = load4(y0, x0);
+          px[ll][1][t] = load4(y1, x0);
         }
       }
     }
 #pragma unroll
     for (int ll = 0; ll < 2; ++ll) {
-      const int l = 2 * wave + ll;
+      const int l = 2 * wave + ll, y0 = row0 + 2 * l, y1 = y0 + 1;
 #pragma unroll
-      for (int t = 0; t < NX; ++t) {
-        const int x = lane + 64 * t;
-        if (x < m) {
+      for (int t = 0; t < NC; ++t) {
+        const int x0 = 4 * (lane + 64 * t);
+        if (x0 < m) {
           const uint32_t a = px[ll][0][t], b = px[ll][1][t];
-          if (a < 0x100u) diff |= a ^ p00;
-          if (b < 0x100u) diff |= b ^ p00;
-          z[l * line + sk(x)] = {(float)(a & 0xffu), (float)(b & 0xffu)};
+          diff |= ((a ^ pat) & inside(y0, x0)) | ((b ^ pat) & inside(y1, x0));
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (x0 + k < m) z[l * line + sk(x0 + k)] = {(float)((a >> (8 * k)) & 0xffu), (float)((b >> (8 * k)) & 0xffu)};
         }
       }
     }
