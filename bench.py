@@ -176,6 +176,17 @@ WORKLOADS = {
     "l240": dict(kind="fft", h=480, w=480, n=240, grid=(2, 2), origin=(0, 0), stride=(240, 240), batch=512, s=15,
                  name="l240: FftMethod 480x480, 2x2 grid of 240x240 patches (transform size 240), batch=512 per GPU",
                  bytes_per_pair=2 * 480 * 480 + 4 * 8),
+    # transform sizes whose two-stage plans end in an odd radix (10 x 25, 16 x 25, 16 x 27): tuned transforms with the real-only
+    # slots of the spectrum taken from the images' exact integer sums (r06)
+    "l250": dict(kind="fft", h=512, w=512, n=250, grid=(2, 2), origin=(0, 0), stride=(250, 250), batch=512, s=15,
+                 name="l250: FftMethod 512x512, 2x2 grid of 250x250 patches (tuned transforms 10 x 25), batch=512 per GPU",
+                 bytes_per_pair=2 * 4 * 250 * 250 + 4 * 8),
+    "l400": dict(kind="fft", h=800, w=800, n=400, grid=(2, 2), origin=(0, 0), stride=(400, 400), batch=128, s=15,
+                 name="l400: FftMethod 800x800, 2x2 grid of 400x400 patches (tuned transforms 16 x 25), batch=128 per GPU",
+                 bytes_per_pair=2 * 800 * 800 + 4 * 8),
+    "l432": dict(kind="fft", h=864, w=864, n=432, grid=(2, 2), origin=(0, 0), stride=(432, 432), batch=128, s=15,
+                 name="l432: FftMethod 864x864, 2x2 grid of 432x432 patches (tuned transforms 16 x 27), batch=128 per GPU",
+                 bytes_per_pair=2 * 864 * 864 + 4 * 8),
     "l480": dict(kind="fft", h=480, w=480, n=480, grid=(1, 1), origin=(0, 0), stride=(480, 480), batch=512, s=15,
                  name="l480: FftMethod 480x480, ONE 480x480 patch (the reference's whole-frame fallback), batch=512 per GPU",
                  bytes_per_pair=2 * 480 * 480 + 8),

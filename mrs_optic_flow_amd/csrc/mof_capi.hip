@@ -156,7 +156,9 @@ static hipError_t large_alloc(mof_fft_engine* e, int cap) {
   if ((err = hipMalloc(&e->d_zh, (size_t)2 * cap * zhf * sizeof(float))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_dt, (size_t)cap * zhf * sizeof(float))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_cand, (size_t)cap * mof::pcl_candidates(e->plan) * sizeof(float2))) != hipSuccess) return err;
-  if ((err = hipMalloc(&e->d_flags, (size_t)4 * cap * sizeof(int))) != hipSuccess) return err;  // [0, 2 cap): per pair (cur | prev); [2 cap, 4 cap): per image of a video pass
+  // [0, 2 cap): flags per pair (cur | prev); [2 cap, 4 cap): flags per image of a video pass; [4 cap, 12 cap): four exact pixel sums per image
+  // (the tuned transform sizes whose Nyquist bin is not exact: 250, 400, 432)
+  if ((err = hipMalloc(&e->d_flags, (size_t)12 * cap * sizeof(int))) != hipSuccess) return err;
   if ((err = hipMalloc(&e->d_cdc, (size_t)cap * sizeof(float))) != hipSuccess) return err;
   e->cap = cap;
   return hipSuccess;
@@ -205,8 +207,11 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
   // r06: 200, 216, 270, 288, 300, 320, 360, 384, 450 too, and patches that PAD to one of these sizes (193 .. 216, 226 .. 240, 251 .. 256, 271 .. 288, 301 .. 320, 325 .. 360, 376 .. 384,
   // 451 .. 480): the row kernel
   // zero-pads, the column kernel applies the box-zero rule of padded constant patches from the row kernel's flags
-  const bool tuned = tuned_on && a.downscale == 1 && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 256 || e->plan.m == 270 || e->plan.m == 288 || e->plan.m == 300 || e->plan.m == 320 || e->plan.m == 360 ||
-                                                            e->plan.m == 384 || e->plan.m == 450 || e->plan.m == 480 || e->plan.m == 512);
+  const bool tuned = tuned_on && a.downscale == 1 && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 250 || e->plan.m == 256 || e->plan.m == 270 || e->plan.m == 288 || e->plan.m == 300 || e->plan.m == 320 || e->plan.m == 360 ||
+                                                            e->plan.m == 384 || e->plan.m == 400 || e->plan.m == 432 || e->plan.m == 450 || e->plan.m == 480 || e->plan.m == 512);
+  // (250 = 10 x 25, 400 = 16 x 25, 432 = 16 x 27: no plan of theirs ends in an even radix, so the Nyquist bins of their transforms are not exact
+  //  -- the row kernel accumulates each image's four exact integer sums and the column kernel takes the real-only slots from those)
+  const bool odd_tail = e->plan.m == 250 || e->plan.m == 400 || e->plan.m == 432;
   // r06, a VIDEO on the tuned transforms (pair k = (frame k + 1, frame k): mof_fft_process_sequence_device, or any caller whose cur = prev + one frame):
   // every frame's row spectra are formed ONCE per pass -- Zh slot = frame * patches + patch, so pair q = k * patches + patch finds its previous
   // image at slot q and its current one at slot q + patches, which is exactly what the column kernel's (zh_prev, zh_cur, stride) takes; the
@@ -229,19 +234,21 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
       src.stride_x = a.stride_x;
       src.stride_y = a.stride_y;
       int* fs = e->d_flags + (size_t)2 * e->cap;  // per image of this pass: (np + 1) * patches <= 2 cap
+      int* sums = e->d_flags + (size_t)4 * e->cap;  // four ints per image slot
       HIP_TRY(hipMemsetAsync(fs, 0, (size_t)(nq + patches) * sizeof(int), s));
+      if (odd_tail) HIP_TRY(hipMemsetAsync(sums, 0, (size_t)4 * (nq + patches) * sizeof(int), s));
       const int frames_per_launch = 65534 / patches > 0 ? 65534 / patches : 1;
       for (int j0 = 0; j0 < np + 1; j0 += frames_per_launch) {
         const int nj = np + 1 - j0 < frames_per_launch ? np + 1 - j0 : frames_per_launch;
         mof::PclSrc sj = src;
         sj.base[0] += (size_t)j0 * a.prev_stride;
         HIP_TRY(mof::launch_sr_rows_real_src(sj, e->d_twiddles, e->d_zh + (size_t)j0 * patches * zhf, zhf, fs + (size_t)j0 * patches, e->plan.m,
-                                             nj * patches, a.channels, e->plan.n, s));
+                                             nj * patches, a.channels, e->plan.n, s, sums + (size_t)4 * j0 * patches));
       }
       HIP_TRY(mof::launch_pcl_seq_flags(fs, e->d_flags, patches, nq, s));
       const float* zp = e->d_zh;
       const float* zc = e->d_zh + (size_t)patches * zhf;
-      HIP_TRY(mof::launch_sr_cols_seq(zp, zc, zhf, e->d_twiddles, e->d_dt, e->plan.m, nq, 1, s, e->d_flags, e->plan.n));
+      HIP_TRY(mof::launch_sr_cols_seq(zp, zc, zhf, e->d_twiddles, e->d_dt, e->plan.m, nq, 1, s, e->d_flags, e->plan.n, sums, sums + (size_t)4 * patches, 4));
       HIP_TRY(mof::launch_pcl_cdc(zp, zc, zhf, e->plan.m, e->d_cdc, nq, s));
       HIP_TRY(mof::launch_sr_rows_inv(e->d_dt, e->d_twiddles, e->d_cand, e->plan.m, nq, s));
       mof::PclFinal f{};
@@ -270,6 +277,8 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
     src.stride_x = a.stride_x;
     src.stride_y = a.stride_y;
     HIP_TRY(hipMemsetAsync(e->d_flags, 0, (size_t)2 * nq * sizeof(int), s));
+    int* sums = e->d_flags + (size_t)4 * e->cap;  // four ints per image 2 q + which
+    if (tuned && odd_tail) HIP_TRY(hipMemsetAsync(sums, 0, (size_t)8 * nq * sizeof(int), s));
     // (launch_pcl_rows splits at 65534 images on pair boundaries: keep a pass's image count a multiple of 2 * patches below that)
     const int pairs_per_launch = 65534 / (2 * patches) > 0 ? 65534 / (2 * patches) : 1;
     for (int j0 = 0; j0 < np; j0 += pairs_per_launch) {
@@ -279,13 +288,14 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
       sj.base[1] += (size_t)j0 * a.prev_stride;
       if (tuned)
         HIP_TRY(mof::launch_sr_rows_real_src(sj, e->d_twiddles, e->d_zh + (size_t)2 * j0 * patches * zhf, zhf,
-                                             e->d_flags + (size_t)2 * j0 * patches, e->plan.m, 2 * nj * patches, a.channels, e->plan.n, s));
+                                             e->d_flags + (size_t)2 * j0 * patches, e->plan.m, 2 * nj * patches, a.channels, e->plan.n, s,
+                                             sums + (size_t)8 * j0 * patches));
       else
         HIP_TRY(mof::launch_pcl_rows(sj, e->plan, e->d_twiddles, e->d_zh + (size_t)2 * j0 * patches * zhf, zhf,
                                      e->d_flags + (size_t)2 * j0 * patches, 2 * nj * patches, a.channels, a.downscale, s));
     }
     if (tuned) {
-      HIP_TRY(mof::launch_sr_cols_seq(e->d_zh + zhf, e->d_zh, 2 * zhf, e->d_twiddles, e->d_dt, e->plan.m, nq, 1, s, e->d_flags, e->plan.n));
+      HIP_TRY(mof::launch_sr_cols_seq(e->d_zh + zhf, e->d_zh, 2 * zhf, e->d_twiddles, e->d_dt, e->plan.m, nq, 1, s, e->d_flags, e->plan.n, sums + 4, sums, 8));
       HIP_TRY(mof::launch_pcl_cdc(e->d_zh + zhf, e->d_zh, 2 * zhf, e->plan.m, e->d_cdc, nq, s));
       HIP_TRY(mof::launch_sr_rows_inv(e->d_dt, e->d_twiddles, e->d_cand, e->plan.m, nq, s));
     } else {

@@ -222,13 +222,15 @@ hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float*
 // K5s on patches of frames (FftMethod patches of 240 / 256 / 480 pixels) and K7 alone: the tuned transforms under the FFT engine's
 // large-patch pipeline; flags as launch_pcl_rows
 hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, float* zh, size_t zh_stride, int* flags, int res, int n_images,
-                                   int channels, int n, hipStream_t stream);  // n <= res: the unpadded patch size (zeros beyond n x n)
+                                   int channels, int n, hipStream_t stream, int* sums = nullptr);  // n <= res: the unpadded patch size (zeros beyond n x n);
+                                   // sums: 4 ints per image (zeroed), the exact sums sum (+-1)^y (+-1)^x p -- filled by the plans whose Nyquist bin is not exact (250, 400, 432)
 hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* cand, int res, int n_pairs, hipStream_t stream);
 // a video's per-image flags fs[frame * patches + patch] -> the per-pair layout the column kernel and the tail read: f2[2 q] = cur = fs[q + patches],
 // f2[2 q + 1] = prev = fs[q] (pair q = k * patches + patch of frames k + 1, k)
 hipError_t launch_pcl_seq_flags(const int* fs, int* f2, int patches, int n_pairs, hipStream_t stream);
 hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* twiddles, float* Dt, int res,
-                              int n_pairs, int run, hipStream_t stream, const int* flags = nullptr, int n = 0);  // flags + n < res: the box-zero rule of padded constant patches (run = 1)
+                              int n_pairs, int run, hipStream_t stream, const int* flags = nullptr, int n = 0,  // flags + n < res: the box-zero rule of padded constant patches (run = 1)
+                              const int* sums_prev = nullptr, const int* sums_cur = nullptr, int sums_stride = 0);  // the rows kernel's exact sums, pair p at p * sums_stride ints
 // K56 (sr_fused_kernel.hip): K5s + K6s in one kernel, the row transforms as a dense product on the matrix cores -- reads the u8
 // log-polar images instead of Zh. `frags` = sr_fused_fragments(res) on the device. Same pair / run semantics as K6s.
 bool sr_fused_supported(int res);

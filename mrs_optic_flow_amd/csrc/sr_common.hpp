@@ -66,6 +66,29 @@ template <>
 struct SrPlan<450> {
   static constexpr int R1 = 15, R2 = 30, Y2 = 31, LINE = 465;
 };
+// r06: sizes whose only two-stage plans end in an ODD radix (250 = 10 x 25, 400 = 16 x 25, 432 = 16 x 27): bin N/2 of a line passes twiddles, so
+// the four real-only CCS slots would carry rounding noise where the reference's are exact integers -- and C = P / (P^2 + eps) turns a P of 1e-4
+// that should be 0 into a bin of magnitude 300. These plans declare NYQ_EXACT = false: the row kernel then also forms the four exact
+// integer sums of every image (sum (+-1)^y (+-1)^x p), and the column kernel takes the real-only slots from THEM (SrExactSlots below).
+template <>
+struct SrPlan<250> {
+  static constexpr int R1 = 10, R2 = 25, Y2 = 26, LINE = 261;
+  static constexpr bool NYQ_EXACT = false;
+};
+template <>
+struct SrPlan<400> {
+  static constexpr int R1 = 16, R2 = 25, Y2 = 26, LINE = 417;
+  static constexpr bool NYQ_EXACT = false;
+};
+template <>
+struct SrPlan<432> {
+  static constexpr int R1 = 16, R2 = 27, Y2 = 28, LINE = 449;
+  static constexpr bool NYQ_EXACT = false;
+};
+template <class PL, class = void>
+struct SrNyqExact { static constexpr bool value = true; };
+template <class PL>
+struct SrNyqExact<PL, decltype((void)PL::NYQ_EXACT)> { static constexpr bool value = PL::NYQ_EXACT; };
 template <>
 struct SrPlan<512> {  // 16 x 32 (patches of 501 .. 512 pixels)
   static constexpr int R1 = 16, R2 = 32, Y2 = 33, LINE = 529;
@@ -142,6 +165,46 @@ __device__ __forceinline__ void butterfly18(cf* v) {  // 9 x 2, decimation in ti
     v[k1 + 9] = {a[k1].x - t.x, a[k1].y - t.y};
   }
 }
+// R = RA x RB with a radix-RB decimation in time: RB interleaved sub-sequences through the RA-point butterfly, twiddles W_R^{j k1}, then RB-point
+// butterflies across them: X[k1 + RA k2]. (Odd R: no exact Nyquist bin to protect -- SrPlan::NYQ_EXACT = false takes care of the slots.)
+__device__ __forceinline__ void butterfly25(cf* v) {  // 5 x 5
+  const cf w[17] = {{1.00000000000000000000f, -0.00000000000000000000f}, {0.96858316112863107605f, -0.24868988716485479484f}, {0.87630668004386358394f, -0.48175367410171532345f}, {0.72896862742141155245f, -0.68454710592868861507f}, {0.53582679497899654564f, -0.84432792550201507531f}, {0.30901699437494745126f, -0.95105651629515353118f}, {0.06279051952931352654f, -0.99802672842827155897f}, {-0.18738131458572460097f, -0.98228725072868872115f}, {-0.42577929156507271502f, -0.90482705246601946580f}, {-0.63742398974868974548f, -0.77051324277578925326f}, {-0.80901699437494734024f, -0.58778525229247324813f}, {-0.92977648588825134723f, -0.36812455268467814129f}, {-0.99211470131447776488f, -0.12533323356430453588f}, {-0.99211470131447787590f, 0.12533323356430428608f}, {-0.92977648588825145826f, 0.36812455268467791925f}, {-0.80901699437494778433f, 0.58778525229247269301f}, {-0.63742398974868952344f, 0.77051324277578936428f}};
+  cf a[5][5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+#pragma unroll
+    for (int n1 = 0; n1 < 5; ++n1) a[j][n1] = v[5 * n1 + j];
+    butterfly5(a[j]);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1) {
+    cf t[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) t[j] = (j * k1 == 0) ? a[j][k1] : cmul(a[j][k1], w[j * k1]);
+    butterfly5(t);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) v[k1 + 5 * k2] = t[k2];
+  }
+}
+__device__ __forceinline__ void butterfly27(cf* v) {  // 9 x 3
+  const cf w[17] = {{1.00000000000000000000f, -0.00000000000000000000f}, {0.97304487057982380627f, -0.23061587074244016549f}, {0.89363264032341227505f, -0.44879918020046216665f}, {0.76604444311897801345f, -0.64278760968653925190f}, {0.59715859170278617896f, -0.80212319275504373461f}, {0.39607976603915689973f, -0.91821610688027399672f}, {0.17364817766693041445f, -0.98480775301220802032f}, {-0.05814482891047577373f, -0.99830815827126817563f}, {-0.28680323271109020578f, -0.95798951231548890028f}, {-0.49999999999999977796f, -0.86602540378443870761f}, {-0.68624163786873348947f, -0.72737364157304884582f}, {-0.83548781141293626540f, -0.54950897807080623103f}, {-0.93969262078590831688f, -0.34202014332566887944f}, {-0.99323835774194302317f, -0.11609291412522992903f}, {-0.99323835774194302317f, 0.11609291412523012332f}, {-0.93969262078590853893f, 0.34202014332566821331f}, {-0.83548781141293648744f, 0.54950897807080600899f}};
+  cf a[3][9];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int n1 = 0; n1 < 9; ++n1) a[j][n1] = v[3 * n1 + j];
+    butterfly9(a[j]);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 9; ++k1) {
+    cf t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[j] = (j * k1 == 0) ? a[j][k1] : cmul(a[j][k1], w[j * k1]);
+    butterfly3(t);
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) v[k1 + 9 * k2] = t[k2];
+  }
+}
 __device__ __forceinline__ void butterfly30(cf* v) {  // 15 x 2, decimation in time (as butterfly18): bin 15 = sum(even) - sum(odd), no twiddle
   const cf w[15] = {{1.00000000000000000000f, -0.00000000000000000000f}, {0.97814760073380568883f, -0.20791169081775931482f}, {0.91354545764260086660f, -0.40673664307580015276f}, {0.80901699437494745126f, -0.58778525229247313710f}, {0.66913060635885823757f, -0.74314482547739413310f}, {0.50000000000000011102f, -0.86602540378443859659f}, {0.30901699437494745126f, -0.95105651629515353118f}, {0.10452846326765345697f, -0.99452189536827328986f}, {-0.10452846326765333207f, -0.99452189536827340088f}, {-0.30901699437494734024f, -0.95105651629515364220f}, {-0.49999999999999977796f, -0.86602540378443870761f}, {-0.66913060635885790450f, -0.74314482547739446616f}, {-0.80901699437494734024f, -0.58778525229247324813f}, {-0.91354545764260097762f, -0.40673664307580004174f}, {-0.97814760073380568883f, -0.20791169081775931482f}};
   cf a[15], b[15];
@@ -168,6 +231,8 @@ __device__ __forceinline__ void bfly(cf* v) {
   if constexpr (R == 15) butterfly15(v);
   else if constexpr (R == 32) butterfly32(v);
   else if constexpr (R == 30) butterfly30(v);
+  else if constexpr (R == 27) butterfly27(v);
+  else if constexpr (R == 25) butterfly25(v);
   else if constexpr (R == 24) butterfly24(v);
   else if constexpr (R == 20) butterfly20(v);
   else if constexpr (R == 18) butterfly18(v);

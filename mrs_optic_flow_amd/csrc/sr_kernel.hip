@@ -887,6 +887,9 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
     case 216: return launch_sr_rows_inv_n<216>(a, n_pairs, stream);
     case 240: return launch_sr_rows_inv_n<240>(a, n_pairs, stream);
     case 256: return launch_sr_rows_inv_n<256>(a, n_pairs, stream);
+    case 250: return launch_sr_rows_inv_n<250>(a, n_pairs, stream);
+    case 400: return launch_sr_rows_inv_n<400>(a, n_pairs, stream);
+    case 432: return launch_sr_rows_inv_n<432>(a, n_pairs, stream);
     case 270: return launch_sr_rows_inv_n<270>(a, n_pairs, stream);
     case 300: return launch_sr_rows_inv_n<300>(a, n_pairs, stream);
     case 450: return launch_sr_rows_inv_n<450>(a, n_pairs, stream);

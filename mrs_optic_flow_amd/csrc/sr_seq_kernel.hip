@@ -110,7 +110,8 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint
 // gray or BGR8 through the node's CV_RGB2GRAY) and the constant-image flags the FFT tail wants (as pcl_rows_kernel sets them).
 template <int N, int CH, bool PAD>  // PAD: n < N, the patch is zero-padded to the transform size (the unpadded form pays nothing for it)
 __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc src, const float* __restrict__ twiddles,
-                                                                           float* __restrict__ zh, size_t zh_stride, int* __restrict__ flags, int n) {
+                                                                           float* __restrict__ zh, size_t zh_stride, int* __restrict__ flags, int n,
+                                                                           int* __restrict__ sums) {
   using P = SrPlan<N>;
   using R = RowsReal<N>;
   constexpr int H = N / 2;
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
   };
   const uint32_t p00 = px4(0, 0) & 0xffu, pat = p00 * 0x01010101u;
   uint32_t diff = 0u;
+  int s00 = 0, s01 = 0, s10 = 0, s11 = 0;
   cf* mine = z + 4 * wave * P::LINE;
   {
     constexpr int ND = (N + 3) / 4, NL = (4 * ND + 63) / 64;  // (N = 270, 450: the last chunk of a row is half full)
@@ -175,10 +177,35 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
       if (i < 4 * ND) {
         const int l = i / ND, d = i % ND, y = row0 + 8 * wave + 2 * l;
         diff |= ((c[k] ^ pat) & inside(y, d)) | ((p[k] ^ pat) & inside(y + 1, d));
+        if constexpr (!SrNyqExact<P>::value) {
+          // the four exact integer sums of the image (pixels outside the patch were loaded as zeros): row y is even, y + 1 odd; byte b of a chunk
+          // is column 4 d + b, so the byte parity is the column parity
+          const int ce = (int)((c[k] & 0xffu) + ((c[k] >> 16) & 0xffu)), co = (int)(((c[k] >> 8) & 0xffu) + (c[k] >> 24));
+          const int pe = (int)((p[k] & 0xffu) + ((p[k] >> 16) & 0xffu)), po = (int)(((p[k] >> 8) & 0xffu) + (p[k] >> 24));
+          s00 += ce + co + pe + po;
+          s01 += ce - co + pe - po;  // (-1)^x
+          s10 += ce + co - pe - po;  // (-1)^y
+          s11 += ce - co - pe + po;  // (-1)^(x + y)
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           mine[l * P::LINE + 4 * d + b] = {(float)((c[k] >> (8 * b)) & 0xffu), (float)((p[k] >> (8 * b)) & 0xffu)};
       }
+    }
+  }
+  if constexpr (!SrNyqExact<P>::value) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s00 += __shfl_xor(s00, off, 64);
+      s01 += __shfl_xor(s01, off, 64);
+      s10 += __shfl_xor(s10, off, 64);
+      s11 += __shfl_xor(s11, off, 64);
+    }
+    if (lane == 0 && sums) {  // (zeroed by the caller; 255 * 432^2 < 2^31)
+      atomicAdd(&sums[4 * img + 0], s00);
+      atomicAdd(&sums[4 * img + 1], s01);
+      atomicAdd(&sums[4 * img + 2], s10);
+      atomicAdd(&sums[4 * img + 3], s11);
     }
   }
   if (flags) {  // bit 0: some pixel differs from pixel (0, 0); bit 1: pixel (0, 0) is not zero (zeroed by the caller)
@@ -208,7 +235,8 @@ constexpr int SEQ_CW = MOF_SEQ_CW;  // columns per wave
 template <int N, bool BOX = false>  // BOX: patches zero-padded to N -- the box-zero rule of padded CONSTANT patches (the plain form pays nothing for it)
 __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur,
                                                          size_t zh_stride, const float* __restrict__ twiddles,
-                                                         float* __restrict__ Dt, int n_pairs, int run, const int* __restrict__ flags, int n) {
+                                                         float* __restrict__ Dt, int n_pairs, int run, const int* __restrict__ flags, int n,
+                                                         const int* __restrict__ sums_prev, const int* __restrict__ sums_cur, int sums_stride) {
   using P = SrPlan<N>;
   constexpr int H = N / 2, CW = SEQ_CW;
   constexpr int MV = (N + 63) / 64;       // bins per lane and line (v = lane + 64 m)
@@ -278,7 +306,17 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
         const int v = lane + 64 * m;
         const int vv = v < N ? v : N - 1;  // (lanes past the line repeat its last bin: the wave-uniform branch inside
         const cf a = lds_read(&z[s * P::LINE + vv]);  //  cross_power_ab wants every lane to take part)
-        cf C = cross_power_ab(a, ap[s][m], u_edge && (vv == 0 || vv == H));
+        cf av = a, bv = ap[s][m];
+        if constexpr (!SrNyqExact<P>::value) {
+          // the four real-only CCS slots from the images' exact integer sums (doubled as the spectra are: Zh = 2 x the row transform): bins
+          // (v, u) in {0, N/2}^2 -> sums[(v ? 2 : 0) + (u ? 1 : 0)] = sum (+-1)^y (+-1)^x p  (run = 1: one pair per wave walk)
+          if (u_edge && (vv == 0 || vv == H)) {
+            const int slot = (vv == H ? 2 : 0) + (u == H ? 1 : 0);
+            av = {2.f * (float)sums_cur[(size_t)(p0 + j) * sums_stride + slot], 0.f};
+            bv = {2.f * (float)sums_prev[(size_t)(p0 + j) * sums_stride + slot], 0.f};
+          }
+        }
+        cf C = cross_power_ab(av, bv, u_edge && (vv == 0 || vv == H));
         if constexpr (BOX) {
           if (box_zeros && (box_zero_line(u, zq) || box_zero_line(vv, zq))) C = {0.f, 0.f};
         }
@@ -461,7 +499,7 @@ hipError_t launch_rows_real_n(const uint8_t* lp, size_t lp_stride, const float* 
 
 template <int N>
 hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh, size_t zh_stride, int* flags, int n_images, int channels,
-                                  int n, hipStream_t stream) {
+                                  int n, int* sums, hipStream_t stream) {
   using R = RowsReal<N>;
   constexpr size_t lds = sizeof(cf) * R::LINES * SrPlan<N>::LINE;
   const bool pad = n < N;
@@ -482,12 +520,13 @@ hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh,
     const dim3 g(R::GROUPS, (unsigned)nf), b(R::T);
     float* zo = zh + (size_t)f0 * zh_stride;
     int* fl = flags ? flags + f0 : nullptr;
+    int* su = sums ? sums + (size_t)4 * f0 : nullptr;
     if (channels == 3) {
-      if (pad) hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3, true>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n);
-      else hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3, false>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n);
+      if (pad) hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3, true>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n, su);
+      else hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3, false>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n, su);
     } else {
-      if (pad) hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 1, true>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n);
-      else hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 1, false>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n);
+      if (pad) hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 1, true>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n, su);
+      else hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 1, false>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n, su);
     }
   }
   return hipGetLastError();
@@ -495,7 +534,8 @@ hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh,
 
 template <int N>
 hipError_t launch_cols_seq_n(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* tw, float* Dt, int n_pairs,
-                             int run, const int* flags, int n, hipStream_t stream) {
+                             int run, const int* flags, int n, const int* sums_prev, const int* sums_cur, int sums_stride, hipStream_t stream) {
+  if (!SrNyqExact<SrPlan<N>>::value && (!sums_prev || !sums_cur || run != 1)) return hipErrorInvalidValue;  // (this plan's real-only slots come from the exact sums)
   constexpr int H = N / 2;
   const unsigned groups = (H + 1 + SEQ_CW - 1) / SEQ_CW, runs = (unsigned)((n_pairs + run - 1) / run);
   if constexpr (N == 480) {
@@ -506,8 +546,8 @@ hipError_t launch_cols_seq_n(const float* zh_prev, const float* zh_cur, size_t z
       return hipGetLastError();
     }
   }
-  if (flags && n < N) hipLaunchKernelGGL((sr_cols_seq_kernel<N, true>), dim3(groups, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run, flags, n);
-  else hipLaunchKernelGGL((sr_cols_seq_kernel<N, false>), dim3(groups, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run, flags, n);
+  if (flags && n < N) hipLaunchKernelGGL((sr_cols_seq_kernel<N, true>), dim3(groups, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride);
+  else hipLaunchKernelGGL((sr_cols_seq_kernel<N, false>), dim3(groups, runs), dim3(64), 0, stream, zh_prev, zh_cur, zh_stride, tw, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride);
   return hipGetLastError();
 }
 
@@ -532,29 +572,32 @@ hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float*
 }
 
 hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, float* zh, size_t zh_stride, int* flags, int res, int n_images,
-                                   int channels, int n, hipStream_t stream) {
+                                   int channels, int n, hipStream_t stream, int* sums) {
   if (n_images <= 0) return hipSuccess;
   if ((src.paired != 1 && src.paired != 2) || (channels != 1 && channels != 3) || n < 2 || n > res) return hipErrorInvalidValue;
   switch (res) {
-    case 200: return launch_rows_real_src_n<200>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 216: return launch_rows_real_src_n<216>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 240: return launch_rows_real_src_n<240>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 256: return launch_rows_real_src_n<256>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 270: return launch_rows_real_src_n<270>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 300: return launch_rows_real_src_n<300>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 450: return launch_rows_real_src_n<450>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 288: return launch_rows_real_src_n<288>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 320: return launch_rows_real_src_n<320>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 360: return launch_rows_real_src_n<360>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 384: return launch_rows_real_src_n<384>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
-    case 512: return launch_rows_real_src_n<512>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, stream);
+    case 200: return launch_rows_real_src_n<200>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 216: return launch_rows_real_src_n<216>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 240: return launch_rows_real_src_n<240>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 256: return launch_rows_real_src_n<256>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 250: return launch_rows_real_src_n<250>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 400: return launch_rows_real_src_n<400>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 432: return launch_rows_real_src_n<432>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 270: return launch_rows_real_src_n<270>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 300: return launch_rows_real_src_n<300>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 450: return launch_rows_real_src_n<450>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 288: return launch_rows_real_src_n<288>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 320: return launch_rows_real_src_n<320>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 360: return launch_rows_real_src_n<360>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 384: return launch_rows_real_src_n<384>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 512: return launch_rows_real_src_n<512>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
 hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* twiddles, float* Dt, int res,
-                              int n_pairs, int run, hipStream_t stream, const int* flags, int n) {
+                              int n_pairs, int run, hipStream_t stream, const int* flags, int n, const int* sums_prev, const int* sums_cur, int sums_stride) {
   if (n_pairs <= 0) return hipSuccess;
   if (run < 1) run = 1;
   if (flags && run != 1) return hipErrorInvalidValue;  // (the box-zero flags are per independent pair: image 2 p = cur, 2 p + 1 = prev)
@@ -562,19 +605,22 @@ hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t 
   // a run longer than one pair walks cur(p) as prev(p + 1): only valid for a contiguous sequence
   if (run > 1 && zh_cur != zh_prev + zh_stride) return hipErrorInvalidValue;
   switch (res) {
-    case 200: return launch_cols_seq_n<200>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 216: return launch_cols_seq_n<216>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 240: return launch_cols_seq_n<240>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 256: return launch_cols_seq_n<256>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 270: return launch_cols_seq_n<270>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 300: return launch_cols_seq_n<300>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 450: return launch_cols_seq_n<450>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 288: return launch_cols_seq_n<288>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 320: return launch_cols_seq_n<320>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 360: return launch_cols_seq_n<360>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 384: return launch_cols_seq_n<384>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
-    case 512: return launch_cols_seq_n<512>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, stream);
+    case 200: return launch_cols_seq_n<200>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 216: return launch_cols_seq_n<216>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 240: return launch_cols_seq_n<240>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 256: return launch_cols_seq_n<256>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 250: return launch_cols_seq_n<250>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 400: return launch_cols_seq_n<400>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 432: return launch_cols_seq_n<432>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 270: return launch_cols_seq_n<270>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 300: return launch_cols_seq_n<300>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 450: return launch_cols_seq_n<450>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 288: return launch_cols_seq_n<288>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 320: return launch_cols_seq_n<320>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 360: return launch_cols_seq_n<360>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 384: return launch_cols_seq_n<384>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 512: return launch_cols_seq_n<512>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     default: return hipErrorInvalidValue;
   }
 }
