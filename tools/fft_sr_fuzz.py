@@ -58,7 +58,8 @@ for trial in range(n_fft):
     r = rng.integers(0, 10)
     n = int(rng.choice([32, 64, 64, 120, 128, 240, 256])) if r < 4 else (int(rng.integers(8, 201)) if r < 9 else int(rng.integers(136, 301)))
     if LARGE_BAND:  # MOF_FUZZ_LARGE=1: the band the tuned large-patch kernels serve since r06 (padded sides 200 .. 384 and what lies between them)
-        n = int(rng.integers(193, 401))
+        lo, hi = (int(v) for v in os.environ["MOF_FUZZ_LARGE"].split("-")) if "-" in os.environ["MOF_FUZZ_LARGE"] else (193, 400)  # ("240-440": a band of one's own)
+        n = int(rng.integers(lo, hi + 1))
     gx, gy = (int(rng.integers(1, 6)), int(rng.integers(1, 5))) if n <= 135 else (int(rng.integers(1, 3)), int(rng.integers(1, 3)))
     sx, sy = int(rng.integers(max(1, n // 3), n + 40)), int(rng.integers(max(1, n // 3), n + 40))
     ox, oy = int(rng.integers(0, 9)), int(rng.integers(0, 9))

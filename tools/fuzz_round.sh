@@ -12,7 +12,7 @@ LOGS=$R/gpurun_out/${TAG}_fuzz_logs
 mkdir -p $LOGS
 {
   echo "# tools/fuzz_round.sh $TAG: library $(md5sum $R/mrs_optic_flow_amd/libmof_hip.so | cut -c1-12), git $(git -C $R rev-parse --short HEAD 2>/dev/null || echo '-'), $(date -u +%FT%TZ)"
-  [ -n "$MOF_FUZZ_LARGE" ] && echo "# MOF_FUZZ_LARGE=$MOF_FUZZ_LARGE: every FftMethod / video trial at a patch size in 193 .. 400"
+  [ -n "$MOF_FUZZ_LARGE" ] && echo "# MOF_FUZZ_LARGE=$MOF_FUZZ_LARGE: every FftMethod / video trial at a patch size in 193 .. 400 (or the band lo-hi given)"
   echo "# fft_sr_fuzz.py <seed> $TRIALS 12: random FftMethod layouts at random patch sizes + estimator settings + sequence trials; bm_fuzz.py <seed> 60"
   echo "# bars: tests/tolerances.py (1e-4 px against both oracles; a patch that misses it is classified from its input pixels, tests/conditioning.py, and held to 1e-4 + 2 x the scatter of independent f32 transforms on it, <= 1e-3 px; unpinned -- integer peak only -- where those scatter further)"
 } > $OUT
