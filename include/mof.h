@@ -191,9 +191,24 @@ int mof_fft_process_sequence_device_bgr(mof_fft_engine* e, const uint8_t* d_fram
  * in BYTES (3 per pixel). Otherwise as mof_fft_process_batch_device. */
 int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                      size_t prev_stride, size_t pitch, int n_pairs, double* d_out_xy, void* stream);
-/* Same on HOST pointers (upload, run, download, synchronous). */
+/* Same on HOST pointers, synchronous: what a caller that holds its frames in host memory (a replayed camera log, the node's cv::Mat
+ * frames of optic_flow.cpp:1465) calls. r06: a three-slot pipeline (csrc/host_pipe.hpp) -- chunks of about 16 MB of frames are uploaded on
+ * a copy stream of the engine's own while the previous chunk runs through mof_fft_process_batch_device on the engine's stream (so the
+ * results are that entry's bits) and the calling thread packs the next one:
+ *   - frames in PINNED memory (mof_host_alloc / mof_host_register below, or the caller's own hipHostMalloc) are DMA'd from where they lie;
+ *     pageable frames are packed into pinned staging first (MOF_HOST_THREADS helpers, default 4);
+ *   - a VIDEO -- cur == prev + prev_stride and cur_stride == prev_stride, i.e. pair k = (frame k + 1, frame k) of one run of frames, what
+ *     consecutive processImage calls see (FftMethod.cpp:1872) -- is uploaded once per frame (MOF_HOST_VIDEO=0: as two batches).
+ * PCIe-bound either way (profiles/r06_host_entries.txt); never what bench.py's `value` reports. */
 int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
                                size_t prev_stride, size_t pitch, int n_pairs, double* out_xy);
+
+/* Pinned (page-locked) host memory for callers that do not link HIP themselves: hipHostMalloc / hipHostFree / hipHostRegister /
+ * hipHostUnregister behind the C ABI. Frames handed to the *_batch_host entries from such memory skip the staging copy. */
+int mof_host_alloc(size_t bytes, void** out);
+int mof_host_free(void* p);
+int mof_host_register(void* p, size_t bytes);
+int mof_host_unregister(void* p);
 
 /* Waits for the engine's own stream. */
 int mof_fft_sync(mof_fft_engine* e);
@@ -297,6 +312,8 @@ int mof_bm_process_batch_device(mof_bm_engine* e, const uint8_t* d_cur, size_t c
 int mof_bm_process_batch_device_bgr(mof_bm_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,
                                     size_t prev_stride, size_t pitch, int n_pairs, int8_t* d_dx, int8_t* d_dy,
                                     int8_t* d_mode, void* stream);
+/* On HOST pointers, synchronous: the same upload / run / download pipeline as mof_fft_process_batch_host (pinned frames DMA'd in place,
+ * a video uploaded once per frame), chunks through mof_bm_process_batch_device. */
 int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
                               size_t prev_stride, size_t pitch, int n_pairs, int8_t* dx, int8_t* dy, int8_t* mode);
 int mof_bm_sync(mof_bm_engine* e);

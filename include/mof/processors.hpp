@@ -125,6 +125,18 @@ class FftMethod {
                   "mof_fft_process_sequence_device");
   }
 
+  // A video in HOST memory (a replayed camera log): frame i at frames + i * frame_stride, rows `pitch` bytes apart. Returns the vectors the
+  // processImage calls of frames 1 .. n - 1 would return, pair-major ((n_frames - 1) * sqNum^2 entries). The frames go up once each on a
+  // copy stream while the previous chunk is computed (mof_fft_process_batch_host; frames in pinned memory -- mof_host_alloc /
+  // mof_host_register -- are DMA'd from where they lie). The stateful previous frame of processImage is not touched.
+  std::vector<Point2d> processVideo(const uint8_t* frames, size_t frame_stride, size_t pitch, int n_frames) {
+    if (n_frames < 2) return {};
+    std::vector<Point2d> speeds((size_t)(n_frames - 1) * cfg_.grid_x * cfg_.grid_y);
+    detail::check(mof_fft_process_batch_host(engine_, frames + frame_stride, frame_stride, frames, frame_stride, pitch, n_frames - 1,
+                                             reinterpret_cast<double*>(speeds.data())), "mof_fft_process_batch_host");
+    return speeds;
+  }
+
   int sqNum() const { return cfg_.grid_x; }
   int invalidPatches() const { return last_invalid_; }
   const mof_fft_config& config() const { return cfg_; }

@@ -8,7 +8,7 @@ loudly if it is missing or no HIP device is present -- there is no CPU fallback.
 """
 from . import _capi  # noqa: F401
 from ._capi import MofError, MofLibraryError  # noqa: F401
-from .engine import BlockMethod, FastSpacedBMMethod, FftMethod, ScaleRotationEstimator, release_captured  # noqa: F401
+from .engine import BlockMethod, FastSpacedBMMethod, FftMethod, ScaleRotationEstimator, pinned_empty, release_captured  # noqa: F401
 
 __all__ = ["FftMethod", "BlockMethod", "FastSpacedBMMethod", "ScaleRotationEstimator", "MofError", "MofLibraryError",
-           "release_captured"]
+           "release_captured", "pinned_empty"]

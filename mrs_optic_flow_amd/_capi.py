@@ -81,6 +81,10 @@ SYMBOLS = {
     "mof_fft_process_sequence_device_bgr": (_I, [_VP, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_fft_process_batch_device_bgr": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_fft_process_batch_host": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP]),
+    "mof_host_alloc": (_I, [_SZ, C.POINTER(_VP)]),
+    "mof_host_free": (_I, [_VP]),
+    "mof_host_register": (_I, [_VP, _SZ]),
+    "mof_host_unregister": (_I, [_VP]),
     "mof_fft_sync": (_I, [_VP]),
     "mof_shard_slab_pairs": (_I, [_I, _I]),
     "mof_shard_partition": (_I, [_I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "capi_graph.hpp"
+#include "host_pipe.hpp"
 #include "mof_kernels.h"
 
 namespace {
@@ -136,6 +137,8 @@ struct mof_fft_engine {
   bool scratch_used = false;
   std::atomic<bool> busy{false};
   std::atomic<bool> graph_pinned{false};  // a batch call was captured into a HIP graph (capi_graph.hpp)
+  std::mutex host_mu;                     // mof_fft_process_batch_host: upload / run / download pipeline (host_pipe.hpp), made by its first call
+  mof::HostPipe* host_pipe = nullptr;
 };
 
 static void large_free(mof_fft_engine* e) {
@@ -359,6 +362,8 @@ struct mof_bm_engine {
   bool have_pair = false;      // a processImage call has been made (both frame slots are meaningful)
   std::atomic<bool> busy{false};
   std::atomic<bool> graph_pinned{false};
+  std::mutex host_mu;          // mof_bm_process_batch_host's pipeline (host_pipe.hpp)
+  mof::HostPipe* host_pipe = nullptr;
 };
 
 extern "C" {
@@ -566,6 +571,7 @@ static void fft_destroy_now(void* p) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
+  delete e->host_pipe;
   large_free(e);
   if (e->scratch_ev) (void)hipEventDestroy(e->scratch_ev);
   if (e->d_twiddles) (void)hipFree(e->d_twiddles);
@@ -852,34 +858,51 @@ int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur
   if (!cur || !prev || !out_xy || n_pairs < 0 || pitch < (size_t)e->cfg.frame_width)
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  mof::RelaxedCapture relaxed;  // the temporaries below must not disturb a capture on another thread
-  const size_t fb = e->frame_bytes, res = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
-  uint8_t *d_c = nullptr, *d_p = nullptr;
-  double* d_o = nullptr;
-  std::vector<uint8_t> pc(fb * n_pairs), pp(fb * n_pairs);
-  for (int k = 0; k < n_pairs; ++k) {
-    pack_frame(pc.data() + fb * k, cur + cur_stride * k, pitch, e->cfg.frame_width, e->cfg.frame_height);
-    pack_frame(pp.data() + fb * k, prev + prev_stride * k, pitch, e->cfg.frame_width, e->cfg.frame_height);
+  mof::RelaxedCapture relaxed;  // the pipeline's first-call allocations must not disturb a capture on another thread
+  const size_t res = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2 * sizeof(double);
+  {
+    std::lock_guard<std::mutex> lock(e->host_mu);
+    if (!e->host_pipe) e->host_pipe = new mof::HostPipe(e->frame_bytes, &res, 1);
   }
-  int rc = MOF_OK;
-  hipError_t he;
-  if ((he = hipMalloc(&d_c, fb * n_pairs)) != hipSuccess || (he = hipMalloc(&d_p, fb * n_pairs)) != hipSuccess ||
-      (he = hipMalloc(&d_o, res * n_pairs * sizeof(double))) != hipSuccess ||
-      (he = mof::copy_on(e->stream, d_c, pc.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess ||
-      (he = mof::copy_on(e->stream, d_p, pp.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess) {
-    rc = fail(MOF_ERR_HIP, "batch upload: %s", hipGetErrorString(he));
-  }
-  if (rc == MOF_OK)
-    rc = mof_fft_process_batch_device(e, d_c, fb, d_p, fb, (size_t)e->cfg.frame_width, n_pairs, d_o, e->stream);
-  if (rc == MOF_OK && ((he = hipStreamSynchronize(e->stream)) != hipSuccess ||
-                       (he = mof::copy_on(e->stream, out_xy, d_o, res * n_pairs * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess))
-    rc = fail(MOF_ERR_HIP, "batch download: %s", hipGetErrorString(he));
-  if (d_c) (void)hipFree(d_c);
-  if (d_p) (void)hipFree(d_p);
-  if (d_o) (void)hipFree(d_o);
+  const mof::HostPipe::Out out{out_xy, res};
+  hipError_t he = hipSuccess;
+  // chunks of frames go up on the pipe's copy stream while the engine's stream runs the previous chunk through the DEVICE batch entry
+  // (its kernels, its bits); a video -- cur = prev + one frame -- arrives as the two views of ONE uploaded run
+  const int rc = e->host_pipe->process(
+      cur, cur_stride, prev, prev_stride, pitch, e->cfg.frame_width, e->cfg.frame_height, n_pairs, &out, e->stream,
+      [e](const mof::HostPipe::Chunk& c, hipStream_t s) {
+        return mof_fft_process_batch_device(e, c.d_cur, c.stride, c.d_prev, c.stride, (size_t)e->cfg.frame_width, c.count,
+                                            static_cast<double*>(c.d_out[0]), s);
+      },
+      &he);
+  if (rc == -1) return fail(MOF_ERR_HIP, "host batch pipeline: %s", hipGetErrorString(he));
   return rc;
 } catch (const std::bad_alloc&) {
   return fail(MOF_ERR_NO_MEMORY, "mof_fft_process_batch_host: out of host memory");
+}
+
+/* Pinned host memory for callers that do not link HIP themselves: frames handed to the *_batch_host entries from such memory are DMA'd
+ * from where they lie (host_pipe.hpp). */
+int mof_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return fail(MOF_ERR_BAD_ARG, "mof_host_alloc: null result pointer or zero bytes");
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return MOF_OK;
+}
+int mof_host_free(void* p) {
+  if (!p) return MOF_OK;
+  HIP_TRY(hipHostFree(p));
+  return MOF_OK;
+}
+int mof_host_register(void* p, size_t bytes) {
+  if (!p || bytes == 0) return fail(MOF_ERR_BAD_ARG, "mof_host_register: null pointer or zero bytes");
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return MOF_OK;
+}
+int mof_host_unregister(void* p) {
+  if (!p) return fail(MOF_ERR_BAD_ARG, "mof_host_unregister: null pointer");
+  HIP_TRY(hipHostUnregister(p));
+  return MOF_OK;
 }
 
 int mof_fft_sync(mof_fft_engine* e) {
@@ -1000,6 +1023,7 @@ static void bm_destroy_now(void* p) {
   mof::RelaxedCapture relaxed;
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  delete e->host_pipe;
   if (e->d_frames[0]) (void)hipFree(e->d_frames[0]);
   if (e->d_frames[1]) (void)hipFree(e->d_frames[1]);
   if (e->d_dx) (void)hipFree(e->d_dx);
@@ -1180,34 +1204,22 @@ int mof_bm_process_batch_host(mof_bm_engine* e, const uint8_t* cur, size_t cur_s
     return fail(MOF_ERR_BAD_ARG, "bad batch arguments");
   HIP_TRY(hipSetDevice(e->cfg.device));
   mof::RelaxedCapture relaxed;
-  const size_t fb = e->frame_bytes, nb = (size_t)e->cfg.grid_x * e->cfg.grid_y;
-  std::vector<uint8_t> pc(fb * n_pairs), pp(fb * n_pairs);
-  for (int k = 0; k < n_pairs; ++k) {
-    pack_frame(pc.data() + fb * k, cur + cur_stride * k, pitch, e->cfg.frame_width, e->cfg.frame_height);
-    pack_frame(pp.data() + fb * k, prev + prev_stride * k, pitch, e->cfg.frame_width, e->cfg.frame_height);
+  const size_t nb = (size_t)e->cfg.grid_x * e->cfg.grid_y;
+  const size_t bpp[3] = {nb, nb, 8};
+  {
+    std::lock_guard<std::mutex> lock(e->host_mu);
+    if (!e->host_pipe) e->host_pipe = new mof::HostPipe(e->frame_bytes, bpp, 3);
   }
-  uint8_t *d_c = nullptr, *d_p = nullptr;
-  int8_t *d_x = nullptr, *d_y = nullptr, *d_m = nullptr;
-  int rc = MOF_OK;
-  hipError_t he;
-  if ((he = hipMalloc(&d_c, fb * n_pairs)) != hipSuccess || (he = hipMalloc(&d_p, fb * n_pairs)) != hipSuccess ||
-      (he = hipMalloc(&d_x, nb * n_pairs)) != hipSuccess || (he = hipMalloc(&d_y, nb * n_pairs)) != hipSuccess ||
-      (he = hipMalloc(&d_m, 8 * (size_t)n_pairs)) != hipSuccess ||
-      (he = mof::copy_on(e->stream, d_c, pc.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess ||
-      (he = mof::copy_on(e->stream, d_p, pp.data(), fb * n_pairs, hipMemcpyHostToDevice)) != hipSuccess)
-    rc = fail(MOF_ERR_HIP, "batch upload: %s", hipGetErrorString(he));
-  if (rc == MOF_OK)
-    rc = mof_bm_process_batch_device(e, d_c, fb, d_p, fb, (size_t)e->cfg.frame_width, n_pairs, d_x, d_y, d_m, e->stream);
-  if (rc == MOF_OK && ((he = hipStreamSynchronize(e->stream)) != hipSuccess ||
-                       (he = mof::copy_on(e->stream, dx, d_x, nb * n_pairs, hipMemcpyDeviceToHost)) != hipSuccess ||
-                       (he = mof::copy_on(e->stream, dy, d_y, nb * n_pairs, hipMemcpyDeviceToHost)) != hipSuccess ||
-                       (he = mof::copy_on(e->stream, mode, d_m, 8 * (size_t)n_pairs, hipMemcpyDeviceToHost)) != hipSuccess))
-    rc = fail(MOF_ERR_HIP, "batch download: %s", hipGetErrorString(he));
-  if (d_c) (void)hipFree(d_c);
-  if (d_p) (void)hipFree(d_p);
-  if (d_x) (void)hipFree(d_x);
-  if (d_y) (void)hipFree(d_y);
-  if (d_m) (void)hipFree(d_m);
+  const mof::HostPipe::Out outs[3] = {{dx, nb}, {dy, nb}, {mode, 8}};
+  hipError_t he = hipSuccess;
+  const int rc = e->host_pipe->process(
+      cur, cur_stride, prev, prev_stride, pitch, e->cfg.frame_width, e->cfg.frame_height, n_pairs, outs, e->stream,
+      [e](const mof::HostPipe::Chunk& c, hipStream_t s) {
+        return mof_bm_process_batch_device(e, c.d_cur, c.stride, c.d_prev, c.stride, (size_t)e->cfg.frame_width, c.count,
+                                           static_cast<int8_t*>(c.d_out[0]), static_cast<int8_t*>(c.d_out[1]), static_cast<int8_t*>(c.d_out[2]), s);
+      },
+      &he);
+  if (rc == -1) return fail(MOF_ERR_HIP, "host batch pipeline: %s", hipGetErrorString(he));
   return rc;
 } catch (const std::bad_alloc&) {
   return fail(MOF_ERR_NO_MEMORY, "mof_bm_process_batch_host: out of host memory");

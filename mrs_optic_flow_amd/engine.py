@@ -28,6 +28,37 @@ def _np_u8(frame) -> np.ndarray:
     return a
 
 
+def _host_batch_views(cur, prev):
+    """The two [n, H, W] uint8 arrays of a host batch as the C ABI takes them -- (cur, prev, cur_stride, prev_stride, pitch) -- WITHOUT a copy
+    when their rows are dense runs of bytes with one pitch: a video handed over as ``frames[1:], frames[:-1]`` keeps its memory, which is
+    how the library sees that it is one (include/mof.h, mof_fft_process_batch_host)."""
+    cur, prev = np.asarray(cur), np.asarray(prev)
+    if cur.shape != prev.shape or cur.ndim != 3:
+        raise ValueError("cur and prev must be [n, H, W] arrays of one shape")
+
+    def usable(a):
+        return a.dtype == np.uint8 and a.strides[2] == 1 and a.strides[1] >= a.shape[2] and (a.shape[0] < 2 or a.strides[0] > 0)
+
+    if not (usable(cur) and usable(prev) and cur.strides[1] == prev.strides[1]):
+        cur, prev = np.ascontiguousarray(cur, dtype=np.uint8), np.ascontiguousarray(prev, dtype=np.uint8)
+    return cur, prev, max(cur.strides[0], 0), max(prev.strides[0], 0), cur.strides[1]
+
+
+def pinned_empty(shape, dtype=np.uint8) -> np.ndarray:
+    """A numpy array in page-locked host memory (mof_host_alloc): frames kept in one are DMA'd by the *_batch_host entries from where they
+    lie. The memory is returned when the array (and every view of it) is gone."""
+    import weakref
+
+    lib = _capi.load()
+    dt = np.dtype(dtype)
+    nbytes = max(1, int(np.prod(shape)) * dt.itemsize)
+    p = C.c_void_p()
+    check(lib.mof_host_alloc(nbytes, C.byref(p)))
+    buf = (C.c_uint8 * nbytes).from_address(p.value)
+    weakref.finalize(buf, lib.mof_host_free, C.c_void_p(p.value))
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
 def _stream_ptr(stream):
     if stream is None:
         return None
@@ -197,16 +228,11 @@ class FftMethod:
 
     # -- batched --------------------------------------------------------------------------------
     def process_batch_host(self, cur: np.ndarray, prev: np.ndarray) -> np.ndarray:
-        cur = np.ascontiguousarray(cur, dtype=np.uint8)
-        prev = np.ascontiguousarray(prev, dtype=np.uint8)
-        if cur.shape != prev.shape or cur.ndim != 3:
-            raise ValueError("cur and prev must be [n, H, W] arrays of one shape")
+        cur, prev, cs, ps, pitch = _host_batch_views(cur, prev)
         self._check_shape(cur)
         n = cur.shape[0]
         out = np.empty((n, self.n_patches, 2), np.float64)
-        fb = cur.shape[1] * cur.shape[2]
-        check(self._lib.mof_fft_process_batch_host(self._h, cur.ctypes.data, fb, prev.ctypes.data, fb, cur.shape[2], n,
-                                                   out.ctypes.data))
+        check(self._lib.mof_fft_process_batch_host(self._h, cur.ctypes.data, cs, prev.ctypes.data, ps, pitch, n, out.ctypes.data))
         return out
 
     def process_batch_device(self, cur, prev, out=None, stream=None):
@@ -348,17 +374,13 @@ class _BmBase:
         return np.array([self.refine(mode, 2, refine == "faithful")])
 
     def process_batch_host(self, cur: np.ndarray, prev: np.ndarray):
-        cur = np.ascontiguousarray(cur, dtype=np.uint8)
-        prev = np.ascontiguousarray(prev, dtype=np.uint8)
-        if cur.shape != prev.shape or cur.ndim != 3:
-            raise ValueError("cur and prev must be [n, H, W] arrays of one shape")
+        cur, prev, cs, ps, pitch = _host_batch_views(cur, prev)
         self._check_shape(cur)
         n = cur.shape[0]
         dx = np.empty((n, self.cfg.grid_y, self.cfg.grid_x), np.int8)
         dy = np.empty_like(dx)
         mode = np.empty((n, 8), np.int8)
-        fb = cur.shape[1] * cur.shape[2]
-        check(self._lib.mof_bm_process_batch_host(self._h, cur.ctypes.data, fb, prev.ctypes.data, fb, cur.shape[2], n,
+        check(self._lib.mof_bm_process_batch_host(self._h, cur.ctypes.data, cs, prev.ctypes.data, ps, pitch, n,
                                                   dx.ctypes.data, dy.ctypes.data, mode.ctypes.data))
         return dx, dy, mode
 

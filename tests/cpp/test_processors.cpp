@@ -74,6 +74,26 @@ int main(int argc, char** argv) {
       }
       return 0;
     }
+    if (argc >= 7 && !std::strcmp(argv[1], "fftvideo")) {  // a video in HOST memory: FftMethod::processVideo (pageable, then pinned through mof_host_register)
+      const int fs = std::atoi(argv[2]), sps = std::atoi(argv[3]), n = std::atoi(argv[5]);
+      const double mps = std::atof(argv[4]);
+      auto frames = read_all(argv[6], (size_t)fs * fs * n);
+      mof::FftMethod proc(fs, sps, mps);
+      const size_t per = (size_t)proc.sqNum() * proc.sqNum();
+      auto pageable = proc.processVideo(frames.data(), (size_t)fs * fs, (size_t)fs, n);
+      if (mof_host_register(frames.data(), frames.size()) != MOF_OK) throw std::runtime_error(mof_last_error());
+      auto pinned = proc.processVideo(frames.data(), (size_t)fs * fs, (size_t)fs, n);
+      if (mof_host_unregister(frames.data()) != MOF_OK) throw std::runtime_error(mof_last_error());
+      if (pageable.size() != per * (n - 1) || pinned.size() != pageable.size() ||
+          std::memcmp(pageable.data(), pinned.data(), pageable.size() * sizeof(mof::Point2d)) != 0)
+        throw std::runtime_error("pinned and pageable videos disagree");
+      for (int t = 0; t + 1 < n; ++t) {
+        std::printf("pair %d n %zu", t, per);
+        for (size_t i = 0; i < per; ++i) std::printf(" %.17g %.17g", pageable[(size_t)t * per + i].x, pageable[(size_t)t * per + i].y);
+        std::printf("\n");
+      }
+      return 0;
+    }
     if (argc >= 7 && !std::strcmp(argv[1], "fftseq")) {
       const int fs = std::atoi(argv[2]), sps = std::atoi(argv[3]), n = std::atoi(argv[5]);
       const double mps = std::atof(argv[4]);

@@ -124,6 +124,14 @@ def test_cpp_mirror_sequence_entries(gpu, tmp_path):
         got = np.array([float(v) for v in tok[4:]]).reshape(9, 2)
         want, _ = O.fft_process(frames[t + 1], frames[t], lay, 64)
         assert np.allclose(got, want, rtol=0, atol=1e-4, equal_nan=True)
+    # the same video from HOST memory (FftMethod::processVideo -> mof_fft_process_batch_host): what the stateful processImage calls return
+    stateful = _run(["fft", fs, sps, 80, n], frames, tmp_path)
+    lines = _run(["fftvideo", fs, sps, 80, n], frames, tmp_path)
+    assert len(lines) == n - 1
+    for t, tok in enumerate(lines):
+        want = np.array([float(v) for v in stateful[t + 1][4:]]).reshape(9, 2)
+        got = np.array([float(v) for v in tok[4:]]).reshape(9, 2)
+        assert np.array_equal(got, want, equal_nan=True)  # (N = 64: the pair kernel behind both)
     res, M, nf = 240, 40.0, 5
     base = sr_scenes.canvas(8, res)
     video = np.stack([sr_scenes.view(base, res, 1.0 + 0.012 * t, 1.4 * t) for t in range(nf)])
