@@ -656,6 +656,35 @@ for _n in (100, 144, 150, 162, 180, 192):
     WORKLOADS[f"t{_n}"] = _tile_workload(_n)
 
 
+def host_entries_record(n=512):
+    """The PCIe-INCLUSIVE rate of the host-pointer batch entry at c2 (mof_fft_process_batch_host, csrc/host_pipe.hpp: a three-slot upload /
+    run / download pipeline over the device entry; host frames in, host results out) -- never `value`, which starts with the batch in HBM.
+    Four memory layouts: pageable / pinned frames, as two pair buffers or as one video (cur = prev + one frame: each frame uploaded once)."""
+    import numpy as np
+
+    from mrs_optic_flow_amd import FftMethod, pinned_empty, synth
+    w = WORKLOADS["c2"]
+    fm = FftMethod(sample_point_size=w["n"], frame_shape=(w["h"], w["w"]), grid=w["grid"], origin=w["origin"], stride=w["stride"])
+    base, _, _, _ = synth.batch_np(64, w["h"], w["w"], w["s"], classes=False, k0=3)
+    frames = np.ascontiguousarray(np.tile(base, ((n + 64) // 64, 1, 1))[: n + 1])
+    pin = pinned_empty(frames.shape)
+    pin[:] = frames
+    pc, pp = pinned_empty((n,) + frames.shape[1:]), pinned_empty((n,) + frames.shape[1:])
+    pc[:] = frames[1:]
+    pp[:] = frames[:-1]
+    rec = {"workload": "c2", "pairs_per_call": n, "unit": "frame pairs/s, host frames in -> host results out (PCIe-inclusive; best of 3 calls)"}
+    for label, c, p, up in (("pageable_pairs", frames[1:].copy(), frames[:-1].copy(), 2 * n), ("pageable_video", frames[1:], frames[:-1], n + 1),
+                            ("pinned_pairs", pc, pp, 2 * n), ("pinned_video", pin[1:], pin[:-1], n + 1)):
+        fm.process_batch_host(c, p)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fm.process_batch_host(c, p)
+            best = min(best, time.perf_counter() - t0)
+        rec[label] = {"value": round(n / best, 1), "frames_gb_per_s": round(up * w["h"] * w["w"] / best / 1e9, 2)}
+    return rec
+
+
 def native_group_run(tag: str, wl, n_dev: int, steps: int, warmup: int, share_gpu: bool, sync_per_step: bool = False, settle_s: float = 0.4):
     """The batched-frames mode through the NATIVE shard group (mof_shard_fft_* / mof_shard_bm_*, csrc/mof_shard.hip): ONE process, no
     torch.distributed -- one engine and one HIP stream per device inside the library, ceil(B / G) contiguous shards, one in-place RCCL
@@ -1036,6 +1065,10 @@ def main() -> None:
                                        for tag, st in (("c3", 50), ("c4", 20), ("c5", 40), ("c2seq", 50), ("c4seq", 10), ("c5seq", 40), ("ref", 50), ("refseq", 50),
                                                        ("bmref", 50), ("refrt", 50), ("reflr", 50),
                                                        ("p60", 50), ("l160", 40), ("l200", 20), ("l240", 20), ("l480", 20))}  # the planned kernel, the half-tile kernel (r05), the large-patch pipeline
+            try:
+                line["host_entries"] = host_entries_record()
+            except BaseException as e:
+                line["host_entries"] = {"error": f"{type(e).__name__}: {e}"}
         emit(line)
     if world > 1:
         dist.barrier()

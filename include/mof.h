@@ -199,7 +199,9 @@ int mof_fft_process_batch_device_bgr(mof_fft_engine* e, const uint8_t* d_cur, si
  *     pageable frames are packed into pinned staging first (MOF_HOST_THREADS helpers, default 4);
  *   - a VIDEO -- cur == prev + prev_stride and cur_stride == prev_stride, i.e. pair k = (frame k + 1, frame k) of one run of frames, what
  *     consecutive processImage calls see (FftMethod.cpp:1872) -- is uploaded once per frame (MOF_HOST_VIDEO=0: as two batches).
- * PCIe-bound either way (profiles/r06_host_entries.txt); never what bench.py's `value` reports. */
+ * PCIe-bound either way (profiles/r06_host_entries.txt); never what bench.py's `value` reports. The pipeline's buffers (three slots of two
+ * chunks of frames on the device, the same again in pinned host memory once a pageable caller shows up: about 100 MB each) are made by the
+ * first call and live until mof_fft_destroy. Calls on one engine are serialised. */
 int mof_fft_process_batch_host(mof_fft_engine* e, const uint8_t* cur, size_t cur_stride, const uint8_t* prev,
                                size_t prev_stride, size_t pitch, int n_pairs, double* out_xy);
 
