@@ -430,6 +430,14 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
 int mof_sr_process_sequence_device(mof_sr_engine* e, const uint8_t* d_frames, size_t frame_stride, size_t pitch,
                                    int n_frames, double* d_out, void* stream, int* n_gated);
 
+/* The same video in HOST memory, synchronous: exactly the n_frames consecutive mof_sr_process calls (gate resolved, the estimator's state
+ * continued and left as they would leave it), with the frames uploaded in chunks on a copy stream beside the previous chunk's kernels
+ * (csrc/host_pipe.hpp; frames in pinned memory -- mof_host_alloc / mof_host_register -- are DMA'd from where they lie). out receives
+ * n_frames * 4 doubles; *n_gated (may be NULL) the number of gated frames. A failure half-way leaves the state as the last completed
+ * CHUNK left it (the frames before it have been consumed). */
+int mof_sr_process_sequence_host(mof_sr_engine* e, const uint8_t* frames, size_t frame_stride, size_t pitch, int n_frames,
+                                 double* out, int* n_gated);
+
 /* The remap stage alone: cv::logPolar(src, dst, Point2f(res/2, res/2), M, interpolation) (scaleRotationEstimator.cpp:45
  * INTER_CUBIC, :112 INTER_LANCZOS4) on n_images res x res CV_8UC1 crops (image i at d_src + i*src_stride, `pitch` bytes
  * per row) into tightly packed res*res outputs at d_dst + i*res*res. As with cv::remap's BORDER_TRANSPARENT,

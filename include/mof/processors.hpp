@@ -364,6 +364,13 @@ class scaleRotationEstimator {
                   "mof_sr_process_sequence_device");
     return gated;
   }
+  // The same video in HOST memory (mof_sr_process_sequence_host): out4 = n_frames * 4 doubles; the frames are uploaded in chunks beside the
+  // previous chunk's kernels (pinned frames -- mof_host_alloc / mof_host_register -- from where they lie). Returns the number of gated frames.
+  int processVideo(const uint8_t* frames, size_t frame_stride, size_t pitch, int n_frames, double* out4) {
+    int gated = 0;
+    detail::check(mof_sr_process_sequence_host(engine_, frames, frame_stride, pitch, n_frames, out4, &gated), "mof_sr_process_sequence_host");
+    return gated;
+  }
   mof_sr_engine* handle() { return engine_; }
 
  private:

@@ -127,6 +127,7 @@ SYMBOLS = {
     "mof_sr_process": (_I, [_VP, _VP, _SZ, _VP]),
     "mof_sr_process_batch_device": (_I, [_VP, _VP, _SZ, _VP, _SZ, _SZ, _I, _VP, _VP]),
     "mof_sr_process_sequence_device": (_I, [_VP, _VP, _SZ, _SZ, _I, _VP, _VP, C.POINTER(_I)]),
+    "mof_sr_process_sequence_host": (_I, [_VP, _VP, _SZ, _SZ, _I, _VP, C.POINTER(_I)]),
     "mof_sr_logpolar_batch_device": (_I, [_VP, _VP, _SZ, _SZ, _I, _I, _VP, _VP]),
     "mof_geom_layout_reference": (_I, [_VP, _I, _I]),
     "mof_geom_undistort_points": (_I, [_VP, C.c_double, _VP, _I, _VP]),

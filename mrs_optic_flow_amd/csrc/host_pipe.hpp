@@ -126,6 +126,59 @@ class HostPipe {
     return rc;
   }
 
+  // A run of FRAMES (no pairing: the estimator's video, whose device entry is stateful and -- resolving its gate -- synchronous): chunk k + 1 is
+  // packed and its upload queued BEFORE chunk k is handed to `run`, so the DMA rides beside the kernels and the read-back of chunk k.
+  // run(chunk with d_cur = the frames, d_prev = nullptr, count = frames, stream) must have finished its work on `compute` when it returns an
+  // error; on success the pipe itself waits for `compute` before it reads the results.
+  template <class Run>
+  int process_frames(const uint8_t* frames, size_t stride, size_t pitch, int row_bytes, int rows, int n_frames, const Out* outs,
+                     hipStream_t compute, Run&& run, hipError_t* err) {
+    std::lock_guard<std::mutex> lock(mu_);
+    *err = hipSuccess;
+    if ((*err = ensure_device()) != hipSuccess) return -1;
+    const size_t span = stride * (size_t)(n_frames - 1) + pitch * (size_t)(rows - 1) + row_bytes;
+    const bool pinned = host_pointer_is_pinned(frames) && host_pointer_is_pinned(frames + span - 1);
+    if (!pinned && (*err = ensure_staging()) != hipSuccess) return -1;
+    const int per = 2 * chunk_;  // a slot holds two chunks of frames
+    auto queue = [&](int i) -> hipError_t {  // upload of chunk i into slot i % SLOTS
+      Slot& s = slot_[i % SLOTS];
+      const int f0 = i * per, c = std::min(per, n_frames - f0);
+      hipError_t e = upload(s, 0, frames + stride * (size_t)f0, stride, pitch, row_bytes, rows, c, pinned);
+      if (e == hipSuccess) e = hipEventRecord(s.up, copy_);
+      return e;
+    };
+    const int n_chunks = (n_frames + per - 1) / per;
+    int rc = 0;
+    if ((*err = queue(0)) != hipSuccess) rc = -1;
+    for (int i = 0; i < n_chunks && rc == 0; ++i) {
+      Slot& s = slot_[i % SLOTS];
+      const int f0 = i * per, c = std::min(per, n_frames - f0);
+      if (i + 1 < n_chunks && (*err = queue(i + 1)) != hipSuccess) { rc = -1; break; }  // (slot i + 1 was drained two chunks ago: everything below is synchronous)
+      if ((*err = hipStreamWaitEvent(compute, s.up, 0)) != hipSuccess) { rc = -1; break; }
+      Chunk ch{};
+      ch.d_cur = s.d_frames;
+      ch.d_prev = nullptr;
+      ch.stride = fb_;
+      ch.count = c;
+      for (int k = 0; k < n_outs_; ++k) ch.d_out[k] = s.d_out[k];
+      rc = run(ch, compute);
+      if (rc != 0) break;
+      for (int k = 0; k < n_outs_ && *err == hipSuccess; ++k)
+        *err = hipMemcpyAsync(s.h_out[k], s.d_out[k], out_bpp_[k] * (size_t)c, hipMemcpyDeviceToHost, compute);
+      if (*err == hipSuccess) *err = hipStreamSynchronize(compute);
+      if (*err != hipSuccess) { rc = -1; break; }
+      for (int k = 0; k < n_outs_; ++k)
+        std::memcpy(static_cast<uint8_t*>(outs[k].user) + outs[k].bytes_per_pair * (size_t)f0, s.h_out[k], outs[k].bytes_per_pair * (size_t)c);
+    }
+    if (rc != 0) {
+      (void)hipStreamSynchronize(copy_);
+      (void)hipStreamSynchronize(compute);
+    } else {
+      (void)hipStreamSynchronize(copy_);  // (the last queued upload has been consumed; nothing may outlive the call)
+    }
+    return rc;
+  }
+
   void release() {
     for (Slot& s : slot_) {
       if (s.d_frames) (void)hipFree(s.d_frames);
@@ -161,8 +214,8 @@ class HostPipe {
     for (Slot& s : slot_) {
       if ((e = hipMalloc(&s.d_frames, (size_t)2 * chunk_ * fb_)) != hipSuccess) return e;
       for (int i = 0; i < n_outs_; ++i) {
-        if ((e = hipMalloc(&s.d_out[i], out_bpp_[i] * (size_t)chunk_)) != hipSuccess) return e;
-        if ((e = hipHostMalloc(&s.h_out[i], out_bpp_[i] * (size_t)chunk_, hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipMalloc(&s.d_out[i], out_bpp_[i] * (size_t)2 * chunk_)) != hipSuccess) return e;  // (2 x: a slot of the FRAMES form holds two chunks)
+        if ((e = hipHostMalloc(&s.h_out[i], out_bpp_[i] * (size_t)2 * chunk_, hipHostMallocDefault)) != hipSuccess) return e;
       }
       if ((e = hipEventCreateWithFlags(&s.up, hipEventDisableTiming)) != hipSuccess) return e;
       if ((e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;

@@ -16,10 +16,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "capi_graph.hpp"
+#include "host_pipe.hpp"
 #include "mof.h"
 #include "mof_kernels.h"
 
@@ -284,6 +286,8 @@ struct mof_sr_engine {
   bool generic = false;
   mof::PcPlan plan{};
   std::atomic<bool> busy{false};
+  std::mutex host_mu;  // mof_sr_process_sequence_host: the upload pipeline (host_pipe.hpp), made by its first call
+  mof::HostPipe* host_pipe = nullptr;
   // a batch call was captured into a HIP graph: the graph's kernel nodes hold raw pointers into the scratch below, so
   // from then on the scratch neither grows nor is freed until mof_sr_release_graphs (capi_graph.hpp)
   std::atomic<bool> graph_pinned{false};
@@ -449,6 +453,7 @@ static void sr_destroy_now(void* p) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->scratch_ev && e->scratch_used) (void)hipEventSynchronize(e->scratch_ev);  // a batch on a caller's stream may still use the scratch
+  delete e->host_pipe;
   void* dev[] = {e->d_boxes[0], e->d_boxes[1], e->d_sboxes[0], e->d_sboxes[1], e->d_map, e->d_w_cubic, e->d_w_lanczos, e->d_wp[0], e->d_wp[1], e->d_twiddles, e->d_frame, e->d_temp_im, e->d_zh_prev, e->d_wfrag,
                  e->d_lp,  e->d_Zt,      e->d_Dt,        e->d_cand,     e->d_out, e->d_degen};
   for (void* p : dev)
@@ -817,6 +822,41 @@ int mof_sr_process_sequence_device(mof_sr_engine* e, const uint8_t* d_frames, si
     *n_gated = gated_total;
   }
   return MOF_OK;
+}
+
+int mof_sr_process_sequence_host(mof_sr_engine* e, const uint8_t* frames, size_t frame_stride, size_t pitch, int n_frames,
+                                 double* out, int* n_gated) try {
+  if (!e) return mof::capi_fail(MOF_ERR_NOT_INIT, "null engine");
+  if (n_gated) *n_gated = 0;
+  if (n_frames == 0) return MOF_OK;
+  const int res = e->cfg.resolution;
+  if (!frames || !out || n_frames < 0 || pitch < (size_t)res) return mof::capi_fail(MOF_ERR_BAD_ARG, "bad video arguments");
+  SR_TRY(hipSetDevice(e->cfg.device));
+  mof::RelaxedCapture relaxed;
+  const size_t bpp = 4 * sizeof(double);
+  {
+    std::lock_guard<std::mutex> lock(e->host_mu);
+    if (!e->host_pipe) e->host_pipe = new mof::HostPipe((size_t)res * res, &bpp, 1);
+  }
+  const mof::HostPipe::Out o{out, bpp};
+  hipError_t he = hipSuccess;
+  int gated_total = 0;
+  // the frames go up in chunks on the pipe's copy stream, each chunk runs through the DEVICE video entry -- stateful, so chunk k + 1
+  // continues where chunk k stopped, and with the gate resolved (n_gated != NULL there), i.e. exactly the frame-by-frame calls
+  const int rc = e->host_pipe->process_frames(
+      frames, frame_stride, pitch, res, res, n_frames, &o, e->stream,
+      [e, &gated_total](const mof::HostPipe::Chunk& c, hipStream_t s) {
+        int g = 0;
+        const int r = mof_sr_process_sequence_device(e, c.d_cur, c.stride, (size_t)e->cfg.resolution, c.count, static_cast<double*>(c.d_out[0]), s, &g);
+        gated_total += g;
+        return r;
+      },
+      &he);
+  if (rc == -1) return mof::capi_fail(MOF_ERR_HIP, "host video pipeline: %s", hipGetErrorString(he));
+  if (n_gated) *n_gated = gated_total;
+  return rc;
+} catch (const std::bad_alloc&) {
+  return mof::capi_fail(MOF_ERR_NO_MEMORY, "mof_sr_process_sequence_host: out of host memory");
 }
 
 int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t cur_stride, const uint8_t* d_prev,

@@ -481,6 +481,22 @@ class ScaleRotationEstimator:
         check(self._lib.mof_sr_process(self._h, f.ctypes.data, f.strides[0], out.ctypes.data))
         return float(out[0]), float(out[1])
 
+    def process_sequence_host(self, frames) -> np.ndarray:
+        """frames: numpy uint8 [n, res, res] video in HOST memory (any frame stride / row pitch; pinned_empty() memory is DMA'd in place)
+        -> float64 [n, 4] = what n consecutive processImage calls return (scale, rot, pt.x, pt.y), continuing and updating the engine's
+        state; ``self.last_gated`` = gated frames. Synchronous (mof_sr_process_sequence_host)."""
+        f = np.asarray(frames)
+        if f.ndim != 3 or tuple(f.shape[1:]) != (self.cfg.resolution, self.cfg.resolution):
+            raise ValueError("scaleRotationEstimator accepts only square images of its resolution")
+        if not (f.dtype == np.uint8 and f.strides[2] == 1 and f.strides[1] >= f.shape[2] and (f.shape[0] < 2 or f.strides[0] > 0)):
+            f = np.ascontiguousarray(f, dtype=np.uint8)
+        out = np.zeros((f.shape[0], 4), np.float64)
+        gated = C.c_int(0)
+        check(self._lib.mof_sr_process_sequence_host(self._h, f.ctypes.data, max(f.strides[0], 0), f.strides[1], f.shape[0], out.ctypes.data,
+                                                     C.byref(gated)))
+        self.last_gated = gated.value
+        return out
+
     def process_batch_device(self, cur, prev, stream=None):
         """cur, prev: torch uint8 [n, res, res] views (any pitch/stride) -> float64 [n, 4] = scale, rot, pt.x, pt.y."""
         import torch

@@ -104,3 +104,46 @@ def test_pinned_host_memory_of_the_c_abi(gpu):
     assert np.array_equal(got, want, equal_nan=True)
     t = torch.from_numpy(frames).to(gpu)
     assert np.array_equal(fm.process_batch_device(t[1:], t[:-1]).cpu().numpy(), want, equal_nan=True)
+
+
+_SR_SCRIPT = r"""
+import os, sys
+sys.path[:0] = [{root!r}, {tests!r}]
+import numpy as np, torch
+import sr_scenes
+from mrs_optic_flow_amd import ScaleRotationEstimator, pinned_empty
+res, M, n = 240, 40.0, 23
+base = sr_scenes.canvas(11, res)
+video = np.stack([sr_scenes.view(base, res, 1.0 + 0.01 * t, 1.2 * t - 5.0) for t in range(n)])
+video[9] = 0        # an all-zero frame: the degenerate pair and the gate (scaleRotationEstimator.cpp:119-121) are part of the contract
+one = ScaleRotationEstimator(res, M)
+want = np.array([one.processImage(f) for f in video])        # the frame-by-frame calls: (scale, rot)
+dev = ScaleRotationEstimator(res, M)
+want4 = dev.process_sequence_device(torch.from_numpy(video).cuda()).cpu().numpy()
+assert np.array_equal(want4[:, :2], want)
+gated0 = dev.last_gated
+checked = 0
+pin = pinned_empty(video.shape); pin[:] = video
+wide = np.zeros((n, res, res + 9), np.uint8); wide[:, :, :res] = video
+for label, v in (("pageable", video), ("pinned", pin), ("pitched", wide[:, :, :res]), ("strided", np.repeat(video, 2, 0)[::2])):
+    est = ScaleRotationEstimator(res, M)
+    got = est.process_sequence_host(v)
+    assert np.array_equal(got, want4), label
+    assert est.last_gated == gated0, (label, est.last_gated, gated0)
+    # the state continues: the same video again, now on an armed estimator, in two calls == one device call of the same shape
+    a = est.process_sequence_host(v[:7]); b = est.process_sequence_host(v[7:])
+    again = dev.process_sequence_device(torch.from_numpy(video).cuda()).cpu().numpy() if label == "pageable" else again
+    assert np.array_equal(np.concatenate([a, b]), again), label
+    checked += 1
+print("sr host video ok", checked)
+"""
+
+
+@pytest.mark.parametrize("env", [{"MOF_HOST_CHUNK": "1"}, {"MOF_HOST_CHUNK": "3", "MOF_HOST_THREADS": "2"}, {}])
+def test_estimator_video_from_host_memory_is_the_frame_by_frame_calls(gpu, env):
+    """mof_sr_process_sequence_host: chunks of 2 / 6 frames (a slot of the frames form holds two chunks) and the default, pageable /
+    pinned / pitched / strided videos with an all-zero frame inside: the (scale, rot) of the stateful processImage loop and the (pt.x,
+    pt.y) and gate count of the device video entry, bit for bit, and the state carried from one call into the next."""
+    script = _SR_SCRIPT.format(root=ROOT, tests=os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "sr host video ok 4" in r.stdout, (env, r.stdout[-1500:], r.stderr[-2500:])

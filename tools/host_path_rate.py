@@ -44,3 +44,13 @@ print(f"# host-pointer batch entries, {n} pairs per call, best of 4 (MOF_HOST_CH
 table("c2", FftMethod(sample_point_size=64, frame_shape=(480, 752), grid=(8, 8), origin=(1, 1), stride=(98, 59)), 480, 752)
 table("ref", FftMethod(480, 120, 80.0), 480, 480)
 table("c3", FastSpacedBMMethod(16, 16, 8, (480, 752)), 480, 752)
+
+# the estimator's video from host memory (mof_sr_process_sequence_host): frames per second, every frame uploaded once
+from mrs_optic_flow_amd import ScaleRotationEstimator
+est = ScaleRotationEstimator(480, 49.9)
+video = frames_of(480, 480)[:n]
+pinv = pinned_empty(video.shape)
+pinv[:] = video
+for label, v in (("pageable video", video), ("pinned video", pinv)):
+    t = rate(lambda: est.process_sequence_host(v))
+    print(f"c5seq {label:15s}: {n / t:10,.0f} frames/s ({t * 1e3:7.1f} ms per {n} frames, {n * 480 * 480 / t / 1e9:5.1f} GB/s of frames over PCIe)", flush=True)
