@@ -99,8 +99,18 @@ __device__ __forceinline__ void butterfly8_tw(cf* v, const cf* tw) {
   v[7] = csub(e3, w3);
 }
 
+// A/B (-DMOF_BFLY_PRIO_IN=a -DMOF_BFLY_PRIO_OUT=b): issue priority of a wave inside its radix-16 butterflies against the LDS phases around
+// them (r06, profiles/r06_bfly_prio_ab.txt: butterflies first -4 .. -5 % at c2 and -7 % at c4, LDS phases first +-0 -- off)
+#if defined(MOF_BFLY_PRIO_IN)
+#define MOF_BFLY_ENTER() __builtin_amdgcn_s_setprio(MOF_BFLY_PRIO_IN)
+#define MOF_BFLY_LEAVE() __builtin_amdgcn_s_setprio(MOF_BFLY_PRIO_OUT)
+#else
+#define MOF_BFLY_ENTER() ((void)0)
+#define MOF_BFLY_LEAVE() ((void)0)
+#endif
 template <>
 __device__ __forceinline__ void butterfly<16>(cf* v) {
+  MOF_BFLY_ENTER();
   // 16 = 4 x 4: four radix-4 over n1 (stride 4), twiddle W16^{n2 k1}, four radix-4 over n2
   const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
   cf t[4][4];
@@ -123,6 +133,7 @@ __device__ __forceinline__ void butterfly<16>(cf* v) {
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = a[k2];
   }
+  MOF_BFLY_LEAVE();
 }
 
 __device__ __forceinline__ void butterfly3(cf* a) {
