@@ -112,12 +112,20 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, 
     constexpr int NC = 4;  // ceil(960 / 4 / 64)
     uint32_t px[2][2][NC];
     const uint32_t pat = p00 * 0x01010101u;
+    const bool tiny = n < 4;  // (no whole chunk in a row: the byte loop; wave-uniform)
     auto load4 = [&](int y, int x0) -> uint32_t {
-      if (y >= n || x0 >= n) return 0u;
-      if (x0 + 3 < n) return fetch_px4_l<DS, CH>(base, src.pitch, y, x0);
-      uint32_t v = 0u;  // the last chunk of a row whose length is not a multiple of four
-      for (int b = 0; x0 + b < n; ++b) v |= fetch_px_l<DS, CH>(base, src.pitch, y, x0 + b) << (8 * b);
-      return v;
+      if (tiny) {
+        if (y >= n || x0 >= n) return 0u;
+        uint32_t v = 0u;
+        for (int b = 0; x0 + b < n; ++b) v |= fetch_px_l<DS, CH>(base, src.pitch, y, x0 + b) << (8 * b);
+        return v;
+      }
+      // branch-free (r06, as the tuned row kernel's px4): an unconditional load of row min(y, n - 1), of the four pixels that end no later
+      // than the row does; what lies outside the patch is shifted / masked away -- so that all of a lane's loads are in flight together
+      const int yc = y < n ? y : n - 1, xc = x0 < n - 4 ? x0 : n - 4, sh = x0 - xc;
+      uint32_t v = fetch_px4_l<DS, CH>(base, src.pitch, yc, xc);
+      v = sh >= 4 ? 0u : v >> (8 * (sh & 3));
+      return y < n ? v : 0u;
     };
     auto inside = [&](int y, int x0) -> uint32_t {
       if (y >= n || x0 >= n) return 0u;
@@ -161,6 +169,9 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, 
   if (row0 + 4 * wave < m) pass_lines<EXACT>(z, tw, pl, rows, 2 * wave, 2, lane, false);
   __syncthreads();
   // untangle the two rows of every line (doubled: the 1/2 is folded into cross_power_ab's eps) and store transposed
+  // (row pitch of Zh[u][row]: a multiple of 8 complex, so that a workgroup's 16 rows = 128 bytes per bin start on a 64-byte sector; with
+  //  pitch m the sizes with m % 8 != 0 paid 30 - 50 % on these stores -- r06, as sr_zh_pitch of the tuned transforms)
+  const int zp = (m + 7) & ~7;
   cf* out = reinterpret_cast<cf*>(zh + (size_t)img * zh_stride) + row0;
   for (int i = tid; i < PCL_LINES * NU; i += PCL_T) {
     const int u = i >> 3, j = i & 7, r = row0 + 2 * j;
@@ -168,8 +179,8 @@ __global__ void __launch_bounds__(PCL_T) pcl_rows_kernel(PclSrc src, PcPlan pl, 
     const cf zk = z[j * line + sk(u)], zm = z[j * line + sk(u == 0 ? 0 : m - u)];
     cf a2, b2;
     untangle2(zk, zm, &a2, &b2);
-    out[(size_t)u * m + 2 * j] = a2;
-    if (r + 1 < m) out[(size_t)u * m + 2 * j + 1] = b2;
+    out[(size_t)u * zp + 2 * j] = a2;
+    if (r + 1 < m) out[(size_t)u * zp + 2 * j + 1] = b2;
   }
 }
 
@@ -189,8 +200,9 @@ __global__ void __launch_bounds__(PCL_T) pcl_cols_kernel(const float* __restrict
   for (int k = tid; k < m; k += PCL_T) tw[k] = {twiddles[2 * k], twiddles[2 * k + 1]};
   const bool active = u < NU;
   if (active) {
-    const cf* c = reinterpret_cast<const cf*>(zh_cur + (size_t)pair * zh_stride) + (size_t)u * m;
-    const cf* p = reinterpret_cast<const cf*>(zh_prev + (size_t)pair * zh_stride) + (size_t)u * m;
+    const int zp = (m + 7) & ~7;  // (Zh's row pitch, pcl_rows_kernel)
+    const cf* c = reinterpret_cast<const cf*>(zh_cur + (size_t)pair * zh_stride) + (size_t)u * zp;
+    const cf* p = reinterpret_cast<const cf*>(zh_prev + (size_t)pair * zh_stride) + (size_t)u * zp;
     constexpr int NX = 15;
     cf cv[NX], pv[NX];  // both lines in flight before the first LDS write
 #pragma unroll
@@ -474,7 +486,7 @@ hipError_t launch_pcl_seq_flags(const int* fs, int* f2, int patches, int n_pairs
   return hipGetLastError();
 }
 
-size_t pcl_zh_floats(const PcPlan& pl) { return (size_t)((pl.m >> 1) + 1) * pl.m * 2; }
+size_t pcl_zh_floats(const PcPlan& pl) { return (size_t)((pl.m >> 1) + 1) * (((pl.m + 7) & ~7) + 8) * 2; }  // (room for the tuned transforms' row pitch, sr_zh_pitch; the planned kernels use pitch m)
 int pcl_candidates(const PcPlan& pl) { return (((pl.m + 1) >> 1) + PCL_LINES - 1) / PCL_LINES; }
 
 hipError_t launch_pcl_rows(const PclSrc& src, const PcPlan& pl, const float* twiddles, float* zh, size_t zh_stride, int* flags,

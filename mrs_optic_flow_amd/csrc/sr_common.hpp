@@ -85,6 +85,12 @@ struct SrPlan<432> {
   static constexpr int R1 = 16, R2 = 27, Y2 = 28, LINE = 449;
   static constexpr bool NYQ_EXACT = false;
 };
+// Row pitch (complex elements) of the transposed row spectra Zh[u][row]: a row workgroup stores 8 rows = 64 bytes per bin u, so the pitch is
+// kept a multiple of 8 -- with the plain pitch N the 64-byte pieces of the sizes with N % 8 != 0 (250, 270, 300, 450) straddled two 64-byte
+// sectors each and the row kernel ran 3 - 5 x slower on its stores (r06: profiles/r06_zh_pitch_ab.txt)
+// (250 -> 256 puts the bins of one store instruction 2 KB apart; 264 instead: -2 %, measured -- the plain round-up stays)
+template <int N>
+constexpr int sr_zh_pitch() { return (N + 7) & ~7; }
 template <class PL, class = void>
 struct SrNyqExact { static constexpr bool value = true; };
 template <class PL>

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_kernel(const uint
     const cf zk = z[j * P::LINE + u], zm = z[j * P::LINE + (N - u) % N];
     cf a2, b2;
     untangle2(zk, zm, &a2, &b2);  // 2 * DFT(row 2j)[u], 2 * DFT(row 2j + 1)[u]
-    stream_store(reinterpret_cast<float4*>(out + (size_t)u * N + 2 * j), make_float4(a2.x, a2.y, b2.x, b2.y));
+    stream_store(reinterpret_cast<float4*>(out + (size_t)u * sr_zh_pitch<N>() + 2 * j), make_float4(a2.x, a2.y, b2.x, b2.y));
   }
 }
 
@@ -132,22 +132,26 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
   constexpr bool EDGE = PAD || (N % 4 != 0) || R::TAIL;
   const int ne = PAD ? n : N;
   auto px4 = [&](int y, int d) -> uint32_t {  // pixels 4d .. 4d+3 of patch row y, one byte each
-    if (EDGE && (y >= ne || 4 * d >= ne)) return 0u;
-    const uint8_t* r = base + (size_t)y * src.pitch + (size_t)CH * 4 * d;
-    if (!EDGE || 4 * d + 3 < ne) {
-      if constexpr (CH == 1) {
-        uint32_t v;
-        __builtin_memcpy(&v, r, 4);  // (any alignment: the patch origin and the pitch are the caller's)
-        return v;
-      } else {
-        uint32_t v = 0;
+    // EDGE, branch-free (r06): the load itself is unconditional -- row min(y, ne - 1), the four pixels that END no later than the row does --
+    // and what lies outside the patch is shifted / masked away afterwards. With a branch per chunk (rows past the patch, the half-full last
+    // chunk in a byte loop) every chunk's load waited for the previous one's: the sizes with a tail (250, 270, 300, 450) ran 1.7 x slower per
+    // pixel than their neighbours (tools/size_probe.py).
+    const int yc = EDGE ? (y < ne ? y : ne - 1) : y;
+    const int xc = EDGE ? (4 * d < ne - 4 ? 4 * d : ne - 4) : 4 * d;
+    const uint8_t* r = base + (size_t)yc * src.pitch + (size_t)CH * xc;
+    uint32_t v;
+    if constexpr (CH == 1) {
+      __builtin_memcpy(&v, r, 4);  // (any alignment: the patch origin and the pitch are the caller's)
+    } else {
+      v = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) v |= rgb2gray_fixed(r[3 * b], r[3 * b + 1], r[3 * b + 2]) << (8 * b);
-        return v;
-      }
+      for (int b = 0; b < 4; ++b) v |= rgb2gray_fixed(r[3 * b], r[3 * b + 1], r[3 * b + 2]) << (8 * b);
     }
-    uint32_t v = 0;  // the last chunk of a row whose length is not a multiple of four
-    for (int b = 0; 4 * d + b < ne; ++b) v |= (CH == 1 ? (uint32_t)r[b] : rgb2gray_fixed(r[3 * b], r[3 * b + 1], r[3 * b + 2])) << (8 * b);
+    if constexpr (EDGE) {
+      const int sh = 4 * d - xc;  // 0: a whole chunk; 1 .. 3: the last chunk of a row whose length is not a multiple of four; >= 4: past the row
+      v = sh >= 4 ? 0u : v >> (8 * (sh & 3));
+      v = y < ne ? v : 0u;
+    }
     return v;
   };
   auto inside = [&](int y, int d) -> uint32_t {  // byte mask of the chunk's pixels that lie inside the n x n patch
@@ -201,12 +205,14 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
       s10 += __shfl_xor(s10, off, 64);
       s11 += __shfl_xor(s11, off, 64);
     }
+#ifndef MOF_SR_SUMS_ABLATE  // (diagnostic build: no atomics -- results wrong by design)
     if (lane == 0 && sums) {  // (zeroed by the caller; 255 * 432^2 < 2^31)
       atomicAdd(&sums[4 * img + 0], s00);
       atomicAdd(&sums[4 * img + 1], s01);
       atomicAdd(&sums[4 * img + 2], s10);
       atomicAdd(&sums[4 * img + 3], s11);
     }
+#endif
   }
   if (flags) {  // bit 0: some pixel differs from pixel (0, 0); bit 1: pixel (0, 0) is not zero (zeroed by the caller)
     if (__builtin_amdgcn_ballot_w64(diff != 0u) != 0ull && lane == 0) atomicOr(&flags[img], 1);
@@ -222,7 +228,10 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
     const cf zk = z[j * P::LINE + u], zm = z[j * P::LINE + (N - u) % N];
     cf a2, b2;
     untangle2(zk, zm, &a2, &b2);
-    stream_store(reinterpret_cast<float4*>(out + (size_t)u * N + 2 * j), make_float4(a2.x, a2.y, b2.x, b2.y));
+#ifdef MOF_SR_ABL_ROWSTORE  // (diagnostic build, results wrong by design: what the row kernel's stores cost)
+    if (a2.x == 123456.f)
+#endif
+    stream_store(reinterpret_cast<float4*>(out + (size_t)u * sr_zh_pitch<N>() + 2 * j), make_float4(a2.x, a2.y, b2.x, b2.y));
   }
 }
 
@@ -257,7 +266,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
 #pragma unroll
       for (int m = 0; m < MQ; ++m) {
         const int q = lane + 64 * m;
-        if (q < N / 2) t[s][m] = stream_load(reinterpret_cast<const float4*>(Zf + (size_t)u * N + 2 * q));
+        if (q < N / 2) t[s][m] = stream_load(reinterpret_cast<const float4*>(Zf + (size_t)u * sr_zh_pitch<N>() + 2 * q));
       }
     }
 #pragma unroll
@@ -399,7 +408,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MOF_K6P
   // column spectra of one frame's two lines: out[q] = X[k1 + 15 (q + 16 h)]. ONE instance of this code serves every frame (the loop
   // below starts at the run's previous frame): a run walked in one launch and the same frames fed one at a time round identically.
   auto forward = [&](const float* __restrict__ frame, cf* out) {
-    const cf* line = reinterpret_cast<const cf*>(frame) + (size_t)u1 * N + n2;
+    const cf* line = reinterpret_cast<const cf*>(frame) + (size_t)u1 * sr_zh_pitch<N>() + n2;
     cf a[R1];
 #pragma unroll
     for (int n1 = 0; n1 < R1; ++n1) {
@@ -553,7 +562,7 @@ hipError_t launch_cols_seq_n(const float* zh_prev, const float* zh_cur, size_t z
 
 }  // namespace
 
-size_t sr_zh_floats(int res) { return (size_t)(res / 2 + 1) * res * 2; }
+size_t sr_zh_floats(int res) { return (size_t)(res / 2 + 1) * (((res + 7) & ~7) + 8) * 2; }  // (pitch: sr_zh_pitch)
 
 hipError_t launch_sr_identity(double* out, hipStream_t stream) {
   hipLaunchKernelGGL(sr_identity_kernel, dim3(1), dim3(64), 0, stream, out);
