@@ -187,6 +187,10 @@ WORKLOADS = {
     "l432": dict(kind="fft", h=864, w=864, n=432, grid=(2, 2), origin=(0, 0), stride=(432, 432), batch=128, s=15,
                  name="l432: FftMethod 864x864, 2x2 grid of 432x432 patches (tuned transforms 16 x 27), batch=128 per GPU",
                  bytes_per_pair=2 * 864 * 864 + 4 * 8),
+    # beyond 512: the tuned transforms with a first radix up to 32 (r06: 24 x 30)
+    "l720": dict(kind="fft", h=720, w=720, n=720, grid=(1, 1), origin=(0, 0), stride=(720, 720), batch=128, s=15,
+                 name="l720: FftMethod 720x720, ONE 720x720 patch (tuned transforms 24 x 30), batch=128 per GPU",
+                 bytes_per_pair=2 * 720 * 720 + 8),
     "l480": dict(kind="fft", h=480, w=480, n=480, grid=(1, 1), origin=(0, 0), stride=(480, 480), batch=512, s=15,
                  name="l480: FftMethod 480x480, ONE 480x480 patch (the reference's whole-frame fallback), batch=512 per GPU",
                  bytes_per_pair=2 * 480 * 480 + 8),

@@ -210,8 +210,11 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
   // r06: 200, 216, 270, 288, 300, 320, 360, 384, 450 too, and patches that PAD to one of these sizes (193 .. 216, 226 .. 240, 251 .. 256, 271 .. 288, 301 .. 320, 325 .. 360, 376 .. 384,
   // 451 .. 480): the row kernel
   // zero-pads, the column kernel applies the box-zero rule of padded constant patches from the row kernel's flags
-  const bool tuned = tuned_on && a.downscale == 1 && (e->plan.m == 200 || e->plan.m == 216 || e->plan.m == 240 || e->plan.m == 250 || e->plan.m == 256 || e->plan.m == 270 || e->plan.m == 288 || e->plan.m == 300 || e->plan.m == 320 || e->plan.m == 360 ||
-                                                            e->plan.m == 384 || e->plan.m == 400 || e->plan.m == 432 || e->plan.m == 450 || e->plan.m == 480 || e->plan.m == 512);
+  static const int tuned_sizes[] = {200, 216, 240, 250, 256, 270, 288, 300, 320, 324, 360, 384, 400, 432, 450, 480, 486, 500, 512,
+                                    540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};  // (r06: 324, 486, 500 and every even size above 512 -- first radix up to 32)
+  bool tuned = false;
+  for (int t : tuned_sizes) tuned = tuned || e->plan.m == t;
+  tuned = tuned && tuned_on && a.downscale == 1;
   // (250 = 10 x 25, 400 = 16 x 25, 432 = 16 x 27: no plan of theirs ends in an even radix, so the Nyquist bins of their transforms are not exact
   //  -- the row kernel accumulates each image's four exact integer sums and the column kernel takes the real-only slots from those)
   const bool odd_tail = e->plan.m == 250 || e->plan.m == 400 || e->plan.m == 432;

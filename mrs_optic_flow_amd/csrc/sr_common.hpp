@@ -107,6 +107,73 @@ template <>
 struct SrPlan<384> {
   static constexpr int R1 = 12, R2 = 32, Y2 = 33, LINE = 397;
 };
+// r06: first radix up to 32 (stage 2 of wave_fft then runs 32 lanes per line, two lines per pass): every even size cv::getOptimalDFTSize
+// can return between 512 and 960, and 324 / 486 / 500 below -- all with an even last radix whose Nyquist bin passes no twiddle
+// (16, 18 and 30 by decimation in time, 20 / 24 by their Cooley-Tukey split, 32), so the real-only slots stay exact.
+template <>
+struct SrPlan<324> {  // 18 x 18
+  static constexpr int R1 = 18, R2 = 18, Y2 = 19, LINE = 343;
+};
+template <>
+struct SrPlan<486> {  // 27 x 18
+  static constexpr int R1 = 27, R2 = 18, Y2 = 19, LINE = 513;
+};
+template <>
+struct SrPlan<500> {  // 25 x 20
+  static constexpr int R1 = 25, R2 = 20, Y2 = 21, LINE = 525;
+};
+template <>
+struct SrPlan<540> {  // 27 x 20
+  static constexpr int R1 = 27, R2 = 20, Y2 = 21, LINE = 567;
+};
+template <>
+struct SrPlan<576> {  // 18 x 32
+  static constexpr int R1 = 18, R2 = 32, Y2 = 33, LINE = 595;
+};
+template <>
+struct SrPlan<600> {  // 25 x 24
+  static constexpr int R1 = 25, R2 = 24, Y2 = 25, LINE = 625;
+};
+template <>
+struct SrPlan<640> {  // 20 x 32
+  static constexpr int R1 = 20, R2 = 32, Y2 = 33, LINE = 661;
+};
+template <>
+struct SrPlan<648> {  // 27 x 24
+  static constexpr int R1 = 27, R2 = 24, Y2 = 25, LINE = 675;
+};
+template <>
+struct SrPlan<720> {  // 24 x 30
+  static constexpr int R1 = 24, R2 = 30, Y2 = 31, LINE = 745;
+};
+template <>
+struct SrPlan<750> {  // 25 x 30
+  static constexpr int R1 = 25, R2 = 30, Y2 = 31, LINE = 775;
+};
+template <>
+struct SrPlan<768> {  // 24 x 32
+  static constexpr int R1 = 24, R2 = 32, Y2 = 33, LINE = 793;
+};
+template <>
+struct SrPlan<800> {  // 25 x 32
+  static constexpr int R1 = 25, R2 = 32, Y2 = 33, LINE = 825;
+};
+template <>
+struct SrPlan<810> {  // 27 x 30
+  static constexpr int R1 = 27, R2 = 30, Y2 = 31, LINE = 837;
+};
+template <>
+struct SrPlan<864> {  // 27 x 32
+  static constexpr int R1 = 27, R2 = 32, Y2 = 33, LINE = 891;
+};
+template <>
+struct SrPlan<900> {  // 30 x 30
+  static constexpr int R1 = 30, R2 = 30, Y2 = 31, LINE = 931;
+};
+template <>
+struct SrPlan<960> {  // 30 x 32
+  static constexpr int R1 = 30, R2 = 32, Y2 = 33, LINE = 991;
+};
 template <>
 struct SrPlan<216> {  // 12 x 18: three lines per stage-1 pass (54 of 64 lanes), twelve of sixteen lanes per line in stage 2
   static constexpr int R1 = 12, R2 = 18, Y2 = 19, LINE = 229;
@@ -289,7 +356,7 @@ __device__ __forceinline__ void wave_fft(cf* __restrict__ z, int nl, int lane, c
     }
   }
   wave_sync();
-  {
+  if constexpr (P::R1 <= 16) {
     // 16 lanes per line (15 of them active when R1 = 15); nl = 2 leaves the upper half of the wave idle
     const int l = lane >> 4, k1 = lane & 15;
     const bool on = l < nl && k1 < P::R1;
@@ -300,6 +367,21 @@ __device__ __forceinline__ void wave_fft(cf* __restrict__ z, int nl, int lane, c
       for (int n2 = 0; n2 < P::R2; ++n2) v[n2] = lds_read(&line[P::Y2 * k1 + n2]);
       bfly<P::R2>(v);
       sink(line, l, k1, v);
+    }
+  } else {
+    // R1 = 17 .. 32 (r06): 32 lanes per line, two lines per pass (a pass reads and rewrites its own two lines only)
+    static_assert(P::R1 <= 32, "one lane per first-stage bin");
+    for (int l0 = 0; l0 < nl; l0 += 2) {
+      const int l = l0 + (lane >> 5), k1 = lane & 31;
+      const bool on = l < nl && k1 < P::R1;
+      cf* line = z + l * P::LINE;
+      cf v[P::R2];
+      if (on) {
+#pragma unroll
+        for (int n2 = 0; n2 < P::R2; ++n2) v[n2] = lds_read(&line[P::Y2 * k1 + n2]);
+        bfly<P::R2>(v);
+        sink(line, l, k1, v);
+      }
     }
   }
   wave_sync();

@@ -899,6 +899,22 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
     case 384: return launch_sr_rows_inv_n<384>(a, n_pairs, stream);
     case 480: return launch_sr_rows_inv_n<480>(a, n_pairs, stream);
     case 512: return launch_sr_rows_inv_n<512>(a, n_pairs, stream);
+    case 324: return launch_sr_rows_inv_n<324>(a, n_pairs, stream);
+    case 486: return launch_sr_rows_inv_n<486>(a, n_pairs, stream);
+    case 500: return launch_sr_rows_inv_n<500>(a, n_pairs, stream);
+    case 540: return launch_sr_rows_inv_n<540>(a, n_pairs, stream);
+    case 576: return launch_sr_rows_inv_n<576>(a, n_pairs, stream);
+    case 600: return launch_sr_rows_inv_n<600>(a, n_pairs, stream);
+    case 640: return launch_sr_rows_inv_n<640>(a, n_pairs, stream);
+    case 648: return launch_sr_rows_inv_n<648>(a, n_pairs, stream);
+    case 720: return launch_sr_rows_inv_n<720>(a, n_pairs, stream);
+    case 750: return launch_sr_rows_inv_n<750>(a, n_pairs, stream);
+    case 768: return launch_sr_rows_inv_n<768>(a, n_pairs, stream);
+    case 800: return launch_sr_rows_inv_n<800>(a, n_pairs, stream);
+    case 810: return launch_sr_rows_inv_n<810>(a, n_pairs, stream);
+    case 864: return launch_sr_rows_inv_n<864>(a, n_pairs, stream);
+    case 900: return launch_sr_rows_inv_n<900>(a, n_pairs, stream);
+    case 960: return launch_sr_rows_inv_n<960>(a, n_pairs, stream);
     default: return hipErrorInvalidValue;
   }
 }

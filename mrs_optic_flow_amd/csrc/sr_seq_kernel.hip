@@ -39,7 +39,7 @@ namespace {
 #endif
 template <int N>
 struct RowsReal {
-  static constexpr int ROWS = (N % 32 == 0 && MOF_K5S_ROWS32) ? 32 : (N % 16 == 0 ? 16 : 8);  // (200: 25 one-wave workgroups of 8 rows per image)
+  static constexpr int ROWS = N > 512 ? 8 : ((N % 32 == 0 && MOF_K5S_ROWS32) ? 32 : (N % 16 == 0 ? 16 : 8));  // (200: 25 one-wave workgroups of 8 rows per image; beyond 512: one wave = four lines = up to 31 KB of LDS per workgroup)
   static constexpr bool TAIL = N % ROWS != 0;  // (270, 300, 450: the last one-wave workgroup holds 3, 2 or 1 row pairs; the rest of its lines are zeros and are not stored)
   static_assert((N % ROWS == 0 || ROWS == 8) && ROWS % 8 == 0 && N % 2 == 0, "whole workgroups of four-line waves, a tail only behind one-wave workgroups");
   static constexpr int GROUPS = (N + ROWS - 1) / ROWS;
@@ -601,6 +601,22 @@ hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, flo
     case 384: return launch_rows_real_src_n<384>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 512: return launch_rows_real_src_n<512>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 324: return launch_rows_real_src_n<324>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 486: return launch_rows_real_src_n<486>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 500: return launch_rows_real_src_n<500>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 540: return launch_rows_real_src_n<540>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 576: return launch_rows_real_src_n<576>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 600: return launch_rows_real_src_n<600>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 640: return launch_rows_real_src_n<640>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 648: return launch_rows_real_src_n<648>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 720: return launch_rows_real_src_n<720>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 750: return launch_rows_real_src_n<750>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 768: return launch_rows_real_src_n<768>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 800: return launch_rows_real_src_n<800>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 810: return launch_rows_real_src_n<810>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 864: return launch_rows_real_src_n<864>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 900: return launch_rows_real_src_n<900>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 960: return launch_rows_real_src_n<960>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -630,6 +646,22 @@ hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t 
     case 384: return launch_cols_seq_n<384>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 512: return launch_cols_seq_n<512>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 324: return launch_cols_seq_n<324>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 486: return launch_cols_seq_n<486>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 500: return launch_cols_seq_n<500>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 540: return launch_cols_seq_n<540>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 576: return launch_cols_seq_n<576>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 600: return launch_cols_seq_n<600>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 640: return launch_cols_seq_n<640>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 648: return launch_cols_seq_n<648>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 720: return launch_cols_seq_n<720>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 750: return launch_cols_seq_n<750>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 768: return launch_cols_seq_n<768>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 800: return launch_cols_seq_n<800>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 810: return launch_cols_seq_n<810>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 864: return launch_cols_seq_n<864>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 900: return launch_cols_seq_n<900>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 960: return launch_cols_seq_n<960>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     default: return hipErrorInvalidValue;
   }
 }
