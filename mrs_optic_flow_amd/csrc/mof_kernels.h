@@ -204,7 +204,8 @@ std::vector<uint32_t> sr_weight_planes(const std::vector<int16_t>& weights, int 
 // tile = 8 (per-wave boxes) or 16 (super-tile boxes shared by a workgroup)
 std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave, int tile_px);
 
-bool sr_resolution_supported(int res);
+bool sr_resolution_supported(int res);      // tuned transforms (K5s / K6s / K7) exist for this resolution
+bool sr_pair_kernels_supported(int res);   // ... and the packed pair kernels K5 / K6 (240, 256, 480)
 int sr_candidates(int res);
 hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp /*2 cubic, 4 lanczos4*/, int n_images, hipStream_t stream);
 hipError_t launch_sr_phase_correlate(const SrPcArgs& a, int res, int n_pairs, hipStream_t stream);

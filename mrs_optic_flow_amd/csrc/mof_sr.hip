@@ -920,7 +920,7 @@ int mof_sr_process_batch_device(mof_sr_engine* e, const uint8_t* d_cur, size_t c
     // Same-box c5: 360 k pairs/s against 354 k for the packed pair kernels (K5 / K6 of sr_kernel.hip, MOF_SR_PAIR_SEQ=0), and
     // the batch entry now computes exactly what the stateful entry computes for a fresh estimator fed (prev, cur): same bits.
     static const bool via_frames = [] { const char* v = getenv("MOF_SR_PAIR_SEQ"); return !v || atoi(v) != 0; }();
-    if (via_frames || e->generic) {  // (the packed pair kernels exist for the tuned resolutions only)
+    if (via_frames || e->generic || !mof::sr_pair_kernels_supported(res)) {  // (the packed pair kernels exist for 240 / 256 / 480 only)
       const size_t zhf = zh_floats(e);
       if (use_fused(e)) {
         SR_TRY(cols_fused(e, lp_buf + nn, lp_buf, 2 * nn, n, 1, s));

@@ -19,6 +19,7 @@
 // round trip between them, done by a single wave on the lines it owns (no workgroup barrier inside a transform).
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -751,7 +752,19 @@ __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
   }
 }
 
-bool sr_resolution_supported(int res) { return res == 240 || res == 256 || res == 480; }
+// Resolutions whose transforms are the tuned in-register ones (K5s / K6s / K7): the estimator's own three, and (r06) every transform size the
+// FFT engine's large patches brought along whose Nyquist bin is exact (250 / 400 / 432 would need the exact-sums form of the row kernel: they stay
+// on the planned pipeline, like every resolution that is not itself one of these sizes). MOF_SR_TUNED_ALL=0: the three only (A/B, tests).
+bool sr_pair_kernels_supported(int res) { return res == 240 || res == 256 || res == 480; }  // K5 / K6 (packed pairs), K56, K6p
+bool sr_resolution_supported(int res) {
+  static const bool all = [] { const char* v = getenv("MOF_SR_TUNED_ALL"); return !v || atoi(v) != 0; }();
+  if (sr_pair_kernels_supported(res)) return true;
+  if (!all) return false;
+  static const int sizes[] = {200, 216, 270, 288, 300, 320, 324, 360, 384, 450, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
+  for (int t : sizes)
+    if (res == t) return true;
+  return false;
+}
 
 template <int K>
 static hipError_t launch_lp_lds(const SrLpArgs& a, int n_images, hipStream_t stream) {
@@ -859,6 +872,32 @@ hipError_t launch_sr_peak(const SrPcArgs& a, int res, int n_pairs, hipStream_t s
     case 240: return launch_sr_peak_n<240>(a, n_pairs, stream);
     case 256: return launch_sr_peak_n<256>(a, n_pairs, stream);
     case 480: return launch_sr_peak_n<480>(a, n_pairs, stream);
+    case 200: return launch_sr_peak_n<200>(a, n_pairs, stream);
+    case 216: return launch_sr_peak_n<216>(a, n_pairs, stream);
+    case 270: return launch_sr_peak_n<270>(a, n_pairs, stream);
+    case 288: return launch_sr_peak_n<288>(a, n_pairs, stream);
+    case 300: return launch_sr_peak_n<300>(a, n_pairs, stream);
+    case 320: return launch_sr_peak_n<320>(a, n_pairs, stream);
+    case 324: return launch_sr_peak_n<324>(a, n_pairs, stream);
+    case 360: return launch_sr_peak_n<360>(a, n_pairs, stream);
+    case 384: return launch_sr_peak_n<384>(a, n_pairs, stream);
+    case 450: return launch_sr_peak_n<450>(a, n_pairs, stream);
+    case 486: return launch_sr_peak_n<486>(a, n_pairs, stream);
+    case 500: return launch_sr_peak_n<500>(a, n_pairs, stream);
+    case 512: return launch_sr_peak_n<512>(a, n_pairs, stream);
+    case 540: return launch_sr_peak_n<540>(a, n_pairs, stream);
+    case 576: return launch_sr_peak_n<576>(a, n_pairs, stream);
+    case 600: return launch_sr_peak_n<600>(a, n_pairs, stream);
+    case 640: return launch_sr_peak_n<640>(a, n_pairs, stream);
+    case 648: return launch_sr_peak_n<648>(a, n_pairs, stream);
+    case 720: return launch_sr_peak_n<720>(a, n_pairs, stream);
+    case 750: return launch_sr_peak_n<750>(a, n_pairs, stream);
+    case 768: return launch_sr_peak_n<768>(a, n_pairs, stream);
+    case 800: return launch_sr_peak_n<800>(a, n_pairs, stream);
+    case 810: return launch_sr_peak_n<810>(a, n_pairs, stream);
+    case 864: return launch_sr_peak_n<864>(a, n_pairs, stream);
+    case 900: return launch_sr_peak_n<900>(a, n_pairs, stream);
+    case 960: return launch_sr_peak_n<960>(a, n_pairs, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -576,7 +576,18 @@ hipError_t launch_sr_rows_real(const uint8_t* lp, size_t lp_stride, const float*
     case 240: return launch_rows_real_n<240>(lp, lp_stride, twiddles, zh, zh_stride, n_frames, stream);
     case 256: return launch_rows_real_n<256>(lp, lp_stride, twiddles, zh, zh_stride, n_frames, stream);
     case 480: return launch_rows_real_n<480>(lp, lp_stride, twiddles, zh, zh_stride, n_frames, stream);
-    default: return hipErrorInvalidValue;
+    default: {
+      // (r06) the other tuned sizes: the frame form of the row kernel that the FFT engine's large patches use -- tightly packed log-polar
+      // images are ONE patch per "frame" of a video whose patch is the whole image
+      PclSrc src{};
+      src.base[0] = lp;
+      src.stride[0] = lp_stride;
+      src.pitch = (size_t)res;
+      src.paired = 2;
+      src.grid_x = src.grid_y = 1;
+      src.stride_x = src.stride_y = res;
+      return launch_sr_rows_real_src(src, twiddles, zh, zh_stride, nullptr, res, n_frames, 1, res, stream, nullptr);
+    }
   }
 }
 
