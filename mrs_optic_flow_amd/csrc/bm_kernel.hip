@@ -481,12 +481,26 @@ static hipError_t launch_scan16(const BmArgs& a, int n_pairs, hipStream_t stream
   return hipGetLastError();
 }
 
+// r06: every even radius up to 16 (tools/bm_size_probe.py: radius 12 ran 3 x slower than radius 16 on the generic kernel -- for less work)
+template <class F>
+static bool scan16_dispatch(int radius, F&& f) {
+  switch (radius) {
+    case 2: f(std::integral_constant<int, 2>{}); return true;
+    case 4: f(std::integral_constant<int, 4>{}); return true;
+    case 6: f(std::integral_constant<int, 6>{}); return true;
+    case 8: f(std::integral_constant<int, 8>{}); return true;
+    case 10: f(std::integral_constant<int, 10>{}); return true;
+    case 12: f(std::integral_constant<int, 12>{}); return true;
+    case 14: f(std::integral_constant<int, 14>{}); return true;
+    case 16: f(std::integral_constant<int, 16>{}); return true;
+    default: return false;
+  }
+}
 static bool fast16_ok(const BmArgs& a) {
-  if (a.block != 16 || (a.step % 4) != 0 || !(a.radius == 8 || a.radius == 16)) return false;
+  if (a.block != 16 || (a.step % 4) != 0) return false;
   int bpw, wpr, sd;
-  size_t lds;
-  if (a.radius == 16) scan16_plan<16>(a, &bpw, &wpr, &sd, &lds);
-  else scan16_plan<8>(a, &bpw, &wpr, &sd, &lds);
+  size_t lds = 0;
+  if (!scan16_dispatch(a.radius, [&](auto r) { scan16_plan<decltype(r)::value>(a, &bpw, &wpr, &sd, &lds); })) return false;
   return lds <= 64 * 1024;
 }
 
@@ -688,7 +702,9 @@ static hipError_t launch_bm_generic_g(const BmArgs& a, int n_pairs, const BmPlan
 
 hipError_t launch_bm_scan(const BmArgs& a, int n_pairs, hipStream_t stream) {
   if (fast16_ok(a) && !getenv("MOF_BM_GENERIC")) {
-    return a.radius == 16 ? launch_scan16<16>(a, n_pairs, stream) : launch_scan16<8>(a, n_pairs, stream);
+    hipError_t err = hipErrorInvalidValue;
+    scan16_dispatch(a.radius, [&](auto r) { err = launch_scan16<decltype(r)::value>(a, n_pairs, stream); });
+    return err;
   }
   BmPlan p = bm_plan(a.block, a.radius, a.grid_x);
   if (p.xb == 0) return hipErrorInvalidValue;

@@ -200,3 +200,25 @@ def test_refine_matches_oracle(gpu):
     from mrs_optic_flow_amd import MofError
     with pytest.raises(MofError):
         eng.refine((400, 0))
+
+
+@pytest.mark.parametrize("radius", [2, 4, 6, 8, 10, 12, 14, 16])
+def test_fast_16x16_scan_at_every_even_radius(gpu, radius):
+    """r06: bm_scan16_kernel<R> (blocks of 16 x 16, v_qsad_pk_u16_u8 on register-resident blocks) serves every even scan radius up to 16,
+    not only c3's 8 and 16. Bit-exact against the oracle on random frames with ties (small alphabet), the low-contrast rule on, steps 0 / 4 / 8,
+    block rows that fill a wave exactly, spill into a second one, or hold a single block; gray and BGR8."""
+    rng = np.random.default_rng(100 + radius)
+    for step, gx, gy, extra in ((0, 1, 1, 0), (4, 5, 2, 3), (8, 64 // max(1, radius // 2) + 1, 1, 7), (8, 3, 3, 0), (0, 9, 2, 11)):
+        S = 16 + step
+        w, h = gx * S + 2 * radius + extra % S, gy * S + 2 * radius + (extra % 5)  # (FastSpacedBMMethod_OCL.cpp:82-90: (size - 2 r) / S blocks per axis)
+        levels = 256 if step else 4  # (a four-level alphabet: many exact ties, the first minimum in row-major order must win)
+        cur = rng.integers(0, levels, (3, h, w), dtype=np.uint8)
+        prev = np.roll(cur, (int(rng.integers(-2, 3)), int(rng.integers(-2, 3))), axis=(1, 2))
+        prev = np.clip(prev.astype(np.int32) + rng.integers(-1, 2, prev.shape), 0, 255).astype(np.uint8)
+        eng = FastSpacedBMMethod(16, radius, step, (h, w))
+        assert (eng.cfg.grid_x, eng.cfg.grid_y) == (gx, gy), (eng.cfg.grid_x, eng.cfg.grid_y, gx, gy)
+        cfg = O.bm_config_fast_spaced(w, h, 16, step, radius)
+        dx, dy, mode = (v.cpu().numpy() for v in eng.process_batch_device(torch.from_numpy(cur).to(gpu), torch.from_numpy(prev).to(gpu)))
+        for k in range(3):
+            wdx, wdy, wmode = O.bm_process(cur[k], prev[k], cfg)
+            assert (dx[k] == wdx).all() and (dy[k] == wdy).all() and tuple(mode[k, :2]) == wmode, (radius, step, gx, gy, k)
