@@ -1068,7 +1068,7 @@ def main() -> None:
             line["other_workloads"] = {tag: measure_other(tag, dev, st, 5)
                                        for tag, st in (("c3", 50), ("c4", 20), ("c5", 40), ("c2seq", 50), ("c4seq", 10), ("c5seq", 40), ("ref", 50), ("refseq", 50),
                                                        ("bmref", 50), ("refrt", 50), ("reflr", 50),
-                                                       ("p60", 50), ("l160", 40), ("l200", 20), ("l240", 20), ("l480", 20))}  # the planned kernel, the half-tile kernel (r05), the large-patch pipeline
+                                                       ("p60", 50), ("l160", 40), ("l200", 20), ("l240", 20), ("l250", 20), ("l400", 20), ("l480", 20), ("l720", 20))}  # the planned kernel, the half-tile kernel (r05), the large-patch pipeline
             try:
                 line["host_entries"] = host_entries_record()
             except BaseException as e:
