@@ -63,6 +63,7 @@ struct PclSrc {
   int paired;              // 1: image f = 2 (pair * patches + patch) + which (0 cur, 1 prev); 0: image f = base[0] + f * stride[0];
                            // 2 (r06, a VIDEO): image f = frame * patches + patch of base[0] + frame * stride[0] -- every frame transformed once
   int grid_x, grid_y, origin_x, origin_y, stride_x, stride_y;  // patch grid inside a frame (paired)
+  int sums_stride;         // ints between the exact-sum quadruples of consecutive images (sr_rows_real_src_kernel; 0 = 4: a dense array)
 };
 struct PclFinal {
   const float* Dt;         // [pairs][m/2 + 1][m] complex
@@ -205,7 +206,8 @@ std::vector<uint32_t> sr_weight_planes(const std::vector<int16_t>& weights, int 
 std::vector<SrTileBox> sr_tile_boxes(const std::vector<SrMapEntry>& map, int res, int ksize, int* lds_per_wave, int tile_px);
 
 bool sr_resolution_supported(int res);      // tuned transforms (K5s / K6s / K7) exist for this resolution
-bool sr_pair_kernels_supported(int res);   // ... and the packed pair kernels K5 / K6 (240, 256, 480)
+bool sr_pair_kernels_supported(int res);
+bool sr_transform_size_tuned(int m, bool* exact_nyquist);  // the tuned transforms exist for transform size m (the FFT engine's list)   // ... and the packed pair kernels K5 / K6 (240, 256, 480)
 int sr_candidates(int res);
 hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp /*2 cubic, 4 lanczos4*/, int n_images, hipStream_t stream);
 hipError_t launch_sr_phase_correlate(const SrPcArgs& a, int res, int n_pairs, hipStream_t stream);

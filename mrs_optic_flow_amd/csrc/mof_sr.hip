@@ -285,6 +285,11 @@ struct mof_sr_engine {
   // pc_large_kernel.hip on the size cv::phaseCorrelate pads to, plan.m = getOptimalDFTSize(resolution)
   bool generic = false;
   mof::PcPlan plan{};
+  // r06: a generic resolution whose PADDED size plan.m has tuned transforms runs K5s (the zero-padding frame form of the row kernel) / K6s /
+  // K7 and only the final kernel of the planned pipeline. pad_sums: plan.m is 250 / 400 / 432 (odd last radix) -- the four exact pixel sums of
+  // a frame sit `sums_off` floats into its Zh slot (the slack behind the padded rows), so they travel wherever the slot is copied
+  bool tuned_pad = false, pad_sums = false;
+  size_t sums_off = 0;
   std::atomic<bool> busy{false};
   std::mutex host_mu;  // mof_sr_process_sequence_host: the upload pipeline (host_pipe.hpp), made by its first call
   mof::HostPipe* host_pipe = nullptr;
@@ -318,6 +323,20 @@ hipError_t rows_real(const mof_sr_engine* e, const uint8_t* lp, size_t lp_stride
   src.base[0] = lp;
   src.stride[0] = lp_stride;
   src.pitch = (size_t)res;  // log-polar images are tightly packed
+  if (e->tuned_pad) {
+    src.paired = 2;  // "a video whose one patch is the whole image": image f = base[0] + f * stride[0]
+    src.grid_x = src.grid_y = 1;
+    src.stride_x = src.stride_y = res;
+    int* sums = nullptr;
+    if (e->pad_sums) {
+      sums = reinterpret_cast<int*>(zh + e->sums_off);
+      src.sums_stride = (int)zh_stride;
+      const hipError_t err = n_frames == 1 ? hipMemsetAsync(sums, 0, 4 * sizeof(int), s)  // (the row kernel adds into them; the stateful call passes no stride)
+                                           : hipMemset2DAsync(sums, zh_stride * sizeof(float), 0, 4 * sizeof(int), (size_t)n_frames, s);
+      if (err != hipSuccess) return err;
+    }
+    return mof::launch_sr_rows_real_src(src, e->d_twiddles, zh, zh_stride, nullptr, e->plan.m, n_frames, 1, res, s, sums);
+  }
   return mof::launch_pcl_rows(src, e->plan, e->d_twiddles, zh, zh_stride, nullptr, n_frames, 1, 1, s);
 }
 // K56: K5s + K6s in one kernel on the u8 log-polar images (MOF_SR_FUSED, tuned resolutions)
@@ -331,6 +350,10 @@ hipError_t cols_fused(const mof_sr_engine* e, const uint8_t* lp_prev, const uint
 }
 hipError_t cols_seq(const mof_sr_engine* e, const float* zh_prev, const float* zh_cur, size_t zh_stride, int n_pairs, int run, hipStream_t s) {
   if (!e->generic) return mof::launch_sr_cols_seq(zh_prev, zh_cur, zh_stride, e->d_twiddles, e->d_Dt, e->cfg.resolution, n_pairs, run, s);
+  if (e->tuned_pad)
+    return mof::launch_sr_cols_seq(zh_prev, zh_cur, zh_stride, e->d_twiddles, e->d_Dt, e->plan.m, n_pairs, run, s, nullptr, e->cfg.resolution,
+                                   e->pad_sums ? reinterpret_cast<const int*>(zh_prev + e->sums_off) : nullptr,
+                                   e->pad_sums ? reinterpret_cast<const int*>(zh_cur + e->sums_off) : nullptr, (int)zh_stride);
   return mof::launch_pcl_cols(zh_prev, zh_cur, zh_stride, e->plan, e->d_twiddles, e->d_Dt, nullptr, nullptr, n_pairs, s);
 }
 hipError_t peak(const mof_sr_engine* e, const mof::SrPcArgs& a, int n_pairs, hipStream_t s) {
@@ -342,6 +365,11 @@ hipError_t peak(const mof_sr_engine* e, const mof::SrPcArgs& a, int n_pairs, hip
   f.mode = 0;
   f.M_log = a.M;
   f.out = a.out;
+  if (e->tuned_pad) {  // K7 forms the candidates; L8 (the planned pipeline's final kernel: it knows the padded geometry) reads them
+    const hipError_t err = mof::launch_sr_rows_inv(a.Dt, a.twiddles, a.cand, e->plan.m, n_pairs, s);
+    if (err != hipSuccess) return err;
+    return mof::launch_pcl_peak(f, e->plan, n_pairs, s, true);
+  }
   return mof::launch_pcl_peak(f, e->plan, n_pairs, s);
 }
 
@@ -532,6 +560,15 @@ int mof_sr_create(const mof_sr_config* cfg, mof_sr_engine** out) try {
   e->cfg = *cfg;
   e->generic = generic;
   e->plan = plan;
+  if (generic) {
+    static const bool all = [] { const char* v = getenv("MOF_SR_TUNED_ALL"); return !v || atoi(v) != 0; }();
+    bool exact = true;
+    if (all && mof::sr_transform_size_tuned(plan.m, &exact)) {
+      e->tuned_pad = true;
+      e->pad_sums = !exact;
+      e->sums_off = (size_t)((plan.m >> 1) + 1) * ((plan.m + 7) & ~7) * 2;  // behind the padded rows; pcl_zh_floats leaves 16 floats per row of slack
+    }
+  }
   e->chunk = chunk_pairs(cfg->batch_chunk);
   e->two_lanes = two_lane_default(cfg->pipeline_lanes);
   for (int k = 0; k < tn; ++k) {

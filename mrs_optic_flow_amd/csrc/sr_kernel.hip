@@ -755,6 +755,19 @@ __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
 // Resolutions whose transforms are the tuned in-register ones (K5s / K6s / K7): the estimator's own three, and (r06) every transform size the
 // FFT engine's large patches brought along whose Nyquist bin is exact (250 / 400 / 432 would need the exact-sums form of the row kernel: they stay
 // on the planned pipeline, like every resolution that is not itself one of these sizes). MOF_SR_TUNED_ALL=0: the three only (A/B, tests).
+bool sr_transform_size_tuned(int m, bool* exact_nyquist) {
+  static const int exact[] = {200, 216, 240, 256, 270, 288, 300, 320, 324, 360, 384, 450, 480, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
+  for (int t : exact)
+    if (m == t) {
+      if (exact_nyquist) *exact_nyquist = true;
+      return true;
+    }
+  if (m == 250 || m == 400 || m == 432) {  // odd last radix: the real-only slots come from the images' exact integer sums
+    if (exact_nyquist) *exact_nyquist = false;
+    return true;
+  }
+  return false;
+}
 bool sr_pair_kernels_supported(int res) { return res == 240 || res == 256 || res == 480; }  // K5 / K6 (packed pairs), K56, K6p
 bool sr_resolution_supported(int res) {
   static const bool all = [] { const char* v = getenv("MOF_SR_TUNED_ALL"); return !v || atoi(v) != 0; }();

@@ -207,10 +207,11 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
     }
 #ifndef MOF_SR_SUMS_ABLATE  // (diagnostic build: no atomics -- results wrong by design)
     if (lane == 0 && sums) {  // (zeroed by the caller; 255 * 432^2 < 2^31)
-      atomicAdd(&sums[4 * img + 0], s00);
-      atomicAdd(&sums[4 * img + 1], s01);
-      atomicAdd(&sums[4 * img + 2], s10);
-      atomicAdd(&sums[4 * img + 3], s11);
+      int* q = sums + (size_t)(src.sums_stride ? src.sums_stride : 4) * img;
+      atomicAdd(&q[0], s00);
+      atomicAdd(&q[1], s01);
+      atomicAdd(&q[2], s10);
+      atomicAdd(&q[3], s11);
     }
 #endif
   }
@@ -529,7 +530,7 @@ hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh,
     const dim3 g(R::GROUPS, (unsigned)nf), b(R::T);
     float* zo = zh + (size_t)f0 * zh_stride;
     int* fl = flags ? flags + f0 : nullptr;
-    int* su = sums ? sums + (size_t)4 * f0 : nullptr;
+    int* su = sums ? sums + (size_t)(src.sums_stride ? src.sums_stride : 4) * f0 : nullptr;
     if (channels == 3) {
       if (pad) hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3, true>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n, su);
       else hipLaunchKernelGGL((sr_rows_real_src_kernel<N, 3, false>), g, b, lds, stream, s, tw, zo, zh_stride, fl, n, su);
@@ -544,7 +545,8 @@ hipError_t launch_rows_real_src_n(const PclSrc& src, const float* tw, float* zh,
 template <int N>
 hipError_t launch_cols_seq_n(const float* zh_prev, const float* zh_cur, size_t zh_stride, const float* tw, float* Dt, int n_pairs,
                              int run, const int* flags, int n, const int* sums_prev, const int* sums_cur, int sums_stride, hipStream_t stream) {
-  if (!SrNyqExact<SrPlan<N>>::value && (!sums_prev || !sums_cur || run != 1)) return hipErrorInvalidValue;  // (this plan's real-only slots come from the exact sums)
+  if (!SrNyqExact<SrPlan<N>>::value && (!sums_prev || !sums_cur)) return hipErrorInvalidValue;  // (this plan's real-only slots come from the exact sums; a run
+  // of pairs in time finds pair j's quadruples at (p0 + j) * sums_stride of either pointer -- sums that live inside the Zh slots walk with them)
   constexpr int H = N / 2;
   const unsigned groups = (H + 1 + SEQ_CW - 1) / SEQ_CW, runs = (unsigned)((n_pairs + run - 1) / run);
   if constexpr (N == 480) {
