@@ -179,7 +179,8 @@ __global__ void __launch_bounds__(1024) sr_logpolar_lds_kernel(SrLpArgs a, int n
 // -- a few dozen line look-ups per image -- and gathers from there. The box of image i+1 is fetched into registers
 // BEFORE the taps of image i are gathered (U images form a group whose boxes travel together), so the memory latency
 // hides behind the arithmetic.
-// Needs pitch % 4 == 0 and src_stride % 4 == 0 (then a row's misalignment is the same for every row and image).
+// With pitch % 4 == 0 and src_stride % 4 == 0 a row's misalignment is the same for every row and image and the box is fetched with aligned
+// dwords; other layouts fetch every box row from its exact first byte (unaligned dword loads, r06).
 // LDS dwords of a wave's box: whole 64-lane slot rows of the ring class (4, 8 or 16 dwords per lane) that holds the
 // largest box of the map
 __host__ __device__ inline int lp_box_capacity(int box_dwords_max) {
@@ -289,7 +290,10 @@ __global__ void __launch_bounds__(256, (SUPER ? (K == 4 ? MOF_LP_SUPER_WPE4 : MO
   const int bx = box.x0, by = box.y0, bw = box.w, bh = box.h;
   const int lpd = (bw + 3 + 3) / 4 + 1, cnt = bh * lpd;
   const uint8_t* src = a.src + (size_t)img0 * a.src_stride;
-  const uint32_t mis = (uint32_t)(uintptr_t)(src + (size_t)by * a.pitch + bx) & 3u;
+  // (r06: a layout whose rows or frames are NOT a multiple of four bytes apart -- resolution 250, 270, 350, 450 packed tightly -- has a different
+  //  misalignment in every row: there the box rows are fetched from their exact first byte with unaligned dword loads, mis = 0)
+  const bool dword_layout = ((a.pitch | a.src_stride) & 3) == 0;
+  const uint32_t mis = dword_layout ? (uint32_t)(uintptr_t)(src + (size_t)by * a.pitch + bx) & 3u : 0u;
   const uint8_t* b0 = src + (size_t)by * a.pitch + bx - mis;  // dword-aligned; the same offset in every image
   // Box dword i = lane + 64 t comes from byte offset goff[t]. Slots past the box, or past the last needed byte of a
   // row (they may lie outside the buffer), re-read the box's first dword and park it in a dump slot behind the box, so
@@ -805,14 +809,29 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
   // (MOF_SR_LP_STAGED=0 falls back to the table-in-LDS formulation, kept for A/B runs and unaligned layouts)
   static const bool staged_on = [] { const char* e = getenv("MOF_SR_LP_STAGED"); return !e || atoi(e) != 0; }();
   constexpr int NR = 16;
-  if (staged_on && !global_w && n_images >= 4 && a.pitch % 4 == 0 && a.src_stride % 4 == 0 && a.boxes && a.wplanes &&
-      a.box_dwords_max <= 64 * NR) {
+  // (r06) layouts whose rows / frames are not whole dwords apart are staged from unaligned dwords: the last dword of the LAST row of an image may
+  // then reach up to three bytes past that image -- into the next one, harmless, except behind the last image of the caller's buffer. So the
+  // last image of such a batch takes the per-pixel kernel (`finish`), the others the staged one.
+  const bool dword_layout = ((a.pitch | a.src_stride) & 3) == 0;
+  const int n_st = dword_layout ? n_images : n_images - 1;  // images of the staged launch
+  auto finish = [&]() -> hipError_t {
+    if (n_st < n_images) {
+      SrLpArgs last = a;
+      last.src = a.src + (size_t)n_st * a.src_stride;
+      last.dst = a.dst + (size_t)n_st * a.dst_stride;
+      const dim3 grid1((unsigned)(((a.res + 31) / 32) * ((a.res + 7) / 8)), 1u);
+      if (interp == 2) hipLaunchKernelGGL(sr_logpolar_kernel<4>, grid1, dim3(256), 0, stream, last);
+      else hipLaunchKernelGGL(sr_logpolar_kernel<8>, grid1, dim3(256), 0, stream, last);
+    }
+    return hipGetLastError();
+  };
+  if (staged_on && !global_w && n_st >= 4 && a.boxes && a.wplanes && a.box_dwords_max <= 64 * NR) {
     const int tiles = (a.res + 7) / 8, n_tiles = tiles * tiles;
     // images per wave: long runs amortise the per-tile set-up; short ones keep the images that the resident waves
     // share within the L2 (MOF_SR_LP_IPW: diagnostic override)
     static const int forced_ipw = [] { const char* e = getenv("MOF_SR_LP_IPW"); return e ? atoi(e) : 0; }();
-    const int ipw = forced_ipw > 0 ? forced_ipw : (n_images >= 128 ? 32 : (n_images >= 64 ? 16 : (n_images >= 16 ? 8 : 4)));
-    const int groups = (n_images + ipw - 1) / ipw;
+    const int ipw = forced_ipw > 0 ? forced_ipw : (n_st >= 128 ? 32 : (n_st >= 64 ? 16 : (n_st >= 16 ? 8 : 4)));
+    const int groups = (n_st + ipw - 1) / ipw;
     static const bool xcd_off = [] { const char* e = getenv("MOF_SR_LP_XCD"); return e && atoi(e) == 0; }();
     const int nq = (n_tiles + 3) / 4;
     const int xcd_groups = (groups >= 8 && !xcd_off) ? groups : 0;  // fewer than 8 groups would leave XCDs idle
@@ -828,21 +847,21 @@ hipError_t launch_sr_logpolar(const SrLpArgs& a, int interp, int n_images, hipSt
       static const bool long_ring = [] { const char* e = getenv("MOF_SR_LP_RING"); return e && atoi(e) == 16; }();
       const bool short_ring = !long_ring && a.sbox_dwords_max <= 256 * NRS;
       if (interp == 2 && short_ring)
-        hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NRS, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
+        hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NRS, true>), dim3(sblocks), dim3(256), slds, stream, a, n_st, ipw, xcd_groups);
       else if (interp == 2)
-        hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
+        hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, true>), dim3(sblocks), dim3(256), slds, stream, a, n_st, ipw, xcd_groups);
       else if (short_ring)
-        hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NRS, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
+        hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NRS, true>), dim3(sblocks), dim3(256), slds, stream, a, n_st, ipw, xcd_groups);
       else
-        hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, true>), dim3(sblocks), dim3(256), slds, stream, a, n_images, ipw, xcd_groups);
-      return hipGetLastError();
+        hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, true>), dim3(sblocks), dim3(256), slds, stream, a, n_st, ipw, xcd_groups);
+      return finish();
     }
     const size_t lds = (size_t)4 * 2 * sizeof(uint32_t) * lp_box_capacity(a.box_dwords_max);
     if (interp == 2)
-      hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, false>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<4, NR, false>), dim3(blocks), dim3(256), lds, stream, a, n_st, ipw, xcd_groups);
     else
-      hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, false>), dim3(blocks), dim3(256), lds, stream, a, n_images, ipw, xcd_groups);
-    return hipGetLastError();
+      hipLaunchKernelGGL((sr_logpolar_staged_kernel<8, NR, false>), dim3(blocks), dim3(256), lds, stream, a, n_st, ipw, xcd_groups);
+    return finish();
   }
   if (!global_w && n_images >= 4) return interp == 2 ? launch_lp_lds<4>(a, n_images, stream) : launch_lp_lds<8>(a, n_images, stream);
   const dim3 grid((unsigned)(((a.res + 31) / 32) * ((a.res + 7) / 8)), (unsigned)n_images);
