@@ -813,7 +813,7 @@ static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame
   }
   // the run index rides gridDim.z (at most 65535 per launch): a very long video goes out in several launches
   const size_t per_pair = (size_t)e->cfg.grid_x * e->cfg.grid_y * 2;
-  const int max_pairs = 65535 * ((khalf && !run_set) ? 4 : run);  // (the half-tile launcher's own run length is at least 4)
+  const int max_pairs = 65535 * (run_set ? run : (khalf ? 4 : (full ? 2 : run)));  // (the launchers' own run lengths are at least 4 / 2)
   for (int k0 = 0; k0 < n_pairs; k0 += max_pairs) {
     const int nk = n_pairs - k0 < max_pairs ? n_pairs - k0 : max_pairs;
     mof::PcArgs c = a;
@@ -821,7 +821,7 @@ static int fft_sequence(mof_fft_engine* e, const uint8_t* d_frames, size_t frame
     c.out = d_out_xy + (size_t)k0 * per_pair;
     if (khalf) HIP_TRY(mof::launch_pc_half_sequence(c, kh_m, n, nk, run_set ? run : 0, (hipStream_t)stream));  // (0: the launcher picks the run length)
     else if (half) HIP_TRY(mof::launch_pc_sequence_half(c, n, nk, run, (hipStream_t)stream));
-    else HIP_TRY(mof::launch_pc_sequence(c, nk, run, (hipStream_t)stream));
+    else HIP_TRY(mof::launch_pc_sequence(c, nk, run_set ? run : 0, (hipStream_t)stream));  // (0: the launcher picks the run length)
   }
   return MOF_OK;
 }

@@ -313,6 +313,24 @@ hipError_t pc_configure_sequence() {
 // a.cur = frame 0, a.cur_stride = bytes between frames; pair k = (frame k + 1, frame k), k < n_pairs; a.prev unused.
 hipError_t launch_pc_sequence(const PcArgs& a, int n_pairs, int run, hipStream_t stream) {
   if (n_pairs <= 0) return hipSuccess;
+  if (run == 0) {
+    // r06 (tools/video_probe.py: 128 pairs of 8 x 8 patches ran slower as a video than as pairs): fixed runs of 16 pairs left half of the
+    // resident slots empty on a short video. As the half-tile kernel does (pc_half_kernel.hip): workgroups of a launch all last run + ~0.5
+    // transforms (a run's first frame has no inverse), the launch lasts ceil(workgroups / slots) rounds of that -- the least product wins.
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const long slots = (long)cus * 4, patches = (long)a.grid_x * a.grid_y;  // four workgroups per CU (one 36 KB tile each)
+    auto cost = [&](int r) {
+      const long wgs = patches * ((n_pairs + r - 1) / r), rounds = (wgs + slots - 1) / slots;
+      return (double)rounds * ((double)r + 0.5);
+    };
+    double best = cost(2);
+    for (int r = 3; r <= 64; ++r) best = cost(r) < best ? cost(r) : best;
+    // ... the SHORTEST run within 3 % of it: the dispatcher is not round-synchronous, long runs leave a ragged tail (c2seq, 1024 pairs: the
+    // model rates runs of 64 1.5 % ahead of 16, measured they are 5 % behind)
+    for (int r = 2; r <= 64 && run == 0; ++r)
+      if (cost(r) <= 1.03 * best) run = r;
+  }
   if (run < 1) run = 1;
   const int runs = (n_pairs + run - 1) / run;
   if (runs > 65535 || (a.channels != 1 && a.channels != 3) || a.downscale != 1) return hipErrorInvalidValue;
