@@ -276,7 +276,7 @@ struct mof_sr_engine {
   uint8_t* h_stage = nullptr;
   double* h_out = nullptr;
   double* h_seq = nullptr;       // pinned [chunk][4]: a pass's results, read back when a sequence call resolves the gate
-  int seq_run = 16;              // pairs one wave of K6s walks in time (MOF_SR_SEQ_RUN overrides)
+  int seq_run = 0;               // pairs one wave of K6s walks in time: 0 = chosen per pass (seq_run_for), MOF_SR_SEQ_RUN fixes it (r05: 16)
   int chunk = 0;                 // frame pairs per pipeline pass
   int scratch_pairs = 0;         // pairs per pass the scratch holds now (1 after create, `chunk` after the first batch)
   bool two_lanes = false;        // remap of pass k+1 beside the transforms of pass k (mof_sr_config.pipeline_lanes == 2)
@@ -347,6 +347,26 @@ bool fused_requested() {
 bool use_fused(const mof_sr_engine* e) { return e->d_wfrag != nullptr; }  // (the fragments exist only when the knob was set at create)
 hipError_t cols_fused(const mof_sr_engine* e, const uint8_t* lp_prev, const uint8_t* lp_cur, size_t lp_stride, int n_pairs, int run, hipStream_t s) {
   return mof::launch_sr_cols_fused(lp_prev, lp_cur, lp_stride, e->d_wfrag, e->d_twiddles, e->d_Dt, e->cfg.resolution, n_pairs, run, s);
+}
+// Run length of K6s for a pass of m consecutive pairs (r06; tools/video_probe.py showed the same shape on the FFT engine's video kernel): a
+// wave walks `run` pairs one after the other, so a short video in runs of 16 leaves most of the chip idle -- 64 frames of 480^2 are 61 column
+// groups x 4 runs = 244 one-wave workgroups on 2048 slots. Workgroups last run + ~0.6 column transforms (the first pair's previous spectra
+// are transformed too), the launch lasts ceil(workgroups / slots) rounds: the shortest run within 3 % of the least product.
+int seq_run_for(const mof_sr_engine* e, int m) {
+  if (e->seq_run > 0) return e->seq_run;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device) != hipSuccess || cus <= 0) cus = 256;
+  const int tn = e->generic ? e->plan.m : e->cfg.resolution;
+  const long groups = (tn / 2 + 1 + 3) / 4, slots = (long)cus * (tn > 600 ? 4 : 8);  // one-wave workgroups, one or two per SIMD
+  auto cost = [&](int r) {
+    const long wgs = groups * ((m + r - 1) / r), rounds = (wgs + slots - 1) / slots;
+    return (double)rounds * ((double)r + 0.6);
+  };
+  double best = cost(1);
+  for (int r = 2; r <= 32; ++r) best = cost(r) < best ? cost(r) : best;
+  for (int r = 1; r <= 32; ++r)
+    if (cost(r) <= 1.03 * best) return r;
+  return 16;
 }
 hipError_t cols_seq(const mof_sr_engine* e, const float* zh_prev, const float* zh_cur, size_t zh_stride, int n_pairs, int run, hipStream_t s) {
   if (!e->generic) return mof::launch_sr_cols_seq(zh_prev, zh_cur, zh_stride, e->d_twiddles, e->d_Dt, e->cfg.resolution, n_pairs, run, s);
@@ -816,7 +836,7 @@ int mof_sr_process_sequence_device(mof_sr_engine* e, const uint8_t* d_frames, si
         lp_tables(e, 4, &lp);
         SR_TRY(mof::launch_sr_logpolar(lp, 4, m, s));  // INTER_LANCZOS4, :112 -- every frame once
         SR_TRY(rows_real(e, e->d_lp + nn, nn, zh + zhf, zhf, m, s));
-        SR_TRY(cols_seq(e, zh, zh + zhf, zhf, m, e->seq_run, s));
+        SR_TRY(cols_seq(e, zh, zh + zhf, zhf, m, seq_run_for(e, m), s));
         mof::SrPcArgs a = pc_args(e, nullptr, nullptr, 0, d_out + 4 * (size_t)done);
         SR_TRY(peak(e, a, m, s));
         carry = m;
