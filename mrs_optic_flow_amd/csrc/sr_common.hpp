@@ -19,10 +19,15 @@ struct SrPlan;
 #ifndef MOF_SR_LINE480  // (A/B: tools/ab_sr_line.sh)
 #define MOF_SR_LINE480 497
 #endif
+// (A/B, r06: -DMOF_SR_480_R1=24 -DMOF_SR_480_R2=20 -DMOF_SR_LINE480=505 and the like -- the first radix may be up to 32 now)
+#ifndef MOF_SR_480_R1
+#define MOF_SR_480_R1 15
+#define MOF_SR_480_R2 32
+#endif
 template <>
 struct SrPlan<480> {
-  static constexpr int R1 = 15, R2 = 32, Y2 = 33, LINE = MOF_SR_LINE480;
-  static_assert(LINE >= R1 * Y2, "the padded stage-1 output fits a line");
+  static constexpr int R1 = MOF_SR_480_R1, R2 = MOF_SR_480_R2, Y2 = R2 + 1, LINE = MOF_SR_LINE480;
+  static_assert(R1 * R2 == 480 && LINE >= R1 * Y2 && LINE >= 480, "the padded stage-1 output fits a line");
 };
 template <>
 struct SrPlan<240> {
