@@ -112,6 +112,27 @@ template <>
 struct SrPlan<384> {
   static constexpr int R1 = 12, R2 = 32, Y2 = 33, LINE = 397;
 };
+// r06, below the FFT engine's large-patch band (its own kernels serve these patch sizes; here for the ESTIMATOR at small resolutions)
+template <>
+struct SrPlan<128> {  // 8 x 16
+  static constexpr int R1 = 8, R2 = 16, Y2 = 17, LINE = 137;
+};
+template <>
+struct SrPlan<144> {  // 9 x 16
+  static constexpr int R1 = 9, R2 = 16, Y2 = 17, LINE = 153;
+};
+template <>
+struct SrPlan<160> {  // 10 x 16
+  static constexpr int R1 = 10, R2 = 16, Y2 = 17, LINE = 171;
+};
+template <>
+struct SrPlan<180> {  // 10 x 18
+  static constexpr int R1 = 10, R2 = 18, Y2 = 19, LINE = 191;
+};
+template <>
+struct SrPlan<192> {  // 12 x 16
+  static constexpr int R1 = 12, R2 = 16, Y2 = 17, LINE = 205;
+};
 // r06: first radix up to 32 (stage 2 of wave_fft then runs 32 lanes per line, two lines per pass): every even size cv::getOptimalDFTSize
 // can return between 512 and 960, and 324 / 486 / 500 below -- all with an even last radix whose Nyquist bin passes no twiddle
 // (16, 18 and 30 by decimation in time, 20 / 24 by their Cooley-Tukey split, 32), so the real-only slots stay exact.
@@ -316,6 +337,7 @@ __device__ __forceinline__ void bfly(cf* v) {
   else if constexpr (R == 18) butterfly18(v);
   else if constexpr (R == 12) butterfly12(v);
   else if constexpr (R == 10) butterfly10(v);
+  else if constexpr (R == 9) butterfly9(v);
   else butterfly<R>(v);
 }
 

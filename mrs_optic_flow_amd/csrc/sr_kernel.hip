@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
 // FFT engine's large patches brought along whose Nyquist bin is exact (250 / 400 / 432 would need the exact-sums form of the row kernel: they stay
 // on the planned pipeline, like every resolution that is not itself one of these sizes). MOF_SR_TUNED_ALL=0: the three only (A/B, tests).
 bool sr_transform_size_tuned(int m, bool* exact_nyquist) {
-  static const int exact[] = {200, 216, 240, 256, 270, 288, 300, 320, 324, 360, 384, 450, 480, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
+  static const int exact[] = {128, 144, 160, 180, 192, 200, 216, 240, 256, 270, 288, 300, 320, 324, 360, 384, 450, 480, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
   for (int t : exact)
     if (m == t) {
       if (exact_nyquist) *exact_nyquist = true;
@@ -777,7 +777,7 @@ bool sr_resolution_supported(int res) {
   static const bool all = [] { const char* v = getenv("MOF_SR_TUNED_ALL"); return !v || atoi(v) != 0; }();
   if (sr_pair_kernels_supported(res)) return true;
   if (!all) return false;
-  static const int sizes[] = {200, 216, 270, 288, 300, 320, 324, 360, 384, 450, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
+  static const int sizes[] = {128, 144, 160, 180, 192, 200, 216, 270, 288, 300, 320, 324, 360, 384, 450, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
   for (int t : sizes)
     if (res == t) return true;
   return false;
@@ -904,6 +904,11 @@ hipError_t launch_sr_peak(const SrPcArgs& a, int res, int n_pairs, hipStream_t s
     case 240: return launch_sr_peak_n<240>(a, n_pairs, stream);
     case 256: return launch_sr_peak_n<256>(a, n_pairs, stream);
     case 480: return launch_sr_peak_n<480>(a, n_pairs, stream);
+    case 128: return launch_sr_peak_n<128>(a, n_pairs, stream);
+    case 144: return launch_sr_peak_n<144>(a, n_pairs, stream);
+    case 160: return launch_sr_peak_n<160>(a, n_pairs, stream);
+    case 180: return launch_sr_peak_n<180>(a, n_pairs, stream);
+    case 192: return launch_sr_peak_n<192>(a, n_pairs, stream);
     case 200: return launch_sr_peak_n<200>(a, n_pairs, stream);
     case 216: return launch_sr_peak_n<216>(a, n_pairs, stream);
     case 270: return launch_sr_peak_n<270>(a, n_pairs, stream);
@@ -970,6 +975,11 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
     case 384: return launch_sr_rows_inv_n<384>(a, n_pairs, stream);
     case 480: return launch_sr_rows_inv_n<480>(a, n_pairs, stream);
     case 512: return launch_sr_rows_inv_n<512>(a, n_pairs, stream);
+    case 128: return launch_sr_rows_inv_n<128>(a, n_pairs, stream);
+    case 144: return launch_sr_rows_inv_n<144>(a, n_pairs, stream);
+    case 160: return launch_sr_rows_inv_n<160>(a, n_pairs, stream);
+    case 180: return launch_sr_rows_inv_n<180>(a, n_pairs, stream);
+    case 192: return launch_sr_rows_inv_n<192>(a, n_pairs, stream);
     case 324: return launch_sr_rows_inv_n<324>(a, n_pairs, stream);
     case 486: return launch_sr_rows_inv_n<486>(a, n_pairs, stream);
     case 500: return launch_sr_rows_inv_n<500>(a, n_pairs, stream);

@@ -614,6 +614,11 @@ hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, flo
     case 384: return launch_rows_real_src_n<384>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 512: return launch_rows_real_src_n<512>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 128: return launch_rows_real_src_n<128>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 144: return launch_rows_real_src_n<144>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 160: return launch_rows_real_src_n<160>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 180: return launch_rows_real_src_n<180>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 192: return launch_rows_real_src_n<192>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 324: return launch_rows_real_src_n<324>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 486: return launch_rows_real_src_n<486>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 500: return launch_rows_real_src_n<500>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
@@ -659,6 +664,11 @@ hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t 
     case 384: return launch_cols_seq_n<384>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 512: return launch_cols_seq_n<512>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 128: return launch_cols_seq_n<128>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 144: return launch_cols_seq_n<144>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 160: return launch_cols_seq_n<160>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 180: return launch_cols_seq_n<180>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 192: return launch_cols_seq_n<192>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 324: return launch_cols_seq_n<324>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 486: return launch_cols_seq_n<486>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 500: return launch_cols_seq_n<500>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);

@@ -355,11 +355,11 @@ def test_video_form_of_the_tuned_large_patch_path(gpu):
 
 # ---- scaleRotationEstimator at any even resolution (scaleRotationEstimator.cpp:3-32) ----
 @pytest.mark.parametrize("res,M", [(320, 45.0), (360, 49.9), (400, 49.9), (128, 25.0), (200, 35.0), (250, 40.0), (300, 49.9),
-                                    (350, 49.9), (500, 60.0), (192, 30.0), (640, 70.0), (720, 75.0), (270, 40.0), (208, 35.0), (336, 49.9), (416, 55.0), (432, 55.0), (496, 60.0)])
+                                    (350, 49.9), (500, 60.0), (192, 30.0), (640, 70.0), (720, 75.0), (270, 40.0), (208, 35.0), (336, 49.9), (416, 55.0), (432, 55.0), (496, 60.0), (160, 30.0), (180, 30.0), (144, 28.0)])
 def test_scale_rotation_at_any_resolution(gpu, res, M):
     """r06: 200, 270, 300, 320, 360, 500, 640, 720 are tuned transform sizes of the FFT engine's large patches with an exact Nyquist bin -- the
     estimator runs K5s / K6s / K7 there; 208 (-> 216), 336 / 350 (-> 360), 416 (-> 432), 496 (-> 500) PAD to a tuned size and 250 / 400 / 432 are the
-    odd-last-radix sizes (exact pixel sums inside the Zh slots): K5s' zero-padding frame form / K6s / K7 + the planned final kernel. 128, 192:
+    odd-last-radix sizes (exact pixel sums inside the Zh slots): K5s' zero-padding frame form / K6s / K7 + the planned final kernel. 128, 160, 180, 192: tuned plans of their own (8 / 10 / 10 / 12 x 16 or 18); 144:
     the planned pipeline (MOF_SR_TUNED_ALL=0 in the child test below: everywhere)."""
     import sr_scenes
     from mrs_optic_flow_amd import ScaleRotationEstimator
@@ -402,7 +402,7 @@ def test_scale_rotation_planned_pipeline_at_the_tuned_sizes(gpu):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_generic.py"), "-q", "-x", "-m", "gpu", "-k",
-                          "scale_rotation_at_any_resolution and (320 or 500 or 270 or 640 or 350 or 400 or 250)", "-p", "no:cacheprovider"],
+                          "scale_rotation_at_any_resolution and (320 or 500 or 270 or 640 or 350 or 400 or 250 or 128 or 192)", "-p", "no:cacheprovider"],
                          env=dict(os.environ, MOF_SR_TUNED_ALL="0"), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
