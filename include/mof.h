@@ -117,9 +117,9 @@ typedef struct mof_fft_engine mof_fft_engine;
  * transformed on its own, the previous spectrum waiting in registers) for N = 120 -- the reference's default, two workgroups per CU --,
  * for every N whose padded size is an even 136 .. 192, and for padded sizes 60 / 72 / 90 / 96 / 100 / 120; a planned kernel on the full M x M tile for
  * every other N with M <= 135 ("planned", csrc/pc_kernel_generic.hip); a planned pipeline through HBM scratch for larger patches up to
- * M = 960 ("planned-large", csrc/pc_large_kernel.hip; r06: wherever M is EVEN -- every size from 200 to 960 -- the transforms inside
- * it are the scale / rotation estimator's tuned in-register ones (csrc/sr_seq_kernel.hip: the row kernel zero-pads, 250 / 400 / 432 take
- * their real-only spectrum slots from exact integer pixel sums); the planned transforms remain for odd M: 225, 243, 375, 405, 625, 675, 729). mof_fft_create fails with MOF_ERR_UNSUPPORTED
+ * M = 960 ("planned-large", csrc/pc_large_kernel.hip; r06: at every M from 200 to 960, even or odd, the transforms inside it are the
+ * scale / rotation estimator's tuned in-register ones (csrc/sr_seq_kernel.hip: the row kernel zero-pads, 250 / 400 / 432 take their
+ * real-only spectrum slots from exact integer pixel sums); the planned transforms remain for the long-range mode and as the A/B form). mof_fft_create fails with MOF_ERR_UNSUPPORTED
  * only beyond that, and for MOF_PEAK_OCL on sizes the reference's OpenCL branch cannot plan either (odd, not 5-smooth) or M > 135.
  * The large-patch pipeline owns scratch (three half-spectrum planes per patch pair of a pass); it grows with the first batch
  * that needs more -- never inside a HIP graph capture: run the largest batch once before capturing. */
@@ -352,7 +352,7 @@ typedef struct mof_sr_config {
   int resolution;   /* side of the square image (scaleRotationEstimator.cpp:5): any even value >= 16 that pads to <= 960. 240, 256
                        and 480 have the full set of hand-tuned kernels; r06: every resolution whose padded size is an even
                        200 .. 960, or 128 / 144 / 160 / 180 / 192, runs the tuned transforms too (MOF_SR_TUNED_ALL=0: those three
-                       only); the rest (below 126, or padding to an odd size) run the planned pipeline on the padded size                        */
+                       only); the rest (below 126) run the planned pipeline on the padded size                           */
   double magnitude; /* log-polar magnitude M (scale_rot_magnitude, config/default.yaml:13: 49.9)      */
   int device;
   int logpolar_variant; /* MOF_LOGPOLAR_CV4 (0, default) or MOF_LOGPOLAR_CV3: see below              */

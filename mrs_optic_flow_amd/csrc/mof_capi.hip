@@ -210,7 +210,8 @@ static int launch_large(mof_fft_engine* e, const mof::PcArgs& a, int n_pairs, hi
   // r06: 200, 216, 270, 288, 300, 320, 360, 384, 450 too, and patches that PAD to one of these sizes (193 .. 216, 226 .. 240, 251 .. 256, 271 .. 288, 301 .. 320, 325 .. 360, 376 .. 384,
   // 451 .. 480): the row kernel
   // zero-pads, the column kernel applies the box-zero rule of padded constant patches from the row kernel's flags
-  static const int tuned_sizes[] = {200, 216, 240, 250, 256, 270, 288, 300, 320, 324, 360, 384, 400, 432, 450, 480, 486, 500, 512,
+  static const int tuned_sizes[] = {225, 243, 375, 405, 625, 675, 729,  // (r06: the odd sizes too)
+                                    200, 216, 240, 250, 256, 270, 288, 300, 320, 324, 360, 384, 400, 432, 450, 480, 486, 500, 512,
                                     540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};  // (r06: 324, 486, 500 and every even size above 512 -- first radix up to 32)
   bool tuned = false;
   for (int t : tuned_sizes) tuned = tuned || e->plan.m == t;

@@ -133,6 +133,38 @@ template <>
 struct SrPlan<192> {  // 12 x 16
   static constexpr int R1 = 12, R2 = 16, Y2 = 17, LINE = 205;
 };
+// r06: the ODD transform sizes getOptimalDFTSize can return in the large-patch band (patches of 217 .. 225, 241 .. 243, 361 .. 375, 401 .. 405,
+// 601 .. 625, 649 .. 675, 721 .. 729). Two real rows still share a complex line -- the last row of an image shares its line with a row of zeros --,
+// there are (N + 1) / 2 = N / 2 + 1 half-spectrum columns as for even N, no Nyquist bin (only bin (0, 0) is real-only), every bin u > 0 has a
+// distinct Hermitian partner N - u. LINE >= N + 1: the last 16-byte piece of a line carries one element past it.
+template <>
+struct SrPlan<225> {  // 15 x 15
+  static constexpr int R1 = 15, R2 = 15, Y2 = 16, LINE = 241;
+};
+template <>
+struct SrPlan<243> {  // 9 x 27
+  static constexpr int R1 = 9, R2 = 27, Y2 = 28, LINE = 253;
+};
+template <>
+struct SrPlan<375> {  // 15 x 25
+  static constexpr int R1 = 15, R2 = 25, Y2 = 26, LINE = 391;
+};
+template <>
+struct SrPlan<405> {  // 15 x 27
+  static constexpr int R1 = 15, R2 = 27, Y2 = 28, LINE = 421;
+};
+template <>
+struct SrPlan<625> {  // 25 x 25
+  static constexpr int R1 = 25, R2 = 25, Y2 = 26, LINE = 651;
+};
+template <>
+struct SrPlan<675> {  // 25 x 27
+  static constexpr int R1 = 25, R2 = 27, Y2 = 28, LINE = 701;
+};
+template <>
+struct SrPlan<729> {  // 27 x 27
+  static constexpr int R1 = 27, R2 = 27, Y2 = 28, LINE = 757;
+};
 // r06: first radix up to 32 (stage 2 of wave_fft then runs 32 lanes per line, two lines per pass): every even size cv::getOptimalDFTSize
 // can return between 512 and 960, and 324 / 486 / 500 below -- all with an even last radix whose Nyquist bin passes no twiddle
 // (16, 18 and 30 by decimation in time, 20 / 24 by their Cooley-Tukey split, 32), so the real-only slots stay exact.

@@ -625,15 +625,25 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
   const cf* Dt = reinterpret_cast<const cf*>(a.Dt) + (size_t)(MOF_SR_L2_ABLATE ? 0 : pair) * (H + 1) * N;
   // line l carries rows y1 = 2 (p0 + l), y2 = y1 + 1: E[u] = F[y1][u] + i F[y2][u], F[y][N-u] = conj F[y][u].
   // Dt[u][y1], Dt[u][y2] are neighbours: one 16-byte load; 8 lanes fetch the 16 rows of the workgroup (128 bytes).
+  constexpr bool ODD = (N & 1) != 0;   // (r06) the last row of an odd image shares its line with zeros; every u > 0 has a partner N - u != u
+  constexpr int NLN = (N + 1) / 2;     // lines = row pairs
   {
     constexpr int NL = (SR_LINES * (H + 1) + SR_T - 1) / SR_T;  // all loads in flight before the first LDS write
     float4 t[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int i = tid + SR_T * k;
-      constexpr bool TAIL = H % SR_LINES != 0;  // (200, 216: a line past the last row pair transforms zeros and is left out of the arg-max)
+      constexpr bool TAIL = NLN % SR_LINES != 0;  // (200, 216: a line past the last row pair transforms zeros and is left out of the arg-max)
       if constexpr (TAIL) t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < SR_LINES * (H + 1) && (!TAIL || p0 + i % SR_LINES < H)) t[k] = stream_load(reinterpret_cast<const float4*>(Dt + (size_t)(i / SR_LINES) * N + 2 * (p0 + i % SR_LINES)));
+      if (i < SR_LINES * (H + 1) && (!TAIL || p0 + i % SR_LINES < NLN)) {
+        const cf* d = Dt + (size_t)(i / SR_LINES) * N + 2 * (p0 + i % SR_LINES);
+        if constexpr (ODD) {  // (rows of N complex are not 16-byte aligned; the row behind the last one is zero)
+          const cf g1 = d[0], g2 = 2 * (p0 + i % SR_LINES) + 1 < N ? d[1] : cf{0.f, 0.f};
+          t[k] = make_float4(g1.x, g1.y, g2.x, g2.y);
+        } else {
+          t[k] = stream_load(reinterpret_cast<const float4*>(d));
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
@@ -641,21 +651,21 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
       if (i < SR_LINES * (H + 1)) {
         const int u = i / SR_LINES, l = i % SR_LINES;
         z[l * P::LINE + u] = {t[k].x - t[k].w, t[k].y + t[k].z};
-        if (u > 0 && u < H) z[l * P::LINE + N - u] = {t[k].x + t[k].w, t[k].z - t[k].y};
+        if (u > 0 && (ODD || u < H)) z[l * P::LINE + N - u] = {t[k].x + t[k].w, t[k].z - t[k].y};
       }
     }
   }
   __syncthreads();
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
   wave_fft<N>(z + 4 * wave * P::LINE, 4, lane, tw, [&](cf*, int l, int k1, const cf* v) {
-    if (H % SR_LINES != 0 && p0 + 4 * wave + l >= H) return;
+    if (NLN % SR_LINES != 0 && p0 + 4 * wave + l >= NLN) return;
     const int y1 = 2 * (p0 + 4 * wave + l), y2 = y1 + 1;
     const int r1 = ((y1 + H) % N) * N, r2 = ((y2 + H) % N) * N;  // fftShift + first maximum (minMaxLoc)
 #pragma unroll
     for (int k2 = 0; k2 < P::R2; ++k2) {
       const int xs = (k1 + P::R1 * k2 + H) % N;
       best = better(best, Best{v[k2].x, r1 + xs});
-      best = better(best, Best{v[k2].y, r2 + xs});
+      if (!ODD || y2 < N) best = better(best, Best{v[k2].y, r2 + xs});
     }
   });
 #pragma unroll
@@ -760,7 +770,8 @@ __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
 // FFT engine's large patches brought along whose Nyquist bin is exact (250 / 400 / 432 would need the exact-sums form of the row kernel: they stay
 // on the planned pipeline, like every resolution that is not itself one of these sizes). MOF_SR_TUNED_ALL=0: the three only (A/B, tests).
 bool sr_transform_size_tuned(int m, bool* exact_nyquist) {
-  static const int exact[] = {128, 144, 160, 180, 192, 200, 216, 240, 256, 270, 288, 300, 320, 324, 360, 384, 450, 480, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
+  static const int exact[] = {225, 243, 375, 405, 625, 675, 729,  // (odd: no Nyquist bin to keep exact)
+                              128, 144, 160, 180, 192, 200, 216, 240, 256, 270, 288, 300, 320, 324, 360, 384, 450, 480, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
   for (int t : exact)
     if (m == t) {
       if (exact_nyquist) *exact_nyquist = true;
@@ -888,12 +899,12 @@ static hipError_t launch_sr_pc_n(const SrPcArgs& a, int n_pairs, hipStream_t str
   return hipGetLastError();
 }
 
-int sr_candidates(int res) { return (res / 2 + SR_LINES - 1) / SR_LINES; }
+int sr_candidates(int res) { return ((res + 1) / 2 + SR_LINES - 1) / SR_LINES; }  // (one per workgroup of K7: eight row pairs)
 
 // K7 + K8 alone: from a Dt that somebody else produced (the sequence pipeline, sr_seq_kernel.hip) to (scale, rot, pt)
 template <int N>
 static hipError_t launch_sr_peak_n(const SrPcArgs& a, int n_pairs, hipStream_t stream) {
-  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3((N / 2 + SR_LINES - 1) / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
+  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(((N + 1) / 2 + SR_LINES - 1) / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
   hipLaunchKernelGGL(sr_final_kernel<N>, dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
@@ -947,7 +958,7 @@ static hipError_t launch_sr_rows_inv_n(const SrPcArgs& a, int n_pairs, hipStream
     SrPcArgs b = a;
     b.Dt = a.Dt + (size_t)p0 * (N / 2 + 1) * N * 2;
     b.cand = a.cand + (size_t)p0 * a.n_cand;
-    hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3((N / 2 + SR_LINES - 1) / SR_LINES, (unsigned)np), dim3(SR_T), 0, stream, b);
+    hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(((N + 1) / 2 + SR_LINES - 1) / SR_LINES, (unsigned)np), dim3(SR_T), 0, stream, b);
   }
   return hipGetLastError();
 }
@@ -975,6 +986,13 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
     case 384: return launch_sr_rows_inv_n<384>(a, n_pairs, stream);
     case 480: return launch_sr_rows_inv_n<480>(a, n_pairs, stream);
     case 512: return launch_sr_rows_inv_n<512>(a, n_pairs, stream);
+    case 225: return launch_sr_rows_inv_n<225>(a, n_pairs, stream);
+    case 243: return launch_sr_rows_inv_n<243>(a, n_pairs, stream);
+    case 375: return launch_sr_rows_inv_n<375>(a, n_pairs, stream);
+    case 405: return launch_sr_rows_inv_n<405>(a, n_pairs, stream);
+    case 625: return launch_sr_rows_inv_n<625>(a, n_pairs, stream);
+    case 675: return launch_sr_rows_inv_n<675>(a, n_pairs, stream);
+    case 729: return launch_sr_rows_inv_n<729>(a, n_pairs, stream);
     case 128: return launch_sr_rows_inv_n<128>(a, n_pairs, stream);
     case 144: return launch_sr_rows_inv_n<144>(a, n_pairs, stream);
     case 160: return launch_sr_rows_inv_n<160>(a, n_pairs, stream);

@@ -41,7 +41,7 @@ template <int N>
 struct RowsReal {
   static constexpr int ROWS = N > 512 ? 8 : ((N % 32 == 0 && MOF_K5S_ROWS32) ? 32 : (N % 16 == 0 ? 16 : 8));  // (200: 25 one-wave workgroups of 8 rows per image; beyond 512: one wave = four lines = up to 31 KB of LDS per workgroup)
   static constexpr bool TAIL = N % ROWS != 0;  // (270, 300, 450: the last one-wave workgroup holds 3, 2 or 1 row pairs; the rest of its lines are zeros and are not stored)
-  static_assert((N % ROWS == 0 || ROWS == 8) && ROWS % 8 == 0 && N % 2 == 0, "whole workgroups of four-line waves, a tail only behind one-wave workgroups");
+  static_assert((N % ROWS == 0 || ROWS == 8) && ROWS % 8 == 0, "whole workgroups of four-line waves, a tail only behind one-wave workgroups");  // (odd N: the last row shares its line with zeros)
   static constexpr int GROUPS = (N + ROWS - 1) / ROWS;
   static constexpr int LINES = ROWS / 2;
   static constexpr int T = LINES * 16;
@@ -250,7 +250,9 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
   using P = SrPlan<N>;
   constexpr int H = N / 2, CW = SEQ_CW;
   constexpr int MV = (N + 63) / 64;       // bins per lane and line (v = lane + 64 m)
-  constexpr int MQ = (N / 2 + 63) / 64;   // 16-byte pieces per lane and line
+  constexpr bool ODD = (N & 1) != 0;      // (r06) no Nyquist bin: only bin (0, 0) is real-only; Dt rows are not 16-byte aligned
+  constexpr int NQ = (N + 1) / 2;         // 16-byte pieces of a line (odd N: the last one carries an element past the line)
+  constexpr int MQ = (NQ + 63) / 64;      // 16-byte pieces per lane and line
   __shared__ cf z[CW * P::LINE];
   const int lane = threadIdx.x, u0 = blockIdx.x * CW, p0 = blockIdx.y * run;
   const int np = n_pairs - p0 < run ? n_pairs - p0 : run;
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
 #pragma unroll
       for (int m = 0; m < MQ; ++m) {
         const int q = lane + 64 * m;
-        if (q < N / 2) t[s][m] = stream_load(reinterpret_cast<const float4*>(Zf + (size_t)u * sr_zh_pitch<N>() + 2 * q));
+        if (q < NQ) t[s][m] = stream_load(reinterpret_cast<const float4*>(Zf + (size_t)u * sr_zh_pitch<N>() + 2 * q));
       }
     }
 #pragma unroll
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
 #pragma unroll
       for (int m = 0; m < MQ; ++m) {
         const int q = lane + 64 * m;
-        if (q < N / 2) {
+        if (q < NQ) {
           z[s * P::LINE + 2 * q] = {t[s][m].x, t[s][m].y};
           z[s * P::LINE + 2 * q + 1] = {t[s][m].z, t[s][m].w};
         }
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
 #pragma unroll
     for (int s = 0; s < CW; ++s) {
       const int u = u0 + s > H ? H : u0 + s;
-      const bool u_edge = u == 0 || u == H;
+      const bool u_edge = u == 0 || (!ODD && u == H);
 #pragma unroll
       for (int m = 0; m < MV; ++m) {
         const int v = lane + 64 * m;
@@ -320,13 +322,13 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
         if constexpr (!SrNyqExact<P>::value) {
           // the four real-only CCS slots from the images' exact integer sums (doubled as the spectra are: Zh = 2 x the row transform): bins
           // (v, u) in {0, N/2}^2 -> sums[(v ? 2 : 0) + (u ? 1 : 0)] = sum (+-1)^y (+-1)^x p  (run = 1: one pair per wave walk)
-          if (u_edge && (vv == 0 || vv == H)) {
+          if (u_edge && (vv == 0 || (!ODD && vv == H))) {
             const int slot = (vv == H ? 2 : 0) + (u == H ? 1 : 0);
             av = {2.f * (float)sums_cur[(size_t)(p0 + j) * sums_stride + slot], 0.f};
             bv = {2.f * (float)sums_prev[(size_t)(p0 + j) * sums_stride + slot], 0.f};
           }
         }
-        cf C = cross_power_ab(av, bv, u_edge && (vv == 0 || vv == H));
+        cf C = cross_power_ab(av, bv, u_edge && (vv == 0 || (!ODD && vv == H)));
         if constexpr (BOX) {
           if (box_zeros && (box_zero_line(u, zq) || box_zero_line(vv, zq))) C = {0.f, 0.f};
         }
@@ -337,18 +339,30 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
     wave_sync();
     wave_fft<N>(z, CW, lane, tw, StoreNatural<N>{});
     cf* D = reinterpret_cast<cf*>(Dt) + (size_t)(MOF_SR_L2_ABLATE ? 0 : p0 + j) * (H + 1) * N;
+    if constexpr (ODD) {  // rows of N complex start on odd multiples of 8 bytes: element stores
 #pragma unroll
-    for (int s = 0; s < CW; ++s) {
-      const int u = u0 + s;
+      for (int s = 0; s < CW; ++s) {
+        const int u = u0 + s;
 #pragma unroll
-      for (int m = 0; m < MQ; ++m) {
-        const int q = lane + 64 * m;
-        if (q < N / 2 && u <= H) {
-          const cf a0 = z[s * P::LINE + 2 * q], a1 = z[s * P::LINE + 2 * q + 1];
-          // (MOF_SR_L2_ABLATE = 2: Dt is not stored at all -- thousands of waves storing to the SAME aliased lines serialise in the L2 and
-          //  made the aliased build's K6s 44 % slower; dropping the store bounds the write side from above instead)
-          if (MOF_SR_L2_ABLATE == 2) asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y));
-          else stream_store(reinterpret_cast<float4*>(D + (size_t)u * N + 2 * q), make_float4(a0.x, a0.y, a1.x, a1.y));
+        for (int m = 0; m < MV; ++m) {
+          const int v = lane + 64 * m;
+          if (v < N && u <= H) D[(size_t)u * N + v] = z[s * P::LINE + v];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < CW; ++s) {
+        const int u = u0 + s;
+  #pragma unroll
+        for (int m = 0; m < MQ; ++m) {
+          const int q = lane + 64 * m;
+          if (q < N / 2 && u <= H) {
+            const cf a0 = z[s * P::LINE + 2 * q], a1 = z[s * P::LINE + 2 * q + 1];
+            // (MOF_SR_L2_ABLATE = 2: Dt is not stored at all -- thousands of waves storing to the SAME aliased lines serialise in the L2 and
+            //  made the aliased build's K6s 44 % slower; dropping the store bounds the write side from above instead)
+            if (MOF_SR_L2_ABLATE == 2) asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y));
+            else stream_store(reinterpret_cast<float4*>(D + (size_t)u * N + 2 * q), make_float4(a0.x, a0.y, a1.x, a1.y));
+          }
         }
       }
     }
@@ -614,6 +628,13 @@ hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, flo
     case 384: return launch_rows_real_src_n<384>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 480: return launch_rows_real_src_n<480>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 512: return launch_rows_real_src_n<512>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 225: return launch_rows_real_src_n<225>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 243: return launch_rows_real_src_n<243>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 375: return launch_rows_real_src_n<375>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 405: return launch_rows_real_src_n<405>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 625: return launch_rows_real_src_n<625>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 675: return launch_rows_real_src_n<675>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 729: return launch_rows_real_src_n<729>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 128: return launch_rows_real_src_n<128>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 144: return launch_rows_real_src_n<144>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 160: return launch_rows_real_src_n<160>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
@@ -664,6 +685,13 @@ hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t 
     case 384: return launch_cols_seq_n<384>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 480: return launch_cols_seq_n<480>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 512: return launch_cols_seq_n<512>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 225: return launch_cols_seq_n<225>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 243: return launch_cols_seq_n<243>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 375: return launch_cols_seq_n<375>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 405: return launch_cols_seq_n<405>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 625: return launch_cols_seq_n<625>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 675: return launch_cols_seq_n<675>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 729: return launch_cols_seq_n<729>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 128: return launch_cols_seq_n<128>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 144: return launch_cols_seq_n<144>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 160: return launch_cols_seq_n<160>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
