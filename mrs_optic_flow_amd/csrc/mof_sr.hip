@@ -357,7 +357,8 @@ int seq_run_for(const mof_sr_engine* e, int m) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device) != hipSuccess || cus <= 0) cus = 256;
   const int tn = e->generic ? e->plan.m : e->cfg.resolution;
-  const long groups = (tn / 2 + 1 + 3) / 4, slots = (long)cus * (tn > 600 ? 4 : 8);  // one-wave workgroups, one or two per SIMD
+  const int cw = tn >= 540 ? 2 : 4;  // columns per wave (sr_seq_kernel.hip: seq_cw)
+  const long groups = (tn / 2 + 1 + cw - 1) / cw, slots = (long)cus * 8;  // one-wave workgroups, two per SIMD
   auto cost = [&](int r) {
     const long wgs = groups * ((m + r - 1) / r), rounds = (wgs + slots - 1) / slots;
     return (double)rounds * ((double)r + 0.6);

@@ -241,6 +241,14 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
 #define MOF_SEQ_CW 4
 #endif
 constexpr int SEQ_CW = MOF_SEQ_CW;  // columns per wave
+// (r06) the long lines: two columns per wave -- half the LDS, half of the previous-image spectra in registers (from 640 on four columns put
+// those in AGPRs at one wave per SIMD: VALU 22 % / LDS 23 % at 720, profiles/r06_l720_sq_pmc.csv), and with a first radix above 16 the second
+// stage takes two lines per pass anyway. MOF_SEQ_CW_BIG_FROM: first N of the two-column form (A/B)
+#ifndef MOF_SEQ_CW_BIG_FROM
+#define MOF_SEQ_CW_BIG_FROM 540
+#endif
+template <int N>
+constexpr int seq_cw() { return N >= MOF_SEQ_CW_BIG_FROM ? 2 : SEQ_CW; }
 
 template <int N, bool BOX = false>  // BOX: patches zero-padded to N -- the box-zero rule of padded CONSTANT patches (the plain form pays nothing for it)
 __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur,
@@ -248,7 +256,7 @@ __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict
                                                          float* __restrict__ Dt, int n_pairs, int run, const int* __restrict__ flags, int n,
                                                          const int* __restrict__ sums_prev, const int* __restrict__ sums_cur, int sums_stride) {
   using P = SrPlan<N>;
-  constexpr int H = N / 2, CW = SEQ_CW;
+  constexpr int H = N / 2, CW = seq_cw<N>();
   constexpr int MV = (N + 63) / 64;       // bins per lane and line (v = lane + 64 m)
   constexpr bool ODD = (N & 1) != 0;      // (r06) no Nyquist bin: only bin (0, 0) is real-only; Dt rows are not 16-byte aligned
   constexpr int NQ = (N + 1) / 2;         // 16-byte pieces of a line (odd N: the last one carries an element past the line)
@@ -562,7 +570,7 @@ hipError_t launch_cols_seq_n(const float* zh_prev, const float* zh_cur, size_t z
   if (!SrNyqExact<SrPlan<N>>::value && (!sums_prev || !sums_cur)) return hipErrorInvalidValue;  // (this plan's real-only slots come from the exact sums; a run
   // of pairs in time finds pair j's quadruples at (p0 + j) * sums_stride of either pointer -- sums that live inside the Zh slots walk with them)
   constexpr int H = N / 2;
-  const unsigned groups = (H + 1 + SEQ_CW - 1) / SEQ_CW, runs = (unsigned)((n_pairs + run - 1) / run);
+  const unsigned groups = (H + 1 + seq_cw<N>() - 1) / seq_cw<N>(), runs = (unsigned)((n_pairs + run - 1) / run);
   if constexpr (N == 480) {
     // MOF_SR_COLS_SPLIT=1: K6p, two columns per wave and the radix-32 stage on lane pairs
     static const bool split = [] { const char* v = getenv("MOF_SR_COLS_SPLIT"); return v && atoi(v) != 0; }();
