@@ -613,12 +613,22 @@ __global__ void __launch_bounds__(SR_T) sr_cols_kernel(SrPcArgs a) {
 }
 
 // ---- K7: Hermitian rows back to the real surface, two rows per complex transform; arg-max from registers -----
+// K7's waves: two of four lines each; at the long lines (r06, N >= 540: first radix above 16, both stages of wave_fft take two lines per pass
+// anyway) four of two lines each -- the eight lines in LDS set the workgroups per CU, so that is twice the waves for the same LDS
+#ifndef MOF_K7_LPW2_FROM
+#define MOF_K7_LPW2_FROM 540
+#endif
 template <int N>
-__global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
+struct K7Cfg {
+  static constexpr int LPW = N >= MOF_K7_LPW2_FROM ? 2 : 4;
+  static constexpr int T = SR_LINES / LPW * 64;
+};
+template <int N>
+__global__ void __launch_bounds__(K7Cfg<N>::T) sr_rows_inv_kernel(SrPcArgs a) {
   using P = SrPlan<N>;
-  constexpr int H = N / 2;
+  constexpr int H = N / 2, K7T = K7Cfg<N>::T, LPW = K7Cfg<N>::LPW;
   __shared__ cf z[SR_LINES * P::LINE];
-  __shared__ Best red[SR_T / 64];
+  __shared__ Best red[K7T / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = blockIdx.y, p0 = blockIdx.x * SR_LINES;
   SrTw<N> tw;
   tw.load(a.twiddles, lane);
@@ -628,11 +638,11 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
   constexpr bool ODD = (N & 1) != 0;   // (r06) the last row of an odd image shares its line with zeros; every u > 0 has a partner N - u != u
   constexpr int NLN = (N + 1) / 2;     // lines = row pairs
   {
-    constexpr int NL = (SR_LINES * (H + 1) + SR_T - 1) / SR_T;  // all loads in flight before the first LDS write
+    constexpr int NL = (SR_LINES * (H + 1) + K7T - 1) / K7T;  // all loads in flight before the first LDS write
     float4 t[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-      const int i = tid + SR_T * k;
+      const int i = tid + K7T * k;
       constexpr bool TAIL = NLN % SR_LINES != 0;  // (200, 216: a line past the last row pair transforms zeros and is left out of the arg-max)
       if constexpr (TAIL) t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < SR_LINES * (H + 1) && (!TAIL || p0 + i % SR_LINES < NLN)) {
@@ -647,7 +657,7 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-      const int i = tid + SR_T * k;
+      const int i = tid + K7T * k;
       if (i < SR_LINES * (H + 1)) {
         const int u = i / SR_LINES, l = i % SR_LINES;
         z[l * P::LINE + u] = {t[k].x - t[k].w, t[k].y + t[k].z};
@@ -657,9 +667,9 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
   }
   __syncthreads();
   Best best = {-__builtin_huge_valf(), 0x7fffffff};
-  wave_fft<N>(z + 4 * wave * P::LINE, 4, lane, tw, [&](cf*, int l, int k1, const cf* v) {
-    if (NLN % SR_LINES != 0 && p0 + 4 * wave + l >= NLN) return;
-    const int y1 = 2 * (p0 + 4 * wave + l), y2 = y1 + 1;
+  wave_fft<N>(z + LPW * wave * P::LINE, LPW, lane, tw, [&](cf*, int l, int k1, const cf* v) {
+    if (NLN % SR_LINES != 0 && p0 + LPW * wave + l >= NLN) return;
+    const int y1 = 2 * (p0 + LPW * wave + l), y2 = y1 + 1;
     const int r1 = ((y1 + H) % N) * N, r2 = ((y2 + H) % N) * N;  // fftShift + first maximum (minMaxLoc)
 #pragma unroll
     for (int k2 = 0; k2 < P::R2; ++k2) {
@@ -676,7 +686,7 @@ __global__ void __launch_bounds__(SR_T) sr_rows_inv_kernel(SrPcArgs a) {
   if (lane == 0) red[wave] = best;
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < SR_T / 64; ++w) best = better(best, red[w]);
+    for (int w = 1; w < K7T / 64; ++w) best = better(best, red[w]);
     a.cand[(size_t)pair * a.n_cand + blockIdx.x] = make_float2(best.v, __int_as_float(best.idx));
   }
 }
@@ -894,7 +904,7 @@ static hipError_t launch_sr_pc_n(const SrPcArgs& a, int n_pairs, hipStream_t str
   }
   hipLaunchKernelGGL(sr_rows_fwd_kernel<N>, dim3(N / FWD_ROWS, (unsigned)n_pairs), dim3(FWD_T), fwd_lds, stream, a);
   hipLaunchKernelGGL(sr_cols_kernel<N>, dim3((H + 1 + COLS_CW - 1) / COLS_CW, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
-  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(H / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
+  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(H / SR_LINES, (unsigned)n_pairs), dim3(K7Cfg<N>::T), 0, stream, a);
   hipLaunchKernelGGL(sr_final_kernel<N>, dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
@@ -904,7 +914,7 @@ int sr_candidates(int res) { return ((res + 1) / 2 + SR_LINES - 1) / SR_LINES; }
 // K7 + K8 alone: from a Dt that somebody else produced (the sequence pipeline, sr_seq_kernel.hip) to (scale, rot, pt)
 template <int N>
 static hipError_t launch_sr_peak_n(const SrPcArgs& a, int n_pairs, hipStream_t stream) {
-  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(((N + 1) / 2 + SR_LINES - 1) / SR_LINES, (unsigned)n_pairs), dim3(SR_T), 0, stream, a);
+  hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(((N + 1) / 2 + SR_LINES - 1) / SR_LINES, (unsigned)n_pairs), dim3(K7Cfg<N>::T), 0, stream, a);
   hipLaunchKernelGGL(sr_final_kernel<N>, dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
@@ -958,7 +968,7 @@ static hipError_t launch_sr_rows_inv_n(const SrPcArgs& a, int n_pairs, hipStream
     SrPcArgs b = a;
     b.Dt = a.Dt + (size_t)p0 * (N / 2 + 1) * N * 2;
     b.cand = a.cand + (size_t)p0 * a.n_cand;
-    hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(((N + 1) / 2 + SR_LINES - 1) / SR_LINES, (unsigned)np), dim3(SR_T), 0, stream, b);
+    hipLaunchKernelGGL(sr_rows_inv_kernel<N>, dim3(((N + 1) / 2 + SR_LINES - 1) / SR_LINES, (unsigned)np), dim3(K7Cfg<N>::T), 0, stream, b);
   }
   return hipGetLastError();
 }

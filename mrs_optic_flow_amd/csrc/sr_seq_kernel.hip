@@ -44,7 +44,13 @@ struct RowsReal {
   static_assert((N % ROWS == 0 || ROWS == 8) && ROWS % 8 == 0, "whole workgroups of four-line waves, a tail only behind one-wave workgroups");  // (odd N: the last row shares its line with zeros)
   static constexpr int GROUPS = (N + ROWS - 1) / ROWS;
   static constexpr int LINES = ROWS / 2;
-  static constexpr int T = LINES * 16;
+  // lines per wave: four. (r06 A/B, -DMOF_K5S_LPW2_FROM=540: two lines per wave at the long lines -- twice the waves for the same LDS, as K7 took
+  // it -- LOSES here: 576 +9 %, 640 +17 % time, profiles/r06_lpw2_ab.txt; off)
+#ifndef MOF_K5S_LPW2_FROM
+#define MOF_K5S_LPW2_FROM 1000000
+#endif
+  static constexpr int LPW = N >= MOF_K5S_LPW2_FROM ? 2 : 4;
+  static constexpr int T = LINES / LPW * 64;
 };
 
 template <int N>
@@ -162,15 +168,16 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
   const uint32_t p00 = px4(0, 0) & 0xffu, pat = p00 * 0x01010101u;
   uint32_t diff = 0u;
   int s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-  cf* mine = z + 4 * wave * P::LINE;
+  constexpr int LPW = R::LPW;  // lines of this wave
+  cf* mine = z + LPW * wave * P::LINE;
   {
-    constexpr int ND = (N + 3) / 4, NL = (4 * ND + 63) / 64;  // (N = 270, 450: the last chunk of a row is half full)
+    constexpr int ND = (N + 3) / 4, NL = (LPW * ND + 63) / 64;  // (N = 270, 450: the last chunk of a row is half full)
     uint32_t c[NL], p[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int i = lane + 64 * k;
-      if (i < 4 * ND) {
-        const int l = i / ND, d = i % ND, y = row0 + 8 * wave + 2 * l;
+      if (i < LPW * ND) {
+        const int l = i / ND, d = i % ND, y = row0 + 2 * LPW * wave + 2 * l;
         c[k] = px4(y, d);
         p[k] = px4(y + 1, d);
       }
@@ -178,8 +185,8 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int i = lane + 64 * k;
-      if (i < 4 * ND) {
-        const int l = i / ND, d = i % ND, y = row0 + 8 * wave + 2 * l;
+      if (i < LPW * ND) {
+        const int l = i / ND, d = i % ND, y = row0 + 2 * LPW * wave + 2 * l;
         diff |= ((c[k] ^ pat) & inside(y, d)) | ((p[k] ^ pat) & inside(y + 1, d));
         if constexpr (!SrNyqExact<P>::value) {
           // the four exact integer sums of the image (pixels outside the patch were loaded as zeros): row y is even, y + 1 odd; byte b of a chunk
@@ -220,7 +227,7 @@ __global__ void __launch_bounds__(RowsReal<N>::T) sr_rows_real_src_kernel(PclSrc
     if (blockIdx.x == 0 && tid == 0 && p00 != 0u) atomicOr(&flags[img], 2);
   }
   wave_sync();
-  wave_fft<N>(mine, 4, lane, tw, StoreNatural<N>{});
+  wave_fft<N>(mine, LPW, lane, tw, StoreNatural<N>{});
   __syncthreads();
   cf* out = reinterpret_cast<cf*>(zh + (size_t)img * zh_stride) + row0;
   for (int i = tid; i < R::LINES * (H + 1); i += R::T) {
