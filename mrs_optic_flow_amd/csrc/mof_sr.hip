@@ -357,7 +357,7 @@ int seq_run_for(const mof_sr_engine* e, int m) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device) != hipSuccess || cus <= 0) cus = 256;
   const int tn = e->generic ? e->plan.m : e->cfg.resolution;
-  const int cw = tn >= 540 ? 2 : 4;  // columns per wave (sr_seq_kernel.hip: seq_cw)
+  const int cw = (tn >= 540 || tn == 324 || tn == 486 || tn == 500) ? 2 : 4;  // columns per wave (sr_seq_kernel.hip: seq_cw -- first radix above 16)
   const long groups = (tn / 2 + 1 + cw - 1) / cw, slots = (long)cus * 8;  // one-wave workgroups, two per SIMD
   auto cost = [&](int r) {
     const long wgs = groups * ((m + r - 1) / r), rounds = (wgs + slots - 1) / slots;

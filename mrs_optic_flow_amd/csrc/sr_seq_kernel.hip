@@ -255,7 +255,10 @@ constexpr int SEQ_CW = MOF_SEQ_CW;  // columns per wave
 #define MOF_SEQ_CW_BIG_FROM 540
 #endif
 template <int N>
-constexpr int seq_cw() { return N >= MOF_SEQ_CW_BIG_FROM ? 2 : SEQ_CW; }
+constexpr int seq_cw() {
+  // (two columns wherever the first radix is above 16 -- every N >= 540, and 324 / 486 / 500: 324 +10 %, 500 +5 %, 486 -1 %)
+  return (SrPlan<N>::R1 > 16 || N >= MOF_SEQ_CW_BIG_FROM) ? 2 : SEQ_CW;
+}
 
 template <int N, bool BOX = false>  // BOX: patches zero-padded to N -- the box-zero rule of padded CONSTANT patches (the plain form pays nothing for it)
 __global__ void __launch_bounds__(64) sr_cols_seq_kernel(const float* __restrict__ zh_prev, const float* __restrict__ zh_cur,
