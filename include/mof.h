@@ -351,8 +351,8 @@ int mof_shard_bm_sync(mof_shard_bm* g);
 typedef struct mof_sr_config {
   int resolution;   /* side of the square image (scaleRotationEstimator.cpp:5): any even value >= 16 that pads to <= 960. 240, 256
                        and 480 have the full set of hand-tuned kernels; r06: every resolution whose padded size is an even
-                       200 .. 960, or 128 / 144 / 160 / 180 / 192, runs the tuned transforms too (MOF_SR_TUNED_ALL=0: those three
-                       only); the rest (below 126) run the planned pipeline on the padded size                           */
+                       91 .. 960 but a few below 200 runs the tuned transforms too (MOF_SR_TUNED_ALL=0: those three
+                       only); the rest run the planned pipeline on the padded size                           */
   double magnitude; /* log-polar magnitude M (scale_rot_magnitude, config/default.yaml:13: 49.9)      */
   int device;
   int logpolar_variant; /* MOF_LOGPOLAR_CV4 (0, default) or MOF_LOGPOLAR_CV3: see below              */

@@ -118,6 +118,30 @@ struct SrPlan<128> {  // 8 x 16
   static constexpr int R1 = 8, R2 = 16, Y2 = 17, LINE = 137;
 };
 template <>
+struct SrPlan<96> {  // 8 x 12
+  static constexpr int R1 = 8, R2 = 12, Y2 = 13, LINE = 105;
+};
+template <>
+struct SrPlan<100> {  // 10 x 10
+  static constexpr int R1 = 10, R2 = 10, Y2 = 11, LINE = 111;
+};
+template <>
+struct SrPlan<108> {  // 9 x 12
+  static constexpr int R1 = 9, R2 = 12, Y2 = 13, LINE = 117;
+};
+template <>
+struct SrPlan<120> {  // 12 x 10
+  static constexpr int R1 = 12, R2 = 10, Y2 = 11, LINE = 133;
+};
+template <>
+struct SrPlan<150> {  // 15 x 10
+  static constexpr int R1 = 15, R2 = 10, Y2 = 11, LINE = 165;
+};
+template <>
+struct SrPlan<162> {  // 9 x 18
+  static constexpr int R1 = 9, R2 = 18, Y2 = 19, LINE = 171;
+};
+template <>
 struct SrPlan<144> {  // 9 x 16
   static constexpr int R1 = 9, R2 = 16, Y2 = 17, LINE = 153;
 };

@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(64) sr_final_kernel(SrPcArgs a) {
 // on the planned pipeline, like every resolution that is not itself one of these sizes). MOF_SR_TUNED_ALL=0: the three only (A/B, tests).
 bool sr_transform_size_tuned(int m, bool* exact_nyquist) {
   static const int exact[] = {225, 243, 375, 405, 625, 675, 729,  // (odd: no Nyquist bin to keep exact)
-                              128, 144, 160, 180, 192, 200, 216, 240, 256, 270, 288, 300, 320, 324, 360, 384, 450, 480, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
+                              96, 100, 108, 120, 150, 162, 128, 144, 160, 180, 192, 200, 216, 240, 256, 270, 288, 300, 320, 324, 360, 384, 450, 480, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
   for (int t : exact)
     if (m == t) {
       if (exact_nyquist) *exact_nyquist = true;
@@ -798,7 +798,7 @@ bool sr_resolution_supported(int res) {
   static const bool all = [] { const char* v = getenv("MOF_SR_TUNED_ALL"); return !v || atoi(v) != 0; }();
   if (sr_pair_kernels_supported(res)) return true;
   if (!all) return false;
-  static const int sizes[] = {128, 144, 160, 180, 192, 200, 216, 270, 288, 300, 320, 324, 360, 384, 450, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
+  static const int sizes[] = {96, 100, 108, 120, 150, 162, 128, 144, 160, 180, 192, 200, 216, 270, 288, 300, 320, 324, 360, 384, 450, 486, 500, 512, 540, 576, 600, 640, 648, 720, 750, 768, 800, 810, 864, 900, 960};
   for (int t : sizes)
     if (res == t) return true;
   return false;
@@ -926,6 +926,12 @@ hipError_t launch_sr_peak(const SrPcArgs& a, int res, int n_pairs, hipStream_t s
     case 256: return launch_sr_peak_n<256>(a, n_pairs, stream);
     case 480: return launch_sr_peak_n<480>(a, n_pairs, stream);
     case 128: return launch_sr_peak_n<128>(a, n_pairs, stream);
+    case 96: return launch_sr_peak_n<96>(a, n_pairs, stream);
+    case 100: return launch_sr_peak_n<100>(a, n_pairs, stream);
+    case 108: return launch_sr_peak_n<108>(a, n_pairs, stream);
+    case 120: return launch_sr_peak_n<120>(a, n_pairs, stream);
+    case 150: return launch_sr_peak_n<150>(a, n_pairs, stream);
+    case 162: return launch_sr_peak_n<162>(a, n_pairs, stream);
     case 144: return launch_sr_peak_n<144>(a, n_pairs, stream);
     case 160: return launch_sr_peak_n<160>(a, n_pairs, stream);
     case 180: return launch_sr_peak_n<180>(a, n_pairs, stream);
@@ -1004,6 +1010,12 @@ hipError_t launch_sr_rows_inv(const float* Dt, const float* twiddles, float2* ca
     case 675: return launch_sr_rows_inv_n<675>(a, n_pairs, stream);
     case 729: return launch_sr_rows_inv_n<729>(a, n_pairs, stream);
     case 128: return launch_sr_rows_inv_n<128>(a, n_pairs, stream);
+    case 96: return launch_sr_rows_inv_n<96>(a, n_pairs, stream);
+    case 100: return launch_sr_rows_inv_n<100>(a, n_pairs, stream);
+    case 108: return launch_sr_rows_inv_n<108>(a, n_pairs, stream);
+    case 120: return launch_sr_rows_inv_n<120>(a, n_pairs, stream);
+    case 150: return launch_sr_rows_inv_n<150>(a, n_pairs, stream);
+    case 162: return launch_sr_rows_inv_n<162>(a, n_pairs, stream);
     case 144: return launch_sr_rows_inv_n<144>(a, n_pairs, stream);
     case 160: return launch_sr_rows_inv_n<160>(a, n_pairs, stream);
     case 180: return launch_sr_rows_inv_n<180>(a, n_pairs, stream);

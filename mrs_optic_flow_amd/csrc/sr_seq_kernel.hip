@@ -654,6 +654,12 @@ hipError_t launch_sr_rows_real_src(const PclSrc& src, const float* twiddles, flo
     case 675: return launch_rows_real_src_n<675>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 729: return launch_rows_real_src_n<729>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 128: return launch_rows_real_src_n<128>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 96: return launch_rows_real_src_n<96>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 100: return launch_rows_real_src_n<100>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 108: return launch_rows_real_src_n<108>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 120: return launch_rows_real_src_n<120>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 150: return launch_rows_real_src_n<150>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
+    case 162: return launch_rows_real_src_n<162>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 144: return launch_rows_real_src_n<144>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 160: return launch_rows_real_src_n<160>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
     case 180: return launch_rows_real_src_n<180>(src, twiddles, zh, zh_stride, flags, n_images, channels, n, sums, stream);
@@ -711,6 +717,12 @@ hipError_t launch_sr_cols_seq(const float* zh_prev, const float* zh_cur, size_t 
     case 675: return launch_cols_seq_n<675>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 729: return launch_cols_seq_n<729>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 128: return launch_cols_seq_n<128>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 96: return launch_cols_seq_n<96>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 100: return launch_cols_seq_n<100>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 108: return launch_cols_seq_n<108>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 120: return launch_cols_seq_n<120>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 150: return launch_cols_seq_n<150>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
+    case 162: return launch_cols_seq_n<162>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 144: return launch_cols_seq_n<144>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 160: return launch_cols_seq_n<160>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);
     case 180: return launch_cols_seq_n<180>(zh_prev, zh_cur, zh_stride, twiddles, Dt, n_pairs, run, flags, n, sums_prev, sums_cur, sums_stride, stream);

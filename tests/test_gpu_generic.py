@@ -355,7 +355,7 @@ def test_video_form_of_the_tuned_large_patch_path(gpu):
 
 # ---- scaleRotationEstimator at any even resolution (scaleRotationEstimator.cpp:3-32) ----
 @pytest.mark.parametrize("res,M", [(320, 45.0), (360, 49.9), (400, 49.9), (128, 25.0), (200, 35.0), (250, 40.0), (300, 49.9),
-                                    (350, 49.9), (500, 60.0), (192, 30.0), (640, 70.0), (720, 75.0), (270, 40.0), (208, 35.0), (336, 49.9), (416, 55.0), (432, 55.0), (496, 60.0), (160, 30.0), (180, 30.0), (144, 28.0), (220, 35.0), (370, 50.0)])
+                                    (350, 49.9), (500, 60.0), (192, 30.0), (640, 70.0), (720, 75.0), (270, 40.0), (208, 35.0), (336, 49.9), (416, 55.0), (432, 55.0), (496, 60.0), (160, 30.0), (180, 30.0), (144, 28.0), (220, 35.0), (370, 50.0), (100, 22.0), (120, 25.0), (150, 28.0), (104, 22.0)])
 def test_scale_rotation_at_any_resolution(gpu, res, M):
     """r06: 200, 270, 300, 320, 360, 500, 640, 720 are tuned transform sizes of the FFT engine's large patches with an exact Nyquist bin -- the
     estimator runs K5s / K6s / K7 there; 208 (-> 216), 336 / 350 (-> 360), 416 (-> 432), 496 (-> 500) PAD to a tuned size and 250 / 400 / 432 are the
