@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(SR_T) sr_cols_kernel(SrPcArgs a) {
 #endif
 template <int N>
 struct K7Cfg {
-  static constexpr int LPW = N >= MOF_K7_LPW2_FROM ? 2 : 4;
+  static constexpr int LPW = (SrPlan<N>::R1 > 16 || N >= MOF_K7_LPW2_FROM) ? 2 : 4;  // (also 324 / 486 / 500: +1 .. 4 %)
   static constexpr int T = SR_LINES / LPW * 64;
 };
 template <int N>
