@@ -211,7 +211,12 @@ for trial in range(max(4, n_fft // 4)):
             seq_checked += v == "plain"
             soft += v == "relaxed"
             unpinned += v == "unpinned"
-            same = np.allclose(got[k, p], pairs[k, p], rtol=0, atol=TOL, equal_nan=True)  # (the video entry against the pair entry)
+            # the video entry against the pair entry: equal within the plain bar, or -- on a patch whose inputs do not pin f32 arithmetic (seed 1026,
+            # n = 52: 107 exact-zero bins, an 82-fold cancelling window, f32 libraries up to 29 px apart; the video form 9e-5 px and the pair form
+            # 2.6e-4 px from the f64 oracle) -- the pair entry's result held to the SAME rule as the video entry's (tests/tolerances.py)
+            same = np.allclose(got[k, p], pairs[k, p], rtol=0, atol=TOL, equal_nan=True)
+            if not same:
+                same = judge(pairs[k, p], want64[p], want32[p], f"fuzz{seed}/seq{trial}/pair{k}/pair-entry", p, frames[k + 1], frames[k], lay) != "BAD"
             if v == "BAD" or not same:
                 seq_bad += 1
                 print("SEQ FFT MISMATCH", trial, n, (gx, gy), (ox, oy), (sx, sy), (h, w), nf, k, p, got[k, p], want64[p], want32[p], pairs[k, p])
